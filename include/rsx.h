@@ -1,0 +1,175 @@
+/*
+ * rsx.h — C ABI of librsx.so, the MI355X (gfx950) dense-retrieval search engine.
+ *
+ * This is the drop-in boundary for the search path of RulinShao/retrieval-scaling.
+ * In the reference every entry point below is a call into the third-party FAISS 1.8.0
+ * SWIG module (the reference holds no search arithmetic of its own); the citation on each
+ * function names the reference call site(s) it replaces (paths relative to the reference
+ * repository root).
+ *
+ * Conventions
+ *   - every function returns an int status: RSX_OK (0) or a negative rsx_status;
+ *     rsx_last_error() returns a thread-local message for the last failure on this thread
+ *     (FAISS raises C++ exceptions that SWIG turns into Python RuntimeError; the Python shim
+ *     rsx.py raises RuntimeError(rsx_last_error()) in the same places).
+ *   - plain pointers + sizes only; no torch / numpy types cross this boundary.
+ *   - "x"/"q" pointers may be HOST or DEVICE (HBM) pointers; the library detects which with
+ *     hipPointerGetAttributes.  Output D/I follow the same rule.  The caller owns inputs and
+ *     outputs; the handle owns all device memory of the index; no pointer is retained
+ *     past the call.
+ *   - one in-flight call per handle; callable from any host thread (hipSetDevice per call).
+ *   - vectors are row-major, C-contiguous [n, d]; dtype is RSX_F32 or RSX_F16.
+ *   - search returns D float32 [nq,k], I int64 [nq,k]; unfilled slots I=-1 and
+ *     D=-inf (inner product) / +inf (L2), exactly as faiss.Index.search does.
+ */
+#ifndef RSX_H
+#define RSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rsx_index rsx_index_t;
+
+enum rsx_status {
+    RSX_OK = 0,
+    RSX_ERR_INVALID = -1,      /* bad argument (shape, dtype, k, null pointer) */
+    RSX_ERR_NOT_TRAINED = -2,  /* add/search before train / set_centroids */
+    RSX_ERR_HIP = -3,          /* HIP runtime failure (message has hipGetErrorString) */
+    RSX_ERR_OOM = -4,          /* device or host allocation failed */
+    RSX_ERR_IO = -5,           /* save/load failure */
+    RSX_ERR_UNSUPPORTED = -6   /* valid FAISS request this build does not implement */
+};
+
+enum rsx_metric { RSX_METRIC_INNER_PRODUCT = 0, RSX_METRIC_L2 = 1 }; /* = faiss.METRIC_* */
+enum rsx_dtype { RSX_F32 = 0, RSX_F16 = 1 };
+enum rsx_kind { RSX_KIND_FLAT = 0, RSX_KIND_IVFFLAT = 1, RSX_KIND_IVFPQ = 2 };
+
+/* Thread-local message of the last error raised on the calling thread ("" if none). */
+const char* rsx_last_error(void);
+/* ABI version (major*1000+minor). */
+int rsx_version(void);
+/* Number of visible HIP devices; fails with RSX_ERR_HIP when there is no usable GPU.
+ * There is NO CPU fallback anywhere in this library. */
+int rsx_device_count(int* n);
+
+/* ---- construction ------------------------------------------------------------------ */
+
+/* faiss.IndexFlatIP(d)                         — src/indicies/flat.py:42
+ * (also the coarse quantiser object of ivf_flat.py:143 / ivf_pq.py:146, which this
+ *  library folds into the IVF handles). Vectors are stored as fp16 when every added value
+ *  is fp16-representable (the reference's embeddings are, src/embed.py:137-138), else fp32. */
+int rsx_flat_create(int d, int metric, int device, rsx_index_t** out);
+
+/* faiss.IndexIVFFlat(quantizer, d, nlist, METRIC_INNER_PRODUCT) — src/indicies/ivf_flat.py:144-148 */
+int rsx_ivfflat_create(int d, int nlist, int metric, int device, rsx_index_t** out);
+
+/* faiss.IndexIVFPQ(quantizer, d, nlist, M, nbits, METRIC_INNER_PRODUCT) — src/indicies/ivf_pq.py:147-153
+ * by_residual = true (FAISS default). nbits must be 8. */
+int rsx_ivfpq_create(int d, int nlist, int M, int nbits, int metric, int device, rsx_index_t** out);
+
+/* Python garbage collection of the SWIG object (implicit in the reference). */
+int rsx_destroy(rsx_index_t* h);
+
+/* ---- training ---------------------------------------------------------------------- */
+
+/* index.train(x)                               — src/indicies/ivf_flat.py:162,166; ivf_pq.py:166,170
+ * Coarse k-means with an inner-product quantiser (assignment = argmax <x,c>, spherical
+ * centroids, FAISS Level1Quantizer defaults: niter 10, <=256 points per centroid) and, for
+ * IVFPQ, per-subspace k-means (256 codewords, niter 25) on residuals.
+ * Assignment runs on the GPU; this also replaces the CUDA-only
+ * index_cpu_to_gpu/GpuClonerOptions branch of ivf_flat.py:152-163. No-op for Flat. */
+int rsx_train(rsx_index_t* h, int64_t n, const void* x, int dtype);
+
+/* Import already-trained parameters (what faiss.read_index(<...>.trained) restores:
+ * ivf_flat.py:170, ivf_pq.py:174).  centroids: [nlist, d] f32.  codebooks: [M, 256, d/M] f32. */
+int rsx_set_centroids(rsx_index_t* h, const float* centroids);
+int rsx_set_codebooks(rsx_index_t* h, const float* codebooks);
+int rsx_get_centroids(rsx_index_t* h, float* centroids_out);
+int rsx_get_codebooks(rsx_index_t* h, float* codebooks_out);
+
+/* ---- population -------------------------------------------------------------------- */
+
+/* index.add(x)                                 — flat.py:58; ivf_flat.py:180; ivf_pq.py:185
+ * ids == NULL assigns sequential ids ntotal .. ntotal+n-1 (the only form the reference uses).
+ * IVF: list = argmax-IP centroid; IVFPQ: residual = x - centroid, code = per-subspace nearest
+ * (L2) codeword, first minimum on ties; in-list order = insertion order. */
+int rsx_add(rsx_index_t* h, int64_t n, const void* x, int dtype, const int64_t* ids);
+
+/* Optional: pre-size every inverted list (counts[nlist]) so add never re-lays-out HBM. */
+int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts);
+
+/* Bulk import of one inverted list (FAISS on-disk reader; InvertedLists::add_entries).
+ * IVFPQ: codes [n, M] u8.  IVFFlat: codes = raw vectors [n, d] in `dtype`. */
+int rsx_add_list(rsx_index_t* h, int64_t list_no, int64_t n, const void* codes, int dtype,
+                 const int64_t* ids);
+
+/* Export one inverted list (inspection / parity tests / writer).  Pass NULL to skip an output.
+ * n_out: list length.  codes_out: IVFPQ [n,M] u8; IVFFlat/Flat [n,d] f32 (list_no ignored
+ * for Flat).  ids_out: [n]. */
+int rsx_get_list(rsx_index_t* h, int64_t list_no, int64_t* n_out, void* codes_out,
+                 int64_t* ids_out);
+
+/* ---- search ------------------------------------------------------------------------ */
+
+/* index.nprobe = probe                         — ivf_flat.py:73,149; ivf_pq.py:77,154 */
+int rsx_set_nprobe(rsx_index_t* h, int nprobe);
+
+/* index.search(x, k) -> (D, I)   THE HOT PATH  — flat.py:139; ivf_flat.py:225; ivf_pq.py:230
+ * q: [nq, d] dtype; D: float32 [nq, k]; I: int64 [nq, k].
+ * Result order: score descending (IP) / distance ascending (L2); equal scores by id ascending. */
+int rsx_search(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I);
+
+/* Multi-shard merge of per-shard top-k       — src/search.py:362-367 (post_hoc_merge_topk),
+ *                                               api/serve_main_node.py:150-163 (rerank_elements)
+ * D,I: [nshards, nq, k].  Output [nq, k]: best first; ties keep the earlier shard first, then the
+ * original within-shard order (Python's stable sorted(..., reverse=True)).  ids < 0 are padding.
+ * Pointers may be host or device (all four on the same side). */
+int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
+                   float* D_out, int64_t* I_out, int device);
+
+/* ---- introspection / knobs --------------------------------------------------------- */
+
+/* Integer properties: "ntotal", "nlist", "d", "is_trained", "nprobe", "M", "nbits", "kind",
+ * "metric", "storage_dtype", "code_size", "device", "max_k".
+ * (index.ntotal / index.is_trained — ivf_flat.py:171; ivf_pq.py:175) */
+int rsx_get(rsx_index_t* h, const char* key, int64_t* out);
+
+/* Tuning knobs that do not change results: "query_batch" (max queries per internal pass),
+ * "scan_chunk" (vectors per scan work item, 0 = auto), "profile" (1 = record stage timings). */
+int rsx_set_param(rsx_index_t* h, const char* key, double value);
+
+/* HIP-event timings (ms) of the stages of the last rsx_search on this handle when
+ * "profile"=1: "coarse", "select_probe", "lut", "scan", "select", "finalize", "total",
+ * and "scan_launches".  Used by bench.py for the roofline object. */
+int rsx_get_timing(rsx_index_t* h, const char* key, double* ms);
+
+/* ---- persistence ------------------------------------------------------------------- */
+
+/* faiss.write_index(index, path) / faiss.read_index(path)
+ *   — flat.py:39,63,69; ivf_flat.py:71,167,170,185; ivf_pq.py:75,171,174,190
+ * Native container (magic "RSX1"); the FAISS .faiss reader lives in the Python host layer. */
+int rsx_save(rsx_index_t* h, const char* path);
+int rsx_load(const char* path, int device, rsx_index_t** out);
+
+/* ---- synthetic data (bench / tests) ------------------------------------------------ */
+
+/* Deterministic Gaussian-mixture generator, bit-identical to oracle/orc_synth (integer hash +
+ * Irwin-Hall normal approximation, no transcendental functions):
+ *   centre(j)[t]   = 1.0 * z(seed_c, j, t)
+ *   vector(i)[t]   = fp16( centre(h(seed_x,i) % ncentres)[t] + sigma * z(seed_x, i, t) )
+ * writes rows [i0, i0+n) as fp16 into `out` (host or device pointer, [n, d] fp16). */
+int rsx_synth_vectors(int device, int d, int ncentres, uint32_t seed_c, uint32_t seed_x,
+                      float sigma, int64_t i0, int64_t n, void* out_f16);
+/* queries: q(r) = fp16( vector(h(seed_q, r) % nbase) + sigma_q * z(seed_q, r, t) ) */
+int rsx_synth_queries(int device, int d, int ncentres, uint32_t seed_c, uint32_t seed_x,
+                      float sigma, int64_t nbase, uint32_t seed_q, float sigma_q, int64_t r0,
+                      int64_t n, void* out_f16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSX_H */

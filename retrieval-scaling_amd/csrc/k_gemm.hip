@@ -1,0 +1,392 @@
+// k_gemm.hip — the dense contractions of the search path, on the gfx950 matrix cores.
+//
+//  k_gemm_exact : S = X · Cᵀ with f32-input MFMA (v_mfma_f32_32x32x2_f32).  On gfx950 that
+//                 instruction is bit-for-bit a k-ordered fp32 fmaf chain, so every output equals
+//                 the oracle's `s = fmaf(x[t], c[t], s)` loop: coarse-quantiser scores (the
+//                 quantizer.search inside IndexIVF*::search — reference ivf_flat.py:143,225,
+//                 ivf_pq.py:146,230) and IVF assignment (index.add, ivf_flat.py:180, ivf_pq.py:185)
+//                 are exact and reproducible.  1024 x 4096 x 768 is 6.4 GFLOP: off the critical path.
+//  k_flat_gemm  : Flat scan Q · Xᵀ, fp16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16),
+//                 128x128 tiles staged through padded LDS (IndexFlatIP::search, flat.py:139).
+//                 Candidates only — exact scores come from the fp64 re-rank in k_finalize.
+//  k_list_scan  : IVF-Flat list scan, list-major: one work item = (list, <=16 probing queries,
+//                 row chunk); the list's fp16 rows stream from HBM straight into MFMA B fragments
+//                 (16-byte loads, 64 B contiguous per row per instruction) and are dotted against
+//                 the group's queries held in LDS (v_mfma_f32_16x16x32_f16).  HBM-bound by design:
+//                 a list is read once per batch for all queries that probe it.
+#include "rsx_internal.h"
+
+namespace rsx {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// =======================================================================================
+// exact f32 GEMM
+// =======================================================================================
+template <bool XF16>
+__device__ inline void load16_f32(const void* X, int64_t row, int ldx, int t0, int d, bool vec_ok, float* out) {
+    if (XF16) {
+        const __half* p = (const __half*)X + row * ldx + t0;
+        if (vec_ok && t0 + 16 <= d) {
+            uint4 u0 = *reinterpret_cast<const uint4*>(p);
+            uint4 u1 = *reinterpret_cast<const uint4*>(p + 8);
+            const __half* h0 = reinterpret_cast<const __half*>(&u0);
+            const __half* h1 = reinterpret_cast<const __half*>(&u1);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { out[e] = __half2float(h0[e]); out[8 + e] = __half2float(h1[e]); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) out[e] = (t0 + e < d) ? __half2float(p[e]) : 0.0f;
+        }
+    } else {
+        const float* p = (const float*)X + row * ldx + t0;
+        if (vec_ok && t0 + 16 <= d) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float4 f = *reinterpret_cast<const float4*>(p + 4 * e);
+                out[4 * e] = f.x; out[4 * e + 1] = f.y; out[4 * e + 2] = f.z; out[4 * e + 3] = f.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) out[e] = (t0 + e < d) ? p[e] : 0.0f;
+        }
+    }
+}
+
+template <bool XF16, bool ARGMAX>
+__global__ __launch_bounds__(256) void k_gemm_exact(const void* X, int64_t n, int ldx, int x_vec_ok, const float* C,
+                                                    int nc, int d, int c_vec_ok, float* S, int64_t lds_,
+                                                    uint64_t* partial, int npart) {
+    __shared__ float As[128][33];
+    __shared__ float Bs[128][33];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int64_t row0 = (int64_t)blockIdx.y * 128;
+    const int col0 = blockIdx.x * 128;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    const int sr = tid >> 1, sh = tid & 1;
+    int64_t xr = row0 + sr; if (xr > n - 1) xr = n - 1;
+    int cr = col0 + sr; if (cr > nc - 1) cr = nc - 1;
+
+    float xa[16], cb[16];
+    load16_f32<XF16>(X, xr, ldx, 16 * sh, d, x_vec_ok, xa);
+    load16_f32<false>(C, cr, d, 16 * sh, d, c_vec_ok, cb);
+
+    for (int k0 = 0; k0 < d; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; e++) { As[sr][16 * sh + e] = xa[e]; Bs[sr][16 * sh + e] = cb[e]; }
+        __syncthreads();
+        if (k0 + 32 < d) {
+            load16_f32<XF16>(X, xr, ldx, k0 + 32 + 16 * sh, d, x_vec_ok, xa);
+            load16_f32<false>(C, cr, d, k0 + 32 + 16 * sh, d, c_vec_ok, cb);
+        }
+        const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const int kc = 2 * kk + lk;
+            float a0 = As[wr * 64 + li][kc], a1 = As[wr * 64 + 32 + li][kc];
+            float b0 = Bs[wc * 64 + li][kc], b1 = Bs[wc * 64 + 32 + li][kc];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // C/D layout of 32x32 MFMA: reg r of lane l holds (row i = (r&3) + 8*(r>>2) + 4*(l>>5), col j = l&31)
+    const int lj = lane & 31, lh = lane >> 5;
+    if (!ARGMAX) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int64_t row = row0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    int col = col0 + wc * 64 + tj * 32 + lj;
+                    if (row < n && col < nc) S[row * lds_ + col] = acc[ti][tj][r];
+                }
+    } else {
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int64_t row = row0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                uint64_t best = 0;
+#pragma unroll
+                for (int tj = 0; tj < 2; tj++) {
+                    int col = col0 + wc * 64 + tj * 32 + lj;
+                    uint64_t key = (col < nc) ? make_key(acc[ti][tj][r], (uint32_t)col) : 0ull;
+                    best = key > best ? key : best;
+                }
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {
+                    uint32_t lo = __shfl_xor((uint32_t)(best & 0xffffffffull), off);
+                    uint32_t hi = __shfl_xor((uint32_t)(best >> 32), off);
+                    uint64_t o = ((uint64_t)hi << 32) | lo;
+                    best = o > best ? o : best;
+                }
+                if (lj == 0 && row < n) partial[row * npart + blockIdx.x * 2 + wc] = best;
+            }
+    }
+}
+
+__global__ void k_argmax_reduce(const uint64_t* partial, int64_t n, int npart, int32_t* assign, float* best) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t b = 0;
+    for (int p = 0; p < npart; p++) { uint64_t k = partial[i * npart + p]; b = k > b ? k : b; }
+    assign[i] = b ? (int32_t)key_idx(b) : 0;
+    if (best) best[i] = b ? key_score(b) : -__builtin_inff();
+}
+
+static inline int aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+void launch_gemm_exact_scores(const void* X, int x_f16, int64_t n, int ldx, const float* C, int nc, int d,
+                              float* S, int64_t lds_, hipStream_t st) {
+    if (n <= 0 || nc <= 0) return;
+    dim3 grid((nc + 127) / 128, (unsigned)((n + 127) / 128));
+    int xv = aligned16(X) && (ldx % 8 == 0);
+    int cv = aligned16(C) && (d % 4 == 0);
+    if (x_f16) hipLaunchKernelGGL((k_gemm_exact<true, false>), grid, dim3(256), 0, st, X, n, ldx, xv, C, nc, d, cv, S, lds_, (uint64_t*)nullptr, 0);
+    else hipLaunchKernelGGL((k_gemm_exact<false, false>), grid, dim3(256), 0, st, X, n, ldx, xv, C, nc, d, cv, S, lds_, (uint64_t*)nullptr, 0);
+}
+
+void launch_gemm_exact_argmax(const void* X, int x_f16, int64_t n, int ldx, const float* C, int nc, int d,
+                              uint64_t* partial, int32_t* assign, float* best, hipStream_t st) {
+    if (n <= 0 || nc <= 0) return;
+    // grid.y is limited to 65535 row tiles per launch
+    const int64_t rows_per_launch = 65535ll * 128;
+    int ct = (nc + 127) / 128;
+    int xv = aligned16(X) && (ldx % 8 == 0);
+    int cv = aligned16(C) && (d % 4 == 0);
+    size_t esz = x_f16 ? 2 : 4;
+    for (int64_t r0 = 0; r0 < n; r0 += rows_per_launch) {
+        int64_t nr = n - r0 < rows_per_launch ? n - r0 : rows_per_launch;
+        dim3 grid(ct, (unsigned)((nr + 127) / 128));
+        const void* Xp = (const char*)X + (size_t)r0 * ldx * esz;
+        if (x_f16) hipLaunchKernelGGL((k_gemm_exact<true, true>), grid, dim3(256), 0, st, Xp, nr, ldx, xv, C, nc, d, cv, (float*)nullptr, (int64_t)0, partial + r0 * 2 * ct, 2 * ct);
+        else hipLaunchKernelGGL((k_gemm_exact<false, true>), grid, dim3(256), 0, st, Xp, nr, ldx, xv, C, nc, d, cv, (float*)nullptr, (int64_t)0, partial + r0 * 2 * ct, 2 * ct);
+    }
+    hipLaunchKernelGGL(k_argmax_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, n, 2 * ct, assign, best);
+}
+
+// =======================================================================================
+// Flat scan GEMM (fp16 MFMA)
+// =======================================================================================
+template <bool XF16>
+__device__ inline uint4 load8_as_half(const void* X, int64_t row, int ld, int t0) {
+    if (XF16) {
+        return *reinterpret_cast<const uint4*>((const __half*)X + row * ld + t0);
+    } else {
+        const float* p = (const float*)X + row * ld + t0;
+        float4 f0 = *reinterpret_cast<const float4*>(p);
+        float4 f1 = *reinterpret_cast<const float4*>(p + 4);
+        union { uint4 u; __half h[8]; } c;
+        c.h[0] = __float2half_rn(f0.x); c.h[1] = __float2half_rn(f0.y);
+        c.h[2] = __float2half_rn(f0.z); c.h[3] = __float2half_rn(f0.w);
+        c.h[4] = __float2half_rn(f1.x); c.h[5] = __float2half_rn(f1.y);
+        c.h[6] = __float2half_rn(f1.z); c.h[7] = __float2half_rn(f1.w);
+        return c.u;
+    }
+}
+
+#define FG_STRIDE 144  // bytes per LDS row: 64 halfs + 16 B pad -> conflict-free ds_read_b128
+
+template <bool XF16>
+__global__ __launch_bounds__(256) void k_flat_gemm(const __half* Q16, const void* X, int64_t v0, int64_t nv, int ld,
+                                                   const float* bias, float* temp, int64_t tstride) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * FG_STRIDE];
+    unsigned char* As = smem;                    // queries tile
+    unsigned char* Bs = smem + 128 * FG_STRIDE;  // db rows tile
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int64_t q0 = (int64_t)blockIdx.x * 128;
+    const int64_t vt0 = (int64_t)blockIdx.y * 128;  // column offset inside this chunk
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    uint4 ra[4], rb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        int p = tid + 256 * u, row = p >> 3, slot = p & 7;
+        ra[u] = *reinterpret_cast<const uint4*>(Q16 + (q0 + row) * ld + slot * 8);
+        rb[u] = load8_as_half<XF16>(X, v0 + vt0 + row, ld, slot * 8);
+    }
+    for (int k0 = 0; k0 < ld; k0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int p = tid + 256 * u, row = p >> 3, slot = p & 7;
+            *reinterpret_cast<uint4*>(As + row * FG_STRIDE + slot * 16) = ra[u];
+            *reinterpret_cast<uint4*>(Bs + row * FG_STRIDE + slot * 16) = rb[u];
+        }
+        __syncthreads();
+        if (k0 + 64 < ld) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int p = tid + 256 * u, row = p >> 3, slot = p & 7;
+                ra[u] = *reinterpret_cast<const uint4*>(Q16 + (q0 + row) * ld + k0 + 64 + slot * 8);
+                rb[u] = load8_as_half<XF16>(X, v0 + vt0 + row, ld, k0 + 64 + slot * 8);
+            }
+        }
+        const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            half8 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                a[t] = *reinterpret_cast<const half8*>(As + (wr * 64 + t * 32 + li) * FG_STRIDE + (2 * s + kh) * 16);
+                b[t] = *reinterpret_cast<const half8*>(Bs + (wc * 64 + t * 32 + li) * FG_STRIDE + (2 * s + kh) * 16);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+                for (int tj = 0; tj < 2; tj++)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        }
+    }
+    // A index i = query, B index j = db row
+    const int lj = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+        int64_t col = vt0 + wc * 64 + tj * 32 + lj;
+        float bv = (bias && col < nv) ? bias[v0 + col] : 0.0f;
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int64_t qrow = q0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (col < nv) temp[qrow * tstride + col] = acc[ti][tj][r] + bv;
+            }
+    }
+}
+
+void launch_flat_gemm(const __half* Q16, int nq_pad, const void* X, int x_f16, int64_t v0, int64_t nv, int ld,
+                      const float* bias, float* temp, int64_t tstride, hipStream_t st) {
+    if (nv <= 0 || nq_pad <= 0) return;
+    dim3 grid(nq_pad / 128, (unsigned)((nv + 127) / 128));
+    if (x_f16) hipLaunchKernelGGL(k_flat_gemm<true>, grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, temp, tstride);
+    else hipLaunchKernelGGL(k_flat_gemm<false>, grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, temp, tstride);
+}
+
+// =======================================================================================
+// List scan (IVF-Flat; Flat at small batch)
+// =======================================================================================
+template <bool XF16>
+__global__ __launch_bounds__(256) void k_list_scan(ListScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
+    const int qstride = (a.ld + 8) * 2;  // bytes; (ld+8)*2/16 is odd for ld % 16 == 0 -> conflict-free b128 reads
+    unsigned char* Qs = ls_smem;
+    int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + 16 * qstride);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = blockIdx.x;
+    const int chunk = blockIdx.y;
+
+    int64_t base, len;
+    int np;
+    int l = 0, pair0 = 0;
+    if (a.flat_mode) {
+        base = 0; len = a.flat_n;
+        np = a.nq - 16 * g; if (np > 16) np = 16;
+        if (np <= 0) return;
+    } else {
+        if (g >= *a.total_groups) return;
+        int lo = 0, hi = a.nlist;  // largest l with group_off[l] <= g
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.group_off[mid] <= g) lo = mid; else hi = mid; }
+        l = lo;
+        int gi = g - a.group_off[l];
+        int cnt = a.pair_off[l + 1] - a.pair_off[l];
+        np = cnt - 16 * gi; if (np > 16) np = 16;
+        pair0 = a.pair_off[l] + 16 * gi;
+        base = a.list_base[l]; len = a.list_len[l];
+    }
+    const int64_t len_pad = (len + 15) & ~15ll;
+    const int64_t c0 = (int64_t)chunk * a.chunk_rows;
+    if (c0 >= len_pad) return;
+    int64_t c1 = c0 + a.chunk_rows; if (c1 > len_pad) c1 = len_pad;
+
+    // stage the group's queries (16 rows of ld halfs) and their score-buffer offsets
+    for (int i = 0; i < 16; i++) {
+        int64_t q = -1;
+        if (i < np) {
+            if (a.flat_mode) q = 16 * (int64_t)g + i;
+            else q = a.pairs_sorted[pair0 + i] / a.nprobe;
+        }
+        for (int t = tid * 8; t < a.ld; t += 256 * 8) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q >= 0) v = *reinterpret_cast<const uint4*>(a.Q16 + q * a.ld + t);
+            *reinterpret_cast<uint4*>(Qs + i * qstride + t * 2) = v;
+        }
+    }
+    if (tid < 16) {
+        int64_t off = 0;
+        if (tid < np) {
+            if (a.flat_mode) off = (16 * (int64_t)g + tid) * a.tstride;
+            else {
+                int pidx = a.pairs_sorted[pair0 + tid];
+                int64_t q = pidx / a.nprobe; int j = pidx % a.nprobe;
+                off = q * a.tstride + a.seg_start[q * (a.nprobe + 1) + j];
+            }
+        }
+        segoff[tid] = off;
+    }
+    __syncthreads();
+
+    const int lr = lane & 15, kg = lane >> 4;
+    for (int64_t rb = c0 + w * 16; rb < c1; rb += 64) {
+        const int64_t row = base + rb + lr;
+        floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+        for (int k0 = 0; k0 < a.ld; k0 += 32) {
+            half8 qa = *reinterpret_cast<const half8*>(Qs + lr * qstride + (k0 + 8 * kg) * 2);
+            uint4 xb = load8_as_half<XF16>(a.X, row, a.ld, k0 + 8 * kg);
+            half8 xh = *reinterpret_cast<half8*>(&xb);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, xh, acc, 0, 0, 0);
+        }
+        // C/D layout of 16x16 MFMA: reg r of lane l holds (row i = 4*(l>>4) + r, col j = l&15)
+        //   i = query of the group, j = db row of the block
+        const int64_t rloc = rb + lr;
+        float bv = (a.bias && rloc < len) ? a.bias[base + rloc] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int qi = kg * 4 + r;
+            if (qi < np) {
+                float v = (rloc < len) ? acc[r] + bv : -__builtin_inff();
+                a.temp[segoff[qi] + rloc] = v;
+            }
+        }
+    }
+}
+
+void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
+    if (a.max_groups <= 0 || a.max_chunks <= 0) return;
+    dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
+    size_t shm = (size_t)16 * (a.ld + 8) * 2 + 16 * sizeof(int64_t);
+    if (a.x_f16) {
+        if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_list_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(k_list_scan<true>, grid, dim3(256), shm, st, a);
+    } else {
+        if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_list_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(k_list_scan<false>, grid, dim3(256), shm, st, a);
+    }
+}
+
+}  // namespace rsx

@@ -1,0 +1,220 @@
+// k_pq.hip — product-quantiser kernels of IndexIVFPQ (reference src/indicies/ivf_pq.py:147-153,
+// search :230, add :185).  METRIC_INNER_PRODUCT, by_residual: the look-up table
+// T[q][m][c] = <q_m, codebook[m][c]> does not depend on the list, and
+// score(q, v) = <q, centroid(list(v))> + sum_m T[q][m][code_v[m]].
+//
+//  k_pq_lut    : T for a batch of queries (fp32 fmaf chains, bit-equal to the oracle).
+//  k_pq_scan   : one workgroup = (query, probed list, chunk of slabs).  The query's table is staged
+//                in LDS (M KiB); codes stream from HBM in the slab layout (lane v of a wave reads 16
+//                contiguous bytes, the wave 1 KiB per instruction); each lane gathers its vector's
+//                M table entries from LDS and accumulates them in m order, exactly the sequential
+//                fp32 sum of FAISS's generic IVFPQ scanner; the score goes to the query's row of the
+//                score buffer (coalesced fp32 stores).  Integer/byte work bounded by HBM and the LDS
+//                gather rate — deliberately NOT reshaped into a GEMM.
+//  k_pq_encode : ProductQuantizer::compute_code on residuals: nearest codeword per subspace by
+//                squared L2 (fmaf chain, first minimum), written straight into the slab layout.
+#include "rsx_internal.h"
+
+namespace rsx {
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pq_lut(const float* Q32, int ldq, int d, int M, int dsub,
+                                                const float* codebooks, float* lut, int Mpad) {
+    const int64_t q = blockIdx.x;
+    const int m = blockIdx.y;
+    const int c = threadIdx.x;
+    float s = 0.0f;
+    if (m < M) {
+        const float* qs = Q32 + q * ldq + m * dsub;
+        const float* cw = codebooks + ((int64_t)m * 256 + c) * dsub;
+        for (int t = 0; t < dsub; t++) s = __fmaf_rn(qs[t], cw[t], s);
+    }
+    lut[(q * Mpad + m) * 256 + c] = s;
+}
+void launch_pq_lut(const float* Q32, int ldq, int64_t nq, int d, int M, int Mpad, const float* codebooks,
+                   float* lut, hipStream_t st) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_pq_lut, dim3((unsigned)nq, Mpad), dim3(256), 0, st, Q32, ldq, d, M, d / M, codebooks, lut, Mpad);
+}
+
+// ---------------------------------------------------------------------------------------
+// NCH = Mpad/16 for the 16-byte-granule layout (CB = 16); NCH = 0: generic 4-byte granules.
+template <int NCH>
+__global__ __launch_bounds__(1024) void k_pq_scan(PQScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pq_lut_s[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    const int64_t pair = blockIdx.x;
+    const int chunk = blockIdx.y;
+    const int32_t l = a.probe_list[pair];
+    if (l < 0) return;
+    const int64_t len = a.list_len[l];
+    const int64_t nslab = (len + 63) >> 6;
+    const int64_t s0 = (int64_t)chunk * a.slabs_per_chunk;
+    if (s0 >= nslab) return;
+    int64_t s1 = s0 + a.slabs_per_chunk; if (s1 > nslab) s1 = nslab;
+    const int64_t q = pair / a.nprobe;
+    const int j = (int)(pair - q * a.nprobe);
+    const float dis0 = a.probe_dis0[pair];
+    float* out = a.temp + q * a.tstride + a.seg_start[q * (a.nprobe + 1) + j];
+
+    // stage the query's table: Mpad*256 floats
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.lut + q * a.Mpad * 256);
+        float4* dst = reinterpret_cast<float4*>(pq_lut_s);
+        const int n4 = a.Mpad * 64;
+        for (int i = tid; i < n4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int64_t slab_base = a.list_base[l] >> 6;
+    const int64_t slab_bytes = (int64_t)64 * a.Mpad;
+    for (int64_t s = s0 + w; s < s1; s += nw) {
+        const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
+        float sum = 0.0f;
+        if (NCH > 0) {
+            uint4 c[NCH > 0 ? NCH : 1];
+#pragma unroll
+            for (int g = 0; g < NCH; g++) c[g] = *reinterpret_cast<const uint4*>(sp + g * 1024 + lane * 16);
+#pragma unroll
+            for (int g = 0; g < NCH; g++) {
+                const uint32_t wds[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                    sum += pq_lut_s[(g * 16 + b) * 256 + code];
+                }
+            }
+        } else {
+            const int ng = a.Mpad >> 2;
+            for (int g = 0; g < ng; g++) {
+                uint32_t wd = *reinterpret_cast<const uint32_t*>(sp + g * 256 + lane * 4);
+#pragma unroll
+                for (int b = 0; b < 4; b++) sum += pq_lut_s[(g * 4 + b) * 256 + ((wd >> (8 * b)) & 0xffu)];
+            }
+        }
+        const int64_t pos = s * 64 + lane;
+        out[pos] = (pos < len) ? dis0 + sum : -__builtin_inff();
+    }
+}
+
+template <int NCH>
+static int launch_pq_scan_t(const PQScanArgs& a, dim3 grid, size_t shm, hipStream_t st) {
+    if (hipFuncSetAttribute((const void*)k_pq_scan<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+        return -1;
+    hipLaunchKernelGGL(k_pq_scan<NCH>, grid, dim3(1024), shm, st, a);
+    return 0;
+}
+
+int launch_pq_scan(const PQScanArgs& a, hipStream_t st) {
+    int64_t pairs = a.nq * a.nprobe;
+    if (pairs <= 0 || a.max_chunks <= 0) return 0;
+    dim3 grid((unsigned)pairs, (unsigned)a.max_chunks);
+    size_t shm = (size_t)a.Mpad * 1024;
+    if (shm > 160 * 1024) return -1;
+    if (a.CB == 16) {
+        switch (a.Mpad / 16) {
+            case 1: return launch_pq_scan_t<1>(a, grid, shm, st);
+            case 2: return launch_pq_scan_t<2>(a, grid, shm, st);
+            case 3: return launch_pq_scan_t<3>(a, grid, shm, st);
+            case 4: return launch_pq_scan_t<4>(a, grid, shm, st);
+            case 6: return launch_pq_scan_t<6>(a, grid, shm, st);
+            case 8: return launch_pq_scan_t<8>(a, grid, shm, st);
+            default: return -1;
+        }
+    }
+    return launch_pq_scan_t<0>(a, grid, shm, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Encode: 256 vectors per workgroup (one per thread); the codebook of subspace m is staged in LDS
+// and read with broadcast ds_reads (all lanes the same address: conflict-free).
+template <int DSUB>
+__global__ __launch_bounds__(256) void k_pq_encode(const void* x, int x_f16, int64_t n, int ldx, int d, int M, int Mpad,
+                                                   int CB, int dsub_rt, const float* centroids, const int32_t* assign,
+                                                   const float* codebooks, const int64_t* dest_row, uint8_t* codes,
+                                                   uint8_t* plain_out) {
+    extern __shared__ __attribute__((aligned(16))) float enc_cb[];  // [256][dsub]
+    const int dsub = DSUB > 0 ? DSUB : dsub_rt;
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool valid = i < n;
+    const int64_t ii = valid ? i : n - 1;
+    const float* cen = centroids ? centroids + (int64_t)assign[ii] * d : nullptr;
+    const int64_t drow = (dest_row && valid) ? dest_row[ii] : 0;
+    uint32_t packed = 0;
+    for (int m = 0; m < Mpad; m++) {
+        uint32_t code = 0;
+        if (m < M) {
+            __syncthreads();
+            for (int e = tid; e < 256 * dsub; e += 256) enc_cb[e] = codebooks[(int64_t)m * 256 * dsub + e];
+            __syncthreads();
+            float r[DSUB > 0 ? DSUB : 1];
+            if (DSUB > 0) {
+#pragma unroll
+                for (int t = 0; t < DSUB; t++) {
+                    float xv = x_f16 ? __half2float(((const __half*)x)[ii * ldx + m * dsub + t])
+                                     : ((const float*)x)[ii * ldx + m * dsub + t];
+                    r[t] = cen ? __fsub_rn(xv, cen[m * dsub + t]) : xv;
+                }
+            }
+            float best = __builtin_inff();
+            for (int c = 0; c < 256; c++) {
+                float acc = 0.0f;
+                if (DSUB > 0) {
+#pragma unroll
+                    for (int t = 0; t < DSUB; t++) { float df = __fsub_rn(r[t], enc_cb[c * DSUB + t]); acc = __fmaf_rn(df, df, acc); }
+                } else {
+                    for (int t = 0; t < dsub; t++) {
+                        float xv = x_f16 ? __half2float(((const __half*)x)[ii * ldx + m * dsub + t])
+                                         : ((const float*)x)[ii * ldx + m * dsub + t];
+                        float rv = cen ? __fsub_rn(xv, cen[m * dsub + t]) : xv;
+                        float df = __fsub_rn(rv, enc_cb[c * dsub + t]);
+                        acc = __fmaf_rn(df, df, acc);
+                    }
+                }
+                if (acc < best) { best = acc; code = (uint32_t)c; }
+            }
+        }
+        if (plain_out) {
+            if (valid) plain_out[i * Mpad + m] = (uint8_t)code;
+        } else {
+            packed |= code << (8 * (m & 3));
+            if ((m & 3) == 3) {
+                if (valid) {
+                    int64_t slab = drow >> 6; int v = (int)(drow & 63);
+                    int m0 = m - 3;
+                    int g = m0 / CB, b = m0 - g * CB;
+                    int64_t addr = (slab * (Mpad / CB) + g) * (int64_t)(64 * CB) + v * CB + b;
+                    *reinterpret_cast<uint32_t*>(codes + addr) = packed;
+                }
+                packed = 0;
+            }
+        }
+    }
+}
+
+void launch_pq_encode(const void* x, int x_f16, int64_t n, int ldx, int d, int M, int Mpad, int CB,
+                      const float* centroids, const int32_t* assign, const float* codebooks,
+                      const int64_t* dest_row, uint8_t* codes, uint8_t* plain_out, hipStream_t st) {
+    if (n <= 0) return;
+    int dsub = d / M;
+    dim3 grid((unsigned)((n + 255) / 256));
+    size_t shm = (size_t)256 * dsub * sizeof(float);
+#define RSX_ENC(DS)                                                                                         \
+    case DS:                                                                                                \
+        if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_pq_encode<DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+        hipLaunchKernelGGL(k_pq_encode<DS>, grid, dim3(256), shm, st, x, x_f16, n, ldx, d, M, Mpad, CB, dsub, centroids, assign, \
+                           codebooks, dest_row, codes, plain_out);                                          \
+        break;
+    switch (dsub) {
+        RSX_ENC(2) RSX_ENC(4) RSX_ENC(8) RSX_ENC(12) RSX_ENC(16) RSX_ENC(24) RSX_ENC(32) RSX_ENC(48) RSX_ENC(64)
+        default:
+            if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_pq_encode<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL(k_pq_encode<0>, grid, dim3(256), shm, st, x, x_f16, n, ldx, d, M, Mpad, CB, dsub, centroids,
+                               assign, codebooks, dest_row, codes, plain_out);
+    }
+#undef RSX_ENC
+}
+
+}  // namespace rsx

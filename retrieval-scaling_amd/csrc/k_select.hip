@@ -1,0 +1,361 @@
+// k_select.hip — k-selection, probe set-up, (query,list) grouping, final exact re-rank and the
+// multi-shard merge.  All selection kernels are ONE WAVE (64 lanes) per workgroup: ballots and
+// popcounts give lane-private append slots with no LDS atomics, and the workgroup barrier of a
+// single-wave group is free, so many independent selections share a CU.
+//
+// Replaces, inside faiss.Index*.search (reference call sites flat.py:139, ivf_flat.py:225,
+// ivf_pq.py:230): the per-query heap / reservoir top-k, quantizer->search top-nprobe, and
+// heap_reorder; and src/search.py:362-367 (multi-shard merge).
+#include "rsx_internal.h"
+
+namespace rsx {
+
+// Descending bitonic sort of n (power of two) 64-bit keys in LDS by one wave.
+__device__ inline void bitonic_sort_desc(uint64_t* buf, int n, int lane) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (n >> 1); t += 64) {
+                int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                int j = i + stride;
+                bool desc = ((i & size) == 0);
+                uint64_t x = buf[i], y = buf[j];
+                if ((x < y) == desc) { buf[i] = y; buf[j] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Streaming threshold selection.  The wave keeps up to BUF candidate keys in LDS; a key is
+// appended only if it beats tau (the k-th best key at the last prune); when the buffer would
+// overflow it is sorted, cut to KP keys, and tau is raised.  Exact: a dropped key always has
+// >= k strictly better keys.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_select(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sel_buf[];
+    uint64_t* buf = sel_buf;
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int seg = blockIdx.y;
+    const int KP = a.KP, BUF = a.BUF, k = a.k;
+    int64_t n = a.row_n ? a.row_n[row * a.row_n_stride] : a.n_uniform;
+    int64_t start = (int64_t)seg * a.seg_len;
+    int64_t end = start + a.seg_len;
+    if (end > n) end = n;
+    const float* sf = (const float*)a.in + row * a.row_stride;
+    const uint64_t* sk = (const uint64_t*)a.in + row * a.row_stride;
+
+    int cnt = 0;
+    uint64_t tau = 0;
+    if (a.init) {  // running state: KP keys sorted descending, zero padded
+        for (int i = lane; i < KP; i += 64) buf[i] = a.init[row * KP + i];
+        __syncthreads();
+        cnt = KP;
+        tau = buf[k - 1];
+        __syncthreads();
+    }
+    for (int64_t base = start; base < end; base += 256) {
+        int64_t e0 = base + lane * 4;
+        uint64_t key[4];
+        if (MODE == 0) {
+            float v[4];
+            if (e0 + 3 < end) {
+                float4 f = *reinterpret_cast<const float4*>(sf + e0);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = (e0 + e < end) ? sf[e0 + e] : -__builtin_inff();
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) key[e] = make_key(v[e], a.idx_base + (uint32_t)(e0 + e));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) key[e] = (e0 + e < end) ? sk[e0 + e] : 0ull;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            bool pass = key[e] > tau;
+            uint64_t mask = __ballot(pass);
+            if (mask == 0) continue;
+            int np = __popcll(mask);
+            if (cnt + np > BUF) {
+                for (int i = cnt + lane; i < BUF; i += 64) buf[i] = 0;
+                __syncthreads();
+                bitonic_sort_desc(buf, BUF, lane);
+                cnt = KP;
+                tau = buf[k - 1];
+                __syncthreads();
+                pass = key[e] > tau;
+                mask = __ballot(pass);
+                np = __popcll(mask);
+            }
+            if (pass) buf[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = key[e];
+            cnt += np;
+        }
+    }
+    for (int i = cnt + lane; i < BUF; i += 64) buf[i] = 0;
+    __syncthreads();
+    bitonic_sort_desc(buf, BUF, lane);
+    uint64_t* o = a.out + row * a.out_row_stride + (int64_t)seg * KP;
+    for (int i = lane; i < KP; i += 64) o[i] = buf[i];
+}
+
+void launch_select(const SelectArgs& a, hipStream_t st) {
+    if (a.nrows <= 0 || a.nseg <= 0) return;
+    dim3 grid((unsigned)a.nrows, (unsigned)a.nseg);
+    size_t shm = (size_t)a.BUF * sizeof(uint64_t);
+    if (a.in_is_keys) {
+        if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_select<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(k_select<1>, grid, dim3(64), shm, st, a);
+    } else {
+        if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_select<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(k_select<0>, grid, dim3(64), shm, st, a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Probe set-up: decode the top-nprobe coarse keys of each query into list numbers and coarse
+// scores (dis0), and lay the query's probed lists end to end in its row of the score buffer:
+// seg_start[q][j] = first column of list j's scores, seg_start[q][nprobe] = row length.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_probe_setup(const uint64_t* keys, int KPp, int64_t nq, int nprobe,
+                                                    const int64_t* list_len, int pad_to, int32_t* probe_list,
+                                                    float* dis0, int64_t* seg_start) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t ps_buf[];
+    int64_t* lens = (int64_t*)ps_buf;
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    for (int j = lane; j < nprobe; j += 64) {
+        uint64_t key = keys[q * KPp + j];
+        int32_t l = key ? (int32_t)key_idx(key) : -1;
+        probe_list[q * nprobe + j] = l;
+        dis0[q * nprobe + j] = key ? key_score(key) : -__builtin_inff();
+        int64_t len = (l >= 0) ? list_len[l] : 0;
+        lens[j] = (len + pad_to - 1) / pad_to * pad_to;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int64_t off = 0;
+        int64_t* ss = seg_start + q * (nprobe + 1);
+        for (int j = 0; j < nprobe; j++) { ss[j] = off; off += lens[j]; }
+        ss[nprobe] = off;
+    }
+}
+
+void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
+                        int pad_to, int32_t* probe_list, float* probe_dis0, int64_t* seg_start, hipStream_t st) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_probe_setup, dim3((unsigned)nq), dim3(64), (size_t)nprobe * 8, st, probe_keys, KPp, nq,
+                       nprobe, list_len, pad_to, probe_list, probe_dis0, seg_start);
+}
+
+// ---------------------------------------------------------------------------------------
+// Group the (query, probe) pairs by inverted list so that a list's vectors are streamed from
+// HBM once for all the queries of the batch that probe it (list-major scheduling).
+// ---------------------------------------------------------------------------------------
+__global__ void k_zero_i32(int32_t* p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+__global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int32_t* cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npairs) { int32_t l = probe_list[i]; if (l >= 0) atomicAdd(&cnt[l], 1); }
+}
+// single workgroup exclusive scan over lists: pair_off (pairs) and group_off (groups of 16)
+__global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlist, int32_t* pair_off,
+                                                    int32_t* group_off, int32_t* total_groups) {
+    __shared__ int32_t sp[1024], sg[1024];
+    int t = threadIdx.x;
+    int per = (nlist + 1023) / 1024;
+    int lo = t * per, hi = lo + per;
+    if (hi > nlist) hi = nlist;
+    int32_t ap = 0, ag = 0;
+    for (int l = lo; l < hi; l++) { ap += cnt[l]; ag += (cnt[l] + 15) / 16; }
+    sp[t] = ap; sg[t] = ag;
+    __syncthreads();
+    if (t == 0) {
+        int32_t rp = 0, rg = 0;
+        for (int i = 0; i < 1024; i++) { int32_t x = sp[i], y = sg[i]; sp[i] = rp; sg[i] = rg; rp += x; rg += y; }
+        pair_off[nlist] = rp; group_off[nlist] = rg; *total_groups = rg;
+    }
+    __syncthreads();
+    ap = sp[t]; ag = sg[t];
+    for (int l = lo; l < hi; l++) {
+        pair_off[l] = ap; group_off[l] = ag;
+        ap += cnt[l]; ag += (cnt[l] + 15) / 16;
+    }
+}
+__global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, const int32_t* pair_off,
+                               int32_t* cursor, int32_t* pairs_sorted) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npairs) {
+        int32_t l = probe_list[i];
+        if (l >= 0) { int s = atomicAdd(&cursor[l], 1); pairs_sorted[pair_off[l] + s] = (int32_t)i; }
+    }
+}
+void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int32_t* cnt, int32_t* cursor,
+                        int32_t* pair_off, int32_t* group_off, int32_t* total_groups, int32_t* pairs_sorted,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
+    hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
+    hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, cnt);
+    hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, pair_off, group_off, total_groups);
+    hipLaunchKernelGGL(k_pair_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs,
+                       pair_off, cursor, pairs_sorted);
+}
+
+// ---------------------------------------------------------------------------------------
+// Finalize: one wave per query.  Resolve each surviving candidate to its storage row and id,
+// re-score Flat / IVF-Flat candidates EXACTLY (fp64 accumulation of exact products, rounded
+// once to fp32 — the oracle's canonical arithmetic), sort by (score desc, id asc) and emit k.
+// IVF-PQ scores are already canonical fp32 (sequential LUT sum) and are only re-ordered.
+// ---------------------------------------------------------------------------------------
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t fin_buf[];
+    const int KP = a.KP;
+    int64_t* sid = (int64_t*)fin_buf;
+    int64_t* srow = sid + KP;
+    uint32_t* sord = (uint32_t*)(srow + KP);
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+
+    for (int c = lane; c < KP; c += 64) {
+        uint64_t key = a.state[q * KP + c];
+        int64_t row = -1, id = INT64_MAX;
+        uint32_t ord = 0;
+        if (key) {
+            uint32_t idx = key_idx(key);
+            if (a.kind == KIND_FLAT) {
+                row = idx;
+            } else {
+                const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+                int lo = 0, hi = a.nprobe;  // find j with ss[j] <= idx < ss[j+1]
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
+                int32_t l = a.probe_list[q * a.nprobe + lo];
+                row = a.list_base[l] + ((int64_t)idx - ss[lo]);
+            }
+            id = a.ids ? a.ids[row] : row;
+            ord = (uint32_t)(key >> 32);
+        }
+        sid[c] = id; srow[c] = row; sord[c] = ord;
+    }
+    __syncthreads();
+
+    if (a.kind != KIND_IVFPQ) {
+        const float* qv = a.Q32 + q * a.ldq;
+        for (int c = 0; c < KP; c++) {
+            int64_t row = srow[c];
+            if (row < 0) continue;  // uniform (LDS value)
+            double acc = 0.0;
+            if (a.x_f16) {
+                const __half* xv = (const __half*)a.X + row * a.ld;
+                for (int t = lane; t < a.d; t += 64) {
+                    double qd = (double)qv[t], xd = (double)__half2float(xv[t]);
+                    if (a.metric == 0) acc += qd * xd; else { double df = qd - xd; acc += df * df; }
+                }
+            } else {
+                const float* xv = (const float*)a.X + row * a.ld;
+                for (int t = lane; t < a.d; t += 64) {
+                    double qd = (double)qv[t], xd = (double)xv[t];
+                    if (a.metric == 0) acc += qd * xd; else { double df = qd - xd; acc += df * df; }
+                }
+            }
+            acc = wave_sum_f64(acc);
+            if (lane == 0) {
+                float s = (float)acc;
+                sord[c] = f2ord((a.metric == 0 ? s : 0.0f - s) + 0.0f);
+            }
+        }
+        __syncthreads();
+    }
+
+    // bitonic sort by (ord desc, id asc); invalid entries (ord 0, id INT64_MAX) sink to the end
+    for (int size = 2; size <= KP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (KP >> 1); t += 64) {
+                int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                int j = i + stride;
+                bool desc = ((i & size) == 0);
+                uint32_t oi = sord[i], oj = sord[j];
+                int64_t ii = sid[i], ij = sid[j];
+                bool i_worse = (oi < oj) || (oi == oj && ii > ij);
+                if (i_worse == desc) {
+                    sord[i] = oj; sord[j] = oi; sid[i] = ij; sid[j] = ii;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = lane; j < a.k; j += 64) {
+        bool valid = (j < KP) && sord[j] != 0 && sid[j] != INT64_MAX;
+        float s = valid ? ord2f(sord[j]) : -__builtin_inff();
+        if (a.metric != 0) s = valid ? (0.0f - s) : __builtin_inff();
+        a.D[q * a.k + j] = s;
+        a.I[q * a.k + j] = valid ? sid[j] : -1;
+    }
+}
+
+void launch_finalize(const FinalizeArgs& a, hipStream_t st) {
+    if (a.nq <= 0) return;
+    size_t shm = (size_t)a.KP * (8 + 8 + 4);
+    if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)a.nq), dim3(64), shm, st, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// Multi-shard merge (src/search.py:362-367): concatenate the shards' top-k in shard order and
+// stable-sort by score; ties keep the earlier shard, then the within-shard order.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D,
+                                                   const int64_t* I, float* Do, int64_t* Io, int NP) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t mg_buf[];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int n = nshards * k;
+    for (int p = lane; p < NP; p += 64) {
+        uint64_t key = 0;
+        if (p < n) {
+            int sh = p / k, j = p % k;
+            int64_t src = ((int64_t)sh * nq + q) * k + j;
+            if (I[src] >= 0) {
+                float s = D[src];
+                s = (metric == 0 ? s : 0.0f - s) + 0.0f;
+                if (s == s) key = ((uint64_t)f2ord(s) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)p);
+            }
+        }
+        mg_buf[p] = key;
+    }
+    __syncthreads();
+    bitonic_sort_desc(mg_buf, NP, lane);
+    for (int j = lane; j < k; j += 64) {
+        uint64_t key = mg_buf[j];
+        if (key) {
+            int p = (int)key_idx(key);
+            int sh = p / k, jj = p % k;
+            int64_t src = ((int64_t)sh * nq + q) * k + jj;
+            Do[q * k + j] = D[src];
+            Io[q * k + j] = I[src];
+        } else {
+            Do[q * k + j] = metric == 0 ? -__builtin_inff() : __builtin_inff();
+            Io[q * k + j] = -1;
+        }
+    }
+}
+
+void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do,
+                       int64_t* Io, hipStream_t st) {
+    if (nq <= 0) return;
+    int NP = 64;
+    while (NP < nshards * k) NP <<= 1;
+    size_t shm = (size_t)NP * 8;
+    if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)nq), dim3(64), shm, st, nshards, nq, k, metric, D, I, Do, Io, NP);
+}
+
+}  // namespace rsx

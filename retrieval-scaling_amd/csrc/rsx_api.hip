@@ -1,0 +1,1283 @@
+// rsx_api.hip — C-ABI implementation (include/rsx.h): index objects, HBM layout management,
+// add / train / search drivers, persistence.  Host control plane only; all search arithmetic
+// is in the k_*.hip kernels.  There is no CPU search path: every entry point needs a GPU.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rsx.h"
+#include "rsx_internal.h"
+
+using namespace rsx;
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+struct RsxError : std::runtime_error {
+    int code;
+    RsxError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+#define RSX_THROW(code, ...)                                  \
+    do {                                                      \
+        char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__);  \
+        throw RsxError(code, _b);                             \
+    } while (0)
+#define HIPCHECK(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            int code = (_e == hipErrorOutOfMemory) ? RSX_ERR_OOM : RSX_ERR_HIP;                     \
+            RSX_THROW(code, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                           \
+    } while (0)
+
+template <typename F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return RSX_OK;
+    } catch (const RsxError& e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_err = "host allocation failed";
+        return RSX_ERR_OOM;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return RSX_ERR_INVALID;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// device buffers
+// ---------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        release();
+        size_t want = n + n / 8;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            HIPCHECK(hipMalloc(&p, n));
+            want = n;
+        }
+        bytes = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+static bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// ---------------------------------------------------------------------------------------
+// deterministic host RNG shared with the training spec (splitmix64 Fisher-Yates)
+// ---------------------------------------------------------------------------------------
+static inline uint64_t splitmix(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static void rand_perm(int64_t n, uint64_t seed, std::vector<int64_t>& perm) {
+    perm.resize((size_t)n);
+    uint64_t s = seed;
+    for (int64_t i = 0; i < n; i++) perm[(size_t)i] = i;
+    for (int64_t i = 0; i + 1 < n; i++) {
+        int64_t j = i + (int64_t)(splitmix(s) % (uint64_t)(n - i));
+        std::swap(perm[(size_t)i], perm[(size_t)j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// the index object
+// ---------------------------------------------------------------------------------------
+struct rsx_index {
+    int kind = 0, d = 0, metric = 0, device = 0;
+    int nlist = 1, M = 0, nbits = 8, Mpad = 0, CB = 16, dsub = 0;
+    int nprobe = 1;
+    bool trained = false;
+    int64_t ntotal = 0;
+    hipStream_t st = nullptr;
+
+    // trained parameters
+    std::vector<float> h_centroids, h_codebooks;
+    DevBuf d_centroids, d_codebooks;
+
+    // storage.  PQ: slab layout bytes.  Flat/IVFFlat: rows of ld elements (fp16 or fp32).
+    int ld = 0;               // row stride (elements) of flat rows: d rounded up to 64
+    int storage_f16 = 1;
+    bool storage_decided = false;
+    bool custom_ids = false;  // Flat: ids array only when the caller supplied ids
+    DevBuf data, ids, norms;
+    std::vector<int64_t> h_base, h_len, h_cap;
+    DevBuf d_base, d_len;
+    int64_t total_cap = 0;
+
+    // knobs
+    int query_batch = 1024;
+    int scan_chunk = 0;
+    int profile = 0;
+    int64_t temp_budget = (int64_t)6 << 30;
+
+    // workspace
+    DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_state,
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc;
+    std::map<std::string, double> timing;
+
+    int row_align() const { return kind == KIND_IVFPQ ? 64 : (kind == KIND_FLAT ? 128 : 64); }
+    size_t row_bytes() const { return kind == KIND_IVFPQ ? (size_t)Mpad : (size_t)ld * (storage_f16 ? 2 : 4); }
+};
+
+static void use_device(rsx_index* h) { HIPCHECK(hipSetDevice(h->device)); }
+
+static void upload_dir(rsx_index* h) {
+    size_t nb = (size_t)h->nlist * sizeof(int64_t);
+    h->d_base.ensure(nb);
+    h->d_len.ensure(nb);
+    HIPCHECK(hipMemcpyAsync(h->d_base.p, h->h_base.data(), nb, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(hipMemcpyAsync(h->d_len.p, h->h_len.data(), nb, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+}
+
+// Make every list able to hold need[l] rows; re-lays-out HBM when a list overflows.
+static void ensure_capacity(rsx_index* h, const std::vector<int64_t>& need, bool exact) {
+    const int al = h->row_align();
+    bool grow = false;
+    for (int l = 0; l < h->nlist; l++)
+        if (need[(size_t)l] > h->h_cap[(size_t)l]) { grow = true; break; }
+    bool need_ids = (h->kind != KIND_FLAT) || h->custom_ids;
+    bool need_norms = (h->metric == RSX_METRIC_L2) && h->kind != KIND_IVFPQ;
+    if (!grow && h->data.p && (!need_ids || h->ids.p) && (!need_norms || h->norms.p)) return;
+
+    std::vector<int64_t> ncap(h->h_cap), nbase((size_t)h->nlist);
+    for (int l = 0; l < h->nlist; l++) {
+        int64_t nd = need[(size_t)l];
+        if (nd > ncap[(size_t)l]) ncap[(size_t)l] = round_up(exact ? nd : nd + nd / 2, al);
+        if (ncap[(size_t)l] == 0 && h->kind == KIND_FLAT) ncap[(size_t)l] = al;
+    }
+    int64_t tot = 0;
+    for (int l = 0; l < h->nlist; l++) { nbase[(size_t)l] = tot; tot += ncap[(size_t)l]; }
+    if (tot >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "more than 2^32 storage rows on one device");
+    size_t rb = h->row_bytes();
+    void* ndata = nullptr; void* nids = nullptr; void* nnorms = nullptr;
+    size_t dbytes = (size_t)std::max<int64_t>(tot, al) * rb;
+    HIPCHECK(hipMalloc(&ndata, dbytes));
+    HIPCHECK(hipMemsetAsync(ndata, 0, dbytes, h->st));
+    if (need_ids) { HIPCHECK(hipMalloc(&nids, (size_t)std::max<int64_t>(tot, 1) * 8)); }
+    if (need_norms) {
+        HIPCHECK(hipMalloc(&nnorms, (size_t)std::max<int64_t>(tot, 1) * 4));
+        HIPCHECK(hipMemsetAsync(nnorms, 0, (size_t)std::max<int64_t>(tot, 1) * 4, h->st));
+    }
+    if (h->data.p && h->ntotal > 0) {
+        DevBuf ob, nb2;
+        size_t nb = (size_t)h->nlist * 8;
+        ob.ensure(nb); nb2.ensure(nb);
+        HIPCHECK(hipMemcpyAsync(ob.p, h->h_base.data(), nb, hipMemcpyHostToDevice, h->st));
+        HIPCHECK(hipMemcpyAsync(nb2.p, nbase.data(), nb, hipMemcpyHostToDevice, h->st));
+        h->d_len.ensure(nb);
+        HIPCHECK(hipMemcpyAsync(h->d_len.p, h->h_len.data(), nb, hipMemcpyHostToDevice, h->st));
+        int64_t unit_rows = (h->kind == KIND_IVFPQ) ? 64 : 1;
+        int64_t unit_bytes = (int64_t)rb * unit_rows;
+        launch_copy_lists(h->nlist, ob.as<int64_t>(), nb2.as<int64_t>(), h->d_len.as<int64_t>(), h->data.as<uint8_t>(),
+                          (uint8_t*)ndata, unit_rows, unit_bytes, (need_ids && h->ids.p) ? h->ids.as<int64_t>() : nullptr,
+                          (int64_t*)nids, (need_norms && h->norms.p) ? h->norms.as<float>() : nullptr, (float*)nnorms,
+                          h->st);
+        HIPCHECK(hipStreamSynchronize(h->st));
+    }
+    h->data.release(); h->data.p = ndata; h->data.bytes = dbytes;
+    if (need_ids) { h->ids.release(); h->ids.p = nids; h->ids.bytes = (size_t)std::max<int64_t>(tot, 1) * 8; }
+    if (need_norms) { h->norms.release(); h->norms.p = nnorms; h->norms.bytes = (size_t)std::max<int64_t>(tot, 1) * 4; }
+    h->h_cap = ncap; h->h_base = nbase; h->total_cap = tot;
+    upload_dir(h);
+}
+
+// Flat / IVF-Flat keep fp16 rows while every value ever added is fp16-representable, else fp32.
+static void upgrade_storage_to_f32(rsx_index* h) {
+    if (!h->storage_f16) return;
+    if (h->data.p && h->total_cap > 0) {
+        void* nd = nullptr;
+        size_t nbytes = (size_t)std::max<int64_t>(h->total_cap, h->row_align()) * h->ld * 4;
+        HIPCHECK(hipMalloc(&nd, nbytes));
+        launch_widen_storage(h->data.as<__half>(), (float*)nd, (int64_t)std::max<int64_t>(h->total_cap, h->row_align()) * h->ld, h->st);
+        HIPCHECK(hipStreamSynchronize(h->st));
+        h->data.release(); h->data.p = nd; h->data.bytes = nbytes;
+    }
+    h->storage_f16 = 0;
+}
+
+// Stage `n` rows of caller data on the device; returns the device pointer (caller's own if it
+// already lives in HBM).
+static const void* stage_rows(rsx_index* h, DevBuf& buf, const void* x, int64_t n, int d, int dtype) {
+    size_t bytes = (size_t)n * d * (dtype == RSX_F16 ? 2 : 4);
+    if (is_device_ptr(x)) return x;
+    buf.ensure(bytes);
+    HIPCHECK(hipMemcpyAsync(buf.p, x, bytes, hipMemcpyHostToDevice, h->st));
+    return buf.p;
+}
+
+static void set_centroids(rsx_index* h, const float* c) {
+    size_t n = (size_t)h->nlist * h->d;
+    h->h_centroids.assign(c, c + n);
+    h->d_centroids.ensure(n * 4);
+    HIPCHECK(hipMemcpyAsync(h->d_centroids.p, h->h_centroids.data(), n * 4, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+}
+static void set_codebooks(rsx_index* h, const float* c) {
+    size_t n = (size_t)h->M * 256 * h->dsub;
+    h->h_codebooks.assign(c, c + n);
+    h->d_codebooks.ensure(n * 4);
+    HIPCHECK(hipMemcpyAsync(h->d_codebooks.p, h->h_codebooks.data(), n * 4, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+}
+static void update_trained(rsx_index* h) {
+    if (h->kind == KIND_FLAT) h->trained = true;
+    else if (h->kind == KIND_IVFFLAT) h->trained = !h->h_centroids.empty();
+    else h->trained = !h->h_centroids.empty() && !h->h_codebooks.empty();
+}
+
+// ---------------------------------------------------------------------------------------
+// creation
+// ---------------------------------------------------------------------------------------
+static rsx_index* create_common(int kind, int d, int nlist, int M, int nbits, int metric, int device) {
+    if (d <= 0) RSX_THROW(RSX_ERR_INVALID, "d must be positive (got %d)", d);
+    if (metric != RSX_METRIC_INNER_PRODUCT && metric != RSX_METRIC_L2) RSX_THROW(RSX_ERR_INVALID, "unknown metric %d", metric);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        RSX_THROW(RSX_ERR_HIP, "no HIP device available: librsx has no CPU path");
+    }
+    if (device < 0 || device >= ndev) RSX_THROW(RSX_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    std::unique_ptr<rsx_index> h(new rsx_index());
+    h->kind = kind; h->d = d; h->metric = metric; h->device = device;
+    h->nlist = (kind == KIND_FLAT) ? 1 : nlist;
+    if (kind != KIND_FLAT && nlist <= 0) RSX_THROW(RSX_ERR_INVALID, "nlist must be positive (got %d)", nlist);
+    h->ld = (int)round_up(d, 64);
+    if (kind == KIND_IVFPQ) {
+        if (nbits != 8) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: only nbits = 8 is implemented (got %d)", nbits);
+        if (M <= 0 || d % M != 0) RSX_THROW(RSX_ERR_INVALID, "IVFPQ: d (%d) must be a multiple of M (%d)", d, M);
+        if (metric != RSX_METRIC_INNER_PRODUCT)
+            RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: only METRIC_INNER_PRODUCT is implemented (the reference builds every index with it)");
+        h->M = M; h->nbits = nbits; h->dsub = d / M;
+        h->Mpad = (int)round_up(M, 4);
+        h->CB = (h->Mpad % 16 == 0) ? 16 : 4;
+        if (h->CB == 16) {
+            int nch = h->Mpad / 16;
+            if (!(nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8)) h->CB = 4;
+        }
+        if ((size_t)h->Mpad * 1024 > 160 * 1024) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: M = %d needs more than 160 KiB of LDS for the look-up table", M);
+    }
+    HIPCHECK(hipSetDevice(device));
+    HIPCHECK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+    h->h_base.assign((size_t)h->nlist, 0);
+    h->h_len.assign((size_t)h->nlist, 0);
+    h->h_cap.assign((size_t)h->nlist, 0);
+    update_trained(h.get());
+    return h.release();
+}
+
+// ---------------------------------------------------------------------------------------
+// add
+// ---------------------------------------------------------------------------------------
+static void decide_storage(rsx_index* h, const void* dx, int64_t n, int dtype) {
+    if (h->kind == KIND_IVFPQ) return;
+    if (dtype == RSX_F16) { h->storage_decided = true; return; }
+    if (h->storage_decided && !h->storage_f16) return;
+    h->w_flag.ensure(sizeof(int));
+    HIPCHECK(hipMemsetAsync(h->w_flag.p, 0, sizeof(int), h->st));
+    launch_check_f16((const float*)dx, n * h->d, h->w_flag.as<int>(), h->st);
+    int flag = 0;
+    HIPCHECK(hipMemcpyAsync(&flag, h->w_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+    if (flag) upgrade_storage_to_f32(h);
+    h->storage_decided = true;
+}
+
+static void add_batch(rsx_index* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
+    const void* dx = stage_rows(h, h->w_x, x, n, h->d, dtype);
+    const int64_t* dids = nullptr;
+    if (ids) {
+        if (is_device_ptr(ids)) dids = ids;
+        else {
+            h->w_idsin.ensure((size_t)n * 8);
+            HIPCHECK(hipMemcpyAsync(h->w_idsin.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+            dids = h->w_idsin.as<int64_t>();
+        }
+    }
+    decide_storage(h, dx, n, dtype);
+
+    if (h->kind == KIND_FLAT) {
+        if (ids && !h->custom_ids) {
+            if (h->ntotal > 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "Flat: cannot switch to explicit ids after sequential adds");
+            h->custom_ids = true;
+        } else if (!ids && h->custom_ids) {
+            RSX_THROW(RSX_ERR_INVALID, "Flat: index was populated with explicit ids; ids required");
+        }
+        std::vector<int64_t> need(1, h->ntotal + n);
+        ensure_capacity(h, need, false);
+        size_t esz = h->storage_f16 ? 2 : 4;
+        launch_scatter_rows(dx, dtype == RSX_F16, n, h->d, nullptr, h->data.as<uint8_t>() + (size_t)h->ntotal * h->ld * esz,
+                            h->storage_f16, h->ld, h->norms.p ? h->norms.as<float>() + h->ntotal : nullptr, dids, 0,
+                            h->custom_ids ? h->ids.as<int64_t>() + h->ntotal : nullptr, h->st);
+        h->h_len[0] = h->ntotal + n;
+        h->ntotal += n;
+        upload_dir(h);
+        return;
+    }
+
+    // IVF: assignment on the matrix cores (exact fp32 chain), placement on the host
+    int ct = (h->nlist + 127) / 128;
+    h->w_partial.ensure((size_t)n * 2 * ct * 8);
+    h->w_assign.ensure((size_t)n * 4);
+    launch_gemm_exact_argmax(dx, dtype == RSX_F16, n, h->d, h->d_centroids.as<float>(), h->nlist, h->d,
+                             h->w_partial.as<uint64_t>(), h->w_assign.as<int32_t>(), nullptr, h->st);
+    std::vector<int32_t> assign((size_t)n);
+    HIPCHECK(hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+
+    std::vector<int64_t> need(h->h_len);
+    std::vector<int64_t> pos((size_t)n);
+    for (int64_t i = 0; i < n; i++) pos[(size_t)i] = need[(size_t)assign[(size_t)i]]++;  // insertion order inside a list
+    ensure_capacity(h, need, false);
+    for (int64_t i = 0; i < n; i++) pos[(size_t)i] += h->h_base[(size_t)assign[(size_t)i]];
+    h->w_dest.ensure((size_t)n * 8);
+    HIPCHECK(hipMemcpyAsync(h->w_dest.p, pos.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+
+    if (h->kind == KIND_IVFPQ) {
+        launch_pq_encode(dx, dtype == RSX_F16, n, h->d, h->d, h->M, h->Mpad, h->CB, h->d_centroids.as<float>(),
+                         h->w_assign.as<int32_t>(), h->d_codebooks.as<float>(), h->w_dest.as<int64_t>(),
+                         h->data.as<uint8_t>(), nullptr, h->st);
+        launch_write_ids(h->w_dest.as<int64_t>(), dids, h->ntotal, n, h->ids.as<int64_t>(), h->st);
+    } else {
+        launch_scatter_rows(dx, dtype == RSX_F16, n, h->d, h->w_dest.as<int64_t>(), h->data.p, h->storage_f16, h->ld,
+                            h->norms.p ? h->norms.as<float>() : nullptr, dids, h->ntotal, h->ids.as<int64_t>(), h->st);
+    }
+    HIPCHECK(hipStreamSynchronize(h->st));  // pos / staging buffers are reused by the next batch
+    h->h_len = need;
+    h->ntotal += n;
+    upload_dir(h);
+}
+
+static void add_all(rsx_index* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
+    const int64_t B = 262144;  // rows per internal batch
+    size_t esz = dtype == RSX_F16 ? 2 : 4;
+    for (int64_t i0 = 0; i0 < n; i0 += B) {
+        int64_t nb = std::min(B, n - i0);
+        add_batch(h, nb, (const char*)x + (size_t)i0 * h->d * esz, dtype, ids ? ids + i0 : nullptr);
+    }
+    HIPCHECK(hipStreamSynchronize(h->st));
+}
+
+// ---------------------------------------------------------------------------------------
+// training (faiss::Clustering / ProductQuantizer::train restated; assignment on the GPU,
+// centroid update on the host in point order so that training is deterministic)
+// ---------------------------------------------------------------------------------------
+static void renorm_rows(int d, int k, float* c) {
+    for (int i = 0; i < k; i++) {
+        float nr = 0.0f;
+        float* r = c + (size_t)i * d;
+        for (int t = 0; t < d; t++) nr = fmaf(r[t], r[t], nr);
+        if (nr > 0.0f) {
+            float inv = 1.0f / sqrtf(nr);
+            for (int t = 0; t < d; t++) r[t] *= inv;
+        }
+    }
+}
+
+// one Lloyd update given assignments; x rows are [n, ldx] with the sub-vector at column offset `col`
+static void kmeans_update(int d, int k, int64_t n, const float* x, int ldx, int col, const int32_t* assign, int astride,
+                          float* cen) {
+    std::vector<int64_t> hassign((size_t)k, 0);
+    std::fill(cen, cen + (size_t)k * d, 0.0f);
+    for (int64_t i = 0; i < n; i++) {
+        int c = assign[(size_t)i * astride];
+        hassign[(size_t)c]++;
+        float* cc = cen + (size_t)c * d;
+        const float* xi = x + (size_t)i * ldx + col;
+        for (int t = 0; t < d; t++) cc[t] += xi[t];
+    }
+    for (int j = 0; j < k; j++) {
+        if (hassign[(size_t)j] == 0) continue;
+        float norm = 1.0f / (float)hassign[(size_t)j];
+        float* cc = cen + (size_t)j * d;
+        for (int t = 0; t < d; t++) cc[t] *= norm;
+    }
+    uint64_t rs = 1234;
+    for (int ci = 0; ci < k; ci++) {
+        if (hassign[(size_t)ci] != 0) continue;
+        int cj = 0;
+        for (;;) {
+            double p = ((double)hassign[(size_t)cj] - 1.0) / (double)(n - k);
+            double r = (double)(splitmix(rs) >> 11) * (1.0 / 9007199254740992.0);
+            if (r < p) break;
+            cj = (cj + 1) % k;
+        }
+        float* a = cen + (size_t)ci * d; float* b = cen + (size_t)cj * d;
+        memcpy(a, b, sizeof(float) * (size_t)d);
+        for (int t = 0; t < d; t++) {
+            if (t % 2 == 0) { a[t] *= 1.0f + 1.0f / 1024.0f; b[t] *= 1.0f - 1.0f / 1024.0f; }
+            else { a[t] *= 1.0f - 1.0f / 1024.0f; b[t] *= 1.0f + 1.0f / 1024.0f; }
+        }
+        hassign[(size_t)ci] = hassign[(size_t)cj] / 2;
+        hassign[(size_t)cj] -= hassign[(size_t)ci];
+    }
+}
+
+static void train_impl(rsx_index* h, int64_t n, const void* x, int dtype) {
+    if (h->kind == KIND_FLAT) return;
+    if (n < h->nlist) RSX_THROW(RSX_ERR_INVALID, "train: %lld training points for %d centroids", (long long)n, h->nlist);
+    const int d = h->d;
+    // training set as fp32 on the host (the reference passes host numpy: ivf_flat.py:135)
+    std::vector<float> hx((size_t)n * d);
+    {
+        const void* dx = stage_rows(h, h->w_x, x, n, d, dtype);
+        DevBuf t32; t32.ensure((size_t)n * d * 4);
+        launch_convert_to_f32(dx, dtype == RSX_F16, d, n, d, t32.as<float>(), d, h->st);
+        HIPCHECK(hipMemcpyAsync(hx.data(), t32.p, (size_t)n * d * 4, hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));
+    }
+    const uint64_t seed = 1234;
+    // ---- coarse quantiser: k-means, IP assignment, spherical centroids, niter 10, <=256 pts/centroid
+    {
+        const int k = h->nlist;
+        int64_t keep = (int64_t)k * 256;
+        std::vector<float> xs;
+        const float* xt = hx.data();
+        int64_t nt = n;
+        if (n > keep) {
+            std::vector<int64_t> perm; rand_perm(n, seed, perm);
+            xs.resize((size_t)keep * d);
+            for (int64_t i = 0; i < keep; i++) memcpy(&xs[(size_t)i * d], &hx[(size_t)perm[(size_t)i] * d], sizeof(float) * (size_t)d);
+            xt = xs.data(); nt = keep;
+        }
+        std::vector<float> cen((size_t)k * d);
+        std::vector<int64_t> perm; rand_perm(nt, seed + 1, perm);
+        for (int j = 0; j < k; j++) memcpy(&cen[(size_t)j * d], xt + (size_t)perm[(size_t)(j % nt)] * d, sizeof(float) * (size_t)d);
+        renorm_rows(d, k, cen.data());
+        DevBuf dxt; dxt.ensure((size_t)nt * d * 4);
+        HIPCHECK(hipMemcpyAsync(dxt.p, xt, (size_t)nt * d * 4, hipMemcpyHostToDevice, h->st));
+        DevBuf dcen; dcen.ensure((size_t)k * d * 4);
+        int ct = (k + 127) / 128;
+        h->w_partial.ensure((size_t)nt * 2 * ct * 8);
+        h->w_assign.ensure((size_t)nt * 4);
+        std::vector<int32_t> assign((size_t)nt);
+        for (int it = 0; it < 10; it++) {
+            HIPCHECK(hipMemcpyAsync(dcen.p, cen.data(), (size_t)k * d * 4, hipMemcpyHostToDevice, h->st));
+            launch_gemm_exact_argmax(dxt.p, 0, nt, d, dcen.as<float>(), k, d, h->w_partial.as<uint64_t>(),
+                                     h->w_assign.as<int32_t>(), nullptr, h->st);
+            HIPCHECK(hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)nt * 4, hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipStreamSynchronize(h->st));
+            kmeans_update(d, k, nt, xt, d, 0, assign.data(), 1, cen.data());
+            renorm_rows(d, k, cen.data());
+        }
+        set_centroids(h, cen.data());
+    }
+    // ---- PQ codebooks on residuals: <=65536 points, per-subspace L2 k-means, niter 25
+    if (h->kind == KIND_IVFPQ) {
+        const int M = h->M, dsub = h->dsub, Mpad = h->Mpad;
+        int64_t keep = 256 * 256;
+        std::vector<float> xs;
+        const float* xt = hx.data();
+        int64_t nt = n;
+        if (n > keep) {
+            std::vector<int64_t> perm; rand_perm(n, seed, perm);
+            xs.resize((size_t)keep * d);
+            for (int64_t i = 0; i < keep; i++) memcpy(&xs[(size_t)i * d], &hx[(size_t)perm[(size_t)i] * d], sizeof(float) * (size_t)d);
+            xt = xs.data(); nt = keep;
+        }
+        if (nt < 256) RSX_THROW(RSX_ERR_INVALID, "train: %lld points cannot train 256 PQ codewords", (long long)nt);
+        DevBuf dxt, dres;
+        dxt.ensure((size_t)nt * d * 4); dres.ensure((size_t)nt * d * 4);
+        HIPCHECK(hipMemcpyAsync(dxt.p, xt, (size_t)nt * d * 4, hipMemcpyHostToDevice, h->st));
+        int ct = (h->nlist + 127) / 128;
+        h->w_partial.ensure((size_t)nt * 2 * ct * 8);
+        h->w_assign.ensure((size_t)nt * 4);
+        launch_gemm_exact_argmax(dxt.p, 0, nt, d, h->d_centroids.as<float>(), h->nlist, d, h->w_partial.as<uint64_t>(),
+                                 h->w_assign.as<int32_t>(), nullptr, h->st);
+        launch_residuals(dxt.as<float>(), nt, d, h->d_centroids.as<float>(), h->w_assign.as<int32_t>(), dres.as<float>(), h->st);
+        std::vector<float> res((size_t)nt * d);
+        HIPCHECK(hipMemcpyAsync(res.data(), dres.p, (size_t)nt * d * 4, hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));
+
+        std::vector<float> cb((size_t)M * 256 * dsub);
+        for (int m = 0; m < M; m++) {
+            std::vector<int64_t> perm; rand_perm(nt, seed + (uint64_t)m + 1, perm);
+            for (int j = 0; j < 256; j++)
+                memcpy(&cb[((size_t)m * 256 + j) * dsub], &res[(size_t)perm[(size_t)(j % nt)] * d + (size_t)m * dsub], sizeof(float) * (size_t)dsub);
+        }
+        DevBuf dcb, dcodes;
+        dcb.ensure(cb.size() * 4); dcodes.ensure((size_t)nt * Mpad);
+        std::vector<uint8_t> codes((size_t)nt * Mpad);
+        std::vector<int32_t> a32((size_t)nt);
+        for (int it = 0; it < 25; it++) {
+            HIPCHECK(hipMemcpyAsync(dcb.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, h->st));
+            launch_pq_encode(dres.p, 0, nt, d, d, M, Mpad, h->CB, nullptr, nullptr, dcb.as<float>(), nullptr, nullptr,
+                             dcodes.as<uint8_t>(), h->st);
+            HIPCHECK(hipMemcpyAsync(codes.data(), dcodes.p, codes.size(), hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipStreamSynchronize(h->st));
+            for (int m = 0; m < M; m++) {
+                for (int64_t i = 0; i < nt; i++) a32[(size_t)i] = codes[(size_t)i * Mpad + m];
+                kmeans_update(dsub, 256, nt, res.data(), d, m * dsub, a32.data(), 1, &cb[(size_t)m * 256 * dsub]);
+            }
+        }
+        set_codebooks(h, cb.data());
+    }
+    update_trained(h);
+}
+
+// ---------------------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------------------
+struct StageTimer {
+    rsx_index* h; bool on;
+    hipEvent_t ev[16]; const char* name[16]; int n = 0;
+    StageTimer(rsx_index* hh) : h(hh), on(hh->profile != 0) {}
+    void mark(const char* nm) {
+        if (!on || n >= 16) return;
+        (void)hipEventCreate(&ev[n]);
+        (void)hipEventRecord(ev[n], h->st);
+        name[n] = nm; n++;
+    }
+    void finish() {
+        if (!on || n == 0) return;
+        (void)hipEventSynchronize(ev[n - 1]);
+        for (int i = 1; i < n; i++) {
+            float ms = 0; (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+            h->timing[name[i]] += ms;
+        }
+        float tot = 0; (void)hipEventElapsedTime(&tot, ev[0], ev[n - 1]);
+        h->timing["total"] += tot;
+        for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]);
+        n = 0;
+    }
+};
+
+static void kp_for(const rsx_index* h, int k, int& KP, int& BUF) {
+    int want;
+    if (h->kind == KIND_IVFPQ) want = (k >= 512) ? k : k + 4;
+    else want = k + std::max(8, k / 16);
+    KP = std::max(16, pow2ceil(want));
+    BUF = std::max(2 * KP, 256);
+}
+
+// top-k of `nrows` rows of fp32 scores (row r valid length: row_n or n_uniform) into state [nrows, KP]
+static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, const int64_t* row_n, int64_t row_n_stride,
+                        int64_t n_max, uint32_t idx_base, int64_t nrows, int KP, int BUF, int k, uint64_t* state,
+                        bool merge_state) {
+    int64_t seg_len = std::max<int64_t>(4096, (int64_t)8 * BUF);
+    seg_len = round_up(seg_len, 256);
+    int nseg = (int)std::max<int64_t>(1, (n_max + seg_len - 1) / seg_len);
+    SelectArgs a{};
+    a.in = scores; a.in_is_keys = 0; a.row_stride = row_stride;
+    a.row_n = row_n; a.row_n_stride = row_n_stride; a.n_uniform = n_max;
+    a.seg_len = seg_len; a.nseg = nseg; a.idx_base = idx_base;
+    a.nrows = nrows; a.KP = KP; a.BUF = BUF; a.k = k;
+    if (nseg == 1) {
+        a.init = merge_state ? state : nullptr;
+        a.out = state; a.out_row_stride = KP;
+        launch_select(a, h->st);
+        return;
+    }
+    h->w_keys1.ensure((size_t)nrows * nseg * KP * 8);
+    a.init = nullptr; a.out = h->w_keys1.as<uint64_t>(); a.out_row_stride = (int64_t)nseg * KP;
+    launch_select(a, h->st);
+    SelectArgs b{};
+    b.in = h->w_keys1.p; b.in_is_keys = 1; b.row_stride = (int64_t)nseg * KP;
+    b.row_n = nullptr; b.n_uniform = (int64_t)nseg * KP;
+    b.seg_len = round_up((int64_t)nseg * KP, 256); b.nseg = 1; b.idx_base = 0;
+    b.init = merge_state ? state : nullptr;
+    b.out = state; b.out_row_stride = KP;
+    b.nrows = nrows; b.KP = KP; b.BUF = BUF; b.k = k;
+    launch_select(b, h->st);
+}
+
+static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI) {
+    StageTimer tm(h);
+    const int d = h->d, ld = h->ld;
+    int KP, BUF;
+    kp_for(h, k, KP, BUF);
+    tm.mark("start");
+    // queries: fp32 copy (exact re-rank, coarse quantiser, LUT) [nq, ld]; fp16 copy for the scans
+    h->w_q32.ensure((size_t)nq * ld * 4);
+    launch_convert_to_f32(dq, dtype == RSX_F16, d, nq, d, h->w_q32.as<float>(), ld, h->st);
+    int64_t nq_pad = round_up(nq, 128);
+    if (h->kind != KIND_IVFPQ) {
+        h->w_q16.ensure((size_t)nq_pad * ld * 2);
+        launch_convert_to_f16(dq, dtype == RSX_F16, nq, d, h->w_q16.as<__half>(), ld, nq_pad, nullptr, h->st);
+    }
+    h->w_state.ensure((size_t)nq * KP * 8);
+    uint64_t* state = h->w_state.as<uint64_t>();
+    tm.mark("convert");
+
+    FinalizeArgs fa{};
+    fa.kind = h->kind; fa.metric = h->metric; fa.state = state; fa.KP = KP; fa.k = k; fa.nq = nq;
+    fa.list_base = h->d_base.as<int64_t>();
+    fa.ids = (h->kind == KIND_FLAT && !h->custom_ids) ? nullptr : h->ids.as<int64_t>();
+    fa.Q32 = h->w_q32.as<float>(); fa.ldq = ld; fa.d = d;
+    fa.X = h->data.p; fa.x_f16 = h->storage_f16; fa.ld = ld;
+    fa.D = dD; fa.I = dI;
+
+    if (h->kind == KIND_FLAT) {
+        const float* bias = nullptr;
+        if (h->metric == RSX_METRIC_L2) {
+            // ranking score = <q,x> - |x|^2/2 ; bias buffer holds -|x|^2/2 (derived from norms)
+            h->w_misc.ensure((size_t)h->ntotal * 4);
+            bias = h->w_misc.as<float>();
+        }
+        const int64_t N = h->ntotal;
+        if (N == 0) {
+            launch_fill_u64(state, nq * KP, 0, h->st);
+        } else if (nq <= 32) {
+            // small batch: stream the database once per group of 16 queries (list-scan kernel)
+            int64_t tstride = round_up(N, 16);
+            h->w_temp.ensure((size_t)nq * tstride * 4);
+            ListScanArgs a{};
+            a.Q16 = h->w_q16.as<__half>(); a.ld = ld; a.X = h->data.p; a.x_f16 = h->storage_f16; a.bias = bias;
+            a.list_base = h->d_base.as<int64_t>(); a.list_len = h->d_len.as<int64_t>();
+            a.flat_mode = 1; a.flat_n = N; a.nq = (int)nq; a.nprobe = 1; a.nlist = 1;
+            a.temp = h->w_temp.as<float>(); a.tstride = tstride;
+            a.chunk_rows = 1024;
+            a.max_groups = (int)((nq + 15) / 16);
+            a.max_chunks = (int)((round_up(N, 16) + a.chunk_rows - 1) / a.chunk_rows);
+            if (a.max_chunks > 65535) { a.chunk_rows = (int)round_up((round_up(N, 16) + 65534) / 65535, 64); a.max_chunks = (int)((round_up(N, 16) + a.chunk_rows - 1) / a.chunk_rows); }
+            launch_list_scan(a, h->st);
+            tm.mark("scan");
+            select_rows(h, h->w_temp.as<float>(), tstride, nullptr, 0, N, 0, nq, KP, BUF, k, state, false);
+            tm.mark("select");
+        } else {
+            const int64_t CH = 65536;
+            h->w_temp.ensure((size_t)nq_pad * CH * 4);
+            launch_fill_u64(state, nq * KP, 0, h->st);
+            for (int64_t v0 = 0; v0 < N; v0 += CH) {
+                int64_t nv = std::min<int64_t>(CH, N - v0);
+                launch_flat_gemm(h->w_q16.as<__half>(), (int)nq_pad, h->data.p, h->storage_f16, v0, nv, ld, bias,
+                                 h->w_temp.as<float>(), CH, h->st);
+                select_rows(h, h->w_temp.as<float>(), CH, nullptr, 0, nv, (uint32_t)v0, nq, KP, BUF, k, state, true);
+            }
+            tm.mark("scan");
+        }
+        launch_finalize(fa, h->st);
+        tm.mark("finalize");
+        tm.finish();
+        return;
+    }
+
+    // ---------------- IVF ----------------
+    const int nlist = h->nlist;
+    const int nprobe = std::min(h->nprobe, nlist);
+    // 1. coarse quantiser (exact fp32) + top-nprobe
+    h->w_coarse.ensure((size_t)nq * nlist * 4);
+    launch_gemm_exact_scores(h->w_q32.p, 0, nq, ld, h->d_centroids.as<float>(), nlist, d, h->w_coarse.as<float>(), nlist, h->st);
+    tm.mark("coarse");
+    int KPp = std::max(16, pow2ceil(nprobe));
+    int BUFp = std::max(2 * KPp, 256);
+    h->w_probekeys.ensure((size_t)nq * KPp * 8);
+    {
+        // row stride nlist may not be a multiple of 4: select_rows needs 16-byte aligned rows
+        if (nlist % 4 != 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "nlist must be a multiple of 4 (got %d)", nlist);
+        select_rows(h, h->w_coarse.as<float>(), nlist, nullptr, 0, nlist, 0, nq, KPp, BUFp, nprobe, h->w_probekeys.as<uint64_t>(), false);
+    }
+    // 2. probe set-up
+    const int pad_to = (h->kind == KIND_IVFPQ) ? 64 : 16;
+    h->w_probelist.ensure((size_t)nq * nprobe * 4);
+    h->w_dis0.ensure((size_t)nq * nprobe * 4);
+    h->w_segstart.ensure((size_t)nq * (nprobe + 1) * 8);
+    launch_probe_setup(h->w_probekeys.as<uint64_t>(), KPp, nq, nprobe, h->d_len.as<int64_t>(), pad_to,
+                       h->w_probelist.as<int32_t>(), h->w_dis0.as<float>(), h->w_segstart.as<int64_t>(), h->st);
+    tm.mark("select_probe");
+    // host-side bound on a query's row of the score buffer: the nprobe longest (padded) lists
+    std::vector<int64_t> lens(h->h_len);
+    for (auto& v : lens) v = round_up(v, pad_to);
+    std::partial_sort(lens.begin(), lens.begin() + nprobe, lens.end(), std::greater<int64_t>());
+    int64_t tmax = 0, maxlen = lens[0];
+    for (int j = 0; j < nprobe; j++) tmax += lens[(size_t)j];
+    tmax = std::max<int64_t>(round_up(tmax, 256), 256);
+    if (tmax >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "probed lists exceed 2^32 vectors per query");
+    h->w_temp.ensure((size_t)nq * tmax * 4);
+
+    if (h->kind == KIND_IVFPQ) {
+        h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4);
+        launch_pq_lut(h->w_q32.as<float>(), ld, nq, d, h->M, h->Mpad, h->d_codebooks.as<float>(), h->w_lut.as<float>(), h->st);
+        tm.mark("lut");
+        PQScanArgs a{};
+        a.codes = h->data.as<uint8_t>(); a.M = h->M; a.Mpad = h->Mpad; a.CB = h->CB;
+        a.list_base = h->d_base.as<int64_t>(); a.list_len = h->d_len.as<int64_t>();
+        a.lut = h->w_lut.as<float>(); a.probe_list = h->w_probelist.as<int32_t>(); a.probe_dis0 = h->w_dis0.as<float>();
+        a.seg_start = h->w_segstart.as<int64_t>(); a.nq = nq; a.nprobe = nprobe;
+        a.temp = h->w_temp.as<float>(); a.tstride = tmax;
+        int64_t max_slabs = std::max<int64_t>(1, maxlen / 64);
+        int64_t spc;
+        if (h->scan_chunk > 0) spc = std::max<int64_t>(16, h->scan_chunk / 64);
+        else {
+            // enough work items to fill 256 CUs several times over, but no smaller than 32 slabs
+            int64_t pairs = nq * nprobe;
+            int64_t want_items = 4096;
+            int64_t chunks = std::max<int64_t>(1, (want_items + pairs - 1) / pairs);
+            spc = std::max<int64_t>(32, (max_slabs + chunks - 1) / chunks);
+        }
+        a.slabs_per_chunk = (int)spc;
+        a.max_chunks = (int)((max_slabs + spc - 1) / spc);
+        if (launch_pq_scan(a, h->st) != 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ scan: no kernel for M=%d", h->M);
+        h->timing["scan_launches"] += 1;
+        tm.mark("scan");
+    } else {
+        // group (query, probe) pairs by list, then list-major MFMA scan
+        int64_t npairs = nq * nprobe;
+        h->w_pairs.ensure((size_t)(npairs + 4 * (size_t)(nlist + 1) + 4) * 4);
+        int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
+        int32_t* cnt = pairs_sorted + npairs;
+        int32_t* cursor = cnt + (nlist + 1);
+        int32_t* pair_off = cursor + (nlist + 1);
+        int32_t* group_off = pair_off + (nlist + 1);
+        int32_t* total_groups = group_off + (nlist + 1);
+        launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, cnt, cursor, pair_off, group_off, total_groups,
+                           pairs_sorted, h->st);
+        tm.mark("group");
+        const float* bias = nullptr;
+        if (h->metric == RSX_METRIC_L2) { bias = h->w_misc.as<float>(); }
+        ListScanArgs a{};
+        a.Q16 = h->w_q16.as<__half>(); a.ld = ld; a.X = h->data.p; a.x_f16 = h->storage_f16; a.bias = bias;
+        a.list_base = h->d_base.as<int64_t>(); a.list_len = h->d_len.as<int64_t>();
+        a.pairs_sorted = pairs_sorted; a.pair_off = pair_off; a.group_off = group_off; a.total_groups = total_groups;
+        a.probe_list = h->w_probelist.as<int32_t>(); a.seg_start = h->w_segstart.as<int64_t>();
+        a.nlist = nlist; a.nprobe = nprobe; a.flat_mode = 0; a.nq = (int)nq;
+        a.temp = h->w_temp.as<float>(); a.tstride = tmax;
+        a.max_groups = (int)std::min<int64_t>(npairs, npairs / 16 + std::min<int64_t>(nlist, npairs));
+        int64_t chunk_rows = h->scan_chunk > 0 ? round_up(h->scan_chunk, 64) : 2048;
+        int64_t want = 2048;  // work items
+        while (chunk_rows > 256 && (int64_t)a.max_groups * ((maxlen + chunk_rows - 1) / chunk_rows) < want) chunk_rows /= 2;
+        a.chunk_rows = (int)chunk_rows;
+        a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
+        launch_list_scan(a, h->st);
+        tm.mark("scan");
+    }
+    // 3. per-query k-selection over the score rows
+    select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + nprobe, nprobe + 1, tmax, 0, nq, KP, BUF, k,
+                state, false);
+    tm.mark("select");
+    fa.probe_list = h->w_probelist.as<int32_t>(); fa.seg_start = h->w_segstart.as<int64_t>(); fa.nprobe = nprobe;
+    launch_finalize(fa, h->st);
+    tm.mark("finalize");
+    tm.finish();
+}
+
+// L2 ranking bias  -|x|^2/2  from the stored squared norms
+__global__ void k_bias_from_norms(const float* norms, float* bias, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bias[i] = -0.5f * norms[i];
+}
+
+static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
+    if (nq < 0 || k <= 0) RSX_THROW(RSX_ERR_INVALID, "search: nq=%lld k=%d", (long long)nq, k);
+    if (k > 2048) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: k = %d exceeds this build's maximum of 2048", k);
+    if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "search before train");
+    if (nq == 0) return;
+    if (!q || !D || !I) RSX_THROW(RSX_ERR_INVALID, "search: null pointer");
+    bool q_dev = is_device_ptr(q), o_dev = is_device_ptr(D);
+    if (o_dev != is_device_ptr(I)) RSX_THROW(RSX_ERR_INVALID, "search: D and I must both be host or both device pointers");
+    size_t esz = dtype == RSX_F16 ? 2 : 4;
+
+    if (h->ntotal == 0) {  // FAISS returns -1 / -inf for an empty index
+        std::vector<float> hd((size_t)nq * k, h->metric == 0 ? -INFINITY : INFINITY);
+        std::vector<int64_t> hi((size_t)nq * k, -1);
+        HIPCHECK(hipMemcpy(D, hd.data(), hd.size() * 4, o_dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+        HIPCHECK(hipMemcpy(I, hi.data(), hi.size() * 8, o_dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+        return;
+    }
+    if (h->metric == RSX_METRIC_L2 && h->kind != KIND_IVFPQ) {
+        int64_t rows = h->total_cap;
+        h->w_misc.ensure((size_t)rows * 4);
+        hipLaunchKernelGGL(k_bias_from_norms, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->st, h->norms.as<float>(),
+                           h->w_misc.as<float>(), rows);
+    }
+    // batch size: bounded by the knob and by the score-buffer budget
+    int64_t qb = std::max(1, h->query_batch);
+    if (h->kind != KIND_FLAT) {
+        const int nprobe = std::min(h->nprobe, h->nlist);
+        const int pad_to = (h->kind == KIND_IVFPQ) ? 64 : 16;
+        std::vector<int64_t> lens(h->h_len);
+        for (auto& v : lens) v = round_up(v, pad_to);
+        std::partial_sort(lens.begin(), lens.begin() + nprobe, lens.end(), std::greater<int64_t>());
+        int64_t tmax = 0;
+        for (int j = 0; j < nprobe; j++) tmax += lens[(size_t)j];
+        tmax = std::max<int64_t>(round_up(tmax, 256), 256);
+        qb = std::max<int64_t>(1, std::min<int64_t>(qb, h->temp_budget / (tmax * 4)));
+    } else if (nq <= 32) {
+        qb = 32;
+    }
+    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+        int64_t nb = std::min(qb, nq - q0);
+        const void* dq;
+        if (q_dev) dq = (const char*)q + (size_t)q0 * h->d * esz;
+        else {
+            h->w_qin.ensure((size_t)nb * h->d * esz);
+            HIPCHECK(hipMemcpyAsync(h->w_qin.p, (const char*)q + (size_t)q0 * h->d * esz, (size_t)nb * h->d * esz, hipMemcpyHostToDevice, h->st));
+            dq = h->w_qin.p;
+        }
+        float* dD; int64_t* dI;
+        if (o_dev) { dD = D + q0 * k; dI = I + q0 * k; }
+        else {
+            h->w_D.ensure((size_t)nb * k * 4); h->w_I.ensure((size_t)nb * k * 8);
+            dD = h->w_D.as<float>(); dI = h->w_I.as<int64_t>();
+        }
+        search_batch(h, nb, dq, dtype, k, dD, dI);
+        if (!o_dev) {
+            HIPCHECK(hipMemcpyAsync(D + q0 * k, dD, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipMemcpyAsync(I + q0 * k, dI, (size_t)nb * k * 8, hipMemcpyDeviceToHost, h->st));
+        }
+        HIPCHECK(hipStreamSynchronize(h->st));
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------
+// list export / import, persistence
+// ---------------------------------------------------------------------------------------
+static void get_list_impl(rsx_index* h, int64_t l, int64_t* n_out, void* codes_out, int64_t* ids_out) {
+    if (h->kind == KIND_FLAT) l = 0;
+    if (l < 0 || l >= h->nlist) RSX_THROW(RSX_ERR_INVALID, "list %lld out of range", (long long)l);
+    int64_t n = h->h_len[(size_t)l], base = h->h_base[(size_t)l];
+    if (n_out) *n_out = n;
+    if (n == 0) return;
+    if (codes_out) {
+        DevBuf t;
+        size_t bytes;
+        if (h->kind == KIND_IVFPQ) {
+            bytes = (size_t)n * h->M;
+            t.ensure(bytes);
+            launch_pq_export_list(h->data.as<uint8_t>(), base, n, h->M, h->Mpad, h->CB, t.as<uint8_t>(), h->st);
+        } else {
+            bytes = (size_t)n * h->d * 4;
+            t.ensure(bytes);
+            size_t esz = h->storage_f16 ? 2 : 4;
+            launch_convert_to_f32(h->data.as<uint8_t>() + (size_t)base * h->ld * esz, h->storage_f16, h->ld, n, h->d, t.as<float>(), h->d, h->st);
+        }
+        HIPCHECK(hipMemcpyAsync(codes_out, t.p, bytes, is_device_ptr(codes_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));
+    }
+    if (ids_out) {
+        if (h->kind == KIND_FLAT && !h->custom_ids) {
+            std::vector<int64_t> v((size_t)n);
+            for (int64_t i = 0; i < n; i++) v[(size_t)i] = i;
+            HIPCHECK(hipMemcpy(ids_out, v.data(), (size_t)n * 8, is_device_ptr(ids_out) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+        } else {
+            HIPCHECK(hipMemcpy(ids_out, h->ids.as<int64_t>() + base, (size_t)n * 8,
+                               is_device_ptr(ids_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+        }
+    }
+}
+
+static void add_list_impl(rsx_index* h, int64_t l, int64_t n, const void* codes, int dtype, const int64_t* ids) {
+    if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "add_list: use rsx_add for Flat");
+    if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "add_list before train");
+    if (l < 0 || l >= h->nlist) RSX_THROW(RSX_ERR_INVALID, "list %lld out of range", (long long)l);
+    if (n <= 0) return;
+    if (!ids) RSX_THROW(RSX_ERR_INVALID, "add_list: ids required");
+    std::vector<int64_t> need(h->h_len);
+    int64_t pos0 = need[(size_t)l];
+    need[(size_t)l] += n;
+    std::vector<int64_t> dest((size_t)n);
+    if (h->kind == KIND_IVFPQ) {
+        ensure_capacity(h, need, true);
+        DevBuf t;
+        const void* dc = codes;
+        if (!is_device_ptr(codes)) {
+            t.ensure((size_t)n * h->M);
+            HIPCHECK(hipMemcpyAsync(t.p, codes, (size_t)n * h->M, hipMemcpyHostToDevice, h->st));
+            dc = t.p;
+        }
+        launch_pq_import_list((const uint8_t*)dc, h->h_base[(size_t)l], pos0, n, h->M, h->Mpad, h->CB, h->data.as<uint8_t>(), h->st);
+        for (int64_t i = 0; i < n; i++) dest[(size_t)i] = h->h_base[(size_t)l] + pos0 + i;
+        h->w_dest.ensure((size_t)n * 8);
+        HIPCHECK(hipMemcpyAsync(h->w_dest.p, dest.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+        const int64_t* dids = ids;
+        DevBuf ti;
+        if (!is_device_ptr(ids)) {
+            ti.ensure((size_t)n * 8);
+            HIPCHECK(hipMemcpyAsync(ti.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+            dids = ti.as<int64_t>();
+        }
+        launch_write_ids(h->w_dest.as<int64_t>(), dids, 0, n, h->ids.as<int64_t>(), h->st);
+        HIPCHECK(hipStreamSynchronize(h->st));
+    } else {
+        const void* dx = stage_rows(h, h->w_x, codes, n, h->d, dtype);
+        decide_storage(h, dx, n, dtype);
+        ensure_capacity(h, need, true);
+        for (int64_t i = 0; i < n; i++) dest[(size_t)i] = h->h_base[(size_t)l] + pos0 + i;
+        h->w_dest.ensure((size_t)n * 8);
+        HIPCHECK(hipMemcpyAsync(h->w_dest.p, dest.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+        const int64_t* dids = ids;
+        DevBuf ti;
+        if (!is_device_ptr(ids)) {
+            ti.ensure((size_t)n * 8);
+            HIPCHECK(hipMemcpyAsync(ti.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+            dids = ti.as<int64_t>();
+        }
+        launch_scatter_rows(dx, dtype == RSX_F16, n, h->d, h->w_dest.as<int64_t>(), h->data.p, h->storage_f16, h->ld,
+                            h->norms.p ? h->norms.as<float>() : nullptr, dids, 0, h->ids.as<int64_t>(), h->st);
+        HIPCHECK(hipStreamSynchronize(h->st));
+    }
+    h->h_len = need;
+    h->ntotal += n;
+    upload_dir(h);
+}
+
+struct FileHeader {
+    char magic[4];
+    int32_t version, kind, d, metric, nlist, M, nbits, trained, storage_f16, custom_ids, nprobe;
+    int64_t ntotal;
+};
+
+static void wr(FILE* f, const void* p, size_t n) {
+    if (n && fwrite(p, 1, n, f) != n) RSX_THROW(RSX_ERR_IO, "short write");
+}
+static void rd(FILE* f, void* p, size_t n) {
+    if (n && fread(p, 1, n, f) != n) RSX_THROW(RSX_ERR_IO, "short read (truncated index file)");
+}
+
+static void save_impl(rsx_index* h, const char* path) {
+    FILE* f = fopen(path, "wb");
+    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s for writing", path);
+    try {
+        FileHeader hd{};
+        memcpy(hd.magic, "RSX1", 4);
+        hd.version = 1; hd.kind = h->kind; hd.d = h->d; hd.metric = h->metric; hd.nlist = h->nlist; hd.M = h->M;
+        hd.nbits = h->nbits; hd.trained = h->trained; hd.storage_f16 = h->storage_f16; hd.custom_ids = h->custom_ids;
+        hd.nprobe = h->nprobe; hd.ntotal = h->ntotal;
+        wr(f, &hd, sizeof(hd));
+        int64_t nc = (int64_t)h->h_centroids.size(), ncb = (int64_t)h->h_codebooks.size();
+        wr(f, &nc, 8); wr(f, h->h_centroids.data(), (size_t)nc * 4);
+        wr(f, &ncb, 8); wr(f, h->h_codebooks.data(), (size_t)ncb * 4);
+        std::vector<uint8_t> buf; std::vector<int64_t> ib;
+        for (int l = 0; l < h->nlist; l++) {
+            int64_t n = h->h_len[(size_t)l];
+            wr(f, &n, 8);
+            if (n == 0) continue;
+            size_t pb = (h->kind == KIND_IVFPQ) ? (size_t)n * h->M : (size_t)n * h->d * 4;
+            buf.resize(pb); ib.resize((size_t)n);
+            get_list_impl(h, l, nullptr, buf.data(), ib.data());
+            wr(f, buf.data(), pb);
+            wr(f, ib.data(), (size_t)n * 8);
+        }
+    } catch (...) { fclose(f); throw; }
+    if (fclose(f) != 0) RSX_THROW(RSX_ERR_IO, "close failed for %s", path);
+}
+
+static rsx_index* load_impl(const char* path, int device) {
+    FILE* f = fopen(path, "rb");
+    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s", path);
+    rsx_index* h = nullptr;
+    try {
+        FileHeader hd{};
+        rd(f, &hd, sizeof(hd));
+        if (memcmp(hd.magic, "RSX1", 4) != 0) RSX_THROW(RSX_ERR_IO, "%s is not an RSX1 index file", path);
+        h = create_common(hd.kind, hd.d, hd.nlist, hd.M, hd.nbits, hd.metric, device);
+        h->nprobe = hd.nprobe;
+        int64_t nc = 0, ncb = 0;
+        rd(f, &nc, 8);
+        std::vector<float> c((size_t)nc); rd(f, c.data(), (size_t)nc * 4);
+        rd(f, &ncb, 8);
+        std::vector<float> cb((size_t)ncb); rd(f, cb.data(), (size_t)ncb * 4);
+        if (nc) { if (nc != (int64_t)h->nlist * h->d) RSX_THROW(RSX_ERR_IO, "bad centroid block"); set_centroids(h, c.data()); }
+        if (ncb) { if (ncb != (int64_t)h->M * 256 * h->dsub) RSX_THROW(RSX_ERR_IO, "bad codebook block"); set_codebooks(h, cb.data()); }
+        update_trained(h);
+        std::vector<int64_t> lens((size_t)h->nlist);
+        long dir_pos = ftell(f);
+        // first pass: list sizes (to reserve exactly)
+        for (int l = 0; l < h->nlist; l++) {
+            int64_t n = 0; rd(f, &n, 8); lens[(size_t)l] = n;
+            size_t pb = (h->kind == KIND_IVFPQ) ? (size_t)n * h->M : (size_t)n * h->d * 4;
+            if (n && fseek(f, (long)(pb + (size_t)n * 8), SEEK_CUR) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
+        }
+        fseek(f, dir_pos, SEEK_SET);
+        if (h->kind != KIND_FLAT) {
+            if (!hd.storage_f16) { h->storage_f16 = 0; h->storage_decided = true; }
+            ensure_capacity(h, lens, true);
+        }
+        std::vector<uint8_t> buf; std::vector<int64_t> ib;
+        for (int l = 0; l < h->nlist; l++) {
+            int64_t n = 0; rd(f, &n, 8);
+            if (n == 0) continue;
+            size_t pb = (h->kind == KIND_IVFPQ) ? (size_t)n * h->M : (size_t)n * h->d * 4;
+            buf.resize(pb); ib.resize((size_t)n);
+            rd(f, buf.data(), pb); rd(f, ib.data(), (size_t)n * 8);
+            if (h->kind == KIND_FLAT) add_all(h, n, buf.data(), RSX_F32, hd.custom_ids ? ib.data() : nullptr);
+            else add_list_impl(h, l, n, buf.data(), RSX_F32, ib.data());
+        }
+    } catch (...) {
+        fclose(f);
+        if (h) { if (h->st) (void)hipStreamDestroy(h->st); delete h; }
+        throw;
+    }
+    fclose(f);
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char* rsx_last_error(void) { return g_err.c_str(); }
+int rsx_version(void) { return 1000; }
+
+int rsx_device_count(int* n) {
+    return guarded([&] {
+        if (!n) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        int c = 0;
+        hipError_t e = hipGetDeviceCount(&c);
+        if (e != hipSuccess || c <= 0) { (void)hipGetLastError(); *n = 0; RSX_THROW(RSX_ERR_HIP, "no HIP device available: librsx has no CPU path"); }
+        *n = c;
+    });
+}
+
+int rsx_flat_create(int d, int metric, int device, rsx_index_t** out) {
+    return guarded([&] { if (!out) RSX_THROW(RSX_ERR_INVALID, "null out"); *out = create_common(KIND_FLAT, d, 1, 0, 8, metric, device); });
+}
+int rsx_ivfflat_create(int d, int nlist, int metric, int device, rsx_index_t** out) {
+    return guarded([&] { if (!out) RSX_THROW(RSX_ERR_INVALID, "null out"); *out = create_common(KIND_IVFFLAT, d, nlist, 0, 8, metric, device); });
+}
+int rsx_ivfpq_create(int d, int nlist, int M, int nbits, int metric, int device, rsx_index_t** out) {
+    return guarded([&] { if (!out) RSX_THROW(RSX_ERR_INVALID, "null out"); *out = create_common(KIND_IVFPQ, d, nlist, M, nbits, metric, device); });
+}
+int rsx_destroy(rsx_index_t* h) {
+    return guarded([&] {
+        if (!h) return;
+        (void)hipSetDevice(h->device);
+        if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+        delete h;
+    });
+}
+
+int rsx_train(rsx_index_t* h, int64_t n, const void* x, int dtype) {
+    return guarded([&] {
+        if (!h || (!x && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
+        use_device(h);
+        train_impl(h, n, x, dtype);
+    });
+}
+int rsx_set_centroids(rsx_index_t* h, const float* c) {
+    return guarded([&] {
+        if (!h || !c) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "Flat has no centroids");
+        if (h->ntotal) RSX_THROW(RSX_ERR_INVALID, "cannot replace centroids of a populated index");
+        use_device(h); set_centroids(h, c); update_trained(h);
+    });
+}
+int rsx_set_codebooks(rsx_index_t* h, const float* c) {
+    return guarded([&] {
+        if (!h || !c) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (h->kind != KIND_IVFPQ) RSX_THROW(RSX_ERR_INVALID, "only IVFPQ has codebooks");
+        if (h->ntotal) RSX_THROW(RSX_ERR_INVALID, "cannot replace codebooks of a populated index");
+        use_device(h); set_codebooks(h, c); update_trained(h);
+    });
+}
+int rsx_get_centroids(rsx_index_t* h, float* out) {
+    return guarded([&] {
+        if (!h || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (h->h_centroids.empty()) RSX_THROW(RSX_ERR_NOT_TRAINED, "no centroids");
+        memcpy(out, h->h_centroids.data(), h->h_centroids.size() * 4);
+    });
+}
+int rsx_get_codebooks(rsx_index_t* h, float* out) {
+    return guarded([&] {
+        if (!h || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (h->h_codebooks.empty()) RSX_THROW(RSX_ERR_NOT_TRAINED, "no codebooks");
+        memcpy(out, h->h_codebooks.data(), h->h_codebooks.size() * 4);
+    });
+}
+
+int rsx_add(rsx_index_t* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
+    return guarded([&] {
+        if (!h || (!x && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
+        if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "add before train");
+        if (n <= 0) return;
+        use_device(h);
+        add_all(h, n, x, dtype, ids);
+    });
+}
+int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts) {
+    return guarded([&] {
+        if (!h || !counts) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        use_device(h);
+        std::vector<int64_t> need(counts, counts + h->nlist);
+        for (int l = 0; l < h->nlist; l++) need[(size_t)l] = std::max(need[(size_t)l], h->h_len[(size_t)l]);
+        ensure_capacity(h, need, true);
+    });
+}
+int rsx_add_list(rsx_index_t* h, int64_t list_no, int64_t n, const void* codes, int dtype, const int64_t* ids) {
+    return guarded([&] {
+        if (!h || (!codes && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        use_device(h);
+        add_list_impl(h, list_no, n, codes, dtype, ids);
+    });
+}
+int rsx_get_list(rsx_index_t* h, int64_t list_no, int64_t* n_out, void* codes_out, int64_t* ids_out) {
+    return guarded([&] {
+        if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        use_device(h);
+        get_list_impl(h, list_no, n_out, codes_out, ids_out);
+    });
+}
+
+int rsx_set_nprobe(rsx_index_t* h, int nprobe) {
+    return guarded([&] {
+        if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (nprobe <= 0) RSX_THROW(RSX_ERR_INVALID, "nprobe must be positive (got %d)", nprobe);
+        if (nprobe > 2048) RSX_THROW(RSX_ERR_UNSUPPORTED, "nprobe = %d exceeds this build's maximum of 2048", nprobe);
+        h->nprobe = nprobe;
+    });
+}
+
+int rsx_search(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
+    return guarded([&] {
+        if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
+        use_device(h);
+        search_impl(h, nq, q, dtype, k, D, I);
+    });
+}
+
+int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do, int64_t* Io,
+                   int device) {
+    return guarded([&] {
+        if (nshards <= 0 || nq < 0 || k <= 0 || !D || !I || !Do || !Io) RSX_THROW(RSX_ERR_INVALID, "merge_topk: bad arguments");
+        if ((int64_t)nshards * k > 16384) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_topk: nshards*k = %lld exceeds 16384", (long long)nshards * k);
+        if (nq == 0) return;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); RSX_THROW(RSX_ERR_HIP, "no HIP device available: librsx has no CPU path"); }
+        HIPCHECK(hipSetDevice(device));
+        bool dev = is_device_ptr(D);
+        size_t nin = (size_t)nshards * nq * k, nout = (size_t)nq * k;
+        if (dev) {
+            launch_merge_topk(nshards, nq, k, metric, D, I, Do, Io, nullptr);
+            HIPCHECK(hipStreamSynchronize(nullptr));
+        } else {
+            DevBuf a, b, c, e;
+            a.ensure(nin * 4); b.ensure(nin * 8); c.ensure(nout * 4); e.ensure(nout * 8);
+            HIPCHECK(hipMemcpy(a.p, D, nin * 4, hipMemcpyHostToDevice));
+            HIPCHECK(hipMemcpy(b.p, I, nin * 8, hipMemcpyHostToDevice));
+            launch_merge_topk(nshards, nq, k, metric, a.as<float>(), b.as<int64_t>(), c.as<float>(), e.as<int64_t>(), nullptr);
+            HIPCHECK(hipMemcpy(Do, c.p, nout * 4, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(Io, e.p, nout * 8, hipMemcpyDeviceToHost));
+        }
+        HIPCHECK(hipGetLastError());
+    });
+}
+
+int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
+    return guarded([&] {
+        if (!h || !key || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        std::string s(key);
+        if (s == "ntotal") *out = h->ntotal;
+        else if (s == "nlist") *out = h->nlist;
+        else if (s == "d") *out = h->d;
+        else if (s == "is_trained") *out = h->trained;
+        else if (s == "nprobe") *out = h->nprobe;
+        else if (s == "M") *out = h->M;
+        else if (s == "nbits") *out = h->nbits;
+        else if (s == "kind") *out = h->kind;
+        else if (s == "metric") *out = h->metric;
+        else if (s == "storage_dtype") *out = (h->kind == KIND_IVFPQ) ? -1 : (h->storage_f16 ? RSX_F16 : RSX_F32);
+        else if (s == "code_size") *out = (h->kind == KIND_IVFPQ) ? h->M : (int64_t)h->d * (h->storage_f16 ? 2 : 4);
+        else if (s == "device") *out = h->device;
+        else if (s == "max_k") *out = 2048;
+        else if (s == "hbm_bytes") *out = (int64_t)(h->data.bytes + h->ids.bytes + h->norms.bytes);
+        else RSX_THROW(RSX_ERR_INVALID, "unknown property '%s'", key);
+    });
+}
+int rsx_set_param(rsx_index_t* h, const char* key, double value) {
+    return guarded([&] {
+        if (!h || !key) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        std::string s(key);
+        if (s == "query_batch") h->query_batch = std::max(1, (int)value);
+        else if (s == "scan_chunk") h->scan_chunk = std::max(0, (int)value);
+        else if (s == "profile") { h->profile = value != 0; h->timing.clear(); }
+        else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;
+        else RSX_THROW(RSX_ERR_INVALID, "unknown parameter '%s'", key);
+    });
+}
+int rsx_get_timing(rsx_index_t* h, const char* key, double* ms) {
+    return guarded([&] {
+        if (!h || !key || !ms) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        auto it = h->timing.find(key);
+        *ms = (it == h->timing.end()) ? 0.0 : it->second;
+    });
+}
+
+int rsx_save(rsx_index_t* h, const char* path) {
+    return guarded([&] {
+        if (!h || !path) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        use_device(h);
+        save_impl(h, path);
+    });
+}
+int rsx_load(const char* path, int device, rsx_index_t** out) {
+    return guarded([&] {
+        if (!path || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        *out = load_impl(path, device);
+    });
+}
+
+int rsx_synth_vectors(int device, int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t i0,
+                      int64_t n, void* out) {
+    return guarded([&] {
+        if (!out || d <= 0 || ncentres <= 0 || n < 0) RSX_THROW(RSX_ERR_INVALID, "synth_vectors: bad arguments");
+        HIPCHECK(hipSetDevice(device));
+        if (is_device_ptr(out)) {
+            launch_synth_vectors(d, ncentres, seed_c, seed_x, sigma, i0, n, (__half*)out, nullptr);
+            HIPCHECK(hipStreamSynchronize(nullptr));
+        } else {
+            DevBuf t; t.ensure((size_t)n * d * 2);
+            launch_synth_vectors(d, ncentres, seed_c, seed_x, sigma, i0, n, t.as<__half>(), nullptr);
+            HIPCHECK(hipMemcpy(out, t.p, (size_t)n * d * 2, hipMemcpyDeviceToHost));
+        }
+        HIPCHECK(hipGetLastError());
+    });
+}
+int rsx_synth_queries(int device, int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t nbase,
+                      uint32_t seed_q, float sigma_q, int64_t r0, int64_t n, void* out) {
+    return guarded([&] {
+        if (!out || d <= 0 || ncentres <= 0 || n < 0 || nbase <= 0) RSX_THROW(RSX_ERR_INVALID, "synth_queries: bad arguments");
+        HIPCHECK(hipSetDevice(device));
+        if (is_device_ptr(out)) {
+            launch_synth_queries(d, ncentres, seed_c, seed_x, sigma, nbase, seed_q, sigma_q, r0, n, (__half*)out, nullptr);
+            HIPCHECK(hipStreamSynchronize(nullptr));
+        } else {
+            DevBuf t; t.ensure((size_t)n * d * 2);
+            launch_synth_queries(d, ncentres, seed_c, seed_x, sigma, nbase, seed_q, sigma_q, r0, n, t.as<__half>(), nullptr);
+            HIPCHECK(hipMemcpy(out, t.p, (size_t)n * d * 2, hipMemcpyDeviceToHost));
+        }
+        HIPCHECK(hipGetLastError());
+    });
+}
+
+}  // extern "C"

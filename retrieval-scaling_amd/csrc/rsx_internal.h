@@ -1,0 +1,162 @@
+// rsx_internal.h — internal declarations shared by the HIP kernels and the C-ABI host code.
+// gfx950 (MI355X / CDNA4) only: wave64, MFMA, 160 KiB LDS.  No portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace rsx {
+
+// ---------------------------------------------------------------------------------------
+// Candidate key: 64-bit, larger = better.  high 32 = order-preserving map of the fp32 score,
+// low 32 = ~idx so that among equal scores the smaller idx wins.  0 = empty slot.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t f2ord(float f) {
+    union { float f; uint32_t u; } c; c.f = f;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t o) {
+    union { float f; uint32_t u; } c;
+    c.u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return c.f;
+}
+// Only scores > -inf are admitted (FAISS: strict comparison against a -inf heap top); NaN never.
+__device__ inline uint64_t make_key(float s, uint32_t idx) {
+    s = s + 0.0f;  // -0 -> +0
+    if (!(s > -__builtin_inff())) return 0ull;
+    return ((uint64_t)f2ord(s) << 32) | (uint64_t)(0xFFFFFFFFu - idx);
+}
+__host__ __device__ inline uint32_t key_idx(uint64_t k) { return 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull); }
+__host__ __device__ inline float key_score(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
+
+enum { KIND_FLAT = 0, KIND_IVFFLAT = 1, KIND_IVFPQ = 2 };
+
+// Inverted-list directory on the device (one entry per list; Flat uses a single list 0).
+//   base : first storage row of the list (PQ: multiple of 64 = slab aligned; flat rows: of 16)
+//   len  : vectors in the list
+//   cap  : rows reserved
+struct ListDir {
+    const int64_t* base;
+    const int64_t* len;
+};
+
+// ---------------------------------------------------------------------------------------
+// Launch wrappers (implemented in the .hip files).  All asynchronous on `st`.
+// ---------------------------------------------------------------------------------------
+
+// k_misc.hip
+void launch_convert_to_f32(const void* src, int src_f16, int64_t src_ld, int64_t n_rows, int d, float* dst, int ld, hipStream_t st);
+void launch_convert_to_f16(const void* src, int src_f16, int64_t n_rows, int d, __half* dst, int ld,
+                           int64_t pad_rows_to, int* not_representable_flag, hipStream_t st);
+void launch_check_f16(const float* x, int64_t count, int* flag, hipStream_t st);
+void launch_write_ids(const int64_t* dest_row, const int64_t* ids_in, int64_t id0, int64_t n, int64_t* ids_storage, hipStream_t st);
+void launch_widen_storage(const __half* src, float* dst, int64_t count, hipStream_t st);
+void launch_residuals(const float* x, int64_t n, int d, const float* centroids, const int32_t* assign, float* out, hipStream_t st);
+void launch_fill_u64(uint64_t* p, int64_t n, uint64_t v, hipStream_t st);
+void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
+void launch_synth_vectors(int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t i0,
+                          int64_t n, __half* out, hipStream_t st);
+void launch_synth_queries(int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t nbase,
+                          uint32_t seed_q, float sigma_q, int64_t r0, int64_t n, __half* out, hipStream_t st);
+// scatter rows of a batch into list storage (IVF-Flat / Flat): dst row = dest_row[i]
+void launch_scatter_rows(const void* x, int x_f16, int64_t n, int d, const int64_t* dest_row, void* storage,
+                         int storage_f16, int ld, float* norms, const int64_t* ids_in, int64_t id0,
+                         int64_t* ids_storage, hipStream_t st);
+// copy lists between two layouts (re-layout on growth). row_bytes = bytes per row group unit.
+void launch_copy_lists(int nlist, const int64_t* old_base, const int64_t* new_base, const int64_t* len,
+                       const uint8_t* old_data, uint8_t* new_data, int64_t unit_rows, int64_t unit_bytes,
+                       const int64_t* old_ids, int64_t* new_ids, const float* old_norms, float* new_norms,
+                       hipStream_t st);
+// export one PQ list from the interleaved slab layout to plain [n, M]
+void launch_pq_export_list(const uint8_t* codes, int64_t base_row, int64_t n, int M, int Mpad, int CB,
+                           uint8_t* out, hipStream_t st);
+// import plain codes [n, M] into the slab layout at rows base_row + pos0 ...
+void launch_pq_import_list(const uint8_t* plain, int64_t base_row, int64_t pos0, int64_t n, int M, int Mpad,
+                           int CB, uint8_t* codes, hipStream_t st);
+
+// k_gemm.hip
+// S[i, c] = <X_i, C_c> as one sequential fp32 fmaf chain over t = 0..d-1 (f32-input MFMA).
+// X: [n, ldx] f32 or f16;  C: [nc, d] f32;  S: [n, lds_] f32.
+void launch_gemm_exact_scores(const void* X, int x_f16, int64_t n, int ldx, const float* C, int nc, int d,
+                              float* S, int64_t lds_, hipStream_t st);
+// assign[i] = argmax_c <X_i, C_c> (first maximum).  partial: workspace [n, 2*ceil(nc/128)] u64.
+void launch_gemm_exact_argmax(const void* X, int x_f16, int64_t n, int ldx, const float* C, int nc, int d,
+                              uint64_t* partial, int32_t* assign, float* best, hipStream_t st);
+// Flat scan: temp[q, v] = <Q_q, X_v> (fp16 MFMA, fp32 accumulate) for v in [v0, v0+nv).
+// Q16: [nq_pad(128), ld] f16; X: [., ld] f16|f32 storage (ld multiple of 64); bias: per-row or null.
+void launch_flat_gemm(const __half* Q16, int nq_pad, const void* X, int x_f16, int64_t v0, int64_t nv,
+                      int ld, const float* bias, float* temp, int64_t tstride, hipStream_t st);
+// List scan (IVF-Flat and small-batch Flat): groups of <=16 (query, probe) pairs per list.
+struct ListScanArgs {
+    const __half* Q16; int ld;             // queries [nq, ld]
+    const void* X; int x_f16;              // storage rows
+    const float* bias;                     // per storage row (L2: -0.5|x|^2) or null
+    const int64_t* list_base; const int64_t* list_len;
+    // grouping (IVF): pairs sorted by list
+    const int32_t* pairs_sorted;           // [P] pair index = q*nprobe + j
+    const int32_t* pair_off;               // [nlist+1]
+    const int32_t* group_off;              // [nlist+1]
+    const int32_t* total_groups;           // device scalar
+    const int32_t* probe_list;             // [nq*nprobe]
+    const int64_t* seg_start;              // [nq, nprobe+1]
+    int nlist; int nprobe;
+    int flat_mode; int64_t flat_n; int nq;  // flat_mode: single list, groups = blocks of 16 queries
+    float* temp; int64_t tstride;
+    int chunk_rows;                         // rows per work item (multiple of 64)
+    int max_groups; int max_chunks;
+};
+void launch_list_scan(const ListScanArgs& a, hipStream_t st);
+
+// k_pq.hip
+void launch_pq_lut(const float* Q32, int ldq, int64_t nq, int d, int M, int Mpad, const float* codebooks,
+                   float* lut, hipStream_t st);
+struct PQScanArgs {
+    const uint8_t* codes; int M; int Mpad; int CB;
+    const int64_t* list_base; const int64_t* list_len;
+    const float* lut;                       // [nq, Mpad, 256]
+    const int32_t* probe_list; const float* probe_dis0; const int64_t* seg_start;
+    int64_t nq; int nprobe;
+    float* temp; int64_t tstride;
+    int slabs_per_chunk; int max_chunks;
+};
+int launch_pq_scan(const PQScanArgs& a, hipStream_t st);  // returns 0, or -1 if the LDS request cannot be met
+// codes for rows of a batch: residual vs centroid[assign] (centroids may be null -> no residual).
+// plain_out != null: write [n, Mpad] row-major instead of the slab layout (training / export).
+void launch_pq_encode(const void* x, int x_f16, int64_t n, int ldx, int d, int M, int Mpad, int CB,
+                      const float* centroids, const int32_t* assign, const float* codebooks,
+                      const int64_t* dest_row, uint8_t* codes, uint8_t* plain_out, hipStream_t st);
+
+// k_select.hip
+struct SelectArgs {
+    const void* in; int in_is_keys;         // float scores (idx = idx_base + column) or u64 keys
+    int64_t row_stride;                     // elements between rows
+    const int64_t* row_n; int64_t row_n_stride; int64_t n_uniform;  // valid elements per row
+    int64_t seg_len; int nseg;
+    uint32_t idx_base;
+    const uint64_t* init;                   // optional [nrows, KP] running state merged in (nseg must be 1)
+    uint64_t* out; int64_t out_row_stride;  // out[row*out_row_stride + seg*KP + i]
+    int64_t nrows; int KP; int BUF; int k;
+};
+void launch_select(const SelectArgs& a, hipStream_t st);
+void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
+                        int pad_to, int32_t* probe_list, float* probe_dis0, int64_t* seg_start, hipStream_t st);
+void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int32_t* cnt, int32_t* cursor,
+                        int32_t* pair_off, int32_t* group_off, int32_t* total_groups, int32_t* pairs_sorted,
+                        hipStream_t st);
+struct FinalizeArgs {
+    int kind; int metric;
+    const uint64_t* state; int KP; int k; int64_t nq;
+    // location resolution
+    const int32_t* probe_list; const int64_t* seg_start; int nprobe;
+    const int64_t* list_base;
+    const int64_t* ids;                     // per storage row, or null (id = row)
+    // exact rerank (Flat / IVF-Flat)
+    const float* Q32; int ldq; int d;
+    const void* X; int x_f16; int ld;
+    float* D; int64_t* I;
+};
+void launch_finalize(const FinalizeArgs& a, hipStream_t st);
+void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
+                       float* Do, int64_t* Io, hipStream_t st);
+
+}  // namespace rsx
