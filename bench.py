@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py — queries/s (+ recall@10) of the MI355X IVF-PQ search path.
+
+Workload (BASELINE.json metric / configs[3]): 100M x 768 IVF-PQ, M = 96, nbits = 8, nlist = 4096,
+nprobe = 32, batch = 1024 queries, k = 10, synthetic Gaussian-mixture fp16 embeddings.
+One "step" = one rsx_search call over one batch of 1024 queries that is already resident in HBM,
+results left in HBM.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+N > 1: STRONG scaling of the same 100M index — rank r holds the contiguous id range r of N (same
+centroids / codebooks everywhere), every rank searches the full batch on its shard, one RCCL
+all-gather of the packed [nq, k] candidates, merge kernel on every rank (sharded.ShardedSearcher).
+
+Rank 0 prints ONE JSON line.  The index build (synthesis, training, add) is setup and is not timed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "retrieval-scaling_amd"))
+sys.path.insert(0, REPO)
+
+D = 768
+SEED_C, SEED_X, SEED_Q = 1234, 10000, 999
+SIGMA, SIGMA_Q = 0.5, 0.1
+NCENTRES = 4096
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100_000_000, help="total vectors in the index (all GPUs)")
+    ap.add_argument("--nlist", type=int, default=4096)
+    ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--m", type=int, default=96)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--chunk", type=int, default=1_000_000, help="vectors synthesised per add call")
+    ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-recall", action="store_true", help="skip the exact ground truth (recall = null)")
+    args = ap.parse_args()
+
+    import torch
+    import rsx
+    from sharded import ShardedSearcher, shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU search path)"
+    torch.cuda.set_device(local_rank)
+    os.environ["RSX_DEVICE"] = str(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_total, nq, k = args.n, args.batch, args.k
+    lo, hi = shard_range(n_total, rank, world)
+    n_local = hi - lo
+    t_setup = time.time()
+
+    # ---------------- train (same deterministic training set on every rank -> identical parameters)
+    index = rsx.IndexIVFPQ(rsx.IndexFlatIP(D), D, args.nlist, args.m, 8, rsx.METRIC_INNER_PRODUCT, device=local_rank)
+    n_train = min(n_total, 256 * args.nlist)
+    xt = torch.empty((n_train, D), dtype=torch.float16, device=dev)
+    # training sample = a strided pass over the whole id range (every chunk contributes)
+    stride = max(1, n_total // n_train)
+    if stride == 1:
+        rsx.synth_vectors(D, NCENTRES, SEED_C, SEED_X, SIGMA, 0, n_train, out=xt)
+    else:
+        blk = 4096
+        for b in range(0, n_train, blk):
+            nb = min(blk, n_train - b)
+            rsx.synth_vectors(D, NCENTRES, SEED_C, SEED_X, SIGMA, (b * stride) % max(1, n_total - nb), nb, out=xt[b:b + nb])
+    t0 = time.time()
+    index.train(xt)
+    del xt
+    if rank == 0:
+        log(f"train: {time.time() - t0:.1f}s on {n_train} vectors")
+    if world > 1:  # belt and braces: every shard must quantise with rank 0's parameters
+        cen = torch.from_numpy(index.get_centroids()).to(dev)
+        cb = torch.from_numpy(index.get_codebooks()).to(dev)
+        dist.broadcast(cen, 0); dist.broadcast(cb, 0)
+        fresh = rsx.IndexIVFPQ(rsx.IndexFlatIP(D), D, args.nlist, args.m, 8, rsx.METRIC_INNER_PRODUCT, device=local_rank)
+        fresh.set_centroids(cen.cpu().numpy()); fresh.set_codebooks(cb.cpu().numpy())
+        index = fresh
+    index.nprobe = args.nprobe
+
+    # ---------------- queries (all steps resident in HBM)
+    nsteps = args.warmup + args.steps
+    Q = torch.empty((nsteps * nq, D), dtype=torch.float16, device=dev)
+    rsx.synth_queries(D, NCENTRES, SEED_C, SEED_X, SIGMA, n_total, SEED_Q, SIGMA_Q, 0, nsteps * nq, out=Q)
+    Qgt = Q[args.warmup * nq:(args.warmup + 1) * nq]  # recall is measured on the first timed batch
+
+    # ---------------- add (+ streaming exact ground truth with the Flat engine)
+    t0 = time.time()
+    buf = torch.empty((args.chunk, D), dtype=torch.float16, device=dev)
+    flat = None if args.no_recall else rsx.IndexFlatIP(D, device=local_rank)
+    gtD = gtI = None
+    for c0 in range(lo, hi, args.chunk):
+        nb = min(args.chunk, hi - c0)
+        rsx.synth_vectors(D, NCENTRES, SEED_C, SEED_X, SIGMA, c0, nb, out=buf[:nb])
+        index.add(buf[:nb])
+        if flat is not None:
+            flat.reset()
+            flat.add(buf[:nb])
+            Dc, Ic = flat.search(Qgt, k)
+            Ic = Ic + c0
+            if gtD is None:
+                gtD, gtI = Dc, Ic
+            else:
+                gtD, gtI = rsx.merge_topk(torch.stack([gtD, Dc]), torch.stack([gtI, Ic]))
+    del buf, flat
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"add: {time.time() - t0:.1f}s for {n_local} vectors/rank; setup total {time.time() - t_setup:.1f}s")
+    assert index.ntotal == n_local
+
+    searcher = ShardedSearcher(index, id_offset=lo) if world > 1 else None
+
+    def step(i):
+        q = Q[i * nq:(i + 1) * nq]
+        if searcher is not None:
+            return searcher.search(q, k)
+        return index.search(q, k)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    index.set_param("profile", 1)      # HIP events on the library's stream around each stage
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nsteps):
+        out = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ms = index.get_timing("scan")
+    scan_launches = index.get_timing("scan_launches")
+    stage_ms = {s: round(index.get_timing(s) / args.steps, 4) for s in
+                ("convert", "coarse", "select_probe", "lut", "scan", "select", "finalize", "total")}
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # algorithmic bytes of the dominant kernel (k_pq_scan): every (query, probed list) pair reads the
+    # list's codes once = M bytes per scanned vector (SURVEY §8d / DESIGN.md).
+    index.set_param("profile", 2)
+    step(args.warmup)
+    scanned = index.get_timing("scanned_vectors")
+    index.set_param("profile", 0)
+    scan_bytes = scanned * args.m
+    ms_per_launch = scan_ms / max(1.0, scan_launches)
+    achieved = scan_bytes / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+
+    # recall@k of the first timed batch against the exact streaming ground truth (all shards merged)
+    D1, I1 = step(args.warmup)
+    recall = None
+    if gtD is not None:
+        if world > 1:
+            gD = torch.empty((world,) + tuple(gtD.shape), dtype=gtD.dtype, device=dev)
+            gI = torch.empty((world,) + tuple(gtI.shape), dtype=gtI.dtype, device=dev)
+            dist.all_gather_into_tensor(gD, gtD.contiguous()); dist.all_gather_into_tensor(gI, gtI.contiguous())
+            gtD, gtI = rsx.merge_topk(gD, gI)
+        a, b = I1.cpu().numpy(), gtI.cpu().numpy()
+        recall = float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a, b)]))
+
+    # ---------------- CPU baseline (rank 0, N = 1): the oracle's FAISS-structured IVFPQ search on the
+    # host cores over a bounded sample of the same queries and the same index.
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and args.cpu_queries > 0:
+        from oracle import oracle as orc
+        ns = min(args.cpu_queries, nq)
+        qs = Qgt[:ns].cpu().numpy().astype(np.float32)
+        cen, cb = index.get_centroids(), index.get_codebooks()
+        pid, _ = orc.coarse_probe(cen, qs, min(args.nprobe, args.nlist))
+        need = np.unique(pid[pid >= 0])
+        off = np.zeros(args.nlist + 1, dtype=np.int64)
+        payload, ids = [], []
+        lens = np.zeros(args.nlist, dtype=np.int64)
+        for l in need:
+            c, i = index.get_list(int(l))
+            payload.append(c); ids.append(i); lens[l] = len(i)
+        np.cumsum(lens, out=off[1:])
+
+        class LM:
+            pass
+        lm = LM()
+        lm.list_off = off
+        lm.payload = np.concatenate(payload) if payload else np.zeros((0, args.m), np.uint8)
+        lm.ids = np.concatenate(ids) if ids else np.zeros(0, np.int64)
+        orc.ivfpq_search(cen, cb, lm, qs[:2], args.nprobe, k, heap=True)  # page in
+        t0 = time.perf_counter()
+        Dc, Ic = orc.ivfpq_search(cen, cb, lm, qs, args.nprobe, k, heap=True)
+        cpu_s = time.perf_counter() - t0
+        cpu = {"value": round(ns / cpu_s, 3), "unit": "queries/s", "cores": orc.num_threads(), "kind": "port",
+               "sample": f"{ns} of the {nq} queries of the first timed batch, same {n_total}-vector index "
+                         f"(probed lists copied to host), oracle orc_ivfpq_search_heap, OpenMP over queries"}
+        parity = bool(np.array_equal(Ic, I1[:ns].cpu().numpy()) and np.array_equal(Dc, D1[:ns].cpu().numpy()))
+        log(f"cpu baseline: {ns} queries in {cpu_s:.2f}s on {orc.num_threads()} threads; parity with GPU ids+scores: {parity}")
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath))
+                if t.get("n") == n_total and t.get("n_gpus") == world:
+                    traffic = t.get("k_pq_scan_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        res = {
+            "metric": "queries/sec + recall@10, 100M x 768 IVF-PQ nprobe=32 batch=1024",
+            "value": round(args.steps * nq / elapsed, 2),
+            "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u8 codes, f32 LUT accumulate",
+            "data": "synthetic",
+            "recall_at_10": recall,
+            "config": {"workload": f"{n_total}x{D} IVF-PQ M={args.m} nbits=8 nlist={args.nlist} nprobe={args.nprobe} "
+                                   f"batch={nq} k={k}, inner product, by_residual",
+                       "vectors_per_gpu": n_local, "parallelism": f"index sharded by id range over {world} GPU(s)"},
+            "roofline": {"bound": "hbm", "kernel": "k_pq_scan", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(ms_per_launch, 4),
+                         "note": "achieved = scanned code bytes (sum over (query, probed list) of len*M) / HIP-event "
+                                 "duration of the scan launch on the library stream, rank 0"},
+            "stage_ms_per_step": stage_ms,
+            "cpu_baseline": cpu,
+            "cpu_parity_ids_and_scores_bit_exact": parity,
+        }
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,6 +99,9 @@ int rsx_get_codebooks(rsx_index_t* h, float* codebooks_out);
  * (L2) codeword, first minimum on ties; in-list order = insertion order. */
 int rsx_add(rsx_index_t* h, int64_t n, const void* x, int dtype, const int64_t* ids);
 
+/* index.reset(): drop every stored vector, keep the trained parameters and the HBM reservation. */
+int rsx_reset(rsx_index_t* h);
+
 /* Optional: pre-size every inverted list (counts[nlist]) so add never re-lays-out HBM. */
 int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts);
 
@@ -139,12 +142,13 @@ int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, c
 int rsx_get(rsx_index_t* h, const char* key, int64_t* out);
 
 /* Tuning knobs that do not change results: "query_batch" (max queries per internal pass),
- * "scan_chunk" (vectors per scan work item, 0 = auto), "profile" (1 = record stage timings). */
+ * "scan_chunk" (vectors per scan work item, 0 = auto), "profile" (1 = record stage timings with HIP
+ * events on the library's stream; 2 = additionally count the vectors each search scanned). */
 int rsx_set_param(rsx_index_t* h, const char* key, double value);
 
 /* HIP-event timings (ms) of the stages of the last rsx_search on this handle when
  * "profile"=1: "coarse", "select_probe", "lut", "scan", "select", "finalize", "total",
- * and "scan_launches".  Used by bench.py for the roofline object. */
+ * "scan_launches" and (profile 2) "scanned_vectors".  Used by bench.py for the roofline object. */
 int rsx_get_timing(rsx_index_t* h, const char* key, double* ms);
 
 /* ---- persistence ------------------------------------------------------------------- */

@@ -711,6 +711,15 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     launch_probe_setup(h->w_probekeys.as<uint64_t>(), KPp, nq, nprobe, h->d_len.as<int64_t>(), pad_to,
                        h->w_probelist.as<int32_t>(), h->w_dis0.as<float>(), h->w_segstart.as<int64_t>(), h->st);
     tm.mark("select_probe");
+    if (h->profile >= 2) {
+        std::vector<int32_t> pl((size_t)nq * nprobe);
+        HIPCHECK(hipMemcpyAsync(pl.data(), h->w_probelist.p, pl.size() * 4, hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));
+        double tot = 0;
+        for (int32_t l : pl) if (l >= 0) tot += (double)h->h_len[(size_t)l];
+        h->timing["scanned_vectors"] += tot;
+        tm.mark("count");
+    }
     // host-side bound on a query's row of the score buffer: the nprobe longest (padded) lists
     std::vector<int64_t> lens(h->h_len);
     for (auto& v : lens) v = round_up(v, pad_to);
@@ -1124,6 +1133,16 @@ int rsx_add(rsx_index_t* h, int64_t n, const void* x, int dtype, const int64_t* 
         add_all(h, n, x, dtype, ids);
     });
 }
+int rsx_reset(rsx_index_t* h) {
+    return guarded([&] {
+        if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        use_device(h);
+        HIPCHECK(hipStreamSynchronize(h->st));
+        std::fill(h->h_len.begin(), h->h_len.end(), 0);
+        h->ntotal = 0;
+        if (h->d_len.p) upload_dir(h);
+    });
+}
 int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts) {
     return guarded([&] {
         if (!h || !counts) RSX_THROW(RSX_ERR_INVALID, "null pointer");
@@ -1220,7 +1239,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         std::string s(key);
         if (s == "query_batch") h->query_batch = std::max(1, (int)value);
         else if (s == "scan_chunk") h->scan_chunk = std::max(0, (int)value);
-        else if (s == "profile") { h->profile = value != 0; h->timing.clear(); }
+        else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;
         else RSX_THROW(RSX_ERR_INVALID, "unknown parameter '%s'", key);
     });

@@ -1,0 +1,86 @@
+"""Multi-GPU search: vectors partitioned across ranks, one all-gather of per-shard top-k, merge.
+
+The reference shards by running independent indexes (Slurm array / HTTP workers) and merging their
+results by score in Python (src/search.py:312-373, api/serve_main_node.py:109-165).  Here the shards
+are the GPUs of one node: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI),
+every rank searches its own shard with the same query batch, ONE collective moves the packed
+[nq, k] (score, id) candidates, and every rank runs the merge kernel (rsx_merge_topk) — result
+order = the reference's: score descending, ties earlier shard first, then within-shard order.
+
+The data path has no other collective: the scan itself never crosses GPUs.
+"""
+import numpy as np
+
+
+def shard_range(n_total, rank, world_size):
+    """Contiguous id range [lo, hi) of `rank` — the reference's shard semantics (global ids are offsets)."""
+    per = (n_total + world_size - 1) // world_size
+    lo = min(rank * per, n_total)
+    return lo, min(lo + per, n_total)
+
+
+def merge_topk_host(D, I, metric=0):
+    """Host restatement of the reference merge (src/search.py:362-367) on arrays [nshards, nq, k]:
+    concat in shard order, stable sort by score (descending for IP), keep k; ids < 0 are padding.
+    Used for JSONL-level merges and for CPU-tensor (gloo) gathers; GPUs use the rsx_merge_topk kernel."""
+    D = np.asarray(D, dtype=np.float32)
+    I = np.asarray(I, dtype=np.int64)
+    ns, nq, k = D.shape
+    Dc = np.transpose(D, (1, 0, 2)).reshape(nq, ns * k)
+    Ic = np.transpose(I, (1, 0, 2)).reshape(nq, ns * k)
+    Do = np.full((nq, k), -np.inf if metric == 0 else np.inf, dtype=np.float32)
+    Io = np.full((nq, k), -1, dtype=np.int64)
+    for q in range(nq):
+        valid = np.nonzero(Ic[q] >= 0)[0]
+        key = -Dc[q, valid] if metric == 0 else Dc[q, valid]
+        order = valid[np.argsort(key, kind="stable")][:k]
+        Do[q, : len(order)] = Dc[q, order]
+        Io[q, : len(order)] = Ic[q, order]
+    return Do, Io
+
+
+class ShardedSearcher:
+    """Wraps a rank-local index whose vectors are ids [id_offset, id_offset + ntotal)."""
+
+    def __init__(self, local_index, id_offset=0, group=None, metric=0):
+        import torch.distributed as dist
+        self.index = local_index
+        self.id_offset = int(id_offset)
+        self.group = group
+        self.metric = metric
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def search(self, q, k):
+        """q: [nq, d] — the SAME batch on every rank (numpy / CPU tensor / CUDA tensor).
+        Returns merged (D, I) [nq, k] on every rank, in the container type of the local result."""
+        import torch
+        import torch.distributed as dist
+        D, I = self.index.search(q, k)
+        as_numpy = not torch.is_tensor(D)
+        if as_numpy:
+            D, I = torch.from_numpy(np.ascontiguousarray(D)), torch.from_numpy(np.ascontiguousarray(I))
+        I = torch.where(I >= 0, I + self.id_offset, I)
+        if self.world_size == 1:
+            return (D.numpy(), I.numpy()) if as_numpy else (D, I)
+        nq = D.shape[0]
+        # one packed buffer -> one collective: [2, nq, k] int64 (scores as raw bits in the low word)
+        backend = dist.get_backend(self.group)
+        dev = D.device
+        if backend == "nccl" and not D.is_cuda:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        packed = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
+        packed[0] = D.to(dev).contiguous().view(torch.int32).to(torch.int64)
+        packed[1] = I.to(dev)
+        gathered = torch.empty((self.world_size, 2, nq, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+        Dall = gathered[:, 0].to(torch.int32).view(torch.float32).contiguous()
+        Iall = gathered[:, 1].contiguous()
+        if Dall.is_cuda:
+            import rsx
+            Dm, Im = rsx.merge_topk(Dall, Iall, metric=self.metric)
+            if as_numpy:
+                return Dm.cpu().numpy(), Im.cpu().numpy()
+            return Dm, Im
+        Dm, Im = merge_topk_host(Dall.numpy(), Iall.numpy(), self.metric)
+        return (Dm, Im) if as_numpy else (torch.from_numpy(Dm), torch.from_numpy(Im))

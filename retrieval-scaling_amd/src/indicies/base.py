@@ -1,0 +1,59 @@
+"""Indexer — the facade the pipeline stages and the serving API construct
+(mirror of reference src/indicies/base.py:14-77; used at src/index.py:56-57, src/search.py:293,
+api/api_index.py:28-29).  File names, dispatch and the search() return are the reference's.
+"""
+import logging
+import os
+
+from src.indicies.flat import FlatIndexer
+from src.indicies.index_utils import get_index_dir_and_embedding_paths
+from src.indicies.ivf_flat import IVFFlatIndexer
+from src.indicies.ivf_pq import IVFPQIndexer
+
+
+def index_file_names(index_args):
+    """(index file name, has a .trained sibling) for cfg.datastore.index — reference base.py:23-27."""
+    index_type = index_args.index_type
+    if "IVF" in index_type:
+        name = f"index_{index_type}.{index_args.sample_train_size}.{index_args.projection_size}.{index_args.ncentroids}.faiss"
+        return name, True
+    return f"index_{index_type}.faiss", False
+
+
+class Indexer(object):
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.args = cfg.datastore.index
+        self.index_type = self.args.index_type
+
+        passage_dir = self.cfg.datastore.embedding.passages_dir
+        index_dir, embedding_paths = get_index_dir_and_embedding_paths(cfg)
+        os.makedirs(index_dir, exist_ok=True)
+        logging.info(f"Indexing for passages: {embedding_paths}")
+        name, has_trained = index_file_names(self.args)
+        index_path = os.path.join(index_dir, name)
+        meta_file = os.path.join(index_dir, name + ".meta")
+        trained_index_path = os.path.join(index_dir, name + ".trained") if has_trained else None
+        pos_map_save_path = os.path.join(index_dir, "passage_pos_id_map.pkl")
+
+        common = dict(embed_paths=embedding_paths, index_path=index_path, meta_file=meta_file,
+                      passage_dir=passage_dir, pos_map_save_path=pos_map_save_path,
+                      dimension=self.args.projection_size)
+        if self.index_type == "Flat":
+            self.datastore = FlatIndexer(**common)
+        elif self.index_type == "IVFFlat":
+            self.datastore = IVFFlatIndexer(trained_index_path=trained_index_path,
+                                            sample_train_size=self.args.sample_train_size, prev_index_path=None,
+                                            ncentroids=self.args.ncentroids, probe=self.args.probe, **common)
+        elif self.index_type == "IVFPQ":
+            self.datastore = IVFPQIndexer(trained_index_path=trained_index_path,
+                                          sample_train_size=self.args.sample_train_size, prev_index_path=None,
+                                          ncentroids=self.args.ncentroids, probe=self.args.probe,
+                                          n_subquantizers=self.args.n_subquantizers, code_size=self.args.n_bits,
+                                          **common)
+        else:
+            raise NotImplementedError
+
+    def search(self, query_embs, k=5):
+        all_scores, all_passages, db_ids = self.datastore.search(query_embs, k)
+        return all_scores, all_passages, db_ids

@@ -1,0 +1,121 @@
+"""GPU: Flat index (IndexFlatIP / L2) through the C-ABI against the oracle and the golden fixtures."""
+import numpy as np
+import pytest
+
+from util import assert_same_results, load_golden, regen_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["flat_ip_d768", "flat_l2_d64", "flat_ip_d100"])
+def test_golden(gpu, name):
+    g = load_golden(name)
+    x, q = regen_gpu(gpu, g)          # also proves the HIP generator is bit-identical to the oracle's
+    ix = gpu.IndexFlat(g["d"], g["metric"])
+    ix.add(x)
+    assert ix.ntotal == g["n"] and ix.storage_dtype == "float16"
+    D, I = ix.search(q, g["k"])
+    assert_same_results(D, I, g["D"], g["I"], name)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("nq", [3, 200])        # 3 -> streaming small-batch kernel, 200 -> MFMA GEMM tiles
+def test_vs_oracle_both_kernels(gpu, orc, metric, nq):
+    d, n, k = 768, 5000, 10
+    x = orc.synth_vectors(d, 12, 21, 22, 0.5, 0, n)
+    q = orc.synth_queries(d, 12, 21, 22, 0.5, n, 23, 0.1, 0, nq)
+    ix = gpu.IndexFlat(d, metric)
+    ix.add(x)
+    D, I = ix.search(q, k)
+    Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), k, metric)
+    assert_same_results(D, I, Dr, Ir, f"flat metric={metric} nq={nq}")
+
+
+def test_edge_cases(gpu):
+    e = load_golden("edge_cases")
+    ix = gpu.IndexFlatIP(32)
+    # empty index: FAISS returns -1 / -inf
+    D, I = ix.search(e["q"], 4)
+    assert (I == -1).all() and np.isneginf(D).all()
+    ix.add(e["x"])
+    D, I = ix.search(e["q"], 8)
+    assert_same_results(D, I, e["D"], e["I"], "duplicates")      # exact ties -> id ascending
+    ix2 = gpu.IndexFlatIP(32)
+    ix2.add(e["x"][:5])
+    D, I = ix2.search(e["q"], 8)                                    # k > ntotal -> -1 / -inf padding
+    assert_same_results(D, I, e["Dk"], e["Ik"], "k>ntotal")
+
+
+def test_incremental_add_and_growth(gpu, orc):
+    d, k = 64, 12
+    x = orc.synth_vectors(d, 5, 31, 32, 0.5, 0, 3000)
+    q = orc.synth_queries(d, 5, 31, 32, 0.5, 3000, 33, 0.1, 0, 50)
+    a = gpu.IndexFlatIP(d)
+    for lo, hi in [(0, 1), (1, 130), (130, 131), (131, 1500), (1500, 3000)]:   # forces several re-layouts
+        a.add(x[lo:hi])
+    b = gpu.IndexFlatIP(d)
+    b.add(x)
+    Da, Ia = a.search(q, k)
+    Db, Ib = b.search(q, k)
+    assert_same_results(Da, Ia, Db, Ib, "incremental")
+    Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), k, 0)
+    assert_same_results(Da, Ia, Dr, Ir, "incremental vs oracle")
+
+
+def test_fp32_values_keep_fp32_storage(gpu, orc):
+    rng = np.random.RandomState(3)
+    d, n = 96, 2000
+    x = rng.randn(n, d).astype(np.float32)          # not fp16-representable
+    q = rng.randn(70, d).astype(np.float32)
+    ix = gpu.IndexFlatIP(d)
+    ix.add(x[:1000].astype(np.float16))             # starts as fp16 storage ...
+    assert ix.storage_dtype == "float16"
+    ix.add(x[1000:])                                # ... and is widened when a non-fp16 value arrives
+    assert ix.storage_dtype == "float32"
+    xs = np.concatenate([x[:1000].astype(np.float16).astype(np.float32), x[1000:]], 0)
+    for qq in (q, q[:5]):
+        D, I = ix.search(qq, 10)
+        Dr, Ir = orc.flat_search(qq, xs, 10, 0)
+        assert np.array_equal(I, Ir), "exact re-rank must recover the exact ids"
+        assert np.allclose(D, Dr, rtol=0, atol=np.abs(Dr).max() * 2 ** -23)   # fp64 sum order: <= 1 ulp of fp32
+
+
+def test_explicit_ids_and_large_k(gpu, orc):
+    d, n = 64, 4000
+    x = orc.synth_vectors(d, 5, 41, 42, 0.5, 0, n)
+    q = orc.synth_queries(d, 5, 41, 42, 0.5, n, 43, 0.1, 0, 40)
+    ids = (np.arange(n, dtype=np.int64) * 7 + 1000003)[::-1].copy()
+    ix = gpu.IndexFlatIP(d)
+    ix.add_with_ids(x, ids)
+    for k in (1, 100, 2048):
+        D, I = ix.search(q, k)
+        Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), k, 0, ids=ids)
+        assert_same_results(D, I, Dr, Ir, f"k={k}")
+    with pytest.raises(RuntimeError, match="2048"):
+        ix.search(q, 4096)
+
+
+def test_device_pointers_match_host_pointers(gpu, orc):
+    import torch
+    d, n = 768, 3000
+    x = orc.synth_vectors(d, 5, 51, 52, 0.5, 0, n)
+    q = orc.synth_queries(d, 5, 51, 52, 0.5, n, 53, 0.1, 0, 129)
+    ix = gpu.IndexFlatIP(d)
+    ix.add(torch.from_numpy(x).cuda())                      # add straight from HBM
+    D, I = ix.search(q, 10)
+    Dt, It = ix.search(torch.from_numpy(q).cuda(), 10)      # query + outputs resident in HBM
+    assert Dt.is_cuda and It.is_cuda
+    assert_same_results(Dt.cpu().numpy(), It.cpu().numpy(), D, I, "device vs host pointers")
+
+
+def test_bad_arguments_raise(gpu):
+    ix = gpu.IndexFlatIP(16)
+    with pytest.raises(AssertionError):
+        ix.add(np.zeros((4, 15), np.float32))
+    with pytest.raises(RuntimeError):
+        gpu.IndexIVFPQ(None, 16, 4, 3, 8, 0)        # d not a multiple of M
+    with pytest.raises(RuntimeError, match="not.*implemented|only"):
+        gpu.IndexIVFPQ(None, 16, 4, 4, 6, 0)        # nbits != 8
+    iv = gpu.IndexIVFFlat(None, 16, 4, 0)
+    with pytest.raises(RuntimeError, match="train"):
+        iv.add(np.zeros((4, 16), np.float32))       # add before train

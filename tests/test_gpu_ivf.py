@@ -1,0 +1,210 @@
+"""GPU: IVF-Flat and IVF-PQ through the C-ABI against the oracle and the golden fixtures."""
+import numpy as np
+import pytest
+
+from util import assert_same_results, load_golden, regen_gpu, sha
+
+pytestmark = pytest.mark.gpu
+
+
+def build_ivfflat(gpu, g, x, metric=0):
+    ix = gpu.IndexIVFFlat(gpu.IndexFlatIP(g["d"]), g["d"], g["nlist"], metric)
+    ix.set_centroids(g["centroids"])
+    ix.add(x)
+    return ix
+
+
+def test_golden_ivfflat(gpu, orc):
+    g = load_golden("ivfflat_d768")
+    x, q = regen_gpu(gpu, g)
+    ix = build_ivfflat(gpu, g, x)
+    # list membership = argmax-IP assignment of the oracle, insertion order inside each list
+    a, _ = orc.assign_ip(g["centroids"], x.astype(np.float32))
+    assert sha(a) == g["assign_sha"]
+    for l in range(g["nlist"]):
+        vecs, ids = ix.get_list(l)
+        want = np.nonzero(a == l)[0]
+        assert np.array_equal(ids, want), f"list {l} membership/order"
+        assert np.array_equal(vecs, x[want].astype(np.float32))
+    ix.nprobe = g["nprobe"]
+    D, I = ix.search(q, g["k"])
+    assert_same_results(D, I, g["D"], g["I"], "ivfflat golden")
+    # nprobe = nlist must reproduce the exhaustive search (and hence the Flat index)
+    ix.nprobe = g["nlist"]
+    D, I = ix.search(q, g["k"])
+    Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), g["k"], 0)
+    assert_same_results(D, I, Dr, Ir, "nprobe=nlist")
+    ix.nprobe = 1000                      # more probes than lists: clamped, as FAISS does
+    D2, I2 = ix.search(q, g["k"])
+    assert_same_results(D2, I2, Dr, Ir, "nprobe>nlist")
+
+
+@pytest.mark.parametrize("name", ["ivfpq_d64_m16", "ivfpq_d768_m96"])
+def test_golden_ivfpq(gpu, orc, name):
+    g = load_golden(name)
+    x, q = regen_gpu(gpu, g)
+    ix = gpu.IndexIVFPQ(gpu.IndexFlatIP(g["d"]), g["d"], g["nlist"], g["M"], 8, gpu.METRIC_INNER_PRODUCT)
+    assert not ix.is_trained
+    ix.set_centroids(g["centroids"])
+    ix.set_codebooks(g["codebooks"])
+    assert ix.is_trained
+    ix.add(x[:1000]); ix.add(x[1000:])
+    assert ix.ntotal == g["n"]
+    # codes are bit-identical to ProductQuantizer::compute_code as restated by the oracle
+    a, _ = orc.assign_ip(g["centroids"], x.astype(np.float32))
+    codes = orc.pq_encode(g["codebooks"], orc.residuals(g["centroids"], x.astype(np.float32), a))
+    assert sha(a) == g["assign_sha"] and sha(codes) == g["codes_sha"]
+    for l in range(g["nlist"]):
+        c, ids = ix.get_list(l)
+        want = np.nonzero(a == l)[0]
+        assert np.array_equal(ids, want), f"list {l} membership/order"
+        assert np.array_equal(c, codes[want]), f"list {l} codes"
+    ix.nprobe = g["nprobe"]
+    D, I = ix.search(q, g["k"])
+    assert_same_results(D, I, g["D"], g["I"], name)           # ids AND fp32 scores bit-exact
+    # same recall@k as the CPU path at identical nprobe (north star) — trivially, since ids are equal
+    Dgt, Igt = orc.flat_search(q.astype(np.float32), x.astype(np.float32), g["k"], 0)
+    rec = np.mean([len(set(a_.tolist()) & set(b_.tolist())) / g["k"] for a_, b_ in zip(I, Igt)])
+    assert abs(rec - g["recall"]) < 1e-12
+    # one query at a time / odd batch sizes give the same answer (work decomposition is invisible)
+    ix.set_param("query_batch", 5)
+    D2, I2 = ix.search(q, g["k"])
+    assert_same_results(D2, I2, g["D"], g["I"], name + " batched")
+    D1, I1 = ix.search(q[7:8], g["k"])
+    assert_same_results(D1, I1, g["D"][7:8], g["I"][7:8], name + " single")
+    ix.set_param("scan_chunk", 64)          # smallest scan chunks: many work items per list
+    D3, I3 = ix.search(q, g["k"])
+    assert_same_results(D3, I3, g["D"], g["I"], name + " chunked")
+
+
+@pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8)])
+def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
+    """Other (d, M): 16-byte-granule and 4-byte-granule code layouts, dsub 8/2/48."""
+    n, nq, k = 6000, 37, 20
+    x = orc.synth_vectors(d, nlist, 61, 62, 0.5, 0, n)
+    q = orc.synth_queries(d, nlist, 61, 62, 0.5, n, 63, 0.1, 0, nq)
+    x32, q32 = x.astype(np.float32), q.astype(np.float32)
+    cen = orc.kmeans(0, x32, nlist, 4, 1234)
+    a, _ = orc.assign_ip(cen, x32)
+    cb = orc.pq_train(orc.residuals(cen, x32, a)[:2000], M, 3, 1234)
+    codes = orc.pq_encode(cb, orc.residuals(cen, x32, a))
+    lm = orc.ListMajor(a, np.arange(n), codes, nlist)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    ix.set_centroids(cen); ix.set_codebooks(cb)
+    ix.add(x)
+    for nprobe in (1, 3, nlist):
+        ix.nprobe = nprobe
+        D, I = ix.search(q, k)
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, nprobe, k)
+        assert_same_results(D, I, Dr, Ir, f"d={d} M={M} nprobe={nprobe}")
+
+
+def test_ivfpq_large_k_and_ties(gpu, orc):
+    d, M, nlist, n = 64, 16, 8, 5000
+    x = orc.synth_vectors(d, nlist, 71, 72, 0.5, 0, n)
+    x[100:140] = x[7]                    # 41 identical vectors -> identical codes -> exact score ties
+    q = np.concatenate([x[7:8], orc.synth_queries(d, nlist, 71, 72, 0.5, n, 73, 0.1, 0, 9)], 0)
+    x32, q32 = x.astype(np.float32), q.astype(np.float32)
+    cen = orc.kmeans(0, x32, nlist, 4, 1234)
+    a, _ = orc.assign_ip(cen, x32)
+    cb = orc.pq_train(orc.residuals(cen, x32, a)[:2000], M, 3, 1234)
+    lm = orc.ListMajor(a, np.arange(n), orc.pq_encode(cb, orc.residuals(cen, x32, a)), nlist)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    ix.set_centroids(cen); ix.set_codebooks(cb); ix.add(x)
+    ix.nprobe = nlist
+    for k in (64, 1000, 2048):
+        D, I = ix.search(q, k)
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, nlist, k)
+        assert np.array_equal(D, Dr), f"k={k} scores"
+        assert np.array_equal(I, Ir), f"k={k} ids (ties by id ascending)"
+
+
+def test_ivfflat_skewed_lists_and_l2(gpu, orc):
+    """One giant list + empty lists; fp32 storage; L2 metric through the bias path."""
+    rng = np.random.RandomState(5)
+    d, nlist, n = 64, 8, 5000
+    cen = rng.randn(nlist, d).astype(np.float32)
+    cen /= np.linalg.norm(cen, axis=1, keepdims=True)
+    x = (cen[0] * 3 + 0.3 * rng.randn(n, d)).astype(np.float32)      # everything lands near centroid 0
+    x[:50] = (cen[5] * 3 + 0.3 * rng.randn(50, d)).astype(np.float32)
+    q = (x[rng.randint(0, n, 45)] + 0.05 * rng.randn(45, d)).astype(np.float32)
+    a, _ = orc.assign_ip(cen, x)
+    assert np.bincount(a, minlength=nlist).max() > 4000
+    for metric in (0, 1):
+        ix = gpu.IndexIVFFlat(None, d, nlist, metric)
+        ix.set_centroids(cen)
+        ix.add(x)
+        assert ix.storage_dtype == "float32"
+        lm = orc.ListMajor(a, np.arange(n), x, nlist)
+        for nprobe in (1, 2, nlist):
+            ix.nprobe = nprobe
+            D, I = ix.search(q, 10)
+            Dr, Ir = orc.ivfflat_search(metric, cen, lm, q, nprobe, 10)
+            assert np.array_equal(I, Ir), f"metric={metric} nprobe={nprobe}"
+            assert np.allclose(D, Dr, rtol=0, atol=max(1e-30, np.abs(Dr[np.isfinite(Dr)]).max() * 2 ** -22))
+
+
+def test_train_matches_oracle(gpu, orc):
+    """rsx_train == the oracle's k-means / PQ training, bit for bit (GPU assignment, host update)."""
+    d, M, nlist, n = 64, 8, 8, 3000
+    x = orc.synth_vectors(d, nlist, 81, 82, 0.5, 0, n)
+    x32 = x.astype(np.float32)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    ix.train(x)
+    assert ix.is_trained
+    cen = orc.kmeans(0, x32[orc.kmeans_sample(n, nlist, 256, 1234)], nlist, 10, 1234)
+    assert np.array_equal(ix.get_centroids(), cen), "coarse centroids"
+    sel = orc.kmeans_sample(n, 256, 256, 1234)
+    at, _ = orc.assign_ip(cen, x32[sel])
+    cb = orc.pq_train(orc.residuals(cen, x32[sel], at), M, 25, 1234)
+    assert np.array_equal(ix.get_codebooks(), cb), "PQ codebooks"
+    ivf = gpu.IndexIVFFlat(None, d, nlist, 0)
+    ivf.train(x32)
+    assert np.array_equal(ivf.get_centroids(), cen)
+
+
+def test_write_read_roundtrip(gpu, orc, tmp_path):
+    g = load_golden("ivfpq_d64_m16")
+    x, q = regen_gpu(gpu, g)
+    ix = gpu.IndexIVFPQ(None, g["d"], g["nlist"], g["M"], 8, 0)
+    ix.set_centroids(g["centroids"]); ix.set_codebooks(g["codebooks"]); ix.add(x)
+    p = str(tmp_path / "pq.faiss")
+    gpu.write_index(ix, p)
+    ix2 = gpu.read_index(p)
+    assert ix2.ntotal == g["n"] and ix2.is_trained
+    ix2.nprobe = g["nprobe"]
+    D, I = ix2.search(q, g["k"])
+    assert_same_results(D, I, g["D"], g["I"], "pq reload")
+    gf = load_golden("flat_ip_d100")
+    xf, qf = regen_gpu(gpu, gf)
+    f = gpu.IndexFlatIP(gf["d"]); f.add(xf)
+    p2 = str(tmp_path / "flat.faiss")
+    gpu.write_index(f, p2)
+    D, I = gpu.read_index(p2).search(qf, gf["k"])
+    assert_same_results(D, I, gf["D"], gf["I"], "flat reload")
+    gi = load_golden("ivfflat_d768")
+    xi, qi = regen_gpu(gpu, gi)
+    iv = gpu.IndexIVFFlat(None, gi["d"], gi["nlist"], 0)
+    iv.set_centroids(gi["centroids"]); iv.add(xi)
+    p3 = str(tmp_path / "ivf.faiss")
+    gpu.write_index(iv, p3)
+    iv2 = gpu.read_index(p3)
+    iv2.nprobe = gi["nprobe"]
+    D, I = iv2.search(qi, gi["k"])
+    assert_same_results(D, I, gi["D"], gi["I"], "ivfflat reload")
+
+
+def test_merge_kernel_matches_reference_rule(gpu, orc):
+    e = load_golden("edge_cases")
+    Do, Io = gpu.merge_topk(e["Dm"], e["Im"])
+    assert np.array_equal(Io, e["Imo"]) and np.array_equal(Do, e["Dmo"])
+    rng = np.random.RandomState(0)
+    D = np.sort(rng.randint(0, 9, size=(8, 33, 10)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    I = rng.randint(0, 10 ** 9, size=(8, 33, 10)).astype(np.int64)
+    I[3, :, 6:] = -1
+    Dr, Ir = orc.merge_topk(D, I, 0)
+    Do, Io = gpu.merge_topk(D, I)
+    assert np.array_equal(Io, Ir) and np.array_equal(Do, Dr)
+    import torch
+    Dt, It = gpu.merge_topk(torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda())
+    assert np.array_equal(It.cpu().numpy(), Ir) and np.array_equal(Dt.cpu().numpy(), Dr)

@@ -1,0 +1,114 @@
+"""GPU: size-independent properties at larger sizes than the oracle can brute-force, and the
+real Indexer facade over pickle shards."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from util import assert_same_results
+
+pytestmark = pytest.mark.gpu
+
+
+def test_properties_200k(gpu, orc):
+    import torch
+    d, n, nlist, M, nq, k = 768, 200_000, 256, 96, 256, 10
+    x = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    gpu.synth_vectors(d, 256, 1234, 10000, 0.5, 0, n, out=x)
+    q = torch.empty((nq, d), dtype=torch.float16, device="cuda")
+    gpu.synth_queries(d, 256, 1234, 10000, 0.5, n, 999, 0.1, 0, nq, out=q)
+    torch.cuda.synchronize()
+    flat = gpu.IndexFlatIP(d); flat.add(x)
+    Dg, Ig = flat.search(q, k)
+    Dg, Ig = Dg.cpu().numpy(), Ig.cpu().numpy()
+    # spot-check the exact index against the oracle on a sample of queries
+    xs = x.cpu().numpy()
+    Dr, Ir = orc.flat_search(q[:8].cpu().numpy().astype(np.float32), xs.astype(np.float32), k, 0)
+    assert_same_results(Dg[:8], Ig[:8], Dr, Ir, "flat 200k")
+    # sharded Flat: two half indexes + merge kernel == one index (exact)
+    h0, h1 = gpu.IndexFlatIP(d), gpu.IndexFlatIP(d)
+    h0.add(x[: n // 2]); h1.add(x[n // 2:])
+    D0, I0 = h0.search(q, k); D1, I1 = h1.search(q, k)
+    Dm, Im = gpu.merge_topk(torch.stack([D0, D1]), torch.stack([I0, I1 + n // 2]))
+    assert_same_results(Dm.cpu().numpy(), Im.cpu().numpy(), Dg, Ig, "sharded flat")
+    # IVF-Flat: nprobe = nlist is exhaustive; recall grows with nprobe
+    ivf = gpu.IndexIVFFlat(None, d, nlist, 0)
+    ivf.train(x[:65536]); ivf.add(x)
+    ivf.nprobe = nlist
+    D, I = ivf.search(q, k)
+    assert_same_results(D.cpu().numpy(), I.cpu().numpy(), Dg, Ig, "ivfflat exhaustive")
+    rec = []
+    for nprobe in (1, 8, 64):
+        ivf.nprobe = nprobe
+        _, I = ivf.search(q, k)
+        I = I.cpu().numpy()
+        rec.append(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(I, Ig)]))
+    assert rec[0] <= rec[1] <= rec[2] and rec[2] > 0.9, rec
+    # IVF-PQ: idempotent, batch-invariant, and identical to the oracle's scan on a sample
+    pq = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    pq.set_centroids(ivf.get_centroids())
+    pq.train(x[:65536]) if False else None
+    cen = ivf.get_centroids()
+    a, _ = orc.assign_ip(cen, xs[:20000].astype(np.float32))
+    cb = orc.pq_train(orc.residuals(cen, xs[:20000].astype(np.float32), a)[:4096], M, 2, 1234)
+    pq.set_codebooks(cb)
+    pq.add(x)
+    pq.nprobe = 16
+    D1, I1 = pq.search(q, k)
+    D2, I2 = pq.search(q, k)
+    assert torch.equal(D1, D2) and torch.equal(I1, I2)
+    pq.set_param("query_batch", 100)
+    D3, I3 = pq.search(q, k)
+    assert torch.equal(D1, D3) and torch.equal(I1, I3)
+    # oracle on the exported lists for 4 queries
+    lists = [pq.get_list(l) for l in range(nlist)]
+    off = np.zeros(nlist + 1, np.int64); np.cumsum([len(i) for _, i in lists], out=off[1:])
+
+    class LM: pass
+    lm = LM(); lm.list_off = off
+    lm.payload = np.concatenate([c for c, _ in lists]); lm.ids = np.concatenate([i for _, i in lists])
+    Dr, Ir = orc.ivfpq_search(cen, cb, lm, q[:4].cpu().numpy().astype(np.float32), 16, k)
+    assert_same_results(D1[:4].cpu().numpy(), I1[:4].cpu().numpy(), Dr, Ir, "ivfpq 200k vs oracle")
+
+
+class NS(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+@pytest.mark.parametrize("index_type", ["Flat", "IVFFlat", "IVFPQ"])
+def test_indexer_facade_on_gpu(gpu, orc, tmp_path, index_type):
+    """Config 1 shape (a few thousand fp16 x 768 passages, k = 3) through Indexer(cfg).search."""
+    from src.indicies.base import Indexer
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "emb")); os.makedirs(os.path.join(tmp, "psg"))
+    d, per = 768, 1800
+    embs = []
+    for s in range(2):
+        e = orc.synth_vectors(d, 16, 11, 100 + s, 0.5, 0, per)
+        embs.append(e)
+        with open(os.path.join(tmp, "emb", f"passages_{s:02d}.pkl"), "wb") as f:
+            pickle.dump((list(range(per)), e), f)
+        with open(os.path.join(tmp, "psg", f"raw_passages-{s}-of-2.pkl"), "wb") as f:
+            pickle.dump([{"text": f"s{s}c{c}"} for c in range(per)], f)
+    cfg = NS(datastore=NS(embedding=NS(embedding_dir=os.path.join(tmp, "emb"), prefix="passages",
+                                       passages_dir=os.path.join(tmp, "psg")),
+                          index=NS(index_type=index_type, index_shard_ids=[0, 1], projection_size=d,
+                                   sample_train_size=3000, ncentroids=16, probe=16, n_subquantizers=96, n_bits=8)))
+    ix = Indexer(cfg)
+    allx = np.concatenate(embs, 0)
+    q = orc.synth_queries(d, 16, 11, 100, 0.5, per, 7, 0.1, 0, 300)
+    scores, passages, db_ids = ix.search(q, k=3)
+    D, I = orc.flat_search(q.astype(np.float32), allx.astype(np.float32), 3, 0)
+    if index_type != "IVFPQ":       # probe = ncentroids -> exhaustive -> identical to brute force
+        assert db_ids == [[[int(i) // per, int(i) % per] for i in row] for row in I]
+        assert scores == D.tolist()
+        assert passages[0][0] == f"s{I[0, 0] // per}c{I[0, 0] % per}"
+    else:
+        got = np.array([[s_ * per + c for s_, c in row] for row in db_ids])
+        rec = np.mean([len(set(a.tolist()) & set(b.tolist())) / 3 for a, b in zip(got, I)])
+        assert rec > 0.3
+    ix2 = Indexer(cfg)              # reload from the files written above
+    s2, p2, d2 = ix2.search(q, k=3)
+    assert d2 == db_ids and s2 == scores and p2 == passages

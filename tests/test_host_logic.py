@@ -1,0 +1,174 @@
+"""CPU: the host-side mirror of the reference interface (paths, file contract, id maps, ctxs, merge),
+driven through a test-double engine (tests/fake_engine.py) so no GPU is needed."""
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from util import GOLDEN
+
+
+class NS(dict):
+    """attribute + .get access, like an OmegaConf node"""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def make_cfg(tmp, index_type, shard_ids, **index_kw):
+    index = NS(index_type=index_type, index_shard_ids=shard_ids, projection_size=32, sample_train_size=600,
+               ncentroids=4, probe=4, n_subquantizers=4, n_bits=8)
+    index.update(index_kw)
+    return NS(
+        datastore=NS(domain="unit", embedding=NS(embedding_dir=os.path.join(tmp, "emb"), prefix="passages",
+                                                 passages_dir=os.path.join(tmp, "psg")), index=index),
+        evaluation=NS(eval_output_dir=os.path.join(tmp, "out"), data=NS(eval_data=os.path.join(tmp, "q.jsonl")),
+                      search=NS(n_docs=3, overwrite=False)),
+        model=NS(),
+    )
+
+
+def write_datastore(tmp, orc, n_shards=2, per=400, d=32):
+    os.makedirs(os.path.join(tmp, "emb"), exist_ok=True)
+    os.makedirs(os.path.join(tmp, "psg"), exist_ok=True)
+    embs = []
+    for s in range(n_shards):
+        e = orc.synth_vectors(d, 6, 11, 100 + s, 0.5, 0, per)
+        embs.append(e)
+        with open(os.path.join(tmp, "emb", f"passages_{s:02d}.pkl"), "wb") as f:
+            pickle.dump((list(range(per)), e), f)          # (ids, fp16 embeddings) — src/embed.py:155-156
+        with open(os.path.join(tmp, "psg", f"raw_passages-{s}-of-{n_shards}.pkl"), "wb") as f:
+            pickle.dump([{"text": f"shard {s} chunk {c} é", "id": c} for c in range(per)], f)
+    return embs
+
+
+@pytest.fixture()
+def fake(monkeypatch, orc):
+    import fake_engine
+    import rsx
+    for name in ("IndexFlatIP", "IndexIVFFlat", "IndexIVFPQ", "read_index", "write_index"):
+        monkeypatch.setattr(rsx, name, getattr(fake_engine, name))
+    return fake_engine
+
+
+def test_paths_match_reference_golden():
+    from src.indicies.index_utils import get_index_dir_and_embedding_paths
+    with open(os.path.join(GOLDEN, "paths_golden.json")) as f:
+        gold = json.load(f)
+    for c in gold["cases"]:
+        cfg = NS(datastore=NS(embedding=NS(embedding_dir=c["embedding_dir"], prefix=c["prefix"]),
+                              index=NS(index_type=c["index_type"], index_shard_ids=c["index_shard_ids"])))
+        index_dir, paths = get_index_dir_and_embedding_paths(cfg)
+        assert index_dir == c["index_dir"] and paths == c["embedding_paths"]
+
+
+def test_index_file_names():
+    # reference src/indicies/base.py:23-30
+    from src.indicies.base import index_file_names
+    a = NS(index_type="IVFPQ", sample_train_size=1000000, projection_size=768, ncentroids=4096)
+    assert index_file_names(a) == ("index_IVFPQ.1000000.768.4096.faiss", True)
+    a.index_type = "IVFFlat"
+    assert index_file_names(a) == ("index_IVFFlat.1000000.768.4096.faiss", True)
+    assert index_file_names(NS(index_type="Flat")) == ("index_Flat.faiss", False)
+
+
+@pytest.mark.parametrize("index_type", ["Flat", "IVFFlat", "IVFPQ"])
+def test_indexer_facade_contract(tmp_path, orc, fake, index_type):
+    from src.indicies.base import Indexer
+    tmp = str(tmp_path)
+    embs = write_datastore(tmp, orc)
+    cfg = make_cfg(tmp, index_type, [1, 0])
+    ix = Indexer(cfg)
+    index_dir = os.path.join(tmp, "emb", f"index_{index_type}", "0_1")
+    name = "index_Flat.faiss" if index_type == "Flat" else f"index_{index_type}.600.32.4.faiss"
+    assert os.path.exists(os.path.join(index_dir, name)) and os.path.exists(os.path.join(index_dir, name + ".meta"))
+    assert os.path.exists(os.path.join(index_dir, "passage_pos_id_map.pkl"))
+    if index_type != "Flat":
+        assert os.path.exists(os.path.join(index_dir, name + ".trained"))
+    ds = ix.datastore
+    assert ds.index.ntotal == 800 and len(ds.index_id_to_db_id) == 800
+    assert ds.index_id_to_db_id[0] == [0, 0] and ds.index_id_to_db_id[400] == [1, 0]   # shard order, sequential ids
+    q = np.concatenate([embs[0][5:6], embs[1][7:8]], 0)
+    scores, passages, db_ids = ix.search(q, k=3)
+    assert isinstance(scores, list) and len(scores) == 2 and len(scores[0]) == 3 and isinstance(scores[0][0], float)
+    assert isinstance(passages[0][0], str) and len(db_ids[0]) == 3
+    if index_type == "Flat":   # inner product: compare with the brute-force oracle over both shards
+        D, I = orc.flat_search(q.astype(np.float32), np.concatenate(embs, 0).astype(np.float32), 3, 0)
+        assert db_ids == [[[int(i) // 400, int(i) % 400] for i in row] for row in I]
+        assert scores == D.tolist()
+        assert passages[0][0] == f"shard {I[0, 0] // 400} chunk {I[0, 0] % 400} é"
+    # second construction loads instead of building (file-existence contract, flat.py:37 / ivf_flat.py:69)
+    mtime = os.path.getmtime(os.path.join(index_dir, name))
+    ix2 = Indexer(cfg)
+    assert os.path.getmtime(os.path.join(index_dir, name)) == mtime
+    s2, p2, d2 = ix2.search(q, k=3)
+    assert d2 == db_ids and s2 == scores
+    if index_type != "Flat":
+        assert ix2.datastore.index.nprobe == 4     # probe applied at load (ivf_flat.py:73)
+
+
+def test_unknown_index_type_raises(tmp_path, orc, fake):
+    from src.indicies.base import Indexer
+    write_datastore(str(tmp_path), orc)
+    with pytest.raises(NotImplementedError):
+        Indexer(make_cfg(str(tmp_path), "PQ", [0]))     # stale configs in the reference hit this (base.py:72)
+
+
+def test_search_driver_and_merge(tmp_path, orc, fake):
+    import src.search as S
+    tmp = str(tmp_path)
+    embs = write_datastore(tmp, orc)
+    data = [{"raw_query": ""}, {"raw_query": "a"}, {"raw_query": "b"}]
+    q = np.concatenate([embs[0][1:2], embs[1][2:3]], 0)
+    outs = []
+    for shard in ([0], [1]):
+        cfg = make_cfg(tmp, "Flat", shard)
+        S.search_dense_topk(cfg, data=data, questions_embedding=q)
+        path = S.get_search_output_path(cfg, shard)
+        assert path == os.path.join(tmp, "out", str(shard[0]), "q_retrieved_results.jsonl")
+        rows = [json.loads(l) for l in open(path)]
+        assert rows[0]["ctxs"] == [None]
+        assert set(rows[1]["ctxs"][0]) == {"id", "source", "retrieval text", "retrieval score"}
+        assert isinstance(rows[1]["ctxs"][0]["retrieval score"], str) and rows[1]["ctxs"][0]["source"] == "unit"
+        outs.append(rows)
+    # multi-index merge == brute force over both shards (scores as the reference serialises them)
+    cfg = make_cfg(tmp, "Flat", [[0], [1]])
+    merged_path = S.post_hoc_merge_topk(cfg)
+    assert merged_path == os.path.join(tmp, "out", "0-1", "q_retrieved_results.jsonl")
+    merged = [json.loads(l) for l in open(merged_path)]
+    allx = np.concatenate(embs, 0).astype(np.float32)
+    D, I = orc.flat_search(q.astype(np.float32), allx, 3, 0)
+    for qi, row in enumerate(merged[1:]):
+        got = [(c["id"], float(c["retrieval score"])) for c in row["ctxs"]]
+        want = [([int(i) // 400, int(i) % 400], float(str(float(s)))) for i, s in zip(I[qi], D[qi])]
+        assert got == want
+    # skip-if-exists contract
+    before = os.path.getmtime(merged_path)
+    S.post_hoc_merge_topk(cfg)
+    assert os.path.getmtime(merged_path) == before
+
+
+def test_merge_ctxs_is_stable():
+    from src.search import merge_ctxs
+    mk = lambda tag, s: {"id": tag, "retrieval score": str(s)}
+    out = merge_ctxs([[mk("a0", 5.0), mk("a1", 3.0)], [mk("b0", 5.0), mk("b1", 4.0)], [mk("c0", 5.0), mk("c1", 4.0)]], 4)
+    assert [c["id"] for c in out] == ["a0", "b0", "c0", "b1"]   # ties keep earlier shard first
+
+
+def test_safe_write_jsonl_removes_partial(tmp_path):
+    from src.search import safe_write_jsonl
+    p = str(tmp_path / "x.jsonl")
+    safe_write_jsonl([{"a": 1}, {"b": {1, 2}}], p)    # a set is not JSON-serialisable
+    assert not os.path.exists(p)
+    safe_write_jsonl([{"a": 1}], p)
+    assert open(p).read() == '{"a": 1}\n'
+
+
+def test_shard_range():
+    from sharded import shard_range
+    spans = [shard_range(103, r, 8) for r in range(8)]
+    assert spans[0][0] == 0 and spans[-1][1] == 103
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

@@ -1,0 +1,31 @@
+#!/bin/bash
+# One GPU-box session: environment facts, GPU tests, smoke, bench, rocprof. Everything is logged under
+# gpurun_out/ so a single call returns as much evidence as possible.  Usage: tools/gpu_round.sh [stage ...]
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+STAGES="${*:-env tests smoke bench_small}"
+for s in $STAGES; do
+  case $s in
+    env)
+      { rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; nproc; free -g | head -2; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; python -c "import faiss" 2>&1 | tail -1; } > gpurun_out/env.log 2>&1 ;;
+    tests)
+      timeout 1500 python -m pytest tests -q -m gpu -x --timeout 600 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log ;;
+    tests_all)
+      timeout 1500 python -m pytest tests -q -m gpu --timeout 600 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log ;;
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log ;;
+    bench_small)
+      timeout 900 python bench.py --n 4000000 --nlist 1024 --steps 5 --warmup 2 --cpu-queries 32 > gpurun_out/bench_small.json 2> gpurun_out/bench_small.log; echo "exit $?" >> gpurun_out/bench_small.log ;;
+    bench)
+      timeout 1700 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "exit $?" >> gpurun_out/bench.log ;;
+    prof)
+      ( cd /tmp && timeout 1700 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --cpu-queries 0 --no-recall > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.log" ); echo "exit $?" >> gpurun_out/prof.log
+      find gpurun_out/prof -name "*stats*" | head >> gpurun_out/prof.log ;;
+    pmc)
+      ( cd /tmp && timeout 1700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o r01 -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --cpu-queries 0 --no-recall > "$OLDPWD/gpurun_out/pmc_bench.json" 2> "$OLDPWD/gpurun_out/pmc.log" ); echo "exit $?" >> gpurun_out/pmc.log ;;
+  esac
+done
+ls -la gpurun_out > gpurun_out/ls.txt
+tail -5 gpurun_out/*.log
