@@ -7,10 +7,21 @@ from util import assert_same_results, load_golden, regen_gpu
 pytestmark = pytest.mark.gpu
 
 
+def test_synth_matches_oracle(gpu, orc):
+    """The HIP generator (bench data) is bit-identical to the oracle's generator."""
+    for d, nc, n in [(768, 64, 3000), (100, 7, 500), (64, 1, 100)]:
+        a = gpu.synth_vectors(d, nc, 1234, 10000, 0.5, 5, n)
+        b = orc.synth_vectors(d, nc, 1234, 10000, 0.5, 5, n)
+        assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"vectors d={d}"
+        qa = gpu.synth_queries(d, nc, 1234, 10000, 0.5, n, 999, 0.1, 3, 50)
+        qb = orc.synth_queries(d, nc, 1234, 10000, 0.5, n, 999, 0.1, 3, 50)
+        assert np.array_equal(qa.view(np.uint16), qb.view(np.uint16)), f"queries d={d}"
+
+
 @pytest.mark.parametrize("name", ["flat_ip_d768", "flat_l2_d64", "flat_ip_d100"])
 def test_golden(gpu, name):
     g = load_golden(name)
-    x, q = regen_gpu(gpu, g)          # also proves the HIP generator is bit-identical to the oracle's
+    x, q = regen_gpu(gpu, g)
     ix = gpu.IndexFlat(g["d"], g["metric"])
     ix.add(x)
     assert ix.ntotal == g["n"] and ix.storage_dtype == "float16"

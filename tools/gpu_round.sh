@@ -20,6 +20,8 @@ for s in $STAGES; do
       timeout 900 python bench.py --n 4000000 --nlist 1024 --steps 5 --warmup 2 --cpu-queries 32 > gpurun_out/bench_small.json 2> gpurun_out/bench_small.log; echo "exit $?" >> gpurun_out/bench_small.log ;;
     bench)
       timeout 1700 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "exit $?" >> gpurun_out/bench.log ;;
+    diag)
+      timeout 300 python tools/diag_synth.py > gpurun_out/diag_synth.log 2>&1 ;;
     prof)
       ( cd /tmp && timeout 1700 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --cpu-queries 0 --no-recall > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.log" ); echo "exit $?" >> gpurun_out/prof.log
       find gpurun_out/prof -name "*stats*" | head >> gpurun_out/prof.log ;;
@@ -28,4 +30,4 @@ for s in $STAGES; do
   esac
 done
 ls -la gpurun_out > gpurun_out/ls.txt
-tail -5 gpurun_out/*.log
+for f in gpurun_out/*.log; do echo "== $f"; tail -n 5 "$f"; done
