@@ -170,7 +170,8 @@ def main():
     step(args.warmup)
     scanned = index.get_timing("scanned_vectors")
     index.set_param("profile", 0)
-    scan_bytes = scanned * args.m
+    launches_per_step = max(1.0, scan_launches / args.steps)
+    scan_bytes = scanned * args.m / launches_per_step          # algorithmic bytes of ONE launch
     ms_per_launch = scan_ms / max(1.0, scan_launches)
     achieved = scan_bytes / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
 
@@ -249,6 +250,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_pq_scan", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(ms_per_launch, 4),
+                         "launches_per_step": launches_per_step,
                          "note": "achieved = scanned code bytes (sum over (query, probed list) of len*M) / HIP-event "
                                  "duration of the scan launch on the library stream, rank 0"},
             "stage_ms_per_step": stage_ms,

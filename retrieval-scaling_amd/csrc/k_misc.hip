@@ -98,7 +98,11 @@ __device__ inline uint32_t synth_pick(uint32_t seed, uint64_t i, uint32_t n) { r
 __device__ inline __half synth_elem(int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, uint64_t i, uint32_t t) {
     uint32_t j = synth_pick(seed_x, i, (uint32_t)ncentres);
     float c = synth_z(seed_c, j, t);
-    return __float2half_rn(__fmaf_rn(sigma, synth_z(seed_x, i, t), c));
+    float v = __fmaf_rn(sigma, synth_z(seed_x, i, t), c);
+    // keep the fp32 rounding step: without this hipcc fuses fma + convert into v_fma_mixlo_f16
+    // (one rounding straight to fp16), which is not what the spec / oracle compute
+    asm volatile("" : "+v"(v));
+    return __float2half_rn(v);
 }
 __global__ void k_synth_vectors(int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t i0,
                                 int64_t n, __half* out) {
@@ -125,7 +129,9 @@ __global__ void k_synth_queries(int d, int ncentres, uint32_t seed_c, uint32_t s
         uint64_t rr = (uint64_t)(r0 + r);
         uint64_t b = synth_pick(seed_q, rr, (uint32_t)nbase);
         float base = __half2float(synth_elem(ncentres, seed_c, seed_x, sigma, b, t));
-        out[e] = __float2half_rn(__fmaf_rn(sigma_q, synth_z(seed_q, rr, t), base));
+        float v = __fmaf_rn(sigma_q, synth_z(seed_q, rr, t), base);
+        asm volatile("" : "+v"(v));
+        out[e] = __float2half_rn(v);
     }
 }
 void launch_synth_queries(int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t nbase,

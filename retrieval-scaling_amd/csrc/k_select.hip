@@ -44,6 +44,11 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     if (end > n) end = n;
     const float* sf = (const float*)a.in + row * a.row_stride;
     const uint64_t* sk = (const uint64_t*)a.in + row * a.row_stride;
+    if (start >= end && !a.init) {  // segment beyond the row's length: no candidates
+        uint64_t* o = a.out + row * a.out_row_stride + (int64_t)seg * KP;
+        for (int i = lane; i < KP; i += 64) o[i] = 0;
+        return;
+    }
 
     int cnt = 0;
     uint64_t tau = 0;

@@ -144,7 +144,7 @@ struct rsx_index {
     int query_batch = 1024;
     int scan_chunk = 0;
     int profile = 0;
-    int64_t temp_budget = (int64_t)6 << 30;
+    int64_t temp_budget = (int64_t)16 << 30;
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_state,
@@ -176,10 +176,15 @@ static void ensure_capacity(rsx_index* h, const std::vector<int64_t>& need, bool
     bool need_norms = (h->metric == RSX_METRIC_L2) && h->kind != KIND_IVFPQ;
     if (!grow && h->data.p && (!need_ids || h->ids.p) && (!need_norms || h->norms.p)) return;
 
+    // Amortised growth: a re-layout moves the whole index, so when ANY list overflows EVERY list gets
+    // headroom proportional to its current need (2x for PQ codes, 1.5x for raw rows); the number of
+    // re-layouts is then logarithmic in the final size instead of one per add batch.
     std::vector<int64_t> ncap(h->h_cap), nbase((size_t)h->nlist);
     for (int l = 0; l < h->nlist; l++) {
         int64_t nd = need[(size_t)l];
-        if (nd > ncap[(size_t)l]) ncap[(size_t)l] = round_up(exact ? nd : nd + nd / 2, al);
+        int64_t want = exact ? nd : (h->kind == KIND_IVFPQ ? 2 * nd + 64 : nd + nd / 2);
+        if (grow && round_up(want, al) > ncap[(size_t)l]) ncap[(size_t)l] = round_up(want, al);
+        if (nd > ncap[(size_t)l]) ncap[(size_t)l] = round_up(nd, al);
         if (ncap[(size_t)l] == 0 && h->kind == KIND_FLAT) ncap[(size_t)l] = al;
     }
     int64_t tot = 0;
