@@ -142,7 +142,8 @@ int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, c
 int rsx_get(rsx_index_t* h, const char* key, int64_t* out);
 
 /* Tuning knobs that do not change results: "query_batch" (max queries per internal pass),
- * "scan_chunk" (vectors per scan work item, 0 = auto), "profile" (1 = record stage timings with HIP
+ * "scan_chunk" (vectors per scan work item, 0 = auto), "scan_kernel" (IVFPQ: 0 = auto, 1 = per-pair
+ * v1 kernel, for A/B measurements), "profile" (1 = record stage timings with HIP
  * events on the library's stream; 2 = additionally count the vectors each search scanned). */
 int rsx_set_param(rsx_index_t* h, const char* key, double value);
 

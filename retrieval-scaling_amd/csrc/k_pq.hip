@@ -127,6 +127,146 @@ int launch_pq_scan(const PQScanArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------
+// k_pq_scan2: list-major scan, TWO queries per LDS read.
+//
+// The v1 kernel above is bound by the LDS gather rate: one ds_read_b32 per (query, vector, m) and
+// ~3.5-way bank conflicts on random codes (measured 8.5 look-ups/clk/CU).  Here the (query, probe)
+// pairs of a batch are grouped by inverted list (k_select.hip: launch_group_pairs, groups of 2); a
+// workgroup takes (list, pair of queries, tile of slabs), stages BOTH queries' tables interleaved
+// as float2 [m][code] and every lane issues ONE ds_read_b64 per (vector, m) that serves both
+// queries: half the LDS instructions at the same conflict rate, and each list's codes are pulled
+// from HBM/L2 once per query pair instead of once per query.  160 KiB of LDS holds 48
+// sub-quantisers of a float2 table (96 KiB), so M = 96 runs in two passes with the partial sums
+// kept in registers; the additions still happen in m = 0..M-1 order, so scores stay bit-identical
+// to v1 / the oracle.
+// NCH = Mpad/16 granules per vector, VPL = slabs per wave per tile (register accumulators).
+struct PQScan2Args {
+    PQScanArgs b;
+    const int32_t* pairs_sorted; const int32_t* pair_off; const int32_t* group_off; const int32_t* total_groups;
+    int nlist; int max_groups; int max_tiles;
+};
+
+template <int NCH, int VPL>
+__global__ __launch_bounds__(1024) void k_pq_scan2(PQScan2Args A) {
+    extern __shared__ __attribute__((aligned(16))) float2 pq_lut2_s[];
+    constexpr int GPC = NCH < 3 ? NCH : 3;  // granules (16 sub-quantisers each) per pass
+    constexpr int NP = (NCH + GPC - 1) / GPC;
+    const PQScanArgs& a = A.b;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = blockIdx.x;
+    if (g >= *A.total_groups) return;
+    int lo = 0, hi = A.nlist;  // largest l with group_off[l] <= g
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.group_off[mid] <= g) lo = mid; else hi = mid; }
+    const int l = lo;
+    const int gi = g - A.group_off[l];
+    const int cnt = A.pair_off[l + 1] - A.pair_off[l];
+    const int np = (cnt - 2 * gi) > 1 ? 2 : 1;
+    const int pair0 = A.pair_off[l] + 2 * gi;
+    const int64_t len = a.list_len[l];
+    const int64_t nslab = (len + 63) >> 6;
+    const int64_t s0 = (int64_t)blockIdx.y * (16 * VPL);
+    if (s0 >= nslab) return;
+    const int p0 = A.pairs_sorted[pair0];
+    const int p1 = (np > 1) ? A.pairs_sorted[pair0 + 1] : p0;
+    const int64_t q0 = p0 / a.nprobe, q1 = p1 / a.nprobe;
+    const float* lut0 = a.lut + q0 * a.Mpad * 256;
+    const float* lut1 = a.lut + q1 * a.Mpad * 256;
+
+    float2 acc[VPL];
+#pragma unroll
+    for (int u = 0; u < VPL; u++) acc[u] = make_float2(0.0f, 0.0f);
+
+    const int64_t slab_base = a.list_base[l] >> 6;
+    const int64_t slab_bytes = (int64_t)64 * a.Mpad;
+#pragma unroll
+    for (int pass = 0; pass < NP; pass++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int g0 = pass * GPC;
+        const int ng = (NCH - g0) < GPC ? (NCH - g0) : GPC;
+        if (pass > 0) __syncthreads();
+        for (int i = tid; i < ng * 16 * 256; i += 1024)
+            pq_lut2_s[i] = make_float2(lut0[g0 * 16 * 256 + i], lut1[g0 * 16 * 256 + i]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < VPL; u++) {
+            const int64_t s = s0 + w + 16 * u;
+            if (s < nslab) {
+                const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
+                uint4 c[GPC];
+#pragma unroll
+                for (int gg = 0; gg < GPC; gg++)
+                    if (gg < ng) c[gg] = *reinterpret_cast<const uint4*>(sp + (g0 + gg) * 1024 + lane * 16);
+                float2 sum = acc[u];
+#pragma unroll
+                for (int gg = 0; gg < GPC; gg++) {
+                    if (gg < ng) {
+                        const uint32_t wds[4] = {c[gg].x, c[gg].y, c[gg].z, c[gg].w};
+#pragma unroll
+                        for (int b = 0; b < 16; b++) {
+                            uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                            float2 t = pq_lut2_s[(gg * 16 + b) * 256 + code];
+                            sum.x += t.x; sum.y += t.y;
+                        }
+                    }
+                }
+                acc[u] = sum;
+            }
+        }
+    }
+    const float d0 = a.probe_dis0[p0], d1 = a.probe_dis0[p1];
+    float* out0 = a.temp + q0 * a.tstride + a.seg_start[q0 * (a.nprobe + 1) + (p0 - (int)q0 * a.nprobe)];
+    float* out1 = a.temp + q1 * a.tstride + a.seg_start[q1 * (a.nprobe + 1) + (p1 - (int)q1 * a.nprobe)];
+#pragma unroll
+    for (int u = 0; u < VPL; u++) {
+        const int64_t s = s0 + w + 16 * u;
+        if (s < nslab) {
+            const int64_t pos = s * 64 + lane;
+            out0[pos] = (pos < len) ? d0 + acc[u].x : -__builtin_inff();
+            if (np > 1) out1[pos] = (pos < len) ? d1 + acc[u].y : -__builtin_inff();
+        }
+    }
+}
+
+template <int NCH, int VPL>
+static int launch_pq_scan2_t(const PQScan2Args& A, hipStream_t st) {
+    constexpr int GPC = NCH < 3 ? NCH : 3;
+    size_t shm = (size_t)GPC * 16 * 256 * sizeof(float2);
+    if (hipFuncSetAttribute((const void*)k_pq_scan2<NCH, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+        return -1;
+    dim3 grid((unsigned)A.max_groups, (unsigned)A.max_tiles);
+    hipLaunchKernelGGL((k_pq_scan2<NCH, VPL>), grid, dim3(1024), shm, st, A);
+    return 0;
+}
+template <int NCH>
+static int launch_pq_scan2_v(const PQScan2Args& A, int vpl, hipStream_t st) {
+    switch (vpl) {
+        case 8: return launch_pq_scan2_t<NCH, 8>(A, st);
+        case 4: return launch_pq_scan2_t<NCH, 4>(A, st);
+        case 2: return launch_pq_scan2_t<NCH, 2>(A, st);
+        default: return launch_pq_scan2_t<NCH, 1>(A, st);
+    }
+}
+// returns 0 on launch, -1 if this (M, layout) has no v2 kernel (caller falls back to k_pq_scan)
+int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int32_t* pair_off, const int32_t* group_off,
+                    const int32_t* total_groups, int nlist, int max_groups, int64_t max_slabs, int vpl, hipStream_t st) {
+    if (a.CB != 16 || max_groups <= 0) return -1;
+    PQScan2Args A;
+    A.b = a; A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
+    A.nlist = nlist; A.max_groups = max_groups;
+    A.max_tiles = (int)((max_slabs + 16 * vpl - 1) / (16 * vpl));
+    if (A.max_tiles > 65535) return -1;
+    switch (a.Mpad / 16) {
+        case 1: return launch_pq_scan2_v<1>(A, vpl, st);
+        case 2: return launch_pq_scan2_v<2>(A, vpl, st);
+        case 3: return launch_pq_scan2_v<3>(A, vpl, st);
+        case 4: return launch_pq_scan2_v<4>(A, vpl, st);
+        case 6: return launch_pq_scan2_v<6>(A, vpl, st);
+        case 8: return launch_pq_scan2_v<8>(A, vpl, st);
+        default: return -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Encode: 256 vectors per workgroup (one per thread); the codebook of subspace m is staged in LDS
 // and read with broadcast ds_reads (all lanes the same address: conflict-free).
 template <int DSUB>

@@ -166,8 +166,8 @@ __global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int32_t* 
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npairs) { int32_t l = probe_list[i]; if (l >= 0) atomicAdd(&cnt[l], 1); }
 }
-// single workgroup exclusive scan over lists: pair_off (pairs) and group_off (groups of 16)
-__global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlist, int32_t* pair_off,
+// single workgroup exclusive scan over lists: pair_off (pairs) and group_off (groups of G pairs)
+__global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlist, int G, int32_t* pair_off,
                                                     int32_t* group_off, int32_t* total_groups) {
     __shared__ int32_t sp[1024], sg[1024];
     int t = threadIdx.x;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
     int lo = t * per, hi = lo + per;
     if (hi > nlist) hi = nlist;
     int32_t ap = 0, ag = 0;
-    for (int l = lo; l < hi; l++) { ap += cnt[l]; ag += (cnt[l] + 15) / 16; }
+    for (int l = lo; l < hi; l++) { ap += cnt[l]; ag += (cnt[l] + G - 1) / G; }
     sp[t] = ap; sg[t] = ag;
     __syncthreads();
     if (t == 0) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
     ap = sp[t]; ag = sg[t];
     for (int l = lo; l < hi; l++) {
         pair_off[l] = ap; group_off[l] = ag;
-        ap += cnt[l]; ag += (cnt[l] + 15) / 16;
+        ap += cnt[l]; ag += (cnt[l] + G - 1) / G;
     }
 }
 __global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, const int32_t* pair_off,
@@ -198,13 +198,13 @@ __global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, const 
         if (l >= 0) { int s = atomicAdd(&cursor[l], 1); pairs_sorted[pair_off[l] + s] = (int32_t)i; }
     }
 }
-void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int32_t* cnt, int32_t* cursor,
-                        int32_t* pair_off, int32_t* group_off, int32_t* total_groups, int32_t* pairs_sorted,
-                        hipStream_t st) {
+void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
+                        int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
+                        int32_t* pairs_sorted, hipStream_t st) {
     hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
     hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
     hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, cnt);
-    hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, pair_off, group_off, total_groups);
+    hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, group_size, pair_off, group_off, total_groups);
     hipLaunchKernelGGL(k_pair_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs,
                        pair_off, cursor, pairs_sorted);
 }

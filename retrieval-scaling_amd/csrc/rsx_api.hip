@@ -143,6 +143,7 @@ struct rsx_index {
     // knobs
     int query_batch = 1024;
     int scan_chunk = 0;
+    int scan_kernel = 0;  // 0 = auto (list-major v2 when the layout allows), 1 = force the per-pair v1 kernel
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
 
@@ -746,18 +747,41 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         a.seg_start = h->w_segstart.as<int64_t>(); a.nq = nq; a.nprobe = nprobe;
         a.temp = h->w_temp.as<float>(); a.tstride = tmax;
         int64_t max_slabs = std::max<int64_t>(1, maxlen / 64);
-        int64_t spc;
-        if (h->scan_chunk > 0) spc = std::max<int64_t>(16, h->scan_chunk / 64);
-        else {
-            // enough work items to fill 256 CUs several times over, but no smaller than 32 slabs
-            int64_t pairs = nq * nprobe;
-            int64_t want_items = 4096;
-            int64_t chunks = std::max<int64_t>(1, (want_items + pairs - 1) / pairs);
-            spc = std::max<int64_t>(32, (max_slabs + chunks - 1) / chunks);
+        int64_t pairs = nq * nprobe;
+        bool done = false;
+        if (h->scan_kernel != 1 && h->CB == 16) {
+            // v2: list-major, two queries per LDS read
+            h->w_pairs.ensure((size_t)(pairs + 4 * (size_t)(nlist + 1) + 4) * 4);
+            int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
+            int32_t* cnt = pairs_sorted + pairs;
+            int32_t* cursor = cnt + (nlist + 1);
+            int32_t* pair_off = cursor + (nlist + 1);
+            int32_t* group_off = pair_off + (nlist + 1);
+            int32_t* total_groups = group_off + (nlist + 1);
+            launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 2, cnt, cursor, pair_off, group_off, total_groups,
+                               pairs_sorted, h->st);
+            tm.mark("group");
+            int max_groups = (int)std::min<int64_t>(pairs, pairs / 2 + std::min<int64_t>(nlist, pairs));
+            int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
+            int vpl = 8;
+            if (h->scan_chunk > 0) vpl = std::max(1, std::min(8, h->scan_chunk / 1024));
+            else while (vpl > 1 && (pairs / 2 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
+            if (vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
+            done = launch_pq_scan2(a, pairs_sorted, pair_off, group_off, total_groups, nlist, max_groups, max_slabs, vpl, h->st) == 0;
         }
-        a.slabs_per_chunk = (int)spc;
-        a.max_chunks = (int)((max_slabs + spc - 1) / spc);
-        if (launch_pq_scan(a, h->st) != 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ scan: no kernel for M=%d", h->M);
+        if (!done) {
+            int64_t spc;
+            if (h->scan_chunk > 0) spc = std::max<int64_t>(16, h->scan_chunk / 64);
+            else {
+                // enough work items to fill 256 CUs several times over, but no smaller than 32 slabs
+                int64_t want_items = 4096;
+                int64_t chunks = std::max<int64_t>(1, (want_items + pairs - 1) / pairs);
+                spc = std::max<int64_t>(32, (max_slabs + chunks - 1) / chunks);
+            }
+            a.slabs_per_chunk = (int)spc;
+            a.max_chunks = (int)((max_slabs + spc - 1) / spc);
+            if (launch_pq_scan(a, h->st) != 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ scan: no kernel for M=%d", h->M);
+        }
         h->timing["scan_launches"] += 1;
         tm.mark("scan");
     } else {
@@ -770,7 +794,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int32_t* pair_off = cursor + (nlist + 1);
         int32_t* group_off = pair_off + (nlist + 1);
         int32_t* total_groups = group_off + (nlist + 1);
-        launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, cnt, cursor, pair_off, group_off, total_groups,
+        launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
                            pairs_sorted, h->st);
         tm.mark("group");
         const float* bias = nullptr;
@@ -1244,6 +1268,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         std::string s(key);
         if (s == "query_batch") h->query_batch = std::max(1, (int)value);
         else if (s == "scan_chunk") h->scan_chunk = std::max(0, (int)value);
+        else if (s == "scan_kernel") h->scan_kernel = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;
         else RSX_THROW(RSX_ERR_INVALID, "unknown parameter '%s'", key);

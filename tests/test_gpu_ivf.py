@@ -75,6 +75,11 @@ def test_golden_ivfpq(gpu, orc, name):
     ix.set_param("scan_chunk", 64)          # smallest scan chunks: many work items per list
     D3, I3 = ix.search(q, g["k"])
     assert_same_results(D3, I3, g["D"], g["I"], name + " chunked")
+    ix.set_param("scan_chunk", 0)
+    ix.set_param("query_batch", 1024)
+    ix.set_param("scan_kernel", 1)          # the per-(query, list) v1 kernel must agree with the list-major v2
+    D4, I4 = ix.search(q, g["k"])
+    assert_same_results(D4, I4, g["D"], g["I"], name + " v1 kernel")
 
 
 @pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8)])

@@ -19,7 +19,7 @@ for s in $STAGES; do
     bench_small)
       timeout 900 python bench.py --n 4000000 --nlist 1024 --steps 5 --warmup 2 --cpu-queries 32 > gpurun_out/bench_small.json 2> gpurun_out/bench_small.log; echo "exit $?" >> gpurun_out/bench_small.log ;;
     bench)
-      timeout 1700 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "exit $?" >> gpurun_out/bench.log ;;
+      timeout 1700 python bench.py --steps 10 --warmup 3 --ab > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "exit $?" >> gpurun_out/bench.log ;;
     diag)
       timeout 300 python tools/diag_synth.py > gpurun_out/diag_synth.log 2>&1 ;;
     prof)
