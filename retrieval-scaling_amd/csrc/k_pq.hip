@@ -153,7 +153,12 @@ __global__ __launch_bounds__(1024) void k_pq_scan2(PQScan2Args A) {
     constexpr int NP = (NCH + GPC - 1) / GPC;
     const PQScanArgs& a = A.b;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = blockIdx.x;
+    // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD
+    // b % 8, each with a private 4 MiB L2).  gridDim.x is a multiple of 8; XCD c takes the contiguous
+    // group range [c*GX/8, (c+1)*GX/8), so the query-pair groups of one list (consecutive g, same
+    // codes) run on ONE XCD close together in time: the list is fetched from HBM once and the other
+    // groups hit that L2.  Placement only affects speed, never results.
+    const int g = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (g >= *A.total_groups) return;
     int lo = 0, hi = A.nlist;  // largest l with group_off[l] <= g
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.group_off[mid] <= g) lo = mid; else hi = mid; }
@@ -233,7 +238,7 @@ static int launch_pq_scan2_t(const PQScan2Args& A, hipStream_t st) {
     size_t shm = (size_t)GPC * 16 * 256 * sizeof(float2);
     if (hipFuncSetAttribute((const void*)k_pq_scan2<NCH, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return -1;
-    dim3 grid((unsigned)A.max_groups, (unsigned)A.max_tiles);
+    dim3 grid((unsigned)((A.max_groups + 7) & ~7), (unsigned)A.max_tiles);
     hipLaunchKernelGGL((k_pq_scan2<NCH, VPL>), grid, dim3(1024), shm, st, A);
     return 0;
 }
