@@ -155,11 +155,16 @@ __global__ __launch_bounds__(1024) void k_pq_scan2(PQScan2Args A) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD
     // b % 8, each with a private 4 MiB L2).  gridDim.x is a multiple of 8; XCD c takes the contiguous
-    // group range [c*GX/8, (c+1)*GX/8), so the query-pair groups of one list (consecutive g, same
+    // group range [c*TG/8, (c+1)*TG/8), so the query-pair groups of one list (consecutive g, same
     // codes) run on ONE XCD close together in time: the list is fetched from HBM once and the other
     // groups hit that L2.  Placement only affects speed, never results.
-    const int g = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (g >= *A.total_groups) return;
+    // The split uses the ACTUAL group count (device scalar), so all 8 XCDs get equal shares.
+    const int tg = *A.total_groups;
+    const int per_xcd = (tg + 7) >> 3;
+    const int gi_x = (int)(blockIdx.x >> 3);
+    if (gi_x >= per_xcd) return;
+    const int g = (int)(blockIdx.x & 7) * per_xcd + gi_x;
+    if (g >= tg) return;
     int lo = 0, hi = A.nlist;  // largest l with group_off[l] <= g
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.group_off[mid] <= g) lo = mid; else hi = mid; }
     const int l = lo;

@@ -59,18 +59,21 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         tau = buf[k - 1];
         __syncthreads();
     }
+    // software pipeline: the next 256-element tile's loads are in flight while this one is filtered
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 0 && start + lane * 4 + 3 < end) nxt = *reinterpret_cast<const float4*>(sf + start + lane * 4);
     for (int64_t base = start; base < end; base += 256) {
         int64_t e0 = base + lane * 4;
         uint64_t key[4];
         if (MODE == 0) {
             float v[4];
             if (e0 + 3 < end) {
-                float4 f = *reinterpret_cast<const float4*>(sf + e0);
-                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+                v[0] = nxt.x; v[1] = nxt.y; v[2] = nxt.z; v[3] = nxt.w;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = (e0 + e < end) ? sf[e0 + e] : -__builtin_inff();
             }
+            if (e0 + 256 + 3 < end) nxt = *reinterpret_cast<const float4*>(sf + e0 + 256);
 #pragma unroll
             for (int e = 0; e < 4; e++) key[e] = make_key(v[e], a.idx_base + (uint32_t)(e0 + e));
         } else {
