@@ -143,13 +143,16 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out);
 
 /* Tuning knobs that do not change results: "query_batch" (max queries per internal pass),
  * "scan_chunk" (vectors per scan work item, 0 = auto), "scan_kernel" (IVFPQ: 0 = auto, 1 = per-pair
- * v1 kernel, for A/B measurements), "profile" (1 = record stage timings with HIP
+ * v1 kernel, 2 = exact list-major kernel; non-zero disables the fast scan), "pq_fast" (IVFPQ: 1 = 8-bit-table
+ * fast scan with certified exact re-rank [default], 0 = exact scan only), "pq_fast_kp" (candidates kept by the
+ * fast scan, 0 = auto), "profile" (1 = record stage timings with HIP
  * events on the library's stream; 2 = additionally count the vectors each search scanned). */
 int rsx_set_param(rsx_index_t* h, const char* key, double value);
 
 /* HIP-event timings (ms) of the stages of the last rsx_search on this handle when
  * "profile"=1: "coarse", "select_probe", "lut", "scan", "select", "finalize", "total",
- * "scan_launches" and (profile 2) "scanned_vectors".  Used by bench.py for the roofline object. */
+ * "scan_launches", "fast_queries", "fallback_queries" (certificate failures re-run exactly) and (profile 2)
+ * "scanned_vectors".  Used by bench.py for the roofline object. */
 int rsx_get_timing(rsx_index_t* h, const char* key, double* ms);
 
 /* ---- persistence ------------------------------------------------------------------- */

@@ -277,6 +277,209 @@ int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int3
 }
 
 // ---------------------------------------------------------------------------------------
+// Fast scan with an 8-bit table + certified exact re-rank.
+//
+// k_pq_scan2 is bound by the LDS gather INSTRUCTION rate (measured ~10 clk per random ds_read_b64,
+// ~7 per ds_read_b32), so the lever is queries served per gathered dword.  k_pq_lut8 quantises each
+// query's table affinely to 8 bits (one scale per query, one offset per sub-quantiser):
+//     T[m][c] ~= mn[m] + scale * u8[m][c],   |error| <= e_m,   e_quant = sum_m e_m
+// k_pq_scan8 interleaves FOUR queries' u8 tables as one dword per (m, code) — M KiB of LDS, a single
+// pass for M = 96 — so one ds_read_b32 per (vector, m) serves four queries; the four sums are exact
+// integers (two 16-bit fields per accumulator register).  The approximate score
+//     a(v) = dis0 + bias + scale * A(v)          (bias = sum_m mn[m])
+// is within eps_q = e_quant + fp32 slack of the canonical fp32 score s(v).  k_select keeps the top K'
+// by a(.), k_finalize re-scores them EXACTLY (sequential fp32 table sum, = oracle) and certifies:
+// if a(K'-th candidate) + eps_q < s(k-th best candidate) no excluded vector can reach the top k, so
+// the result equals the exact search; otherwise the query is flagged and re-run with k_pq_scan2.
+struct PQQParam { float scale, bias, eps, pad; };
+
+__global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int Mpad, const float* probe_dis0,
+                                                 int nprobe, uint8_t* lut8, PQQParam* qp) {
+    __shared__ float s_mn[256], s_rg[256], s_red[8];
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x, lane = c & 63, w = c >> 6;
+    const float* T = lut32 + q * Mpad * 256;
+    // pass 1: per sub-quantiser min / range / max |value|
+    float absmax_sum = 0.0f, maxrange = 0.0f;
+    for (int m = 0; m < Mpad; m++) {
+        float v = T[m * 256 + c];
+        float mn = v, mx = v;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        if (lane == 0) { s_red[w] = mn; s_red[4 + w] = mx; }
+        __syncthreads();
+        mn = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+        mx = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+        __syncthreads();
+        if (c == 0) { s_mn[m] = mn; s_rg[m] = mx - mn; }
+        absmax_sum += fmaxf(fabsf(mn), fabsf(mx));
+        maxrange = fmaxf(maxrange, mx - mn);
+    }
+    __syncthreads();
+    const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
+    const float inv = 1.0f / scale;
+    // pass 2: quantise, accumulate the exact per-sub-quantiser error bound
+    float e_quant = 0.0f, bias = 0.0f;
+    for (int m = 0; m < Mpad; m++) {
+        float v = T[m * 256 + c];
+        float mn = s_mn[m];
+        float u = rintf((v - mn) * inv);
+        u = fminf(fmaxf(u, 0.0f), 255.0f);
+        lut8[(q * Mpad + m) * 256 + c] = (uint8_t)u;
+        float err = fabsf(v - (mn + scale * u));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
+        if (lane == 0) s_red[w] = err;
+        __syncthreads();
+        err = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        __syncthreads();
+        e_quant += err;
+        bias += mn;
+    }
+    if (c == 0) {
+        float d0 = 0.0f;
+        for (int j = 0; j < nprobe; j++) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
+        // fp32 slack: < 300 roundings of relative size 2^-24 on magnitudes bounded by B
+        float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 0.0f;
+        qp[q] = r;
+    }
+}
+void launch_pq_lut8(const float* lut32, int64_t nq, int M, int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
+                    void* qparam, hipStream_t st) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_pq_lut8, dim3((unsigned)nq), dim3(256), 0, st, lut32, M, Mpad, probe_dis0, nprobe, lut8, (PQQParam*)qparam);
+}
+
+struct PQScan8Args {
+    PQScanArgs b;
+    const uint8_t* lut8; const PQQParam* qp;
+    const int32_t* pairs_sorted; const int32_t* pair_off; const int32_t* group_off; const int32_t* total_groups;
+    int nlist; int max_groups; int max_tiles;
+};
+
+template <int NCH, int VPL>
+__global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t pq_lut4_s[];  // [Mpad][256] : byte i = query i
+    const PQScanArgs& a = A.b;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tg = *A.total_groups;
+    const int per_xcd = (tg + 7) >> 3;           // XCD-aware mapping, see k_pq_scan2
+    const int gi_x = (int)(blockIdx.x >> 3);
+    if (gi_x >= per_xcd) return;
+    const int g = (int)(blockIdx.x & 7) * per_xcd + gi_x;
+    if (g >= tg) return;
+    int lo = 0, hi = A.nlist;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.group_off[mid] <= g) lo = mid; else hi = mid; }
+    const int l = lo;
+    const int gi = g - A.group_off[l];
+    const int cnt = A.pair_off[l + 1] - A.pair_off[l];
+    int np = cnt - 4 * gi; if (np > 4) np = 4;
+    const int pair0 = A.pair_off[l] + 4 * gi;
+    const int64_t len = a.list_len[l];
+    const int64_t nslab = (len + 63) >> 6;
+    const int64_t s0 = (int64_t)blockIdx.y * (16 * VPL);
+    if (s0 >= nslab) return;
+
+    int pidx[4]; int64_t qq[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { pidx[i] = A.pairs_sorted[pair0 + (i < np ? i : 0)]; qq[i] = pidx[i] / a.nprobe; }
+    // stage the four tables interleaved: thread handles 4 consecutive codes of one m
+    {
+        const int n4 = a.Mpad * 64;
+        for (int i = tid; i < n4; i += 1024) {
+            uint32_t in[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                in[k] = (k < np) ? *reinterpret_cast<const uint32_t*>(A.lut8 + qq[k] * a.Mpad * 256 + (int64_t)i * 4) : 0u;
+            uint4 o;
+            o.x = (in[0] & 0xffu) | ((in[1] & 0xffu) << 8) | ((in[2] & 0xffu) << 16) | ((in[3] & 0xffu) << 24);
+            o.y = ((in[0] >> 8) & 0xffu) | (((in[1] >> 8) & 0xffu) << 8) | (((in[2] >> 8) & 0xffu) << 16) | (((in[3] >> 8) & 0xffu) << 24);
+            o.z = ((in[0] >> 16) & 0xffu) | (((in[1] >> 16) & 0xffu) << 8) | (((in[2] >> 16) & 0xffu) << 16) | (((in[3] >> 16) & 0xffu) << 24);
+            o.w = (in[0] >> 24) | ((in[1] >> 24) << 8) | ((in[2] >> 24) << 16) | ((in[3] >> 24) << 24);
+            reinterpret_cast<uint4*>(pq_lut4_s)[i] = o;
+        }
+    }
+    __syncthreads();
+
+    const int64_t slab_base = a.list_base[l] >> 6;
+    const int64_t slab_bytes = (int64_t)64 * a.Mpad;
+    float dis0[4], scale[4], bias[4]; float* out[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        PQQParam p = A.qp[qq[i]];
+        scale[i] = p.scale; bias[i] = p.bias; dis0[i] = a.probe_dis0[pidx[i]];
+        out[i] = a.temp + qq[i] * a.tstride + a.seg_start[qq[i] * (a.nprobe + 1) + (pidx[i] - (int)qq[i] * a.nprobe)];
+    }
+#pragma unroll
+    for (int u = 0; u < VPL; u++) {
+        const int64_t s = s0 + w + 16 * u;
+        if (s >= nslab) continue;
+        const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
+        uint4 c[NCH];
+#pragma unroll
+        for (int gg = 0; gg < NCH; gg++) c[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
+        uint32_t acc02 = 0, acc13 = 0;   // 16-bit fields: queries (0,2) and (1,3); 96*255 < 65536
+#pragma unroll
+        for (int gg = 0; gg < NCH; gg++) {
+            const uint32_t wds[4] = {c[gg].x, c[gg].y, c[gg].z, c[gg].w};
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                uint32_t e = pq_lut4_s[(gg * 16 + b) * 256 + code];
+                acc02 += e & 0x00ff00ffu;
+                acc13 += (e >> 8) & 0x00ff00ffu;
+            }
+        }
+        const int64_t pos = s * 64 + lane;
+        const uint32_t A4[4] = {acc02 & 0xffffu, acc13 & 0xffffu, acc02 >> 16, acc13 >> 16};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < np) out[i][pos] = (pos < len) ? dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]) : -__builtin_inff();
+    }
+}
+
+template <int NCH, int VPL>
+static int launch_pq_scan8_t(const PQScan8Args& A, hipStream_t st) {
+    size_t shm = (size_t)NCH * 16 * 256 * 4;
+    if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+        return -1;
+    dim3 grid((unsigned)((A.max_groups + 7) & ~7), (unsigned)A.max_tiles);
+    hipLaunchKernelGGL((k_pq_scan8<NCH, VPL>), grid, dim3(1024), shm, st, A);
+    return 0;
+}
+template <int NCH>
+static int launch_pq_scan8_v(const PQScan8Args& A, int vpl, hipStream_t st) {
+    switch (vpl) {
+        case 8: return launch_pq_scan8_t<NCH, 8>(A, st);
+        case 4: return launch_pq_scan8_t<NCH, 4>(A, st);
+        case 2: return launch_pq_scan8_t<NCH, 2>(A, st);
+        default: return launch_pq_scan8_t<NCH, 1>(A, st);
+    }
+}
+// returns 0 on launch, -1 if this (M, layout) has no fast-scan kernel
+int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
+                    const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups, int nlist,
+                    int max_groups, int64_t max_slabs, int vpl, hipStream_t st) {
+    if (a.CB != 16 || max_groups <= 0 || a.M * 255 >= 65536) return -1;
+    PQScan8Args A;
+    A.b = a; A.lut8 = lut8; A.qp = (const PQQParam*)qparam;
+    A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
+    A.nlist = nlist; A.max_groups = max_groups;
+    A.max_tiles = (int)((max_slabs + 16 * vpl - 1) / (16 * vpl));
+    if (A.max_tiles > 65535) return -1;
+    switch (a.Mpad / 16) {
+        case 1: return launch_pq_scan8_v<1>(A, vpl, st);
+        case 2: return launch_pq_scan8_v<2>(A, vpl, st);
+        case 3: return launch_pq_scan8_v<3>(A, vpl, st);
+        case 4: return launch_pq_scan8_v<4>(A, vpl, st);
+        case 6: return launch_pq_scan8_v<6>(A, vpl, st);
+        case 8: return launch_pq_scan8_v<8>(A, vpl, st);
+        default: return -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Encode: 256 vectors per workgroup (one per thread); the codebook of subspace m is staged in LDS
 // and read with broadcast ds_reads (all lanes the same address: conflict-free).
 template <int DSUB>

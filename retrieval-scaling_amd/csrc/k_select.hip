@@ -255,6 +255,29 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
     }
     __syncthreads();
 
+    if (a.kind == KIND_IVFPQ && a.pq_rescore) {
+        // one lane per candidate: canonical score = dis0 + (((0 + T[0][c0]) + T[1][c1]) + ...), fp32
+        const float* T = a.lut32 + q * a.Mpad * 256;
+        for (int c = lane; c < KP; c += 64) {
+            int64_t row = srow[c];
+            if (row < 0) continue;
+            uint32_t idx = key_idx(a.state[q * KP + c]);
+            const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+            int lo = 0, hi = a.nprobe;
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
+            const float dis0 = a.probe_dis0[q * a.nprobe + lo];
+            const int64_t slab = row >> 6; const int v = (int)(row & 63);
+            const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
+            float sum = 0.0f;
+            for (int m = 0; m < a.M; m++) {
+                int g = m / a.CB, b = m - g * a.CB;
+                uint32_t code = sp[(int64_t)g * (64 * a.CB) + v * a.CB + b];
+                sum += T[m * 256 + code];
+            }
+            sord[c] = f2ord((dis0 + sum) + 0.0f);
+        }
+        __syncthreads();
+    }
     if (a.kind != KIND_IVFPQ) {
         const float* qv = a.Q32 + q * a.ldq;
         for (int c = 0; c < KP; c++) {
@@ -299,6 +322,21 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
             }
             __syncthreads();
         }
+    }
+    if (a.kind == KIND_IVFPQ && a.pq_rescore && lane == 0) {
+        // certificate: every vector outside the candidate set has approximate score <= the K'-th
+        // candidate's, hence exact score <= that + eps; if this is below the exact k-th best
+        // candidate, the top k (ties included) lies inside the candidate set.
+        const float eps = reinterpret_cast<const float*>(a.qparam)[q * 4 + 2];
+        uint64_t last = a.state[q * KP + (KP - 1)];
+        int bad = 0;
+        if (last != 0) {  // the candidate buffer is full: vectors were excluded
+            float a_last = key_score(last);
+            bool have_k = sord[a.k - 1] != 0 && sid[a.k - 1] != INT64_MAX;
+            float s_k = have_k ? ord2f(sord[a.k - 1]) : -__builtin_inff();
+            if (!(a_last + eps < s_k)) bad = 1;
+        }
+        a.uncertain[q] = bad;
     }
     for (int j = lane; j < a.k; j += 64) {
         bool valid = (j < KP) && sord[j] != 0 && sid[j] != INT64_MAX;

@@ -144,12 +144,14 @@ struct rsx_index {
     int query_batch = 1024;
     int scan_chunk = 0;
     int scan_kernel = 0;  // 0 = auto (list-major v2 when the layout allows), 1 = force the per-pair v1 kernel
+    int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
+    int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain;
     std::map<std::string, double> timing;
 
     int row_align() const { return kind == KIND_IVFPQ ? 64 : (kind == KIND_FLAT ? 128 : 64); }
@@ -584,9 +586,10 @@ struct StageTimer {
     }
 };
 
-static void kp_for(const rsx_index* h, int k, int& KP, int& BUF) {
+static void kp_for(const rsx_index* h, int k, bool fast, int& KP, int& BUF) {
     int want;
-    if (h->kind == KIND_IVFPQ) want = (k >= 512) ? k : k + 4;
+    if (h->kind == KIND_IVFPQ && fast) want = h->pq_fast_kp > 0 ? std::max(k, h->pq_fast_kp) : k + std::max(54, k / 2);
+    else if (h->kind == KIND_IVFPQ) want = (k >= 512) ? k : k + 4;
     else want = k + std::max(8, k / 16);
     KP = std::max(16, pow2ceil(want));
     BUF = std::max(2 * KP, 256);
@@ -623,11 +626,16 @@ static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, c
     launch_select(b, h->st);
 }
 
-static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI) {
+static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI,
+                         bool allow_fast = true) {
     StageTimer tm(h);
     const int d = h->d, ld = h->ld;
+    // IVFPQ fast path: needs the 16-byte-granule layout, 16-bit integer sums, and K' <= 4096
+    bool fast = allow_fast && h->kind == KIND_IVFPQ && h->pq_fast != 0 && h->scan_kernel == 0 && h->CB == 16 &&
+                h->M * 255 < 65536;
     int KP, BUF;
-    kp_for(h, k, KP, BUF);
+    kp_for(h, k, fast, KP, BUF);
+    if (fast && KP > 4096) { fast = false; kp_for(h, k, false, KP, BUF); }
     tm.mark("start");
     // queries: fp32 copy (exact re-rank, coarse quantiser, LUT) [nq, ld]; fp16 copy for the scans
     h->w_q32.ensure((size_t)nq * ld * 4);
@@ -749,7 +757,35 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int64_t max_slabs = std::max<int64_t>(1, maxlen / 64);
         int64_t pairs = nq * nprobe;
         bool done = false;
-        if (h->scan_kernel != 1 && h->CB == 16) {
+        if (fast) {
+            // 8-bit tables, 4 queries per LDS read; approximate scores, certified in k_finalize
+            h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
+            h->w_qparam.ensure((size_t)nq * 16);
+            h->w_uncertain.ensure((size_t)nq * 4);
+            launch_pq_lut8(h->w_lut.as<float>(), nq, h->M, h->Mpad, h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(),
+                           h->w_qparam.p, h->st);
+            tm.mark("lut8");
+            h->w_pairs.ensure((size_t)(pairs + 4 * (size_t)(nlist + 1) + 4) * 4);
+            int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
+            int32_t* cnt = pairs_sorted + pairs;
+            int32_t* cursor = cnt + (nlist + 1);
+            int32_t* pair_off = cursor + (nlist + 1);
+            int32_t* group_off = pair_off + (nlist + 1);
+            int32_t* total_groups = group_off + (nlist + 1);
+            launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
+                               pairs_sorted, h->st);
+            tm.mark("group");
+            int max_groups = (int)std::min<int64_t>(pairs, pairs / 4 + std::min<int64_t>(nlist, pairs));
+            int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
+            int vpl = 8;
+            if (h->scan_chunk > 0) vpl = std::max(1, std::min(8, h->scan_chunk / 1024));
+            else while (vpl > 1 && (pairs / 4 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
+            if (vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
+            done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
+                                   total_groups, nlist, max_groups, max_slabs, vpl, h->st) == 0;
+            if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
+        }
+        if (!done && h->scan_kernel != 1 && h->CB == 16) {
             // v2: list-major, two queries per LDS read
             h->w_pairs.ensure((size_t)(pairs + 4 * (size_t)(nlist + 1) + 4) * 4);
             int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
@@ -820,9 +856,32 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 state, false);
     tm.mark("select");
     fa.probe_list = h->w_probelist.as<int32_t>(); fa.seg_start = h->w_segstart.as<int64_t>(); fa.nprobe = nprobe;
+    if (fast) {
+        fa.pq_rescore = 1; fa.codes = h->data.as<uint8_t>(); fa.M = h->M; fa.Mpad = h->Mpad; fa.CB = h->CB;
+        fa.lut32 = h->w_lut.as<float>(); fa.probe_dis0 = h->w_dis0.as<float>(); fa.qparam = h->w_qparam.p;
+        fa.uncertain = h->w_uncertain.as<int32_t>();
+    }
     launch_finalize(fa, h->st);
     tm.mark("finalize");
     tm.finish();
+    if (fast) {
+        // queries whose certificate failed are re-run with the exact scan (rare; results are then exact too)
+        std::vector<int32_t> bad((size_t)nq);
+        HIPCHECK(hipMemcpyAsync(bad.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));
+        size_t esz = dtype == RSX_F16 ? 2 : 4;
+        int64_t nbad = 0;
+        for (int64_t q = 0; q < nq; q++) {
+            if (!bad[(size_t)q]) continue;
+            int64_t q1 = q;
+            while (q1 + 1 < nq && bad[(size_t)(q1 + 1)]) q1++;      // contiguous run
+            search_batch(h, q1 - q + 1, (const char*)dq + (size_t)q * d * esz, dtype, k, dD + q * k, dI + q * k, false);
+            nbad += q1 - q + 1;
+            q = q1;
+        }
+        h->timing["fallback_queries"] += (double)nbad;
+        h->timing["fast_queries"] += (double)nq;
+    }
 }
 
 // L2 ranking bias  -|x|^2/2  from the stored squared norms
@@ -1269,6 +1328,8 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         if (s == "query_batch") h->query_batch = std::max(1, (int)value);
         else if (s == "scan_chunk") h->scan_chunk = std::max(0, (int)value);
         else if (s == "scan_kernel") h->scan_kernel = (int)value;
+        else if (s == "pq_fast") h->pq_fast = (int)value;
+        else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;
         else RSX_THROW(RSX_ERR_INVALID, "unknown parameter '%s'", key);

@@ -123,6 +123,12 @@ int launch_pq_scan(const PQScanArgs& a, hipStream_t st);  // returns 0, or -1 if
 // list-major two-queries-per-LDS-read scan; pairs grouped by list in groups of 2 (launch_group_pairs)
 int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int32_t* pair_off, const int32_t* group_off,
                     const int32_t* total_groups, int nlist, int max_groups, int64_t max_slabs, int vpl, hipStream_t st);
+// 8-bit table fast scan (4 queries per LDS read) — approximate scores, certified by k_finalize
+void launch_pq_lut8(const float* lut32, int64_t nq, int M, int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
+                    void* qparam /* [nq] {scale, bias, eps, pad} */, hipStream_t st);
+int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
+                    const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups, int nlist,
+                    int max_groups, int64_t max_slabs, int vpl, hipStream_t st);
 // codes for rows of a batch: residual vs centroid[assign] (centroids may be null -> no residual).
 // plain_out != null: write [n, Mpad] row-major instead of the slab layout (training / export).
 void launch_pq_encode(const void* x, int x_f16, int64_t n, int ldx, int d, int M, int Mpad, int CB,
@@ -156,6 +162,9 @@ struct FinalizeArgs {
     // exact rerank (Flat / IVF-Flat)
     const float* Q32; int ldq; int d;
     const void* X; int x_f16; int ld;
+    // exact re-score + certificate (IVF-PQ fast scan): candidates carry APPROXIMATE scores
+    int pq_rescore; const uint8_t* codes; int M; int Mpad; int CB;
+    const float* lut32; const float* probe_dis0; const void* qparam; int32_t* uncertain;
     float* D; int64_t* I;
 };
 void launch_finalize(const FinalizeArgs& a, hipStream_t st);

@@ -77,9 +77,29 @@ def test_golden_ivfpq(gpu, orc, name):
     assert_same_results(D3, I3, g["D"], g["I"], name + " chunked")
     ix.set_param("scan_chunk", 0)
     ix.set_param("query_batch", 1024)
-    ix.set_param("scan_kernel", 1)          # the per-(query, list) v1 kernel must agree with the list-major v2
-    D4, I4 = ix.search(q, g["k"])
-    assert_same_results(D4, I4, g["D"], g["I"], name + " v1 kernel")
+    # every scan implementation returns the same bits: fast (8-bit tables + certified re-rank, default),
+    # exact list-major (2), exact per-pair (1)
+    for sk in (1, 2):
+        ix.set_param("scan_kernel", sk)
+        D4, I4 = ix.search(q, g["k"])
+        assert_same_results(D4, I4, g["D"], g["I"], name + f" scan_kernel={sk}")
+    ix.set_param("scan_kernel", 0)
+    ix.set_param("pq_fast", 0)
+    D5, I5 = ix.search(q, g["k"])
+    assert_same_results(D5, I5, g["D"], g["I"], name + " pq_fast=0")
+    ix.set_param("pq_fast", 1)
+    ix.set_param("profile", 1)
+    D6, I6 = ix.search(q, g["k"])
+    assert_same_results(D6, I6, g["D"], g["I"], name + " fast")
+    assert ix.get_timing("fast_queries") == g["nq"]
+    auto_fallbacks = ix.get_timing("fallback_queries")
+    # starve the candidate set: certificates must fail and the exact re-run must repair every query
+    ix.set_param("pq_fast_kp", g["k"])
+    ix.set_param("profile", 1)
+    D7, I7 = ix.search(q, g["k"])
+    assert_same_results(D7, I7, g["D"], g["I"], name + " starved fast scan")
+    assert ix.get_timing("fallback_queries") > auto_fallbacks, "K' = k cannot be certifiable for every query"
+    ix.set_param("pq_fast_kp", 0)
 
 
 @pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8)])
