@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=1_000_000, help="vectors synthesised per add call")
     ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-recall", action="store_true", help="skip the exact ground truth (recall = null)")
+    ap.add_argument("--diag", action="store_true", help="print a fast-vs-exact comparison of the first timed batch and exit")
     ap.add_argument("--ab", action="store_true", help="also time the per-pair v1 scan kernel (same process, same index)")
     args = ap.parse_args()
 
@@ -146,6 +147,34 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.diag:
+        q = Q[args.warmup * nq:(args.warmup + 1) * nq]
+        index.set_param("scan_kernel", 2)
+        De, Ie = index.search(q, k)
+        index.set_param("scan_kernel", 0)
+        index.set_param("profile", 1)
+        Df, If = index.search(q, k)
+        nfb = index.get_timing("fallback_queries")
+        De, Ie, Df, If = De.cpu().numpy(), Ie.cpu().numpy(), Df.cpu().numpy(), If.cpu().numpy()
+        badq = np.nonzero((Ie != If).any(1) | (De != Df).any(1))[0]
+        log(f"diag: fallback queries {nfb}; queries differing fast vs exact: {len(badq)} of {nq}: {badq[:20].tolist()}")
+        for qi in badq[:6]:
+            log(f" q={qi}\n  exact I {Ie[qi].tolist()}\n  fast  I {If[qi].tolist()}\n  exact D {De[qi].tolist()}\n  fast  D {Df[qi].tolist()}")
+        for kp in (128, 512):
+            index.set_param("pq_fast_kp", kp); index.set_param("profile", 1)
+            Dg, Ig = index.search(q, k)
+            Dg, Ig = Dg.cpu().numpy(), Ig.cpu().numpy()
+            nb = int(((Ie != Ig).any(1) | (De != Dg).any(1)).sum())
+            log(f"diag: K'={kp}: fallbacks {index.get_timing('fallback_queries')}, differing queries {nb}")
+        index.set_param("pq_fast_kp", 0)
+        # each query alone through the fast path
+        nb1 = 0
+        for qi in badq[:4]:
+            D1, I1 = index.search(q[qi:qi + 1], k)
+            same = np.array_equal(I1.cpu().numpy()[0], Ie[qi]) and np.array_equal(D1.cpu().numpy()[0], De[qi])
+            log(f"diag: q={qi} alone through the fast path: equal to exact = {same}")
+        return
 
     for i in range(args.warmup):
         step(i)

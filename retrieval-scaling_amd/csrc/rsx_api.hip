@@ -852,8 +852,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         tm.mark("scan");
     }
     // 3. per-query k-selection over the score rows
-    select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + nprobe, nprobe + 1, tmax, 0, nq, KP, BUF, k,
-                state, false);
+    // fast scan: the certificate needs the TRUE top-K' by approximate score, so the selection threshold
+    // is the K'-th key, not the k-th
+    select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + nprobe, nprobe + 1, tmax, 0, nq, KP, BUF,
+                fast ? KP : k, state, false);
     tm.mark("select");
     fa.probe_list = h->w_probelist.as<int32_t>(); fa.seg_start = h->w_segstart.as<int64_t>(); fa.nprobe = nprobe;
     if (fast) {

@@ -61,6 +61,21 @@ def test_properties_200k(gpu, orc):
     pq.set_param("query_batch", 100)
     D3, I3 = pq.search(q, k)
     assert torch.equal(D1, D3) and torch.equal(I1, I3)
+    # fast scan (default) == exact list-major == exact per-pair kernels at a size where selection prunes
+    pq.set_param("query_batch", 1024)
+    for sk in (2, 1):
+        pq.set_param("scan_kernel", sk)
+        Dk, Ik = pq.search(q, k)
+        assert torch.equal(D1, Dk) and torch.equal(I1, Ik), f"scan_kernel={sk}"
+    pq.set_param("scan_kernel", 0)
+    for kk in (1, 100):
+        pq.nprobe = 64
+        Df, If = pq.search(q, kk)
+        pq.set_param("pq_fast", 0)
+        Dx, Ix = pq.search(q, kk)
+        pq.set_param("pq_fast", 1)
+        assert torch.equal(Df, Dx) and torch.equal(If, Ix), f"fast vs exact k={kk}"
+    pq.nprobe = 16
     # oracle on the exported lists for 4 queries
     lists = [pq.get_list(l) for l in range(nlist)]
     off = np.zeros(nlist + 1, np.int64); np.cumsum([len(i) for _, i in lists], out=off[1:])
