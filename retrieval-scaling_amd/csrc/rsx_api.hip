@@ -151,7 +151,7 @@ struct rsx_index {
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI;
     std::map<std::string, double> timing;
 
     int row_align() const { return kind == KIND_IVFPQ ? 64 : (kind == KIND_FLAT ? 128 : 64); }
@@ -563,9 +563,9 @@ static void train_impl(rsx_index* h, int64_t n, const void* x, int dtype) {
 // search
 // ---------------------------------------------------------------------------------------
 struct StageTimer {
-    rsx_index* h; bool on;
+    rsx_index* h; bool on; std::string prefix;
     hipEvent_t ev[16]; const char* name[16]; int n = 0;
-    StageTimer(rsx_index* hh) : h(hh), on(hh->profile != 0) {}
+    StageTimer(rsx_index* hh, const char* pre = "") : h(hh), on(hh->profile != 0), prefix(pre) {}
     void mark(const char* nm) {
         if (!on || n >= 16) return;
         (void)hipEventCreate(&ev[n]);
@@ -577,10 +577,10 @@ struct StageTimer {
         (void)hipEventSynchronize(ev[n - 1]);
         for (int i = 1; i < n; i++) {
             float ms = 0; (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
-            h->timing[name[i]] += ms;
+            h->timing[prefix + name[i]] += ms;
         }
         float tot = 0; (void)hipEventElapsedTime(&tot, ev[0], ev[n - 1]);
-        h->timing["total"] += tot;
+        h->timing[prefix + "total"] += tot;
         for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]);
         n = 0;
     }
@@ -588,11 +588,11 @@ struct StageTimer {
 
 static void kp_for(const rsx_index* h, int k, bool fast, int& KP, int& BUF) {
     int want;
-    if (h->kind == KIND_IVFPQ && fast) want = h->pq_fast_kp > 0 ? std::max(k, h->pq_fast_kp) : k + std::max(54, k / 2);
+    if (h->kind == KIND_IVFPQ && fast) want = h->pq_fast_kp > 0 ? std::max(k, h->pq_fast_kp) : k + std::max(118, k / 2);
     else if (h->kind == KIND_IVFPQ) want = (k >= 512) ? k : k + 4;
     else want = k + std::max(8, k / 16);
     KP = std::max(16, pow2ceil(want));
-    BUF = std::max(2 * KP, 256);
+    BUF = std::max(2 * KP, (h->kind == KIND_IVFPQ && fast) ? 512 : 256);
 }
 
 // top-k of `nrows` rows of fp32 scores (row r valid length: row_n or n_uniform) into state [nrows, KP]
@@ -628,7 +628,7 @@ static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, c
 
 static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI,
                          bool allow_fast = true) {
-    StageTimer tm(h);
+    StageTimer tm(h, allow_fast ? "" : "fb_");
     const int d = h->d, ld = h->ld;
     // IVFPQ fast path: needs the 16-byte-granule layout, 16-bit integer sums, and K' <= 4096
     bool fast = allow_fast && h->kind == KIND_IVFPQ && h->pq_fast != 0 && h->scan_kernel == 0 && h->CB == 16 &&
@@ -818,7 +818,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             a.max_chunks = (int)((max_slabs + spc - 1) / spc);
             if (launch_pq_scan(a, h->st) != 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ scan: no kernel for M=%d", h->M);
         }
-        h->timing["scan_launches"] += 1;
+        h->timing[allow_fast ? "scan_launches" : "fb_scan_launches"] += 1;
         tm.mark("scan");
     } else {
         // group (query, probe) pairs by list, then list-major MFMA scan
@@ -872,14 +872,23 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         HIPCHECK(hipMemcpyAsync(bad.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
         HIPCHECK(hipStreamSynchronize(h->st));
         size_t esz = dtype == RSX_F16 ? 2 : 4;
-        int64_t nbad = 0;
-        for (int64_t q = 0; q < nq; q++) {
-            if (!bad[(size_t)q]) continue;
-            int64_t q1 = q;
-            while (q1 + 1 < nq && bad[(size_t)(q1 + 1)]) q1++;      // contiguous run
-            search_batch(h, q1 - q + 1, (const char*)dq + (size_t)q * d * esz, dtype, k, dD + q * k, dI + q * k, false);
-            nbad += q1 - q + 1;
-            q = q1;
+        std::vector<int64_t> badq;
+        for (int64_t q = 0; q < nq; q++) if (bad[(size_t)q]) badq.push_back(q);
+        int64_t nbad = (int64_t)badq.size();
+        if (nbad > 0) {
+            // gather the uncertified queries into one contiguous batch, search it exactly, scatter the rows back
+            size_t qrow = (size_t)d * esz;
+            h->w_fbq.ensure((size_t)nbad * qrow);
+            h->w_fbD.ensure((size_t)nbad * k * 4);
+            h->w_fbI.ensure((size_t)nbad * k * 8);
+            for (int64_t i = 0; i < nbad; i++)
+                HIPCHECK(hipMemcpyAsync((char*)h->w_fbq.p + (size_t)i * qrow, (const char*)dq + (size_t)badq[(size_t)i] * qrow, qrow,
+                                        hipMemcpyDeviceToDevice, h->st));
+            search_batch(h, nbad, h->w_fbq.p, dtype, k, h->w_fbD.as<float>(), h->w_fbI.as<int64_t>(), false);
+            for (int64_t i = 0; i < nbad; i++) {
+                HIPCHECK(hipMemcpyAsync(dD + badq[(size_t)i] * k, h->w_fbD.as<float>() + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, h->st));
+                HIPCHECK(hipMemcpyAsync(dI + badq[(size_t)i] * k, h->w_fbI.as<int64_t>() + i * k, (size_t)k * 8, hipMemcpyDeviceToDevice, h->st));
+            }
         }
         h->timing["fallback_queries"] += (double)nbad;
         h->timing["fast_queries"] += (double)nq;
