@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     uint64_t* buf = sel_buf;
     const int lane = threadIdx.x;
     const int64_t row = blockIdx.x;
-    const int seg = blockIdx.y;
+    const int seg = blockIdx.y + a.seg_base;
     const int KP = a.KP, BUF = a.BUF, k = a.k;
     int64_t n = a.row_n ? a.row_n[row * a.row_n_stride] : a.n_uniform;
     int64_t start = (int64_t)seg * a.seg_len;
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     }
 
     int cnt = 0;
-    uint64_t tau = 0;
+    uint64_t tau = a.tau_ptr ? a.tau_ptr[row * a.tau_stride] : 0ull;
     if (a.init) {  // running state: KP keys sorted descending, zero padded
         for (int i = lane; i < KP; i += 64) buf[i] = a.init[row * KP + i];
         __syncthreads();
         cnt = KP;
-        tau = buf[k - 1];
+        tau = buf[k - 1] > tau ? buf[k - 1] : tau;
         __syncthreads();
     }
     // software pipeline: the next 256-element tile's loads are in flight while this one is filtered
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
                 __syncthreads();
                 bitonic_sort_desc(buf, BUF, lane);
                 cnt = KP;
-                tau = buf[k - 1];
+                tau = buf[k - 1] > tau ? buf[k - 1] : tau;
                 __syncthreads();
                 pass = key[e] > tau;
                 mask = __ballot(pass);
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
 }
 
 void launch_select(const SelectArgs& a, hipStream_t st) {
-    if (a.nrows <= 0 || a.nseg <= 0) return;
-    dim3 grid((unsigned)a.nrows, (unsigned)a.nseg);
+    if (a.nrows <= 0 || a.nseg - a.seg_base <= 0) return;
+    dim3 grid((unsigned)a.nrows, (unsigned)(a.nseg - a.seg_base));
     size_t shm = (size_t)a.BUF * sizeof(uint64_t);
     if (a.in_is_keys) {
         if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_select<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

@@ -615,7 +615,18 @@ static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, c
     }
     h->w_keys1.ensure((size_t)nrows * nseg * KP * 8);
     a.init = nullptr; a.out = h->w_keys1.as<uint64_t>(); a.out_row_stride = (int64_t)nseg * KP;
-    launch_select(a, h->st);
+    if (nseg >= 4 && !merge_state) {
+        // Phase A: segment 0 of every row (for IVF: the head of the closest list) alone; its k-th key is a
+        // lower bound of the row's final k-th best, so (phase B) the other segments start from that
+        // threshold and append almost nothing — no LDS sorts on the bulk of the row.
+        SelectArgs a0 = a; a0.nseg = 1; a0.seg_base = 0;
+        launch_select(a0, h->st);
+        a.seg_base = 1;
+        a.tau_ptr = h->w_keys1.as<uint64_t>() + (k - 1); a.tau_stride = (int64_t)nseg * KP;
+        launch_select(a, h->st);
+    } else {
+        launch_select(a, h->st);
+    }
     SelectArgs b{};
     b.in = h->w_keys1.p; b.in_is_keys = 1; b.row_stride = (int64_t)nseg * KP;
     b.row_n = nullptr; b.n_uniform = (int64_t)nseg * KP;

@@ -143,6 +143,9 @@ struct SelectArgs {
     int64_t seg_len; int nseg;
     uint32_t idx_base;
     const uint64_t* init;                   // optional [nrows, KP] running state merged in (nseg must be 1)
+    const uint64_t* tau_ptr; int64_t tau_stride;  // optional per-row starting threshold (a key known to be
+                                                  // <= the row's final k-th best): keys <= it are dropped
+    int seg_base;                           // first segment index handled by this launch
     uint64_t* out; int64_t out_row_stride;  // out[row*out_row_stride + seg*KP + i]
     int64_t nrows; int KP; int BUF; int k;
 };
