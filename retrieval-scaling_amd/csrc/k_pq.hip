@@ -13,6 +13,8 @@
 //                gather rate — deliberately NOT reshaped into a GEMM.
 //  k_pq_encode : ProductQuantizer::compute_code on residuals: nearest codeword per subspace by
 //                squared L2 (fmaf chain, first minimum), written straight into the slab layout.
+#include <cstdlib>
+
 #include "rsx_internal.h"
 
 namespace rsx {
@@ -358,7 +360,9 @@ struct PQScan8Args {
     int nlist; int max_groups; int max_tiles;
 };
 
-template <int NCH, int VPL>
+// VAR != 0 are MEASUREMENT-ONLY variants (wrong results; selected with RSX_SCAN8_VARIANT for the cost split
+// in DESIGN.md): 1 = gathers kept, mask/shift accumulate replaced by one add; 2 = no LDS gather at all.
+template <int NCH, int VPL, int VAR = 0>
 __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pq_lut4_s[];  // [Mpad][256] : byte i = query i
     const PQScanArgs& a = A.b;
@@ -426,7 +430,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
 #pragma unroll
             for (int b = 0; b < 16; b++) {
                 uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                if (VAR == 2) { acc02 += code; continue; }
                 uint32_t e = pq_lut4_s[(gg * 16 + b) * 256 + code];
+                if (VAR == 1) { acc02 += e; continue; }
                 acc02 += e & 0x00ff00ffu;
                 acc13 += (e >> 8) & 0x00ff00ffu;
             }
@@ -439,13 +445,13 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
     }
 }
 
-template <int NCH, int VPL>
+template <int NCH, int VPL, int VAR = 0>
 static int launch_pq_scan8_t(const PQScan8Args& A, hipStream_t st) {
     size_t shm = (size_t)NCH * 16 * 256 * 4;
-    if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return -1;
     dim3 grid((unsigned)((A.max_groups + 7) & ~7), (unsigned)A.max_tiles);
-    hipLaunchKernelGGL((k_pq_scan8<NCH, VPL>), grid, dim3(1024), shm, st, A);
+    hipLaunchKernelGGL((k_pq_scan8<NCH, VPL, VAR>), grid, dim3(1024), shm, st, A);
     return 0;
 }
 template <int NCH>
@@ -468,6 +474,12 @@ int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam
     A.nlist = nlist; A.max_groups = max_groups;
     A.max_tiles = (int)((max_slabs + 16 * vpl - 1) / (16 * vpl));
     if (A.max_tiles > 65535) return -1;
+    if (a.Mpad == 96 && vpl == 8) {
+        static int var = -1;
+        if (var < 0) { const char* e = getenv("RSX_SCAN8_VARIANT"); var = e ? atoi(e) : 0; }
+        if (var == 1) return launch_pq_scan8_t<6, 8, 1>(A, st);
+        if (var == 2) return launch_pq_scan8_t<6, 8, 2>(A, st);
+    }
     switch (a.Mpad / 16) {
         case 1: return launch_pq_scan8_v<1>(A, vpl, st);
         case 2: return launch_pq_scan8_v<2>(A, vpl, st);

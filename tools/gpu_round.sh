@@ -22,6 +22,8 @@ for s in $STAGES; do
       timeout 1700 python bench.py --steps 10 --warmup 3 --ab > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "exit $?" >> gpurun_out/bench.log ;;
     diag)
       timeout 300 python tools/diag_synth.py > gpurun_out/diag_synth.log 2>&1 ;;
+    variants)
+      for v in 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
     bench_diag)
       timeout 900 python bench.py --diag --no-recall --cpu-queries 0 > gpurun_out/bench_diag.json 2> gpurun_out/bench_diag.log; echo "exit $?" >> gpurun_out/bench_diag.log ;;
     prof)
