@@ -196,23 +196,32 @@ __global__ __launch_bounds__(1024) void k_pq_scan2(PQScan2Args A) {
         const int g0 = pass * GPC;
         const int ng = (NCH - g0) < GPC ? (NCH - g0) : GPC;
         if (pass > 0) __syncthreads();
+        uint4 cur[GPC], nxt[GPC];
+        if (s0 + w < nslab) {   // first slab of the pass requested before the table staging
+            const uint8_t* sp = a.codes + (slab_base + s0 + w) * slab_bytes;
+#pragma unroll
+            for (int gg = 0; gg < GPC; gg++)
+                if (gg < ng) cur[gg] = *reinterpret_cast<const uint4*>(sp + (g0 + gg) * 1024 + lane * 16);
+        }
         for (int i = tid; i < ng * 16 * 256; i += 1024)
             pq_lut2_s[i] = make_float2(lut0[g0 * 16 * 256 + i], lut1[g0 * 16 * 256 + i]);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < VPL; u++) {
             const int64_t s = s0 + w + 16 * u;
-            if (s < nslab) {
-                const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
-                uint4 c[GPC];
+            const int64_t sn = s + 16;
+            if (u + 1 < VPL && sn < nslab) {   // next slab's codes in flight during this slab's gathers
+                const uint8_t* sp = a.codes + (slab_base + sn) * slab_bytes;
 #pragma unroll
                 for (int gg = 0; gg < GPC; gg++)
-                    if (gg < ng) c[gg] = *reinterpret_cast<const uint4*>(sp + (g0 + gg) * 1024 + lane * 16);
+                    if (gg < ng) nxt[gg] = *reinterpret_cast<const uint4*>(sp + (g0 + gg) * 1024 + lane * 16);
+            }
+            if (s < nslab) {
                 float2 sum = acc[u];
 #pragma unroll
                 for (int gg = 0; gg < GPC; gg++) {
                     if (gg < ng) {
-                        const uint32_t wds[4] = {c[gg].x, c[gg].y, c[gg].z, c[gg].w};
+                        const uint32_t wds[4] = {cur[gg].x, cur[gg].y, cur[gg].z, cur[gg].w};
 #pragma unroll
                         for (int b = 0; b < 16; b++) {
                             uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
@@ -223,6 +232,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan2(PQScan2Args A) {
                 }
                 acc[u] = sum;
             }
+#pragma unroll
+            for (int gg = 0; gg < GPC; gg++) cur[gg] = nxt[gg];
         }
     }
     const float d0 = a.probe_dis0[p0], d1 = a.probe_dis0[p1];
@@ -388,6 +399,22 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
     int pidx[4]; int64_t qq[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { pidx[i] = A.pairs_sorted[pair0 + (i < np ? i : 0)]; qq[i] = pidx[i] / a.nprobe; }
+
+    // Software pipeline of the code stream: the loads of slab u+1 are in flight while slab u is being
+    // gathered, and the first slab is requested before the table staging + barrier.  (Without this
+    // hipcc waits for each slab's loads right after issuing them and the kernel is bound by
+    // exposed memory latency: 4.0 ms even with the LDS gathers removed.)
+    const int64_t slab_base = a.list_base[l] >> 6;
+    const int64_t slab_bytes = (int64_t)64 * a.Mpad;
+    uint4 cur[NCH], nxt[NCH];
+    {
+        const int64_t s = s0 + w;
+        if (s < nslab) {
+            const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
+#pragma unroll
+            for (int gg = 0; gg < NCH; gg++) cur[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
+        }
+    }
     // stage the four tables interleaved: thread handles 4 consecutive codes of one m
     {
         const int n4 = a.Mpad * 64;
@@ -404,10 +431,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
             reinterpret_cast<uint4*>(pq_lut4_s)[i] = o;
         }
     }
-    __syncthreads();
-
-    const int64_t slab_base = a.list_base[l] >> 6;
-    const int64_t slab_bytes = (int64_t)64 * a.Mpad;
     float dis0[4], scale[4], bias[4]; float* out[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -415,33 +438,40 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
         scale[i] = p.scale; bias[i] = p.bias; dis0[i] = a.probe_dis0[pidx[i]];
         out[i] = a.temp + qq[i] * a.tstride + a.seg_start[qq[i] * (a.nprobe + 1) + (pidx[i] - (int)qq[i] * a.nprobe)];
     }
+    __syncthreads();
+
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
         const int64_t s = s0 + w + 16 * u;
-        if (s >= nslab) continue;
-        const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
-        uint4 c[NCH];
+        const int64_t sn = s + 16;
+        if (u + 1 < VPL && sn < nslab) {
+            const uint8_t* sp = a.codes + (slab_base + sn) * slab_bytes;
 #pragma unroll
-        for (int gg = 0; gg < NCH; gg++) c[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
-        uint32_t acc02 = 0, acc13 = 0;   // 16-bit fields: queries (0,2) and (1,3); 96*255 < 65536
-#pragma unroll
-        for (int gg = 0; gg < NCH; gg++) {
-            const uint32_t wds[4] = {c[gg].x, c[gg].y, c[gg].z, c[gg].w};
-#pragma unroll
-            for (int b = 0; b < 16; b++) {
-                uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                if (VAR == 2) { acc02 += code; continue; }
-                uint32_t e = pq_lut4_s[(gg * 16 + b) * 256 + code];
-                if (VAR == 1) { acc02 += e; continue; }
-                acc02 += e & 0x00ff00ffu;
-                acc13 += (e >> 8) & 0x00ff00ffu;
-            }
+            for (int gg = 0; gg < NCH; gg++) nxt[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
         }
-        const int64_t pos = s * 64 + lane;
-        const uint32_t A4[4] = {acc02 & 0xffffu, acc13 & 0xffffu, acc02 >> 16, acc13 >> 16};
+        if (s < nslab) {
+            uint32_t acc02 = 0, acc13 = 0;   // 16-bit fields: queries (0,2) and (1,3); 96*255 < 65536
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (i < np) out[i][pos] = (pos < len) ? dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]) : -__builtin_inff();
+            for (int gg = 0; gg < NCH; gg++) {
+                const uint32_t wds[4] = {cur[gg].x, cur[gg].y, cur[gg].z, cur[gg].w};
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                    if (VAR == 2) { acc02 += code; continue; }
+                    uint32_t e = pq_lut4_s[(gg * 16 + b) * 256 + code];
+                    if (VAR == 1) { acc02 += e; continue; }
+                    acc02 += e & 0x00ff00ffu;
+                    acc13 += (e >> 8) & 0x00ff00ffu;
+                }
+            }
+            const int64_t pos = s * 64 + lane;
+            const uint32_t A4[4] = {acc02 & 0xffffu, acc13 & 0xffffu, acc02 >> 16, acc13 >> 16};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (i < np) out[i][pos] = (pos < len) ? dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]) : -__builtin_inff();
+        }
+#pragma unroll
+        for (int gg = 0; gg < NCH; gg++) cur[gg] = nxt[gg];
     }
 }
 
