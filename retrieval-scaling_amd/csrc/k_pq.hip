@@ -399,22 +399,22 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
     int pidx[4]; int64_t qq[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { pidx[i] = A.pairs_sorted[pair0 + (i < np ? i : 0)]; qq[i] = pidx[i] / a.nprobe; }
-
-    // Software pipeline of the code stream: the loads of slab u+1 are in flight while slab u is being
-    // gathered, and the first slab is requested before the table staging + barrier.  (Without this
-    // hipcc waits for each slab's loads right after issuing them and the kernel is bound by
-    // exposed memory latency: 4.0 ms even with the LDS gathers removed.)
     const int64_t slab_base = a.list_base[l] >> 6;
     const int64_t slab_bytes = (int64_t)64 * a.Mpad;
-    uint4 cur[NCH], nxt[NCH];
-    {
-        const int64_t s = s0 + w;
-        if (s < nslab) {
-            const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
-#pragma unroll
-            for (int gg = 0; gg < NCH; gg++) cur[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
-        }
-    }
+    // L2 prefetch that costs no VGPRs: the wave touches the cache lines of the slab it will read two
+    // steps later with an LDS-DMA load (global_load_lds: destination = a scratch LDS row per wave), so
+    // its real code loads find the lines in L2 instead of exposing a full HBM latency per slab (hipcc
+    // waits for a slab's loads right after issuing them; measured floor without this: 4.0 ms with the
+    // LDS gathers removed).  The scratch row is never read.
+    uint32_t* pf_row = pq_lut4_s + a.Mpad * 256 + w * 64;
+    const int pf_lines = (int)(slab_bytes >> 7);   // 128-byte lines per slab (48 for M = 96)
+#define RSX_PF_SLAB(S)                                                                                 \
+    if ((S) < nslab && lane < pf_lines)                                                                \
+        __builtin_amdgcn_global_load_lds(                                                              \
+            (const __attribute__((address_space(1))) void*)(a.codes + (slab_base + (S)) * slab_bytes + lane * 128), \
+            (__attribute__((address_space(3))) void*)pf_row, 4, 0, 0);
+    RSX_PF_SLAB(s0 + w)
+    RSX_PF_SLAB(s0 + w + 16)
     // stage the four tables interleaved: thread handles 4 consecutive codes of one m
     {
         const int n4 = a.Mpad * 64;
@@ -431,6 +431,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
             reinterpret_cast<uint4*>(pq_lut4_s)[i] = o;
         }
     }
+    __syncthreads();
+
     float dis0[4], scale[4], bias[4]; float* out[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -438,46 +440,47 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
         scale[i] = p.scale; bias[i] = p.bias; dis0[i] = a.probe_dis0[pidx[i]];
         out[i] = a.temp + qq[i] * a.tstride + a.seg_start[qq[i] * (a.nprobe + 1) + (pidx[i] - (int)qq[i] * a.nprobe)];
     }
-    __syncthreads();
-
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
         const int64_t s = s0 + w + 16 * u;
-        const int64_t sn = s + 16;
-        if (u + 1 < VPL && sn < nslab) {
-            const uint8_t* sp = a.codes + (slab_base + sn) * slab_bytes;
+        if (s >= nslab) continue;
+        const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
+        uint4 c[NCH];
 #pragma unroll
-            for (int gg = 0; gg < NCH; gg++) nxt[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
-        }
-        if (s < nslab) {
-            uint32_t acc02 = 0, acc13 = 0;   // 16-bit fields: queries (0,2) and (1,3); 96*255 < 65536
+        for (int gg = 0; gg < NCH; gg++) c[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
+        // All of this slab's codes must have landed BEFORE the prefetch DMA is issued: with an LDS-DMA in
+        // flight hipcc drains vmcnt(0) at the next use of an ordinary load, which would expose the
+        // prefetch's HBM miss.  Issued here it rides under this slab's 96 gathers.
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt/expcnt untouched
+        __builtin_amdgcn_sched_barrier(0);
+        RSX_PF_SLAB(s + 32)
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t acc02 = 0, acc13 = 0;   // 16-bit fields: queries (0,2) and (1,3); 96*255 < 65536
 #pragma unroll
-            for (int gg = 0; gg < NCH; gg++) {
-                const uint32_t wds[4] = {cur[gg].x, cur[gg].y, cur[gg].z, cur[gg].w};
+        for (int gg = 0; gg < NCH; gg++) {
+            const uint32_t wds[4] = {c[gg].x, c[gg].y, c[gg].z, c[gg].w};
 #pragma unroll
-                for (int b = 0; b < 16; b++) {
-                    uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                    if (VAR == 2) { acc02 += code; continue; }
-                    uint32_t e = pq_lut4_s[(gg * 16 + b) * 256 + code];
-                    if (VAR == 1) { acc02 += e; continue; }
-                    acc02 += e & 0x00ff00ffu;
-                    acc13 += (e >> 8) & 0x00ff00ffu;
-                }
+            for (int b = 0; b < 16; b++) {
+                uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                if (VAR == 2) { acc02 += code; continue; }
+                uint32_t e = pq_lut4_s[(gg * 16 + b) * 256 + code];
+                if (VAR == 1) { acc02 += e; continue; }
+                acc02 += e & 0x00ff00ffu;
+                acc13 += (e >> 8) & 0x00ff00ffu;
             }
-            const int64_t pos = s * 64 + lane;
-            const uint32_t A4[4] = {acc02 & 0xffffu, acc13 & 0xffffu, acc02 >> 16, acc13 >> 16};
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (i < np) out[i][pos] = (pos < len) ? dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]) : -__builtin_inff();
         }
+        const int64_t pos = s * 64 + lane;
+        const uint32_t A4[4] = {acc02 & 0xffffu, acc13 & 0xffffu, acc02 >> 16, acc13 >> 16};
 #pragma unroll
-        for (int gg = 0; gg < NCH; gg++) cur[gg] = nxt[gg];
+        for (int i = 0; i < 4; i++)
+            if (i < np) out[i][pos] = (pos < len) ? dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]) : -__builtin_inff();
     }
+#undef RSX_PF_SLAB
 }
 
 template <int NCH, int VPL, int VAR = 0>
 static int launch_pq_scan8_t(const PQScan8Args& A, hipStream_t st) {
-    size_t shm = (size_t)NCH * 16 * 256 * 4;
+    size_t shm = (size_t)NCH * 16 * 256 * 4 + 16 * 64 * 4;  // table + one prefetch scratch row per wave
     if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return -1;
     dim3 grid((unsigned)((A.max_groups + 7) & ~7), (unsigned)A.max_tiles);
