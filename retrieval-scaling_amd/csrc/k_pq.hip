@@ -145,8 +145,31 @@ int launch_pq_scan(const PQScanArgs& a, hipStream_t st) {
 struct PQScan2Args {
     PQScanArgs b;
     const int32_t* pairs_sorted; const int32_t* pair_off; const int32_t* group_off; const int32_t* total_groups;
-    int nlist; int max_groups; int max_tiles;
+    const int32_t* item_off; const int32_t* total_items;   // work items = (list, tile, group), list-major
+    int nlist; int max_items;
 };
+
+// Work-item decode shared by the list-major scans.  Items are ordered (list, tile, group) so that the
+// query groups of one list-tile (same codes) are adjacent; XCD c takes the contiguous item range
+// [c*TI/8, (c+1)*TI/8) (workgroups are dispatched round-robin over the 8 XCDs, block b -> XCD b % 8, each
+// with a private 4 MiB L2), so those groups run on ONE XCD close together in time and the tile is
+// fetched from HBM once.  Placement only affects speed, never results.
+__device__ inline bool pq_decode_item(const int32_t* item_off, const int32_t* group_off, int total_items, int nlist,
+                                      int& l, int& gi, int& tile) {
+    const int per_xcd = (total_items + 7) >> 3;
+    const int ix = (int)(blockIdx.x >> 3);
+    if (ix >= per_xcd) return false;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + ix;
+    if (item >= total_items) return false;
+    int lo = 0, hi = nlist;  // largest l with item_off[l] <= item
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (item_off[mid] <= item) lo = mid; else hi = mid; }
+    l = lo;
+    const int ng = group_off[l + 1] - group_off[l];
+    const int r = item - item_off[l];
+    tile = r / ng;
+    gi = r - tile * ng;
+    return true;
+}
 
 template <int NCH, int VPL>
 __global__ __launch_bounds__(1024) void k_pq_scan2(PQScan2Args A) {
@@ -155,28 +178,14 @@ __global__ __launch_bounds__(1024) void k_pq_scan2(PQScan2Args A) {
     constexpr int NP = (NCH + GPC - 1) / GPC;
     const PQScanArgs& a = A.b;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD
-    // b % 8, each with a private 4 MiB L2).  gridDim.x is a multiple of 8; XCD c takes the contiguous
-    // group range [c*TG/8, (c+1)*TG/8), so the query-pair groups of one list (consecutive g, same
-    // codes) run on ONE XCD close together in time: the list is fetched from HBM once and the other
-    // groups hit that L2.  Placement only affects speed, never results.
-    // The split uses the ACTUAL group count (device scalar), so all 8 XCDs get equal shares.
-    const int tg = *A.total_groups;
-    const int per_xcd = (tg + 7) >> 3;
-    const int gi_x = (int)(blockIdx.x >> 3);
-    if (gi_x >= per_xcd) return;
-    const int g = (int)(blockIdx.x & 7) * per_xcd + gi_x;
-    if (g >= tg) return;
-    int lo = 0, hi = A.nlist;  // largest l with group_off[l] <= g
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.group_off[mid] <= g) lo = mid; else hi = mid; }
-    const int l = lo;
-    const int gi = g - A.group_off[l];
+    int l, gi, tile;
+    if (!pq_decode_item(A.item_off, A.group_off, *A.total_items, A.nlist, l, gi, tile)) return;
     const int cnt = A.pair_off[l + 1] - A.pair_off[l];
     const int np = (cnt - 2 * gi) > 1 ? 2 : 1;
     const int pair0 = A.pair_off[l] + 2 * gi;
     const int64_t len = a.list_len[l];
     const int64_t nslab = (len + 63) >> 6;
-    const int64_t s0 = (int64_t)blockIdx.y * (16 * VPL);
+    const int64_t s0 = (int64_t)tile * (16 * VPL);
     if (s0 >= nslab) return;
     const int p0 = A.pairs_sorted[pair0];
     const int p1 = (np > 1) ? A.pairs_sorted[pair0 + 1] : p0;
@@ -256,7 +265,7 @@ static int launch_pq_scan2_t(const PQScan2Args& A, hipStream_t st) {
     size_t shm = (size_t)GPC * 16 * 256 * sizeof(float2);
     if (hipFuncSetAttribute((const void*)k_pq_scan2<NCH, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return -1;
-    dim3 grid((unsigned)((A.max_groups + 7) & ~7), (unsigned)A.max_tiles);
+    dim3 grid((unsigned)((A.max_items + 7) & ~7));
     hipLaunchKernelGGL((k_pq_scan2<NCH, VPL>), grid, dim3(1024), shm, st, A);
     return 0;
 }
@@ -271,13 +280,13 @@ static int launch_pq_scan2_v(const PQScan2Args& A, int vpl, hipStream_t st) {
 }
 // returns 0 on launch, -1 if this (M, layout) has no v2 kernel (caller falls back to k_pq_scan)
 int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int32_t* pair_off, const int32_t* group_off,
-                    const int32_t* total_groups, int nlist, int max_groups, int64_t max_slabs, int vpl, hipStream_t st) {
-    if (a.CB != 16 || max_groups <= 0) return -1;
+                    const int32_t* total_groups, const int32_t* item_off, const int32_t* total_items, int nlist,
+                    int64_t max_items, int vpl, hipStream_t st) {
+    if (a.CB != 16 || max_items <= 0 || max_items > 0x7fffff00) return -1;
     PQScan2Args A;
     A.b = a; A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
-    A.nlist = nlist; A.max_groups = max_groups;
-    A.max_tiles = (int)((max_slabs + 16 * vpl - 1) / (16 * vpl));
-    if (A.max_tiles > 65535) return -1;
+    A.item_off = item_off; A.total_items = total_items;
+    A.nlist = nlist; A.max_items = (int)max_items;
     switch (a.Mpad / 16) {
         case 1: return launch_pq_scan2_v<1>(A, vpl, st);
         case 2: return launch_pq_scan2_v<2>(A, vpl, st);
@@ -368,7 +377,8 @@ struct PQScan8Args {
     PQScanArgs b;
     const uint8_t* lut8; const PQQParam* qp;
     const int32_t* pairs_sorted; const int32_t* pair_off; const int32_t* group_off; const int32_t* total_groups;
-    int nlist; int max_groups; int max_tiles;
+    const int32_t* item_off; const int32_t* total_items;
+    int nlist; int max_items;
 };
 
 // VAR != 0 are MEASUREMENT-ONLY variants (wrong results; selected with RSX_SCAN8_VARIANT for the cost split
@@ -378,43 +388,19 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pq_lut4_s[];  // [Mpad][256] : byte i = query i
     const PQScanArgs& a = A.b;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tg = *A.total_groups;
-    const int per_xcd = (tg + 7) >> 3;           // XCD-aware mapping, see k_pq_scan2
-    const int gi_x = (int)(blockIdx.x >> 3);
-    if (gi_x >= per_xcd) return;
-    const int g = (int)(blockIdx.x & 7) * per_xcd + gi_x;
-    if (g >= tg) return;
-    int lo = 0, hi = A.nlist;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.group_off[mid] <= g) lo = mid; else hi = mid; }
-    const int l = lo;
-    const int gi = g - A.group_off[l];
+    int l, gi, tile;
+    if (!pq_decode_item(A.item_off, A.group_off, *A.total_items, A.nlist, l, gi, tile)) return;
     const int cnt = A.pair_off[l + 1] - A.pair_off[l];
     int np = cnt - 4 * gi; if (np > 4) np = 4;
     const int pair0 = A.pair_off[l] + 4 * gi;
     const int64_t len = a.list_len[l];
     const int64_t nslab = (len + 63) >> 6;
-    const int64_t s0 = (int64_t)blockIdx.y * (16 * VPL);
+    const int64_t s0 = (int64_t)tile * (16 * VPL);
     if (s0 >= nslab) return;
 
     int pidx[4]; int64_t qq[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { pidx[i] = A.pairs_sorted[pair0 + (i < np ? i : 0)]; qq[i] = pidx[i] / a.nprobe; }
-    const int64_t slab_base = a.list_base[l] >> 6;
-    const int64_t slab_bytes = (int64_t)64 * a.Mpad;
-    // L2 prefetch that costs no VGPRs: the wave touches the cache lines of the slab it will read two
-    // steps later with an LDS-DMA load (global_load_lds: destination = a scratch LDS row per wave), so
-    // its real code loads find the lines in L2 instead of exposing a full HBM latency per slab (hipcc
-    // waits for a slab's loads right after issuing them; measured floor without this: 4.0 ms with the
-    // LDS gathers removed).  The scratch row is never read.
-    uint32_t* pf_row = pq_lut4_s + a.Mpad * 256 + w * 64;
-    const int pf_lines = (int)(slab_bytes >> 7);   // 128-byte lines per slab (48 for M = 96)
-#define RSX_PF_SLAB(S)                                                                                 \
-    if ((S) < nslab && lane < pf_lines)                                                                \
-        __builtin_amdgcn_global_load_lds(                                                              \
-            (const __attribute__((address_space(1))) void*)(a.codes + (slab_base + (S)) * slab_bytes + lane * 128), \
-            (__attribute__((address_space(3))) void*)pf_row, 4, 0, 0);
-    RSX_PF_SLAB(s0 + w)
-    RSX_PF_SLAB(s0 + w + 16)
     // stage the four tables interleaved: thread handles 4 consecutive codes of one m
     {
         const int n4 = a.Mpad * 64;
@@ -433,6 +419,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
     }
     __syncthreads();
 
+    const int64_t slab_base = a.list_base[l] >> 6;
+    const int64_t slab_bytes = (int64_t)64 * a.Mpad;
     float dis0[4], scale[4], bias[4]; float* out[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -448,13 +436,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
         uint4 c[NCH];
 #pragma unroll
         for (int gg = 0; gg < NCH; gg++) c[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
-        // All of this slab's codes must have landed BEFORE the prefetch DMA is issued: with an LDS-DMA in
-        // flight hipcc drains vmcnt(0) at the next use of an ordinary load, which would expose the
-        // prefetch's HBM miss.  Issued here it rides under this slab's 96 gathers.
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt/expcnt untouched
-        __builtin_amdgcn_sched_barrier(0);
-        RSX_PF_SLAB(s + 32)
-        __builtin_amdgcn_sched_barrier(0);
         uint32_t acc02 = 0, acc13 = 0;   // 16-bit fields: queries (0,2) and (1,3); 96*255 < 65536
 #pragma unroll
         for (int gg = 0; gg < NCH; gg++) {
@@ -475,15 +456,14 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
         for (int i = 0; i < 4; i++)
             if (i < np) out[i][pos] = (pos < len) ? dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]) : -__builtin_inff();
     }
-#undef RSX_PF_SLAB
 }
 
 template <int NCH, int VPL, int VAR = 0>
 static int launch_pq_scan8_t(const PQScan8Args& A, hipStream_t st) {
-    size_t shm = (size_t)NCH * 16 * 256 * 4 + 16 * 64 * 4;  // table + one prefetch scratch row per wave
+    size_t shm = (size_t)NCH * 16 * 256 * 4;
     if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return -1;
-    dim3 grid((unsigned)((A.max_groups + 7) & ~7), (unsigned)A.max_tiles);
+    dim3 grid((unsigned)((A.max_items + 7) & ~7));
     hipLaunchKernelGGL((k_pq_scan8<NCH, VPL, VAR>), grid, dim3(1024), shm, st, A);
     return 0;
 }
@@ -498,15 +478,15 @@ static int launch_pq_scan8_v(const PQScan8Args& A, int vpl, hipStream_t st) {
 }
 // returns 0 on launch, -1 if this (M, layout) has no fast-scan kernel
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
-                    const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups, int nlist,
-                    int max_groups, int64_t max_slabs, int vpl, hipStream_t st) {
-    if (a.CB != 16 || max_groups <= 0 || a.M * 255 >= 65536) return -1;
+                    const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
+                    const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
+                    hipStream_t st) {
+    if (a.CB != 16 || max_items <= 0 || max_items > 0x7fffff00 || a.M * 255 >= 65536) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8; A.qp = (const PQQParam*)qparam;
     A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
-    A.nlist = nlist; A.max_groups = max_groups;
-    A.max_tiles = (int)((max_slabs + 16 * vpl - 1) / (16 * vpl));
-    if (A.max_tiles > 65535) return -1;
+    A.item_off = item_off; A.total_items = total_items;
+    A.nlist = nlist; A.max_items = (int)max_items;
     if (a.Mpad == 96 && vpl == 8) {
         static int var = -1;
         if (var < 0) { const char* e = getenv("RSX_SCAN8_VARIANT"); var = e ? atoi(e) : 0; }

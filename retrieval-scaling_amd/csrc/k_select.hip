@@ -171,26 +171,38 @@ __global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int32_t* 
 }
 // single workgroup exclusive scan over lists: pair_off (pairs) and group_off (groups of G pairs)
 __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlist, int G, int32_t* pair_off,
-                                                    int32_t* group_off, int32_t* total_groups) {
-    __shared__ int32_t sp[1024], sg[1024];
+                                                    int32_t* group_off, int32_t* total_groups,
+                                                    const int64_t* list_len, int tile_rows, int32_t* item_off,
+                                                    int32_t* total_items) {
+    __shared__ int32_t sp[1024], sg[1024], si[1024];
     int t = threadIdx.x;
     int per = (nlist + 1023) / 1024;
     int lo = t * per, hi = lo + per;
     if (hi > nlist) hi = nlist;
-    int32_t ap = 0, ag = 0;
-    for (int l = lo; l < hi; l++) { ap += cnt[l]; ag += (cnt[l] + G - 1) / G; }
-    sp[t] = ap; sg[t] = ag;
+    int32_t ap = 0, ag = 0, ai = 0;
+    for (int l = lo; l < hi; l++) {
+        int ng = (cnt[l] + G - 1) / G;
+        ap += cnt[l]; ag += ng;
+        if (tile_rows > 0) ai += ng * (int32_t)((list_len[l] + tile_rows - 1) / tile_rows);
+    }
+    sp[t] = ap; sg[t] = ag; si[t] = ai;
     __syncthreads();
     if (t == 0) {
-        int32_t rp = 0, rg = 0;
-        for (int i = 0; i < 1024; i++) { int32_t x = sp[i], y = sg[i]; sp[i] = rp; sg[i] = rg; rp += x; rg += y; }
+        int32_t rp = 0, rg = 0, ri = 0;
+        for (int i = 0; i < 1024; i++) {
+            int32_t x = sp[i], y = sg[i], z = si[i];
+            sp[i] = rp; sg[i] = rg; si[i] = ri; rp += x; rg += y; ri += z;
+        }
         pair_off[nlist] = rp; group_off[nlist] = rg; *total_groups = rg;
+        if (tile_rows > 0) { item_off[nlist] = ri; *total_items = ri; }
     }
     __syncthreads();
-    ap = sp[t]; ag = sg[t];
+    ap = sp[t]; ag = sg[t]; ai = si[t];
     for (int l = lo; l < hi; l++) {
+        int ng = (cnt[l] + G - 1) / G;
         pair_off[l] = ap; group_off[l] = ag;
-        ap += cnt[l]; ag += (cnt[l] + G - 1) / G;
+        if (tile_rows > 0) { item_off[l] = ai; ai += ng * (int32_t)((list_len[l] + tile_rows - 1) / tile_rows); }
+        ap += cnt[l]; ag += ng;
     }
 }
 __global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, const int32_t* pair_off,
@@ -203,11 +215,13 @@ __global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, const 
 }
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
-                        int32_t* pairs_sorted, hipStream_t st) {
+                        int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
+                        int32_t* total_items, hipStream_t st) {
     hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
     hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
     hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, cnt);
-    hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, group_size, pair_off, group_off, total_groups);
+    hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, group_size, pair_off, group_off, total_groups,
+                       list_len, tile_rows, item_off, total_items);
     hipLaunchKernelGGL(k_pair_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs,
                        pair_off, cursor, pairs_sorted);
 }

@@ -637,6 +637,18 @@ static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, c
     launch_select(b, h->st);
 }
 
+// Upper bound on the number of (list, tile, group) work items of a list-major scan without a host round
+// trip: sum_l ceil(cnt_l/G)*tiles_l <= (nq * TQ)/G + sum_l tiles_l, TQ = tiles of the nprobe longest lists.
+static int64_t max_scan_items(const rsx_index* h, int64_t nq, int nprobe, int G, int tile_rows) {
+    std::vector<int64_t> t((size_t)h->nlist);
+    int64_t all = 0;
+    for (int l = 0; l < h->nlist; l++) { t[(size_t)l] = (h->h_len[(size_t)l] + tile_rows - 1) / tile_rows; all += t[(size_t)l]; }
+    std::partial_sort(t.begin(), t.begin() + nprobe, t.end(), std::greater<int64_t>());
+    int64_t tq = 0;
+    for (int j = 0; j < nprobe; j++) tq += t[(size_t)j];
+    return (nq * tq + G - 1) / G + all + 8;
+}
+
 static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI,
                          bool allow_fast = true) {
     StageTimer tm(h, allow_fast ? "" : "fb_");
@@ -776,45 +788,51 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             launch_pq_lut8(h->w_lut.as<float>(), nq, h->M, h->Mpad, h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(),
                            h->w_qparam.p, h->st);
             tm.mark("lut8");
-            h->w_pairs.ensure((size_t)(pairs + 4 * (size_t)(nlist + 1) + 4) * 4);
-            int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
-            int32_t* cnt = pairs_sorted + pairs;
-            int32_t* cursor = cnt + (nlist + 1);
-            int32_t* pair_off = cursor + (nlist + 1);
-            int32_t* group_off = pair_off + (nlist + 1);
-            int32_t* total_groups = group_off + (nlist + 1);
-            launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, h->st);
-            tm.mark("group");
-            int max_groups = (int)std::min<int64_t>(pairs, pairs / 4 + std::min<int64_t>(nlist, pairs));
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             int vpl = 8;
             if (h->scan_chunk > 0) vpl = std::max(1, std::min(8, h->scan_chunk / 1024));
             else while (vpl > 1 && (pairs / 4 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
             if (vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
-            done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                   total_groups, nlist, max_groups, max_slabs, vpl, h->st) == 0;
-            if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
-        }
-        if (!done && h->scan_kernel != 1 && h->CB == 16) {
-            // v2: list-major, two queries per LDS read
-            h->w_pairs.ensure((size_t)(pairs + 4 * (size_t)(nlist + 1) + 4) * 4);
+            const int tile_rows = 64 * 16 * vpl;
+            h->w_pairs.ensure((size_t)(pairs + 5 * (size_t)(nlist + 1) + 8) * 4);
             int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
             int32_t* cnt = pairs_sorted + pairs;
             int32_t* cursor = cnt + (nlist + 1);
             int32_t* pair_off = cursor + (nlist + 1);
             int32_t* group_off = pair_off + (nlist + 1);
-            int32_t* total_groups = group_off + (nlist + 1);
-            launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 2, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, h->st);
+            int32_t* item_off = group_off + (nlist + 1);
+            int32_t* total_groups = item_off + (nlist + 1);
+            int32_t* total_items = total_groups + 1;
+            launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
+                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, h->st);
             tm.mark("group");
-            int max_groups = (int)std::min<int64_t>(pairs, pairs / 2 + std::min<int64_t>(nlist, pairs));
+            done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
+                                   total_groups, item_off, total_items, nlist, max_scan_items(h, nq, nprobe, 4, tile_rows),
+                                   vpl, h->st) == 0;
+            if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
+        }
+        if (!done && h->scan_kernel != 1 && h->CB == 16) {
+            // v2: list-major, two queries per LDS read
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             int vpl = 8;
             if (h->scan_chunk > 0) vpl = std::max(1, std::min(8, h->scan_chunk / 1024));
             else while (vpl > 1 && (pairs / 2 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
             if (vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
-            done = launch_pq_scan2(a, pairs_sorted, pair_off, group_off, total_groups, nlist, max_groups, max_slabs, vpl, h->st) == 0;
+            const int tile_rows = 64 * 16 * vpl;
+            h->w_pairs.ensure((size_t)(pairs + 5 * (size_t)(nlist + 1) + 8) * 4);
+            int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
+            int32_t* cnt = pairs_sorted + pairs;
+            int32_t* cursor = cnt + (nlist + 1);
+            int32_t* pair_off = cursor + (nlist + 1);
+            int32_t* group_off = pair_off + (nlist + 1);
+            int32_t* item_off = group_off + (nlist + 1);
+            int32_t* total_groups = item_off + (nlist + 1);
+            int32_t* total_items = total_groups + 1;
+            launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 2, cnt, cursor, pair_off, group_off, total_groups,
+                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, h->st);
+            tm.mark("group");
+            done = launch_pq_scan2(a, pairs_sorted, pair_off, group_off, total_groups, item_off, total_items, nlist,
+                                   max_scan_items(h, nq, nprobe, 2, tile_rows), vpl, h->st) == 0;
         }
         if (!done) {
             int64_t spc;
@@ -842,7 +860,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int32_t* group_off = pair_off + (nlist + 1);
         int32_t* total_groups = group_off + (nlist + 1);
         launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
-                           pairs_sorted, h->st);
+                           pairs_sorted, nullptr, 0, nullptr, nullptr, h->st);
         tm.mark("group");
         const float* bias = nullptr;
         if (h->metric == RSX_METRIC_L2) { bias = h->w_misc.as<float>(); }

@@ -122,13 +122,15 @@ struct PQScanArgs {
 int launch_pq_scan(const PQScanArgs& a, hipStream_t st);  // returns 0, or -1 if the LDS request cannot be met
 // list-major two-queries-per-LDS-read scan; pairs grouped by list in groups of 2 (launch_group_pairs)
 int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int32_t* pair_off, const int32_t* group_off,
-                    const int32_t* total_groups, int nlist, int max_groups, int64_t max_slabs, int vpl, hipStream_t st);
+                    const int32_t* total_groups, const int32_t* item_off, const int32_t* total_items, int nlist,
+                    int64_t max_items, int vpl, hipStream_t st);
 // 8-bit table fast scan (4 queries per LDS read) — approximate scores, certified by k_finalize
 void launch_pq_lut8(const float* lut32, int64_t nq, int M, int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
                     void* qparam /* [nq] {scale, bias, eps, pad} */, hipStream_t st);
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
-                    const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups, int nlist,
-                    int max_groups, int64_t max_slabs, int vpl, hipStream_t st);
+                    const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
+                    const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
+                    hipStream_t st);
 // codes for rows of a batch: residual vs centroid[assign] (centroids may be null -> no residual).
 // plain_out != null: write [n, Mpad] row-major instead of the slab layout (training / export).
 void launch_pq_encode(const void* x, int x_f16, int64_t n, int ldx, int d, int M, int Mpad, int CB,
@@ -152,9 +154,11 @@ struct SelectArgs {
 void launch_select(const SelectArgs& a, hipStream_t st);
 void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
                         int pad_to, int32_t* probe_list, float* probe_dis0, int64_t* seg_start, hipStream_t st);
+// tile_rows > 0: also build the (list, tile, group) work-item table: item_off[nlist+1], total_items
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
-                        int32_t* pairs_sorted, hipStream_t st);
+                        int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
+                        int32_t* total_items, hipStream_t st);
 struct FinalizeArgs {
     int kind; int metric;
     const uint64_t* state; int KP; int k; int64_t nq;
