@@ -22,6 +22,9 @@ for s in $STAGES; do
       timeout 1700 python bench.py --steps 10 --warmup 3 --ab > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "exit $?" >> gpurun_out/bench.log ;;
     diag)
       timeout 300 python tools/diag_synth.py > gpurun_out/diag_synth.log 2>&1 ;;
+    configs)
+      timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log
+      timeout 900 python tools/bench_configs.py ivfflat > gpurun_out/cfg_ivfflat.json 2> gpurun_out/cfg_ivfflat.log; echo "exit $?" >> gpurun_out/cfg_ivfflat.log ;;
     variants)
       for v in 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
     bench_diag)
