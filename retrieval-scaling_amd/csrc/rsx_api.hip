@@ -705,7 +705,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             if (a.max_chunks > 65535) { a.chunk_rows = (int)round_up((round_up(N, 16) + 65534) / 65535, 64); a.max_chunks = (int)((round_up(N, 16) + a.chunk_rows - 1) / a.chunk_rows); }
             launch_list_scan(a, h->st);
             tm.mark("scan");
-            select_rows(h, h->w_temp.as<float>(), tstride, nullptr, 0, N, 0, nq, KP, BUF, k, state, false);
+            // threshold = the KP-th approximate key (not the k-th): the exact re-rank needs the true top-KP
+            select_rows(h, h->w_temp.as<float>(), tstride, nullptr, 0, N, 0, nq, KP, BUF, KP, state, false);
             tm.mark("select");
         } else {
             const int64_t CH = 65536;
@@ -715,7 +716,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 int64_t nv = std::min<int64_t>(CH, N - v0);
                 launch_flat_gemm(h->w_q16.as<__half>(), (int)nq_pad, h->data.p, h->storage_f16, v0, nv, ld, bias,
                                  h->w_temp.as<float>(), CH, h->st);
-                select_rows(h, h->w_temp.as<float>(), CH, nullptr, 0, nv, (uint32_t)v0, nq, KP, BUF, k, state, true);
+                select_rows(h, h->w_temp.as<float>(), CH, nullptr, 0, nv, (uint32_t)v0, nq, KP, BUF, KP, state, true);
             }
             tm.mark("scan");
         }
@@ -884,7 +885,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     // fast scan: the certificate needs the TRUE top-K' by approximate score, so the selection threshold
     // is the K'-th key, not the k-th
     select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + nprobe, nprobe + 1, tmax, 0, nq, KP, BUF,
-                fast ? KP : k, state, false);
+                (fast || h->kind == KIND_IVFFLAT) ? KP : k, state, false);
     tm.mark("select");
     fa.probe_list = h->w_probelist.as<int32_t>(); fa.seg_start = h->w_segstart.as<int64_t>(); fa.nprobe = nprobe;
     if (fast) {
