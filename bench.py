@@ -188,7 +188,7 @@ def main():
     scan_ms = index.get_timing("scan")
     scan_launches = index.get_timing("scan_launches")
     stage_ms = {s: round(index.get_timing(s) / args.steps, 4) for s in
-                ("convert", "coarse", "select_probe", "lut", "lut8", "group", "scan", "select", "finalize", "total")}
+                ("convert", "coarse", "select_probe", "lut", "lut8", "group", "scan0", "select0", "scan", "select", "finalize", "total")}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

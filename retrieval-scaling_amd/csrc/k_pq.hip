@@ -379,11 +379,13 @@ struct PQScan8Args {
     const int32_t* pairs_sorted; const int32_t* pair_off; const int32_t* group_off; const int32_t* total_groups;
     const int32_t* item_off; const int32_t* total_items;
     int nlist; int max_items;
+    // filtered output (FILTER = true): keys > tau_key[q] are appended to cand[q][0..cap)
+    const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
 };
 
 // VAR != 0 are MEASUREMENT-ONLY variants (wrong results; selected with RSX_SCAN8_VARIANT for the cost split
 // in DESIGN.md): 1 = gathers kept, mask/shift accumulate replaced by one add; 2 = no LDS gather at all.
-template <int NCH, int VPL, int VAR = 0>
+template <int NCH, int VPL, int VAR = 0, bool FILTER = false>
 __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pq_lut4_s[];  // [Mpad][256] : byte i = query i
     const PQScanArgs& a = A.b;
@@ -421,12 +423,14 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
 
     const int64_t slab_base = a.list_base[l] >> 6;
     const int64_t slab_bytes = (int64_t)64 * a.Mpad;
-    float dis0[4], scale[4], bias[4]; float* out[4];
+    float dis0[4], scale[4], bias[4]; float* out[4]; int64_t segcol[4]; uint64_t tau[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         PQQParam p = A.qp[qq[i]];
         scale[i] = p.scale; bias[i] = p.bias; dis0[i] = a.probe_dis0[pidx[i]];
-        out[i] = a.temp + qq[i] * a.tstride + a.seg_start[qq[i] * (a.nprobe + 1) + (pidx[i] - (int)qq[i] * a.nprobe)];
+        segcol[i] = a.seg_start[qq[i] * (a.nprobe + 1) + (pidx[i] - (int)qq[i] * a.nprobe)];
+        out[i] = a.temp + qq[i] * a.tstride + segcol[i];
+        tau[i] = FILTER ? A.tau_key[qq[i] * A.tau_stride] : 0ull;
     }
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
@@ -453,27 +457,45 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
         const int64_t pos = s * 64 + lane;
         const uint32_t A4[4] = {acc02 & 0xffffu, acc13 & 0xffffu, acc02 >> 16, acc13 >> 16};
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (i < np) out[i][pos] = (pos < len) ? dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]) : -__builtin_inff();
+        for (int i = 0; i < 4; i++) {
+            if (i >= np) continue;
+            const float sc = dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]);
+            if (!FILTER) {
+                out[i][pos] = (pos < len) ? sc : -__builtin_inff();
+            } else {
+                // candidate key in the same index space the score buffer would use (column of the query's row)
+                const uint64_t key = (pos < len) ? make_key(sc, (uint32_t)(segcol[i] + pos)) : 0ull;
+                const bool pass = key > tau[i];
+                const uint64_t mask = __ballot(pass);
+                if (mask) {   // wave-aggregated append: one atomic per wave per query
+                    unsigned long long base = 0;
+                    const int leader = __ffsll((unsigned long long)mask) - 1;
+                    if (lane == leader) base = atomicAdd(&A.cand_cnt[qq[i]], (unsigned long long)__popcll(mask));
+                    base = __shfl(base, leader);
+                    const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (pass && slot < (unsigned long long)A.cand_cap) A.cand[qq[i] * A.cand_cap + slot] = key;
+                }
+            }
+        }
     }
 }
 
-template <int NCH, int VPL, int VAR = 0>
+template <int NCH, int VPL, int VAR = 0, bool FILTER = false>
 static int launch_pq_scan8_t(const PQScan8Args& A, hipStream_t st) {
     size_t shm = (size_t)NCH * 16 * 256 * 4;
-    if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL, VAR, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return -1;
     dim3 grid((unsigned)((A.max_items + 7) & ~7));
-    hipLaunchKernelGGL((k_pq_scan8<NCH, VPL, VAR>), grid, dim3(1024), shm, st, A);
+    hipLaunchKernelGGL((k_pq_scan8<NCH, VPL, VAR, FILTER>), grid, dim3(1024), shm, st, A);
     return 0;
 }
-template <int NCH>
+template <int NCH, bool FILTER = false>
 static int launch_pq_scan8_v(const PQScan8Args& A, int vpl, hipStream_t st) {
     switch (vpl) {
-        case 8: return launch_pq_scan8_t<NCH, 8>(A, st);
-        case 4: return launch_pq_scan8_t<NCH, 4>(A, st);
-        case 2: return launch_pq_scan8_t<NCH, 2>(A, st);
-        default: return launch_pq_scan8_t<NCH, 1>(A, st);
+        case 8: return launch_pq_scan8_t<NCH, 8, 0, FILTER>(A, st);
+        case 4: return launch_pq_scan8_t<NCH, 4, 0, FILTER>(A, st);
+        case 2: return launch_pq_scan8_t<NCH, 2, 0, FILTER>(A, st);
+        default: return launch_pq_scan8_t<NCH, 1, 0, FILTER>(A, st);
     }
 }
 // returns 0 on launch, -1 if this (M, layout) has no fast-scan kernel
@@ -487,6 +509,7 @@ int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam
     A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
+    A.tau_key = nullptr; A.tau_stride = 0; A.cand = nullptr; A.cand_cnt = nullptr; A.cand_cap = 0;
     if (a.Mpad == 96 && vpl == 8) {
         static int var = -1;
         if (var < 0) { const char* e = getenv("RSX_SCAN8_VARIANT"); var = e ? atoi(e) : 0; }
@@ -500,6 +523,29 @@ int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam
         case 4: return launch_pq_scan8_v<4>(A, vpl, st);
         case 6: return launch_pq_scan8_v<6>(A, vpl, st);
         case 8: return launch_pq_scan8_v<8>(A, vpl, st);
+        default: return -1;
+    }
+}
+
+int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
+                           const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
+                           const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
+                           const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
+                           int cand_cap, hipStream_t st) {
+    if (a.CB != 16 || max_items <= 0 || max_items > 0x7fffff00 || a.M * 255 >= 65536) return -1;
+    PQScan8Args A;
+    A.b = a; A.lut8 = lut8; A.qp = (const PQQParam*)qparam;
+    A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
+    A.item_off = item_off; A.total_items = total_items;
+    A.nlist = nlist; A.max_items = (int)max_items;
+    A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap;
+    switch (a.Mpad / 16) {
+        case 1: return launch_pq_scan8_v<1, true>(A, vpl, st);
+        case 2: return launch_pq_scan8_v<2, true>(A, vpl, st);
+        case 3: return launch_pq_scan8_v<3, true>(A, vpl, st);
+        case 4: return launch_pq_scan8_v<4, true>(A, vpl, st);
+        case 6: return launch_pq_scan8_v<6, true>(A, vpl, st);
+        case 8: return launch_pq_scan8_v<8, true>(A, vpl, st);
         default: return -1;
     }
 }

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     const int seg = blockIdx.y + a.seg_base;
     const int KP = a.KP, BUF = a.BUF, k = a.k;
     int64_t n = a.row_n ? a.row_n[row * a.row_n_stride] : a.n_uniform;
+    if (a.row_n && a.n_uniform > 0 && n > a.n_uniform) n = a.n_uniform;   // counts may exceed the buffer capacity
     int64_t start = (int64_t)seg * a.seg_len;
     int64_t end = start + a.seg_len;
     if (end > n) end = n;
@@ -165,9 +166,14 @@ __global__ void k_zero_i32(int32_t* p, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
 }
-__global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int32_t* cnt) {
+// jmin/jmax: only pairs whose probe rank j = i % nprobe lies in [jmin, jmax) take part
+__global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int nprobe, int jmin, int jmax, int32_t* cnt) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npairs) { int32_t l = probe_list[i]; if (l >= 0) atomicAdd(&cnt[l], 1); }
+    if (i < npairs) {
+        int j = (int)(i % nprobe);
+        int32_t l = probe_list[i];
+        if (l >= 0 && j >= jmin && j < jmax) atomicAdd(&cnt[l], 1);
+    }
 }
 // single workgroup exclusive scan over lists: pair_off (pairs) and group_off (groups of G pairs)
 __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlist, int G, int32_t* pair_off,
@@ -205,25 +211,26 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
         ap += cnt[l]; ag += ng;
     }
 }
-__global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, const int32_t* pair_off,
-                               int32_t* cursor, int32_t* pairs_sorted) {
+__global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, int nprobe, int jmin, int jmax,
+                               const int32_t* pair_off, int32_t* cursor, int32_t* pairs_sorted) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npairs) {
+        int j = (int)(i % nprobe);
         int32_t l = probe_list[i];
-        if (l >= 0) { int s = atomicAdd(&cursor[l], 1); pairs_sorted[pair_off[l] + s] = (int32_t)i; }
+        if (l >= 0 && j >= jmin && j < jmax) { int s = atomicAdd(&cursor[l], 1); pairs_sorted[pair_off[l] + s] = (int32_t)i; }
     }
 }
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                         int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
-                        int32_t* total_items, hipStream_t st) {
+                        int32_t* total_items, int nprobe, int jmin, int jmax, hipStream_t st) {
     hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
     hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
-    hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, cnt);
+    hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, nprobe, jmin, jmax, cnt);
     hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, group_size, pair_off, group_off, total_groups,
                        list_len, tile_rows, item_off, total_items);
     hipLaunchKernelGGL(k_pair_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs,
-                       pair_off, cursor, pairs_sorted);
+                       nprobe, jmin, jmax, pair_off, cursor, pairs_sorted);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -350,6 +357,7 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
             float s_k = have_k ? ord2f(sord[a.k - 1]) : -__builtin_inff();
             if (!(a_last + eps < s_k)) bad = 1;
         }
+        if (a.cand_cnt && a.cand_cnt[q] > (unsigned long long)a.cand_cap) bad = 1;   // candidates were dropped
         a.uncertain[q] = bad;
     }
     for (int j = lane; j < a.k; j += 64) {

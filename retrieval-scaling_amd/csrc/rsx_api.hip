@@ -146,12 +146,13 @@ struct rsx_index {
     int scan_kernel = 0;  // 0 = auto (list-major v2 when the layout allows), 1 = force the per-pair v1 kernel
     int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
     int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
+    int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt;
     std::map<std::string, double> timing;
 
     int row_align() const { return kind == KIND_IVFPQ ? 64 : (kind == KIND_FLAT ? 128 : 64); }
@@ -767,6 +768,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     tmax = std::max<int64_t>(round_up(tmax, 256), 256);
     if (tmax >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "probed lists exceed 2^32 vectors per query");
     h->w_temp.ensure((size_t)nq * tmax * 4);
+    bool filtered = false;   // fast path with in-kernel candidate filtering (no full score buffer)
+    int cand_cap = 0;
 
     if (h->kind == KIND_IVFPQ) {
         h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4);
@@ -804,12 +807,40 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             int32_t* item_off = group_off + (nlist + 1);
             int32_t* total_groups = item_off + (nlist + 1);
             int32_t* total_items = total_groups + 1;
+            // Two stages, so that only a sliver of the scores ever leaves the scan kernel:
+            //  stage 1: scan ONLY each query's closest list (probe rank 0) into the score buffer and take its
+            //           top-K' -> state0; its K'-th key is a lower bound of the query's final K'-th best key;
+            //  stage 2: scan the other probes, appending to a small per-query candidate buffer only the keys that
+            //           beat that bound (wave-aggregated atomics); a final select merges them with state0.
+            // A full candidate buffer marks the query uncertain (-> exact fallback), so this is always exact.
+            filtered = (nprobe > 1) && (h->pq_filter != 0);
             launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, h->st);
+                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0,
+                               filtered ? 1 : nprobe, h->st);
             tm.mark("group");
             done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                   total_groups, item_off, total_items, nlist, max_scan_items(h, nq, nprobe, 4, tile_rows),
-                                   vpl, h->st) == 0;
+                                   total_groups, item_off, total_items, nlist,
+                                   max_scan_items(h, nq, filtered ? 1 : nprobe, 4, tile_rows), vpl, h->st) == 0;
+            if (done && filtered) {
+                tm.mark("scan0");
+                // top-K' of the closest list: row prefix [0, seg_start[q][1])
+                select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1, maxlen, 0, nq, KP, BUF,
+                            KP, state, false);
+                tm.mark("select0");
+                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
+                h->w_cand.ensure((size_t)nq * cand_cap * 8);
+                h->w_candcnt.ensure((size_t)nq * 8);
+                HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8, h->st));
+                launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
+                                   pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 1, nprobe,
+                                   h->st);
+                tm.mark("group");
+                done = launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
+                                              total_groups, item_off, total_items, nlist,
+                                              max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
+                                              h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
+                                              h->st) == 0;
+            }
             if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
         }
         if (!done && h->scan_kernel != 1 && h->CB == 16) {
@@ -830,7 +861,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             int32_t* total_groups = item_off + (nlist + 1);
             int32_t* total_items = total_groups + 1;
             launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 2, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, h->st);
+                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, h->st);
             tm.mark("group");
             done = launch_pq_scan2(a, pairs_sorted, pair_off, group_off, total_groups, item_off, total_items, nlist,
                                    max_scan_items(h, nq, nprobe, 2, tile_rows), vpl, h->st) == 0;
@@ -861,7 +892,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int32_t* group_off = pair_off + (nlist + 1);
         int32_t* total_groups = group_off + (nlist + 1);
         launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
-                           pairs_sorted, nullptr, 0, nullptr, nullptr, h->st);
+                           pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, h->st);
         tm.mark("group");
         const float* bias = nullptr;
         if (h->metric == RSX_METRIC_L2) { bias = h->w_misc.as<float>(); }
@@ -882,16 +913,28 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         tm.mark("scan");
     }
     // 3. per-query k-selection over the score rows
-    // fast scan: the certificate needs the TRUE top-K' by approximate score, so the selection threshold
-    // is the K'-th key, not the k-th
-    select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + nprobe, nprobe + 1, tmax, 0, nq, KP, BUF,
-                (fast || h->kind == KIND_IVFFLAT) ? KP : k, state, false);
+    if (filtered) {
+        // merge the filtered candidates (keys) into state0: one wave per query, the whole buffer in one segment
+        SelectArgs b{};
+        b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cand_cap;
+        b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = 1; b.n_uniform = cand_cap;
+        b.seg_len = round_up(cand_cap, 256); b.nseg = 1; b.idx_base = 0;
+        b.init = state; b.out = state; b.out_row_stride = KP;
+        b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;
+        launch_select(b, h->st);
+    } else {
+        // fast scan: the certificate needs the TRUE top-K' by approximate score, so the selection threshold
+        // is the K'-th key, not the k-th
+        select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + nprobe, nprobe + 1, tmax, 0, nq, KP, BUF,
+                    (fast || h->kind == KIND_IVFFLAT) ? KP : k, state, false);
+    }
     tm.mark("select");
     fa.probe_list = h->w_probelist.as<int32_t>(); fa.seg_start = h->w_segstart.as<int64_t>(); fa.nprobe = nprobe;
     if (fast) {
         fa.pq_rescore = 1; fa.codes = h->data.as<uint8_t>(); fa.M = h->M; fa.Mpad = h->Mpad; fa.CB = h->CB;
         fa.lut32 = h->w_lut.as<float>(); fa.probe_dis0 = h->w_dis0.as<float>(); fa.qparam = h->w_qparam.p;
         fa.uncertain = h->w_uncertain.as<int32_t>();
+        if (filtered) { fa.cand_cnt = h->w_candcnt.as<unsigned long long>(); fa.cand_cap = cand_cap; }
     }
     launch_finalize(fa, h->st);
     tm.mark("finalize");
@@ -1371,6 +1414,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "scan_kernel") h->scan_kernel = (int)value;
         else if (s == "pq_fast") h->pq_fast = (int)value;
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
+        else if (s == "pq_filter") h->pq_filter = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;
         else RSX_THROW(RSX_ERR_INVALID, "unknown parameter '%s'", key);

@@ -100,6 +100,10 @@ def test_golden_ivfpq(gpu, orc, name):
     assert_same_results(D7, I7, g["D"], g["I"], name + " starved fast scan")
     assert ix.get_timing("fallback_queries") > auto_fallbacks, "K' = k cannot be certifiable for every query"
     ix.set_param("pq_fast_kp", 0)
+    ix.set_param("pq_filter", 0)            # fast scan through the full score buffer instead of in-kernel filtering
+    D8, I8 = ix.search(q, g["k"])
+    assert_same_results(D8, I8, g["D"], g["I"], name + " unfiltered fast scan")
+    ix.set_param("pq_filter", 1)
 
 
 @pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8)])

@@ -55,6 +55,10 @@ def test_properties_200k(gpu, orc):
     pq.set_codebooks(cb)
     pq.add(x)
     pq.nprobe = 16
+    pq.set_param("pq_filter", 0)
+    Du, Iu = pq.search(q, k)
+    pq.set_param("pq_filter", 1)
+    assert torch.equal(D1, Du) and torch.equal(I1, Iu), "filtered vs unfiltered fast scan"
     D1, I1 = pq.search(q, k)
     D2, I2 = pq.search(q, k)
     assert torch.equal(D1, D2) and torch.equal(I1, I2)
@@ -76,6 +80,10 @@ def test_properties_200k(gpu, orc):
         pq.set_param("pq_fast", 1)
         assert torch.equal(Df, Dx) and torch.equal(If, Ix), f"fast vs exact k={kk}"
     pq.nprobe = 16
+    pq.set_param("pq_filter", 0)
+    Du, Iu = pq.search(q, k)
+    pq.set_param("pq_filter", 1)
+    assert torch.equal(D1, Du) and torch.equal(I1, Iu), "filtered vs unfiltered fast scan"
     # oracle on the exported lists for 4 queries
     lists = [pq.get_list(l) for l in range(nlist)]
     off = np.zeros(nlist + 1, np.int64); np.cumsum([len(i) for _, i in lists], out=off[1:])
