@@ -178,9 +178,14 @@ __global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int nprob
 // single workgroup exclusive scan over lists: pair_off (pairs) and group_off (groups of G pairs)
 __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlist, int G, int32_t* pair_off,
                                                     int32_t* group_off, int32_t* total_groups,
-                                                    const int64_t* list_len, int tile_rows, int32_t* item_off,
-                                                    int32_t* total_items) {
+                                                    const int64_t* list_len, int tile_rows, int tile_cap,
+                                                    int32_t* item_off, int32_t* total_items) {
     __shared__ int32_t sp[1024], sg[1024], si[1024];
+    // tiles of list l that become work items (tile_cap > 0 limits them, e.g. to the first tile only)
+    auto ntiles = [&](int l) {
+        int32_t t = (int32_t)((list_len[l] + tile_rows - 1) / tile_rows);
+        return (tile_cap > 0 && t > tile_cap) ? tile_cap : t;
+    };
     int t = threadIdx.x;
     int per = (nlist + 1023) / 1024;
     int lo = t * per, hi = lo + per;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
     for (int l = lo; l < hi; l++) {
         int ng = (cnt[l] + G - 1) / G;
         ap += cnt[l]; ag += ng;
-        if (tile_rows > 0) ai += ng * (int32_t)((list_len[l] + tile_rows - 1) / tile_rows);
+        if (tile_rows > 0) ai += ng * ntiles(l);
     }
     sp[t] = ap; sg[t] = ag; si[t] = ai;
     __syncthreads();
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
     for (int l = lo; l < hi; l++) {
         int ng = (cnt[l] + G - 1) / G;
         pair_off[l] = ap; group_off[l] = ag;
-        if (tile_rows > 0) { item_off[l] = ai; ai += ng * (int32_t)((list_len[l] + tile_rows - 1) / tile_rows); }
+        if (tile_rows > 0) { item_off[l] = ai; ai += ng * ntiles(l); }
         ap += cnt[l]; ag += ng;
     }
 }
@@ -223,12 +228,12 @@ __global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, int np
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                         int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
-                        int32_t* total_items, int nprobe, int jmin, int jmax, hipStream_t st) {
+                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st) {
     hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
     hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
     hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, nprobe, jmin, jmax, cnt);
     hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, group_size, pair_off, group_off, total_groups,
-                       list_len, tile_rows, item_off, total_items);
+                       list_len, tile_rows, tile_cap, item_off, total_items);
     hipLaunchKernelGGL(k_pair_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs,
                        nprobe, jmin, jmax, pair_off, cursor, pairs_sorted);
 }

@@ -808,37 +808,40 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             int32_t* total_groups = item_off + (nlist + 1);
             int32_t* total_items = total_groups + 1;
             // Two stages, so that only a sliver of the scores ever leaves the scan kernel:
-            //  stage 1: scan ONLY each query's closest list (probe rank 0) into the score buffer and take its
-            //           top-K' -> state0; its K'-th key is a lower bound of the query's final K'-th best key;
-            //  stage 2: scan the other probes, appending to a small per-query candidate buffer only the keys that
-            //           beat that bound (wave-aggregated atomics); a final select merges them with state0.
+            //  stage 1: score ONLY the first tile of each query's closest list (probe rank 0) into the score
+            //           buffer and take its top-K' -> state0; its K'-th key is a lower bound of the query's final
+            //           K'-th best key;
+            //  stage 2: scan everything else (all probes, all tiles, minus that piece) in the multi-query groups,
+            //           appending to a small per-query candidate buffer only the keys that beat the bound
+            //           (wave-aggregated atomics); a final select merges them with state0.
             // A full candidate buffer marks the query uncertain (-> exact fallback), so this is always exact.
             filtered = (nprobe > 1) && (h->pq_filter != 0);
             launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
                                pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0,
-                               filtered ? 1 : nprobe, h->st);
+                               filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
             tm.mark("group");
             done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                    total_groups, item_off, total_items, nlist,
-                                   max_scan_items(h, nq, filtered ? 1 : nprobe, 4, tile_rows), vpl, h->st) == 0;
+                                   filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows), vpl,
+                                   h->st) == 0;
             if (done && filtered) {
                 tm.mark("scan0");
-                // top-K' of the closest list: row prefix [0, seg_start[q][1])
-                select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1, maxlen, 0, nq, KP, BUF,
-                            KP, state, false);
+                // top-K' of the first tile of the closest list: row prefix [0, min(seg_start[q][1], tile_rows))
+                select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
+                            std::min<int64_t>(maxlen, tile_rows), 0, nq, KP, BUF, KP, state, false);
                 tm.mark("select0");
                 cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8);
                 HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8, h->st));
                 launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
-                                   pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 1, nprobe,
+                                   pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                    h->st);
                 tm.mark("group");
                 done = launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist,
                                               max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
-                                              h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
+                                              h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap, 1,
                                               h->st) == 0;
             }
             if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
@@ -861,7 +864,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             int32_t* total_groups = item_off + (nlist + 1);
             int32_t* total_items = total_groups + 1;
             launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 2, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, h->st);
+                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0, h->st);
             tm.mark("group");
             done = launch_pq_scan2(a, pairs_sorted, pair_off, group_off, total_groups, item_off, total_items, nlist,
                                    max_scan_items(h, nq, nprobe, 2, tile_rows), vpl, h->st) == 0;
@@ -892,7 +895,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int32_t* group_off = pair_off + (nlist + 1);
         int32_t* total_groups = group_off + (nlist + 1);
         launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
-                           pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, h->st);
+                           pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, 0, h->st);
         tm.mark("group");
         const float* bias = nullptr;
         if (h->metric == RSX_METRIC_L2) { bias = h->w_misc.as<float>(); }

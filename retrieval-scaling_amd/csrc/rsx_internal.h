@@ -136,7 +136,7 @@ int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void*
                            const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                            const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                            const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                           int cand_cap, hipStream_t st);
+                           int cand_cap, int skip_rank0_tile0, hipStream_t st);
 // codes for rows of a batch: residual vs centroid[assign] (centroids may be null -> no residual).
 // plain_out != null: write [n, Mpad] row-major instead of the slab layout (training / export).
 void launch_pq_encode(const void* x, int x_f16, int64_t n, int ldx, int d, int M, int Mpad, int CB,
@@ -164,7 +164,7 @@ void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int npr
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                         int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
-                        int32_t* total_items, int nprobe, int jmin, int jmax, hipStream_t st);
+                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st);
 struct FinalizeArgs {
     int kind; int metric;
     const uint64_t* state; int KP; int k; int64_t nq;
