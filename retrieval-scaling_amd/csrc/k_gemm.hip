@@ -204,16 +204,40 @@ __device__ inline uint4 load8_as_half(const void* X, int64_t row, int ld, int t0
 
 #define FG_STRIDE 144  // bytes per LDS row: 64 halfs + 16 B pad -> conflict-free ds_read_b128
 
-template <bool XF16>
+// FILTER = false: temp[q, v0 + col] = score (one chunk, 2-D grid: x = query tile, y = db tile).
+// FILTER = true : ONE launch over all remaining db tiles (1-D grid); instead of storing scores the epilogue
+//                 appends the keys that beat the query's running K'-th best key (tau, from the chunks
+//                 already selected) to a per-query candidate buffer.  The 1-D block id is decoded so that
+//                 the QT query tiles of one db tile run on the same XCD (b % 8) back to back: the db tile is
+//                 pulled from HBM once and re-read from that XCD's L2.
+struct FlatFilterArgs {
+    const uint64_t* tau; int64_t tau_stride;     // tau[q * tau_stride]
+    uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
+    int nq; int qt; int64_t ntiles;              // real queries, query tiles, db tiles in [v0, v0 + nv)
+};
+
+template <bool XF16, bool FILTER>
 __global__ __launch_bounds__(256) void k_flat_gemm(const __half* Q16, const void* X, int64_t v0, int64_t nv, int ld,
-                                                   const float* bias, float* temp, int64_t tstride) {
+                                                   const float* bias, float* temp, int64_t tstride, FlatFilterArgs F) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * FG_STRIDE];
+    __shared__ uint64_t s_tau[128];
     unsigned char* As = smem;                    // queries tile
     unsigned char* Bs = smem + 128 * FG_STRIDE;  // db rows tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
-    const int64_t q0 = (int64_t)blockIdx.x * 128;
-    const int64_t vt0 = (int64_t)blockIdx.y * 128;  // column offset inside this chunk
+    int64_t q0, vt0;
+    if (FILTER) {
+        const int64_t b = blockIdx.x;
+        const int64_t i = b >> 3;
+        const int64_t vt = (b & 7) + 8 * (i / F.qt);
+        if (vt >= F.ntiles) return;
+        q0 = (i % F.qt) * 128;
+        vt0 = vt * 128;
+        if (tid < 128) s_tau[tid] = (q0 + tid < F.nq) ? F.tau[(q0 + tid) * F.tau_stride] : ~0ull;
+    } else {
+        q0 = (int64_t)blockIdx.x * 128;
+        vt0 = (int64_t)blockIdx.y * 128;  // column offset inside this chunk
+    }
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -265,16 +289,51 @@ __global__ __launch_bounds__(256) void k_flat_gemm(const __half* Q16, const void
     }
     // A index i = query, B index j = db row
     const int lj = lane & 31, lh = lane >> 5;
+    if (!FILTER) {
 #pragma unroll
-    for (int tj = 0; tj < 2; tj++) {
-        int64_t col = vt0 + wc * 64 + tj * 32 + lj;
-        float bv = (bias && col < nv) ? bias[v0 + col] : 0.0f;
+        for (int tj = 0; tj < 2; tj++) {
+            int64_t col = vt0 + wc * 64 + tj * 32 + lj;
+            float bv = (bias && col < nv) ? bias[v0 + col] : 0.0f;
+#pragma unroll
+            for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int64_t qrow = q0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (col < nv) temp[qrow * tstride + col] = acc[ti][tj][r] + bv;
+                }
+        }
+    } else {
+        float bv[2]; int64_t colv[2];
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            colv[tj] = vt0 + wc * 64 + tj * 32 + lj;
+            bv[tj] = (bias && colv[tj] < nv) ? bias[v0 + colv[tj]] : 0.0f;
+        }
 #pragma unroll
         for (int ti = 0; ti < 2; ti++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                int64_t qrow = q0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (col < nv) temp[qrow * tstride + col] = acc[ti][tj][r] + bv;
+                const int ql = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // query inside the tile
+                const uint64_t tau = s_tau[ql];          // ~0 for padding queries: nothing passes
+                const float tf = key_score(tau);
+#pragma unroll
+                for (int tj = 0; tj < 2; tj++) {
+                    const float sc = acc[ti][tj][r] + bv[tj];
+                    // cheap wave-level reject on the float score; exact decision on the full key
+                    if (!__any(sc >= tf && colv[tj] < nv)) continue;
+                    const uint64_t key = (colv[tj] < nv) ? make_key(sc, (uint32_t)(v0 + colv[tj])) : 0ull;
+                    const bool pass = key > tau;
+                    const uint64_t mask = __ballot(pass);
+                    const uint64_t mine = lh ? (mask >> 32) : (mask & 0xffffffffull);   // my half-wave = my query
+                    if (mine) {
+                        unsigned long long base = 0;
+                        const int leader = (__ffsll((unsigned long long)mine) - 1) + 32 * lh;
+                        if (lane == leader) base = atomicAdd(&F.cand_cnt[q0 + ql], (unsigned long long)__popcll(mine));
+                        base = __shfl(base, leader);
+                        const unsigned long long slot = base + __popcll(mine & ((1ull << lj) - 1ull));
+                        if (pass && slot < (unsigned long long)F.cand_cap) F.cand[(q0 + ql) * F.cand_cap + slot] = key;
+                    }
+                }
             }
     }
 }
@@ -283,8 +342,24 @@ void launch_flat_gemm(const __half* Q16, int nq_pad, const void* X, int x_f16, i
                       const float* bias, float* temp, int64_t tstride, hipStream_t st) {
     if (nv <= 0 || nq_pad <= 0) return;
     dim3 grid(nq_pad / 128, (unsigned)((nv + 127) / 128));
-    if (x_f16) hipLaunchKernelGGL(k_flat_gemm<true>, grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, temp, tstride);
-    else hipLaunchKernelGGL(k_flat_gemm<false>, grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, temp, tstride);
+    FlatFilterArgs F{};
+    if (x_f16) hipLaunchKernelGGL((k_flat_gemm<true, false>), grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, temp, tstride, F);
+    else hipLaunchKernelGGL((k_flat_gemm<false, false>), grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, temp, tstride, F);
+}
+
+// One launch over db rows [v0, v0 + nv): candidates beating tau[q] go to cand[q][0..cap) (count in cand_cnt[q]).
+void launch_flat_gemm_filter(const __half* Q16, int nq_pad, int nq, const void* X, int x_f16, int64_t v0, int64_t nv, int ld,
+                             const float* bias, const uint64_t* tau, int64_t tau_stride, uint64_t* cand,
+                             unsigned long long* cand_cnt, int cand_cap, hipStream_t st) {
+    if (nv <= 0 || nq_pad <= 0) return;
+    FlatFilterArgs F{};
+    F.tau = tau; F.tau_stride = tau_stride; F.cand = cand; F.cand_cnt = cand_cnt; F.cand_cap = cand_cap;
+    F.nq = nq; F.qt = nq_pad / 128; F.ntiles = (nv + 127) / 128;
+    int64_t groups = (F.ntiles + 7) / 8;                 // 8 db tiles (one per XCD) x qt query tiles each
+    int64_t blocks = groups * F.qt * 8;
+    dim3 grid((unsigned)blocks);
+    if (x_f16) hipLaunchKernelGGL((k_flat_gemm<true, true>), grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, (float*)nullptr, (int64_t)0, F);
+    else hipLaunchKernelGGL((k_flat_gemm<false, true>), grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, (float*)nullptr, (int64_t)0, F);
 }
 
 // =======================================================================================

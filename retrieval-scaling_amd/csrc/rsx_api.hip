@@ -147,6 +147,7 @@ struct rsx_index {
     int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
     int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
     int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
+    int flat_filter = 1;  // Flat: one filtered GEMM launch after the first chunk (0 = score buffer per chunk)
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
 
@@ -713,13 +714,49 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             const int64_t CH = 65536;
             h->w_temp.ensure((size_t)nq_pad * CH * 4);
             launch_fill_u64(state, nq * KP, 0, h->st);
-            for (int64_t v0 = 0; v0 < N; v0 += CH) {
+            // chunk 0 through the score buffer: its top-K' gives every query a running threshold
+            int64_t done_rows = 0;
+            auto chunk_pass = [&](int64_t v0) {
                 int64_t nv = std::min<int64_t>(CH, N - v0);
                 launch_flat_gemm(h->w_q16.as<__half>(), (int)nq_pad, h->data.p, h->storage_f16, v0, nv, ld, bias,
                                  h->w_temp.as<float>(), CH, h->st);
                 select_rows(h, h->w_temp.as<float>(), CH, nullptr, 0, nv, (uint32_t)v0, nq, KP, BUF, KP, state, true);
+            };
+            chunk_pass(0);
+            done_rows = std::min<int64_t>(CH, N);
+            tm.mark("scan0");
+            bool filtered_ok = true;
+            if (done_rows < N && h->flat_filter != 0) {
+                // the rest in ONE GEMM launch whose epilogue keeps only keys beating the running K'-th key
+                const int cap = 32768;
+                h->w_cand.ensure((size_t)nq * cap * 8);
+                h->w_candcnt.ensure((size_t)nq * 8);
+                HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8, h->st));
+                launch_flat_gemm_filter(h->w_q16.as<__half>(), (int)nq_pad, (int)nq, h->data.p, h->storage_f16, done_rows,
+                                        N - done_rows, ld, bias, state + (KP - 1), KP, h->w_cand.as<uint64_t>(),
+                                        h->w_candcnt.as<unsigned long long>(), cap, h->st);
+                tm.mark("scan");
+                std::vector<unsigned long long> cnts((size_t)nq);
+                HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, h->st));
+                HIPCHECK(hipStreamSynchronize(h->st));
+                for (auto c : cnts) if (c > (unsigned long long)cap) { filtered_ok = false; break; }
+                if (filtered_ok) {
+                    SelectArgs b{};
+                    b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cap;
+                    b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = 1; b.n_uniform = cap;
+                    b.seg_len = cap; b.nseg = 1; b.idx_base = 0;
+                    b.init = state; b.out = state; b.out_row_stride = KP;
+                    b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;
+                    launch_select(b, h->st);
+                    tm.mark("select");
+                } else {
+                    h->timing["flat_filter_overflows"] += 1;   // adversarial order: redo the rest chunk by chunk
+                }
             }
-            tm.mark("scan");
+            if (done_rows < N && (h->flat_filter == 0 || !filtered_ok)) {
+                for (int64_t v0 = done_rows; v0 < N; v0 += CH) chunk_pass(v0);
+                tm.mark("scan");
+            }
         }
         launch_finalize(fa, h->st);
         tm.mark("finalize");
@@ -1418,6 +1455,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_fast") h->pq_fast = (int)value;
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
         else if (s == "pq_filter") h->pq_filter = (int)value;
+        else if (s == "flat_filter") h->flat_filter = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;
         else RSX_THROW(RSX_ERR_INVALID, "unknown parameter '%s'", key);

@@ -86,6 +86,9 @@ void launch_gemm_exact_argmax(const void* X, int x_f16, int64_t n, int ldx, cons
 // Q16: [nq_pad(128), ld] f16; X: [., ld] f16|f32 storage (ld multiple of 64); bias: per-row or null.
 void launch_flat_gemm(const __half* Q16, int nq_pad, const void* X, int x_f16, int64_t v0, int64_t nv,
                       int ld, const float* bias, float* temp, int64_t tstride, hipStream_t st);
+void launch_flat_gemm_filter(const __half* Q16, int nq_pad, int nq, const void* X, int x_f16, int64_t v0, int64_t nv, int ld,
+                             const float* bias, const uint64_t* tau, int64_t tau_stride, uint64_t* cand,
+                             unsigned long long* cand_cnt, int cand_cap, hipStream_t st);
 // List scan (IVF-Flat and small-batch Flat): groups of <=16 (query, probe) pairs per list.
 struct ListScanArgs {
     const __half* Q16; int ld;             // queries [nq, ld]

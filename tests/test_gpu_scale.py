@@ -26,6 +26,15 @@ def test_properties_200k(gpu, orc):
     xs = x.cpu().numpy()
     Dr, Ir = orc.flat_search(q[:8].cpu().numpy().astype(np.float32), xs.astype(np.float32), k, 0)
     assert_same_results(Dg[:8], Ig[:8], Dr, Ir, "flat 200k")
+    flat.set_param("flat_filter", 0)        # score buffer per chunk instead of the filtered single launch
+    Dn, In = flat.search(q, k)
+    flat.set_param("flat_filter", 1)
+    assert_same_results(Dn.cpu().numpy(), In.cpu().numpy(), Dg, Ig, "flat filtered vs per-chunk")
+    Dk2, Ik2 = flat.search(q, 100)          # larger k through the filtered path
+    flat.set_param("flat_filter", 0)
+    Dk3, Ik3 = flat.search(q, 100)
+    flat.set_param("flat_filter", 1)
+    assert torch.equal(Dk2, Dk3) and torch.equal(Ik2, Ik3)
     # sharded Flat: two half indexes + merge kernel == one index (exact)
     h0, h1 = gpu.IndexFlatIP(d), gpu.IndexFlatIP(d)
     h0.add(x[: n // 2]); h1.add(x[n // 2:])
