@@ -25,6 +25,8 @@ for s in $STAGES; do
     configs)
       timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log
       timeout 900 python tools/bench_configs.py ivfflat > gpurun_out/cfg_ivfflat.json 2> gpurun_out/cfg_ivfflat.log; echo "exit $?" >> gpurun_out/cfg_ivfflat.log ;;
+    cfg_flat_only)
+      timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log ;;
     prof_flat)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_flat.json" 2> "$OLDPWD/gpurun_out/prof_flat.log" ); echo "exit $?" >> gpurun_out/prof_flat.log ;;
     variants)
