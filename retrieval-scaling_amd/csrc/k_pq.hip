@@ -373,6 +373,18 @@ void launch_pq_lut8(const float* lut32, int64_t nq, int M, int Mpad, const float
     hipLaunchKernelGGL(k_pq_lut8, dim3((unsigned)nq), dim3(256), 0, st, lut32, M, Mpad, probe_dis0, nprobe, lut8, (PQQParam*)qparam);
 }
 
+// LDS byte offset (code * 4) of byte K of w in ONE instruction: the SDWA form of v_lshlrev selects the
+// source byte for free (hipcc emits v_bfe + v_lshl_add for the same thing).
+template <int K>
+__device__ __forceinline__ uint32_t code_x4(uint32_t w, uint32_t two) {
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
+    if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
+    if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
+    if (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
+    return r;
+}
+
 struct PQScan8Args {
     PQScanArgs b;
     const uint8_t* lut8; const PQQParam* qp;
@@ -420,19 +432,27 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
             reinterpret_cast<uint4*>(pq_lut4_s)[i] = o;
         }
     }
-    __syncthreads();
 
     const int64_t slab_base = a.list_base[l] >> 6;
     const int64_t slab_bytes = (int64_t)64 * a.Mpad;
-    float dis0[4], scale[4], bias[4]; float* out[4]; int64_t segcol[4]; uint64_t tau[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
+    uint32_t two = 2;
+    asm volatile("" : "+v"(two));   // keep the shift amount in a VGPR for the SDWA operand
+    // per-query output parameters live in LDS behind the table: they are touched once per slab (768 gathers)
+    // and would otherwise pin ~48 VGPRs through the gather loop
+    float* prm_f = reinterpret_cast<float*>(pq_lut4_s + a.Mpad * 256);          // [4][4]: dis0, scale, bias, -
+    int64_t* prm_o = reinterpret_cast<int64_t*>(prm_f + 16);                    // [4][2]: temp offset | row column, query
+    uint64_t* prm_t = reinterpret_cast<uint64_t*>(prm_o + 8);                   // [4]: threshold key
+    if (tid < 4) {
+        const int i = tid;
         PQQParam p = A.qp[qq[i]];
-        scale[i] = p.scale; bias[i] = p.bias; dis0[i] = a.probe_dis0[pidx[i]];
-        segcol[i] = a.seg_start[qq[i] * (a.nprobe + 1) + (pidx[i] - (int)qq[i] * a.nprobe)];
-        out[i] = a.temp + qq[i] * a.tstride + segcol[i];
-        tau[i] = FILTER ? A.tau_key[qq[i] * A.tau_stride] : 0ull;
+        const int64_t col = a.seg_start[qq[i] * (a.nprobe + 1) + (pidx[i] - (int)qq[i] * a.nprobe)];
+        prm_f[i * 4 + 0] = a.probe_dis0[pidx[i]]; prm_f[i * 4 + 1] = p.scale; prm_f[i * 4 + 2] = p.bias;
+        prm_f[i * 4 + 3] = (FILTER && A.skip_rank0_tile0 && tile == 0 && (pidx[i] - (int)qq[i] * a.nprobe) == 0) ? 1.0f : 0.0f;
+        prm_o[i * 2 + 0] = FILTER ? col : qq[i] * a.tstride + col;
+        prm_o[i * 2 + 1] = qq[i];
+        prm_t[i] = FILTER ? A.tau_key[qq[i] * A.tau_stride] : 0ull;
     }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
         const int64_t s = s0 + w + 16 * u;
@@ -447,12 +467,21 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
             const uint32_t wds[4] = {c[gg].x, c[gg].y, c[gg].z, c[gg].w};
 #pragma unroll
             for (int b = 0; b < 16; b++) {
-                uint32_t code = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                if (VAR == 2) { acc02 += code; continue; }
-                uint32_t e = pq_lut4_s[(gg * 16 + b) * 256 + code];
+                uint32_t off4;   // code * 4
+                switch (b & 3) {
+                    case 0: off4 = code_x4<0>(wds[b >> 2], two); break;
+                    case 1: off4 = code_x4<1>(wds[b >> 2], two); break;
+                    case 2: off4 = code_x4<2>(wds[b >> 2], two); break;
+                    default: off4 = code_x4<3>(wds[b >> 2], two); break;
+                }
+                if (VAR == 2) { acc02 += off4; continue; }
+                // raw LDS address (this kernel declares no static LDS, so the dynamic segment starts at 0):
+                // lets hipcc put (m * 1024) in the ds_read offset field instead of adding an unresolved base
+                uint32_t e = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
+                    (uintptr_t)(off4 + (uint32_t)((gg * 16 + b) * 1024)));
                 if (VAR == 1) { acc02 += e; continue; }
-                acc02 += e & 0x00ff00ffu;
-                acc13 += (e >> 8) & 0x00ff00ffu;
+                acc02 += e & 0x00ff00ffu;                                  // queries 0 and 2
+                acc13 += __builtin_amdgcn_perm(e, e, 0x0c030c01u);         // [b1, 0, b3, 0]: queries 1 and 3
             }
         }
         const int64_t pos = s * 64 + lane;
@@ -460,22 +489,23 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (i >= np) continue;
-            if (FILTER && A.skip_rank0_tile0 && tile == 0 && (pidx[i] - (int)qq[i] * a.nprobe) == 0) continue;
-            const float sc = dis0[i] + __fmaf_rn(scale[i], (float)A4[i], bias[i]);
+            if (FILTER && prm_f[i * 4 + 3] != 0.0f) continue;   // scored by the pre-pass
+            const float sc = prm_f[i * 4] + __fmaf_rn(prm_f[i * 4 + 1], (float)A4[i], prm_f[i * 4 + 2]);
             if (!FILTER) {
-                out[i][pos] = (pos < len) ? sc : -__builtin_inff();
+                a.temp[prm_o[i * 2] + pos] = (pos < len) ? sc : -__builtin_inff();
             } else {
                 // candidate key in the same index space the score buffer would use (column of the query's row)
-                const uint64_t key = (pos < len) ? make_key(sc, (uint32_t)(segcol[i] + pos)) : 0ull;
-                const bool pass = key > tau[i];
+                const uint64_t key = (pos < len) ? make_key(sc, (uint32_t)(prm_o[i * 2] + pos)) : 0ull;
+                const bool pass = key > prm_t[i];
                 const uint64_t mask = __ballot(pass);
                 if (mask) {   // wave-aggregated append: one atomic per wave per query
+                    const int64_t q = prm_o[i * 2 + 1];
                     unsigned long long base = 0;
                     const int leader = __ffsll((unsigned long long)mask) - 1;
-                    if (lane == leader) base = atomicAdd(&A.cand_cnt[qq[i]], (unsigned long long)__popcll(mask));
+                    if (lane == leader) base = atomicAdd(&A.cand_cnt[q], (unsigned long long)__popcll(mask));
                     base = __shfl(base, leader);
                     const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (pass && slot < (unsigned long long)A.cand_cap) A.cand[qq[i] * A.cand_cap + slot] = key;
+                    if (pass && slot < (unsigned long long)A.cand_cap) A.cand[q * A.cand_cap + slot] = key;
                 }
             }
         }
@@ -484,7 +514,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
 
 template <int NCH, int VPL, int VAR = 0, bool FILTER = false>
 static int launch_pq_scan8_t(const PQScan8Args& A, hipStream_t st) {
-    size_t shm = (size_t)NCH * 16 * 256 * 4;
+    size_t shm = (size_t)NCH * 16 * 256 * 4 + 256;   // table + per-query output parameters
     if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL, VAR, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return -1;
     dim3 grid((unsigned)((A.max_items + 7) & ~7));

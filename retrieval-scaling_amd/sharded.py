@@ -42,12 +42,13 @@ def merge_topk_host(D, I, metric=0):
 class ShardedSearcher:
     """Wraps a rank-local index whose vectors are ids [id_offset, id_offset + ntotal)."""
 
-    def __init__(self, local_index, id_offset=0, group=None, metric=0):
+    def __init__(self, local_index, id_offset=0, group=None, metric=0, force_collective=False):
         import torch.distributed as dist
         self.index = local_index
         self.id_offset = int(id_offset)
         self.group = group
         self.metric = metric
+        self.force_collective = force_collective   # run the all-gather + merge even with one rank (tests)
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -61,7 +62,7 @@ class ShardedSearcher:
         if as_numpy:
             D, I = torch.from_numpy(np.ascontiguousarray(D)), torch.from_numpy(np.ascontiguousarray(I))
         I = torch.where(I >= 0, I + self.id_offset, I)
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_collective:
             return (D.numpy(), I.numpy()) if as_numpy else (D, I)
         nq = D.shape[0]
         # one packed buffer -> one collective: [2, nq, k] int64 (scores as raw bits in the low word)

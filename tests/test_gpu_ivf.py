@@ -237,3 +237,30 @@ def test_merge_kernel_matches_reference_rule(gpu, orc):
     import torch
     Dt, It = gpu.merge_topk(torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda())
     assert np.array_equal(It.cpu().numpy(), Ir) and np.array_equal(Dt.cpu().numpy(), Dr)
+
+
+def test_sharded_searcher_over_rccl_single_rank(gpu, orc):
+    """The real collective path (RCCL all_gather_into_tensor on HBM tensors + merge kernel) with world_size 1;
+    the 2-rank semantics are covered on CPU by tests/test_sharded_gloo.py."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from sharded import ShardedSearcher
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g = load_golden("ivfpq_d64_m16")
+        x, q = regen_gpu(gpu, g)
+        ix = gpu.IndexIVFPQ(None, g["d"], g["nlist"], g["M"], 8, 0)
+        ix.set_centroids(g["centroids"]); ix.set_codebooks(g["codebooks"]); ix.add(x)
+        ix.nprobe = g["nprobe"]
+        sh = ShardedSearcher(ix, id_offset=1000, force_collective=True)
+        D, I = sh.search(torch.from_numpy(q).cuda(), g["k"])
+        assert D.is_cuda and I.is_cuda
+        assert_same_results(D.cpu().numpy(), I.cpu().numpy() - 1000, g["D"], g["I"], "sharded over RCCL")
+        D2, I2 = sh.search(q, g["k"])          # host arrays in -> host arrays out
+        assert_same_results(D2, I2 - 1000, g["D"], g["I"], "sharded over RCCL (numpy)")
+    finally:
+        dist.destroy_process_group()
