@@ -453,10 +453,12 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
         prm_t[i] = FILTER ? A.tau_key[qq[i] * A.tau_stride] : 0ull;
     }
     __syncthreads();
-#pragma unroll
+    // rolled on purpose: one slab body is ~1000 instructions; unrolling VPL of them overflows the 64 KB
+    // instruction cache
+#pragma unroll 1
     for (int u = 0; u < VPL; u++) {
         const int64_t s = s0 + w + 16 * u;
-        if (s >= nslab) continue;
+        if (s >= nslab) break;
         const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
         uint4 c[NCH];
 #pragma unroll
