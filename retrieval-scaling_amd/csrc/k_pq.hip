@@ -385,6 +385,17 @@ __device__ __forceinline__ uint32_t code_x4(uint32_t w, uint32_t two) {
     return r;
 }
 
+// LDS byte offset (code * stride) of byte K of w in one instruction (24-bit multiply with SDWA byte select)
+template <int K>
+__device__ __forceinline__ uint32_t code_mul(uint32_t w, uint32_t stride) {
+    uint32_t r;
+    if (K == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(stride), "v"(w));
+    if (K == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(stride), "v"(w));
+    if (K == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(stride), "v"(w));
+    if (K == 3) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(stride), "v"(w));
+    return r;
+}
+
 struct PQScan8Args {
     PQScanArgs b;
     const uint8_t* lut8; const PQQParam* qp;
@@ -400,7 +411,8 @@ struct PQScan8Args {
 // in DESIGN.md): 1 = gathers kept, mask/shift accumulate replaced by one add; 2 = no LDS gather at all.
 template <int NCH, int VPL, int VAR = 0, bool FILTER = false>
 __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t pq_lut4_s[];  // [Mpad][256] : byte i = query i
+    extern __shared__ __attribute__((aligned(16))) uint32_t pq_lut4_s[];  // [256][TS] : byte i = query i
+    constexpr int TS = NCH * 16 + 1;   // table row stride in dwords
     const PQScanArgs& a = A.b;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int l, gi, tile;
@@ -429,17 +441,24 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
             o.y = ((in[0] >> 8) & 0xffu) | (((in[1] >> 8) & 0xffu) << 8) | (((in[2] >> 8) & 0xffu) << 16) | (((in[3] >> 8) & 0xffu) << 24);
             o.z = ((in[0] >> 16) & 0xffu) | (((in[1] >> 16) & 0xffu) << 8) | (((in[2] >> 16) & 0xffu) << 16) | (((in[3] >> 16) & 0xffu) << 24);
             o.w = (in[0] >> 24) | ((in[1] >> 24) << 8) | ((in[2] >> 24) << 16) | ((in[3] >> 24) << 24);
-            reinterpret_cast<uint4*>(pq_lut4_s)[i] = o;
+            // table layout [code][m], row stride TS = Mpad + 1 dwords: the gather address is code * (4*TS) plus an
+            // immediate m * 4, and bank = (code * TS + m) % 32 = (code + m) % 32 for Mpad % 32 == 0 -> as
+            // conflict-random as the [m][code] layout.  i enumerates (m, 4 consecutive codes).
+            const int m_ = i >> 6, c_ = (i & 63) * 4;
+            pq_lut4_s[(c_ + 0) * TS + m_] = o.x;
+            pq_lut4_s[(c_ + 1) * TS + m_] = o.y;
+            pq_lut4_s[(c_ + 2) * TS + m_] = o.z;
+            pq_lut4_s[(c_ + 3) * TS + m_] = o.w;
         }
     }
 
     const int64_t slab_base = a.list_base[l] >> 6;
     const int64_t slab_bytes = (int64_t)64 * a.Mpad;
-    uint32_t two = 2;
-    asm volatile("" : "+v"(two));   // keep the shift amount in a VGPR for the SDWA operand
+    uint32_t two = 4 * TS;          // bytes per table row
+    asm volatile("" : "+v"(two));   // keep the multiplier in a VGPR for the SDWA operand
     // per-query output parameters live in LDS behind the table: they are touched once per slab (768 gathers)
     // and would otherwise pin ~48 VGPRs through the gather loop
-    float* prm_f = reinterpret_cast<float*>(pq_lut4_s + a.Mpad * 256);          // [4][4]: dis0, scale, bias, -
+    float* prm_f = reinterpret_cast<float*>(pq_lut4_s + 256 * TS);             // [4][4]: dis0, scale, bias, -
     int64_t* prm_o = reinterpret_cast<int64_t*>(prm_f + 16);                    // [4][2]: temp offset | row column, query
     uint64_t* prm_t = reinterpret_cast<uint64_t*>(prm_o + 8);                   // [4]: threshold key
     if (tid < 4) {
@@ -469,18 +488,18 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
             const uint32_t wds[4] = {c[gg].x, c[gg].y, c[gg].z, c[gg].w};
 #pragma unroll
             for (int b = 0; b < 16; b++) {
-                uint32_t off4;   // code * 4
+                uint32_t off4;   // code * row bytes
                 switch (b & 3) {
-                    case 0: off4 = code_x4<0>(wds[b >> 2], two); break;
-                    case 1: off4 = code_x4<1>(wds[b >> 2], two); break;
-                    case 2: off4 = code_x4<2>(wds[b >> 2], two); break;
-                    default: off4 = code_x4<3>(wds[b >> 2], two); break;
+                    case 0: off4 = code_mul<0>(wds[b >> 2], two); break;
+                    case 1: off4 = code_mul<1>(wds[b >> 2], two); break;
+                    case 2: off4 = code_mul<2>(wds[b >> 2], two); break;
+                    default: off4 = code_mul<3>(wds[b >> 2], two); break;
                 }
                 if (VAR == 2) { acc02 += off4; continue; }
                 // raw LDS address (this kernel declares no static LDS, so the dynamic segment starts at 0):
-                // lets hipcc put (m * 1024) in the ds_read offset field instead of adding an unresolved base
+                // (m * 4) goes into the ds_read offset field, no address add at all
                 uint32_t e = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
-                    (uintptr_t)(off4 + (uint32_t)((gg * 16 + b) * 1024)));
+                    (uintptr_t)(off4 + (uint32_t)((gg * 16 + b) * 4)));
                 if (VAR == 1) { acc02 += e; continue; }
                 acc02 += e & 0x00ff00ffu;                                  // queries 0 and 2
                 acc13 += __builtin_amdgcn_perm(e, e, 0x0c030c01u);         // [b1, 0, b3, 0]: queries 1 and 3
@@ -516,7 +535,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
 
 template <int NCH, int VPL, int VAR = 0, bool FILTER = false>
 static int launch_pq_scan8_t(const PQScan8Args& A, hipStream_t st) {
-    size_t shm = (size_t)NCH * 16 * 256 * 4 + 256;   // table + per-query output parameters
+    size_t shm = (size_t)(NCH * 16 + 1) * 256 * 4 + 256;   // [256][Mpad+1] table + per-query output parameters
     if (hipFuncSetAttribute((const void*)k_pq_scan8<NCH, VPL, VAR, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return -1;
     dim3 grid((unsigned)((A.max_items + 7) & ~7));
