@@ -99,6 +99,12 @@ int rsx_get_codebooks(rsx_index_t* h, float* codebooks_out);
  * (L2) codeword, first minimum on ties; in-list order = insertion order. */
 int rsx_add(rsx_index_t* h, int64_t n, const void* x, int dtype, const int64_t* ids);
 
+/* index.quantizer.assign(x) (FAISS Index::assign on the coarse quantiser): list number of each vector,
+ * argmax <x, centroid> (first maximum) — the same exact fp32 kernel `add` uses.  labels: int64 [n].
+ * Lets a caller count list sizes first and rsx_reserve_lists exactly (needed when the index cannot hold
+ * two copies of itself in HBM, e.g. 100M x 768 fp16 IVF-Flat = 153.6 GB). */
+int rsx_assign(rsx_index_t* h, int64_t n, const void* x, int dtype, int64_t* labels);
+
 /* index.reset(): drop every stored vector, keep the trained parameters and the HBM reservation. */
 int rsx_reset(rsx_index_t* h);
 

@@ -1345,6 +1345,33 @@ int rsx_add(rsx_index_t* h, int64_t n, const void* x, int dtype, const int64_t* 
         add_all(h, n, x, dtype, ids);
     });
 }
+int rsx_assign(rsx_index_t* h, int64_t n, const void* x, int dtype, int64_t* labels) {
+    return guarded([&] {
+        if (!h || (!x && n > 0) || (!labels && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
+        if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "Flat has no coarse quantiser");
+        if (h->h_centroids.empty()) RSX_THROW(RSX_ERR_NOT_TRAINED, "assign before train");
+        use_device(h);
+        const int64_t B = 262144;
+        size_t esz = dtype == RSX_F16 ? 2 : 4;
+        int ct = (h->nlist + 127) / 128;
+        bool out_dev = is_device_ptr(labels);
+        std::vector<int32_t> a32; std::vector<int64_t> a64;
+        for (int64_t i0 = 0; i0 < n; i0 += B) {
+            int64_t nb = std::min(B, n - i0);
+            const void* dx = stage_rows(h, h->w_x, (const char*)x + (size_t)i0 * h->d * esz, nb, h->d, dtype);
+            h->w_partial.ensure((size_t)nb * 2 * ct * 8);
+            h->w_assign.ensure((size_t)nb * 4);
+            launch_gemm_exact_argmax(dx, dtype == RSX_F16, nb, h->d, h->d_centroids.as<float>(), h->nlist, h->d,
+                                     h->w_partial.as<uint64_t>(), h->w_assign.as<int32_t>(), nullptr, h->st);
+            a32.resize((size_t)nb); a64.resize((size_t)nb);
+            HIPCHECK(hipMemcpyAsync(a32.data(), h->w_assign.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipStreamSynchronize(h->st));
+            for (int64_t i = 0; i < nb; i++) a64[(size_t)i] = a32[(size_t)i];
+            HIPCHECK(hipMemcpy(labels + i0, a64.data(), (size_t)nb * 8, out_dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+        }
+    });
+}
 int rsx_reset(rsx_index_t* h) {
     return guarded([&] {
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");

@@ -38,7 +38,7 @@ _lib = None
 ABI_SYMBOLS = [
     "rsx_last_error", "rsx_version", "rsx_device_count", "rsx_flat_create", "rsx_ivfflat_create",
     "rsx_ivfpq_create", "rsx_destroy", "rsx_train", "rsx_set_centroids", "rsx_set_codebooks",
-    "rsx_get_centroids", "rsx_get_codebooks", "rsx_add", "rsx_reset", "rsx_reserve_lists", "rsx_add_list",
+    "rsx_get_centroids", "rsx_get_codebooks", "rsx_add", "rsx_assign", "rsx_reset", "rsx_reserve_lists", "rsx_add_list",
     "rsx_get_list", "rsx_set_nprobe", "rsx_search", "rsx_merge_topk", "rsx_get", "rsx_set_param",
     "rsx_get_timing", "rsx_save", "rsx_load", "rsx_synth_vectors", "rsx_synth_queries",
 ]
@@ -258,6 +258,13 @@ class _IndexIVF(Index):
         c = np.empty((self.nlist, self.d), dtype=np.float32)
         _check(lib().rsx_get_centroids(self._h, c.ctypes.data_as(ctypes.c_void_p)))
         return c
+
+    def assign(self, x):
+        """index.quantizer.assign(x): list number of every vector (exact argmax-IP, as `add` computes it)."""
+        keep, p, n, dt, _ = _as_matrix(x, self.d, "assign")
+        labels = np.empty(n, dtype=np.int64)
+        _check(lib().rsx_assign(self._h, ctypes.c_int64(n), p, dt, labels.ctypes.data_as(ctypes.c_void_p)))
+        return labels
 
     def reserve_lists(self, counts):
         counts = np.ascontiguousarray(counts, dtype=np.int64)

@@ -26,6 +26,15 @@ def test_golden_ivfflat(gpu, orc):
         want = np.nonzero(a == l)[0]
         assert np.array_equal(ids, want), f"list {l} membership/order"
         assert np.array_equal(vecs, x[want].astype(np.float32))
+    # quantizer.assign == the oracle's assignment; counting + exact reserve gives the same index
+    assert np.array_equal(ix.assign(x), a)
+    ix_r = gpu.IndexIVFFlat(None, g["d"], g["nlist"], 0)
+    ix_r.set_centroids(g["centroids"])
+    ix_r.reserve_lists(np.bincount(ix_r.assign(x), minlength=g["nlist"]))
+    ix_r.add(x)
+    ix_r.nprobe = g["nprobe"]
+    Dr_, Ir_ = ix_r.search(q, g["k"])
+    assert_same_results(Dr_, Ir_, g["D"], g["I"], "ivfflat golden (reserved build)")
     ix.nprobe = g["nprobe"]
     D, I = ix.search(q, g["k"])
     assert_same_results(D, I, g["D"], g["I"], "ivfflat golden")

@@ -16,7 +16,7 @@ SC, SX, SQ = 1234, 10000, 999
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", choices=["flat", "ivfflat"])
+    ap.add_argument("which", choices=["flat", "ivfflat", "latency"])
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024)
@@ -27,6 +27,8 @@ def main():
     import torch, rsx
     from oracle import oracle as orc
     dev = torch.device("cuda", 0)
+    if a.which == "latency":
+        return latency(a)
     n = a.n or (10_000_000 if a.which == "flat" else 20_000_000)
     nq, k = a.batch, 10
     Q = torch.empty((nq * (a.steps + 1), D), dtype=torch.float16, device=dev)
@@ -42,6 +44,14 @@ def main():
         rsx.synth_vectors(D, NC, SC, SX, 0.5, 0, nt, out=xt)
         ix.train(xt); del xt
         ix.nprobe = a.nprobe
+        # pass 1: count list sizes with quantizer.assign, reserve exactly (a re-layout of a 153.6 GB index
+        # cannot hold two copies in 288 GB); pass 2: add
+        counts = np.zeros(a.nlist, dtype=np.int64)
+        for c0 in range(0, n, buf.shape[0]):
+            nb = min(buf.shape[0], n - c0)
+            rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb])
+            counts += np.bincount(ix.assign(buf[:nb]), minlength=a.nlist)
+        ix.reserve_lists(counts)
     for c0 in range(0, n, buf.shape[0]):
         nb = min(buf.shape[0], n - c0)
         rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb])
@@ -97,6 +107,38 @@ def main():
             Dr, Ir = orc.ivfflat_search(0, cen, lm, qs, a.nprobe, k)
             ok = bool(np.array_equal(Ir, Iq[:a.check].cpu().numpy()) and np.array_equal(Dr, Dq[:a.check].cpu().numpy()))
         res["oracle_parity_ids_and_scores"] = ok
+    print(json.dumps(res), flush=True)
+
+
+def latency(a):
+    """The reference's own protocol (api/api_index.py:88-95): 30 single-query searches, first 10 warm-up, mean of
+    the last 20 — here on a 100M x 768 IVF-PQ index (M=96, nlist=4096, nprobe=32, k=10), host-resident query."""
+    import torch, rsx
+    dev = torch.device("cuda", 0)
+    n = a.n or 100_000_000
+    ix = rsx.IndexIVFPQ(None, D, a.nlist, 96, 8, rsx.METRIC_INNER_PRODUCT)
+    nt = min(n, 256 * a.nlist)
+    xt = torch.empty((nt, D), dtype=torch.float16, device=dev)
+    rsx.synth_vectors(D, NC, SC, SX, 0.5, 0, nt, out=xt)
+    ix.train(xt); del xt
+    ix.nprobe = a.nprobe
+    buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
+    for c0 in range(0, n, buf.shape[0]):
+        nb = min(buf.shape[0], n - c0)
+        rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb])
+        ix.add(buf[:nb])
+    q = rsx.synth_queries(D, NC, SC, SX, 0.5, n, SQ, 0.1, 0, 30)   # numpy fp16 on the host
+    res = {"config": f"single-query latency, {n}x{D} IVF-PQ M=96 nlist={a.nlist} nprobe={a.nprobe} k=10, host query/result"}
+    for name, k in (("k10", 10), ("k100", 100)):
+        ts = []
+        for i in range(30):
+            t0 = time.perf_counter(); ix.search(q[i:i + 1], k); ts.append(time.perf_counter() - t0)
+        res[f"mean_ms_{name}"] = round(float(np.mean(ts[10:])) * 1e3, 4)
+        res[f"min_ms_{name}"] = round(float(np.min(ts[10:])) * 1e3, 4)
+    ts = []
+    for i in range(30):
+        t0 = time.perf_counter(); ix.search(q[:16], 10); ts.append(time.perf_counter() - t0)
+    res["mean_ms_batch16_k10"] = round(float(np.mean(ts[10:])) * 1e3, 4)
     print(json.dumps(res), flush=True)
 
 

@@ -25,6 +25,10 @@ for s in $STAGES; do
     configs)
       timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log
       timeout 900 python tools/bench_configs.py ivfflat > gpurun_out/cfg_ivfflat.json 2> gpurun_out/cfg_ivfflat.log; echo "exit $?" >> gpurun_out/cfg_ivfflat.log ;;
+    ivfflat100m)
+      timeout 1500 python tools/bench_configs.py ivfflat --n 100000000 > gpurun_out/cfg_ivfflat100m.json 2> gpurun_out/cfg_ivfflat100m.log; echo "exit $?" >> gpurun_out/cfg_ivfflat100m.log ;;
+    latency)
+      timeout 900 python tools/bench_configs.py latency > gpurun_out/cfg_latency.json 2> gpurun_out/cfg_latency.log; echo "exit $?" >> gpurun_out/cfg_latency.log ;;
     cfg_flat_only)
       timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log ;;
     prof_flat)
