@@ -768,17 +768,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     const int nlist = h->nlist;
     const int nprobe = std::min(h->nprobe, nlist);
     // 1. coarse quantiser (exact fp32) + top-nprobe
-    h->w_coarse.ensure((size_t)nq * nlist * 4);
-    launch_gemm_exact_scores(h->w_q32.p, 0, nq, ld, h->d_centroids.as<float>(), nlist, d, h->w_coarse.as<float>(), nlist, h->st);
+    const int nlp = (int)round_up(nlist, 4);   // row stride of the coarse scores: 16-byte aligned rows for k_select
+    h->w_coarse.ensure((size_t)nq * nlp * 4);
+    launch_gemm_exact_scores(h->w_q32.p, 0, nq, ld, h->d_centroids.as<float>(), nlist, d, h->w_coarse.as<float>(), nlp, h->st);
     tm.mark("coarse");
     int KPp = std::max(16, pow2ceil(nprobe));
     int BUFp = std::max(2 * KPp, 256);
     h->w_probekeys.ensure((size_t)nq * KPp * 8);
-    {
-        // row stride nlist may not be a multiple of 4: select_rows needs 16-byte aligned rows
-        if (nlist % 4 != 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "nlist must be a multiple of 4 (got %d)", nlist);
-        select_rows(h, h->w_coarse.as<float>(), nlist, nullptr, 0, nlist, 0, nq, KPp, BUFp, nprobe, h->w_probekeys.as<uint64_t>(), false);
-    }
+    select_rows(h, h->w_coarse.as<float>(), nlp, nullptr, 0, nlist, 0, nq, KPp, BUFp, nprobe, h->w_probekeys.as<uint64_t>(), false);
     // 2. probe set-up
     const int pad_to = (h->kind == KIND_IVFPQ) ? 64 : 16;
     h->w_probelist.ensure((size_t)nq * nprobe * 4);

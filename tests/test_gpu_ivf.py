@@ -115,7 +115,7 @@ def test_golden_ivfpq(gpu, orc, name):
     ix.set_param("pq_filter", 1)
 
 
-@pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8)])
+@pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8), (64, 16, 7)])
 def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
     """Other (d, M): 16-byte-granule and 4-byte-granule code layouts, dsub 8/2/48."""
     n, nq, k = 6000, 37, 20
