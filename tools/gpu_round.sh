@@ -29,6 +29,13 @@ for s in $STAGES; do
       timeout 1500 python tools/bench_configs.py ivfflat --n 100000000 > gpurun_out/cfg_ivfflat100m.json 2> gpurun_out/cfg_ivfflat100m.log; echo "exit $?" >> gpurun_out/cfg_ivfflat100m.log ;;
     latency)
       timeout 900 python tools/bench_configs.py latency > gpurun_out/cfg_latency.json 2> gpurun_out/cfg_latency.log; echo "exit $?" >> gpurun_out/cfg_latency.log ;;
+    pmc_sq)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d "$OLDPWD/gpurun_out/pmc_sq_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --n 2000000 --check 0 --steps 2 > "$OLDPWD/gpurun_out/pmc_sq_flat.json" 2> "$OLDPWD/gpurun_out/pmc_sq_flat.log" ); echo "exit $?" >> gpurun_out/pmc_sq_flat.log
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d "$OLDPWD/gpurun_out/pmc_sq_pq" -o r01 -- python "$OLDPWD/bench.py" --n 20000000 --steps 2 --warmup 1 --cpu-queries 0 --no-recall > "$OLDPWD/gpurun_out/pmc_sq_pq.json" 2> "$OLDPWD/gpurun_out/pmc_sq_pq.log" ); echo "exit $?" >> gpurun_out/pmc_sq_pq.log
+      rm -f gpurun_out/pmc_sq_summary.txt
+      python tools/pmc_summary.py gpurun_out/pmc_sq_flat/r01_results.db gpurun_out/pmc_sq_summary.txt '%k_flat_gemm%' '%k_select%'
+      python tools/pmc_summary.py gpurun_out/pmc_sq_pq/r01_results.db gpurun_out/pmc_sq_summary.txt '%k_pq_scan8%' '%k_pq_lut%' '%k_finalize%'
+      rm -rf gpurun_out/pmc_sq_flat gpurun_out/pmc_sq_pq ;;
     cfg_flat_only)
       timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log ;;
     prof_flat)
