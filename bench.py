@@ -299,8 +299,12 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(ms_per_launch, 4),
                          "launches_per_step": launches_per_step,
+                         "traffic_gbs": (round(traffic / (ms_per_launch * 1e-3) / 1e9, 2) if traffic else None),
                          "note": "achieved = scanned code bytes (sum over (query, probed list) of len*M) / HIP-event "
-                                 "duration of the scan launch on the library stream, rank 0"},
+                                 "duration of the scan launch on the library stream, rank 0. frac > 1 is possible: the "
+                                 "list-major kernel reads each code byte from HBM once for up to 24 grouped queries, so "
+                                 "the algorithmic bytes exceed the measured HBM traffic (`traffic`, PMC FETCH_SIZE); the "
+                                 "kernel is bound by LDS table gathers, not HBM (DESIGN.md 4.1)"},
             "stage_ms_per_step": stage_ms,
             "certificate_fallback_fraction": fallbacks,
             "ab_exact_kernels_same_process": ab,

@@ -315,13 +315,13 @@ int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int3
 // the result equals the exact search; otherwise the query is flagged and re-run with k_pq_scan2.
 struct PQQParam { float scale, bias, eps, pad; };
 
-__global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int Mpad, const float* probe_dis0,
-                                                 int nprobe, uint8_t* lut8, PQQParam* qp) {
-    __shared__ float s_mn[256], s_rg[256], s_red[8];
+// Unfused form (tables too large for LDS): quantises an fp32 table k_pq_lut already wrote to HBM.
+__global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int Mpad, const float* probe_dis0, int nprobe,
+                                                 uint8_t* lut8, PQQParam* qp) {
+    __shared__ float s_mn[256], s_red[8];
     const int64_t q = blockIdx.x;
     const int c = threadIdx.x, lane = c & 63, w = c >> 6;
     const float* T = lut32 + q * Mpad * 256;
-    // pass 1: per sub-quantiser min / range / max |value|
     float absmax_sum = 0.0f, maxrange = 0.0f;
     for (int m = 0; m < Mpad; m++) {
         float v = T[m * 256 + c];
@@ -333,14 +333,13 @@ __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int 
         mn = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
         mx = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
         __syncthreads();
-        if (c == 0) { s_mn[m] = mn; s_rg[m] = mx - mn; }
+        if (c == 0) s_mn[m] = mn;
         absmax_sum += fmaxf(fabsf(mn), fabsf(mx));
         maxrange = fmaxf(maxrange, mx - mn);
     }
     __syncthreads();
     const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
     const float inv = 1.0f / scale;
-    // pass 2: quantise, accumulate the exact per-sub-quantiser error bound
     float e_quant = 0.0f, bias = 0.0f;
     for (int m = 0; m < Mpad; m++) {
         float v = T[m * 256 + c];
@@ -367,10 +366,108 @@ __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int 
         qp[q] = r;
     }
 }
-void launch_pq_lut8(const float* lut32, int64_t nq, int M, int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
-                    void* qparam, hipStream_t st) {
+
+// Fused form: one workgroup builds the query's fp32 table T[m][c] = <q_m, cb[m][c]> (k_pq_lut's fmaf chain,
+// hence the same bits) straight into LDS, derives the affine 8-bit quantisation from it and writes only
+// the u8 table + parameters.  The fp32 table (98 KB/query) never touches HBM; k_finalize recomputes the
+// few entries the exact re-score needs.  LDS: Mpad*1 KiB table + the query + 3*Mpad floats.
+template <int DSUB>   // 8: two float4 loads per codeword; 0: generic dsub
+__global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, const float* codebooks, int dsub, int M,
+                                                  int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
+                                                  PQQParam* qp) {
+    extern __shared__ float sm_lut8f[];
+    float* T = sm_lut8f;                 // [Mpad][256]
+    float* s_q = T + Mpad * 256;         // [M*dsub]
+    float* s_mn = s_q + M * dsub;        // [Mpad]
+    float* s_mx = s_mn + Mpad;           // [Mpad]
+    float* s_err = s_mx + Mpad;          // [Mpad]
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x, lane = c & 63, w = c >> 6;
+    for (int i = c; i < M * dsub; i += 256) s_q[i] = Q32[q * ldq + i];
+    __syncthreads();
+    // A: thread c owns codeword c of every sub-quantiser; the loads of different m are independent
+#pragma unroll 4
+    for (int m = 0; m < M; m++) {
+        float s = 0.0f;
+        if (DSUB == 8) {
+            const float4* cw = (const float4*)(codebooks + ((int64_t)m * 256 + c) * 8);
+            float4 x = cw[0], y = cw[1];
+            const float* qs = s_q + m * 8;
+            s = __fmaf_rn(qs[0], x.x, s); s = __fmaf_rn(qs[1], x.y, s); s = __fmaf_rn(qs[2], x.z, s); s = __fmaf_rn(qs[3], x.w, s);
+            s = __fmaf_rn(qs[4], y.x, s); s = __fmaf_rn(qs[5], y.y, s); s = __fmaf_rn(qs[6], y.z, s); s = __fmaf_rn(qs[7], y.w, s);
+        } else {
+            const float* cw = codebooks + ((int64_t)m * 256 + c) * dsub;
+            const float* qs = s_q + m * dsub;
+            for (int t = 0; t < dsub; t++) s = __fmaf_rn(qs[t], cw[t], s);
+        }
+        T[m * 256 + c] = s;
+    }
+    for (int m = M; m < Mpad; m++) T[m * 256 + c] = 0.0f;
+    __syncthreads();
+    // B: wave w reduces min / max of sub-quantisers w, w+4, ... (4 entries per lane, shuffles only)
+    for (int m = w; m < Mpad; m += 4) {
+        float4 v = *(const float4*)&T[m * 256 + lane * 4];
+        float mn = fminf(fminf(v.x, v.y), fminf(v.z, v.w)), mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        if (lane == 0) { s_mn[m] = mn; s_mx[m] = mx; }
+    }
+    __syncthreads();
+    float maxrange = 0.0f;
+    for (int m = 0; m < Mpad; m++) maxrange = fmaxf(maxrange, s_mx[m] - s_mn[m]);
+    const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
+    const float inv = 1.0f / scale;
+    // C: quantise; 4 consecutive codewords per lane -> one dword store
+    for (int m = w; m < Mpad; m += 4) {
+        float4 v = *(const float4*)&T[m * 256 + lane * 4];
+        const float mn = s_mn[m];
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        uint32_t pk = 0; float err = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float u = rintf((vv[j] - mn) * inv);
+            u = fminf(fmaxf(u, 0.0f), 255.0f);
+            pk |= (uint32_t)u << (8 * j);
+            err = fmaxf(err, fabsf(vv[j] - (mn + scale * u)));
+        }
+        *(uint32_t*)&lut8[(q * Mpad + m) * 256 + lane * 4] = pk;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
+        if (lane == 0) s_err[m] = err;
+    }
+    __syncthreads();
+    if (c == 0) {
+        float absmax_sum = 0.0f, e_quant = 0.0f, bias = 0.0f;
+        for (int m = 0; m < Mpad; m++) {
+            absmax_sum += fmaxf(fabsf(s_mn[m]), fabsf(s_mx[m]));
+            e_quant += s_err[m];
+            bias += s_mn[m];
+        }
+        float d0 = 0.0f;
+        for (int j = 0; j < nprobe; j++) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
+        float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 0.0f;
+        qp[q] = r;
+    }
+}
+
+size_t pq_lut8_fused_lds(int M, int Mpad, int dsub) { return ((size_t)Mpad * 256 + (size_t)M * dsub + 3 * (size_t)Mpad) * 4; }
+
+void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
+                    int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8, void* qparam, hipStream_t st) {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(k_pq_lut8, dim3((unsigned)nq), dim3(256), 0, st, lut32, M, Mpad, probe_dis0, nprobe, lut8, (PQQParam*)qparam);
+    if (lut32) {
+        hipLaunchKernelGGL(k_pq_lut8, dim3((unsigned)nq), dim3(256), 0, st, lut32, M, Mpad, probe_dis0, nprobe, lut8,
+                           (PQQParam*)qparam);
+        return;
+    }
+    const size_t lds = pq_lut8_fused_lds(M, Mpad, dsub);
+    auto kern = dsub == 8 ? k_pq_lut8f<8> : k_pq_lut8f<0>;
+    static bool attr8 = false, attr0 = false;
+    bool& done = dsub == 8 ? attr8 : attr0;
+    if (!done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), lds, st, Q32, ldq, codebooks, dsub, M, Mpad, probe_dis0, nprobe,
+                       lut8, (PQQParam*)qparam);
 }
 
 // LDS byte offset (code * 4) of byte K of w in ONE instruction: the SDWA form of v_lshlrev selects the

@@ -298,7 +298,16 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
             for (int m = 0; m < a.M; m++) {
                 int g = m / a.CB, b = m - g * a.CB;
                 uint32_t code = sp[(int64_t)g * (64 * a.CB) + v * a.CB + b];
-                sum += T[m * 256 + code];
+                float t;
+                if (a.lut32) {
+                    t = T[m * 256 + code];
+                } else {   // the table entry, recomputed with k_pq_lut's fmaf chain (bit-identical)
+                    const float* qs = a.Q32 + q * a.ldq + m * a.dsub;
+                    const float* cw = a.codebooks + ((int64_t)m * 256 + code) * a.dsub;
+                    t = 0.0f;
+                    for (int tt = 0; tt < a.dsub; tt++) t = __fmaf_rn(qs[tt], cw[tt], t);
+                }
+                sum += t;
             }
             sord[c] = f2ord((dis0 + sum) + 0.0f);
         }

@@ -804,11 +804,15 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     h->w_temp.ensure((size_t)nq * tmax * 4);
     bool filtered = false;   // fast path with in-kernel candidate filtering (no full score buffer)
     int cand_cap = 0;
+    // the exact kernels gather fp32 table entries; the fast path builds the table in LDS (when it fits)
+    const bool fused_lut = h->kind == KIND_IVFPQ && fast && pq_lut8_fused_lds(h->M, h->Mpad, h->dsub) <= 160 * 1024 - 64;
 
     if (h->kind == KIND_IVFPQ) {
-        h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4);
-        launch_pq_lut(h->w_q32.as<float>(), ld, nq, d, h->M, h->Mpad, h->d_codebooks.as<float>(), h->w_lut.as<float>(), h->st);
-        tm.mark("lut");
+        if (!fused_lut) {
+            h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4);
+            launch_pq_lut(h->w_q32.as<float>(), ld, nq, d, h->M, h->Mpad, h->d_codebooks.as<float>(), h->w_lut.as<float>(), h->st);
+            tm.mark("lut");
+        }
         PQScanArgs a{};
         a.codes = h->data.as<uint8_t>(); a.M = h->M; a.Mpad = h->Mpad; a.CB = h->CB;
         a.list_base = h->d_base.as<int64_t>(); a.list_len = h->d_len.as<int64_t>();
@@ -823,8 +827,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
             h->w_qparam.ensure((size_t)nq * 16);
             h->w_uncertain.ensure((size_t)nq * 4);
-            launch_pq_lut8(h->w_lut.as<float>(), nq, h->M, h->Mpad, h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(),
-                           h->w_qparam.p, h->st);
+            launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
+                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->st);
             tm.mark("lut8");
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             int vpl = 8;
@@ -969,7 +973,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     fa.probe_list = h->w_probelist.as<int32_t>(); fa.seg_start = h->w_segstart.as<int64_t>(); fa.nprobe = nprobe;
     if (fast) {
         fa.pq_rescore = 1; fa.codes = h->data.as<uint8_t>(); fa.M = h->M; fa.Mpad = h->Mpad; fa.CB = h->CB;
-        fa.lut32 = h->w_lut.as<float>(); fa.probe_dis0 = h->w_dis0.as<float>(); fa.qparam = h->w_qparam.p;
+        fa.lut32 = fused_lut ? nullptr : h->w_lut.as<float>(); fa.codebooks = h->d_codebooks.as<float>(); fa.dsub = h->dsub;
+        fa.probe_dis0 = h->w_dis0.as<float>(); fa.qparam = h->w_qparam.p;
         fa.uncertain = h->w_uncertain.as<int32_t>();
         if (filtered) { fa.cand_cnt = h->w_candcnt.as<unsigned long long>(); fa.cand_cap = cand_cap; }
     }

@@ -128,7 +128,11 @@ int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int3
                     const int32_t* total_groups, const int32_t* item_off, const int32_t* total_items, int nlist,
                     int64_t max_items, int vpl, hipStream_t st);
 // 8-bit table fast scan (4 queries per LDS read) — approximate scores, certified by k_finalize
-void launch_pq_lut8(const float* lut32, int64_t nq, int M, int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
+// lut32 null -> fused form: the fp32 table is built in LDS from Q32 [nq, ldq] and the codebooks (needs
+// pq_lut8_fused_lds(M, Mpad, dsub) <= 160 KiB); otherwise quantises the given fp32 tables.
+size_t pq_lut8_fused_lds(int M, int Mpad, int dsub);
+void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
+                    int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
                     void* qparam /* [nq] {scale, bias, eps, pad} */, hipStream_t st);
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
                     const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
@@ -180,7 +184,9 @@ struct FinalizeArgs {
     const void* X; int x_f16; int ld;
     // exact re-score + certificate (IVF-PQ fast scan): candidates carry APPROXIMATE scores
     int pq_rescore; const uint8_t* codes; int M; int Mpad; int CB;
-    const float* lut32; const float* probe_dis0; const void* qparam; int32_t* uncertain;
+    const float* lut32;            // fp32 tables, or null: entries recomputed from Q32 and `codebooks`
+    const float* codebooks; int dsub;
+    const float* probe_dis0; const void* qparam; int32_t* uncertain;
     const unsigned long long* cand_cnt; int cand_cap;   // filtered scan: per-query candidate counts / capacity
     float* D; int64_t* I;
 };

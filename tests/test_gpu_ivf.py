@@ -115,9 +115,10 @@ def test_golden_ivfpq(gpu, orc, name):
     ix.set_param("pq_filter", 1)
 
 
-@pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8), (64, 16, 7)])
+@pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8), (64, 16, 7), (320, 160, 4)])
 def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
-    """Other (d, M): 16-byte-granule and 4-byte-granule code layouts, dsub 8/2/48."""
+    """Other (d, M): 16-byte-granule and 4-byte-granule code layouts, dsub 8/2/48; M=160 is too large for the
+    LDS-resident table build and takes the unfused table path."""
     n, nq, k = 6000, 37, 20
     x = orc.synth_vectors(d, nlist, 61, 62, 0.5, 0, n)
     q = orc.synth_queries(d, nlist, 61, 62, 0.5, n, 63, 0.1, 0, nq)
