@@ -239,7 +239,7 @@ void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, in
 }
 
 // ---------------------------------------------------------------------------------------
-// Finalize: one wave per query.  Resolve each surviving candidate to its storage row and id,
+// Finalize: one workgroup (1-4 waves) per query.  Resolve each surviving candidate to its storage row and id,
 // re-score Flat / IVF-Flat candidates EXACTLY (fp64 accumulation of exact products, rounded
 // once to fp32 — the oracle's canonical arithmetic), sort by (score desc, id asc) and emit k.
 // IVF-PQ scores are already canonical fp32 (sequential LUT sum) and are only re-ordered.
@@ -250,16 +250,62 @@ __device__ inline double wave_sum_f64(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
+// Exact IVF-PQ score of one stored vector: sum over m (ascending, fp32) of the table entry of its code.
+// The codes of a vector sit in CB-byte granules (one per 64*CB-byte slab row block); one granule is
+// fetched ahead so the dependent code -> codeword loads of different m overlap.
+template <int CB>
+__device__ inline float pq_exact_sum(const uint8_t* sp, int v, int M, const float* T, const float* qv,
+                                     const float* codebooks, int dsub) {
+    constexpr int NW = CB / 4;
+    const int G = (M + CB - 1) / CB;
+    const uint8_t* gp = sp + v * CB;
+    uint32_t cur[NW], nxt[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) cur[i] = ((const uint32_t*)gp)[i];
+    float sum = 0.0f;
+    for (int g = 0; g < G; g++) {
+        const uint32_t* np = (const uint32_t*)(gp + (int64_t)(g + 1 < G ? g + 1 : g) * (64 * CB));
+#pragma unroll
+        for (int i = 0; i < NW; i++) nxt[i] = np[i];
+#pragma unroll
+        for (int b = 0; b < CB; b++) {
+            const int m = g * CB + b;
+            const int mc = m < M ? m : M - 1;
+            const uint32_t code = (cur[b >> 2] >> (8 * (b & 3))) & 255u;
+            float t;
+            if (T) {
+                t = T[mc * 256 + code];
+            } else {   // the table entry, recomputed with k_pq_lut's fmaf chain (bit-identical)
+                const float* qs = qv + mc * dsub;
+                const float* cw = codebooks + ((int64_t)mc * 256 + code) * dsub;
+                t = 0.0f;
+                if (dsub == 8) {
+                    float4 x = ((const float4*)cw)[0], y = ((const float4*)cw)[1];
+                    t = __fmaf_rn(qs[0], x.x, t); t = __fmaf_rn(qs[1], x.y, t); t = __fmaf_rn(qs[2], x.z, t); t = __fmaf_rn(qs[3], x.w, t);
+                    t = __fmaf_rn(qs[4], y.x, t); t = __fmaf_rn(qs[5], y.y, t); t = __fmaf_rn(qs[6], y.z, t); t = __fmaf_rn(qs[7], y.w, t);
+                } else {
+                    for (int tt = 0; tt < dsub; tt++) t = __fmaf_rn(qs[tt], cw[tt], t);
+                }
+            }
+            sum = m < M ? sum + t : sum;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) cur[i] = nxt[i];
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t fin_buf[];
     const int KP = a.KP;
     int64_t* sid = (int64_t*)fin_buf;
     int64_t* srow = sid + KP;
     uint32_t* sord = (uint32_t*)(srow + KP);
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;   // 1..4 waves
+    const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
     const int64_t q = blockIdx.x;
 
-    for (int c = lane; c < KP; c += 64) {
+    for (int c = tid; c < KP; c += nt) {
         uint64_t key = a.state[q * KP + c];
         int64_t row = -1, id = INT64_MAX;
         uint32_t ord = 0;
@@ -282,9 +328,10 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
     __syncthreads();
 
     if (a.kind == KIND_IVFPQ && a.pq_rescore) {
-        // one lane per candidate: canonical score = dis0 + (((0 + T[0][c0]) + T[1][c1]) + ...), fp32
-        const float* T = a.lut32 + q * a.Mpad * 256;
-        for (int c = lane; c < KP; c += 64) {
+        // one thread per candidate: canonical score = dis0 + (((0 + T[0][c0]) + T[1][c1]) + ...), fp32
+        const float* T = a.lut32 ? a.lut32 + q * a.Mpad * 256 : nullptr;
+        const float* qv = a.Q32 + q * a.ldq;
+        for (int c = tid; c < KP; c += nt) {
             int64_t row = srow[c];
             if (row < 0) continue;
             uint32_t idx = key_idx(a.state[q * KP + c]);
@@ -294,30 +341,17 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
             const float dis0 = a.probe_dis0[q * a.nprobe + lo];
             const int64_t slab = row >> 6; const int v = (int)(row & 63);
             const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-            float sum = 0.0f;
-            for (int m = 0; m < a.M; m++) {
-                int g = m / a.CB, b = m - g * a.CB;
-                uint32_t code = sp[(int64_t)g * (64 * a.CB) + v * a.CB + b];
-                float t;
-                if (a.lut32) {
-                    t = T[m * 256 + code];
-                } else {   // the table entry, recomputed with k_pq_lut's fmaf chain (bit-identical)
-                    const float* qs = a.Q32 + q * a.ldq + m * a.dsub;
-                    const float* cw = a.codebooks + ((int64_t)m * 256 + code) * a.dsub;
-                    t = 0.0f;
-                    for (int tt = 0; tt < a.dsub; tt++) t = __fmaf_rn(qs[tt], cw[tt], t);
-                }
-                sum += t;
-            }
+            const float sum = a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
+                                         : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
             sord[c] = f2ord((dis0 + sum) + 0.0f);
         }
         __syncthreads();
     }
     if (a.kind != KIND_IVFPQ) {
         const float* qv = a.Q32 + q * a.ldq;
-        for (int c = 0; c < KP; c++) {
+        for (int c = wv; c < KP; c += nwv) {   // one wave per candidate, lanes over the dimensions
             int64_t row = srow[c];
-            if (row < 0) continue;  // uniform (LDS value)
+            if (row < 0) continue;  // wave-uniform (LDS value)
             double acc = 0.0;
             if (a.x_f16) {
                 const __half* xv = (const __half*)a.X + row * a.ld;
@@ -344,7 +378,7 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
     // bitonic sort by (ord desc, id asc); invalid entries (ord 0, id INT64_MAX) sink to the end
     for (int size = 2; size <= KP; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = lane; t < (KP >> 1); t += 64) {
+            for (int t = tid; t < (KP >> 1); t += nt) {
                 int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
                 int j = i + stride;
                 bool desc = ((i & size) == 0);
@@ -358,7 +392,7 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
             __syncthreads();
         }
     }
-    if (a.kind == KIND_IVFPQ && a.pq_rescore && lane == 0) {
+    if (a.kind == KIND_IVFPQ && a.pq_rescore && tid == 0) {
         // certificate: every vector outside the candidate set has approximate score <= the K'-th
         // candidate's, hence exact score <= that + eps; if this is below the exact k-th best
         // candidate, the top k (ties included) lies inside the candidate set.
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
         if (a.cand_cnt && a.cand_cnt[q] > (unsigned long long)a.cand_cap) bad = 1;   // candidates were dropped
         a.uncertain[q] = bad;
     }
-    for (int j = lane; j < a.k; j += 64) {
+    for (int j = tid; j < a.k; j += nt) {
         bool valid = (j < KP) && sord[j] != 0 && sid[j] != INT64_MAX;
         float s = valid ? ord2f(sord[j]) : -__builtin_inff();
         if (a.metric != 0) s = valid ? (0.0f - s) : __builtin_inff();
@@ -387,7 +421,8 @@ void launch_finalize(const FinalizeArgs& a, hipStream_t st) {
     if (a.nq <= 0) return;
     size_t shm = (size_t)a.KP * (8 + 8 + 4);
     if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)a.nq), dim3(64), shm, st, a);
+    const int waves = std::min(4, std::max(1, (a.KP + 63) / 64));
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)a.nq), dim3(64 * waves), shm, st, a);
 }
 
 // ---------------------------------------------------------------------------------------
