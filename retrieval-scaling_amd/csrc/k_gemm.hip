@@ -338,11 +338,196 @@ __global__ __launch_bounds__(256) void k_flat_gemm(const __half* Q16, const void
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_flat_gemm2: the large-batch Flat scan.  256 queries x 256 db rows per workgroup, 8 waves (2 x 4, each
+// 128 x 64 = 4 x 2 MFMA 32x32x16 tiles -> 6 ds_read_b128 per 8 MFMAs), BK = 64, two 64 KiB LDS stages
+// filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), one barrier per K step.
+//
+// LDS layout per operand: row R at R*128 B; its 16-byte chunk c sits in slot c ^ ((R >> 1) & 7).  A DMA
+// instruction lands 64 lanes x 16 B linearly (8 rows), so lane (r8, p) FETCHES chunk p ^ swz(R); the
+// MFMA operand reads (16 lanes of a ds_read_b128 group = 16 different rows, same chunk) then hit 16
+// different 16-byte slots of the 256-byte bank window: conflict-free without padding.
+// ---------------------------------------------------------------------------------------
+#define FG2_STAGE 65536
+
+__device__ __forceinline__ void fg2_dma16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <bool FILTER>
+__global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pad, const __half* X, int64_t v0, int64_t nv,
+                                                    int ld, const float* bias, float* temp, int64_t tstride,
+                                                    FlatFilterArgs F) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fg2_smem[];   // 2 stages x (A 32 KiB | B 32 KiB), tau[256]
+    uint64_t* s_tau = reinterpret_cast<uint64_t*>(fg2_smem + 2 * FG2_STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 2, wc = w & 3;
+    int64_t q0, vt0;
+    if (FILTER) {
+        const int64_t b = blockIdx.x;
+        const int64_t i = b >> 3;
+        const int64_t vt = (b & 7) + 8 * (i / F.qt);
+        if (vt >= F.ntiles) return;
+        q0 = (i % F.qt) * 256;
+        vt0 = vt * 256;
+        if (tid < 256) s_tau[tid] = (q0 + tid < F.nq) ? F.tau[(q0 + tid) * F.tau_stride] : ~0ull;
+    } else {
+        q0 = (int64_t)blockIdx.x * 256;
+        vt0 = (int64_t)blockIdx.y * 256;
+    }
+
+    // DMA sources: wave w copies blocks [4w, 4w + 4) (8 rows each) of both operands, every stage
+    const char* srcA[4]; const char* srcB[4];
+    {
+        const int r8 = lane >> 3, p = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int R = (4 * w + j) * 8 + r8;
+            const int c = p ^ ((R >> 1) & 7);
+            int64_t qrow = q0 + R; if (qrow > nq_pad - 1) qrow = nq_pad - 1;
+            int64_t xrow = vt0 + R; if (xrow > nv - 1) xrow = nv - 1;
+            srcA[j] = reinterpret_cast<const char*>(Q16 + qrow * ld) + c * 16;
+            srcB[j] = reinterpret_cast<const char*>(X + (v0 + xrow) * ld) + c * 16;
+        }
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* sa = fg2_smem + buf * FG2_STAGE + (4 * w) * 1024;
+        unsigned char* sb = sa + 32768;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            fg2_dma16(srcA[j] + (int64_t)kt * 128, sa + j * 1024);
+            fg2_dma16(srcB[j] + (int64_t)kt * 128, sb + j * 1024);
+        }
+    };
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    const int KT = ld / 64;
+    const int li = lane & 31, kh = lane >> 5;
+    const int sw = (li >> 1) & 7;
+    int offs[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) offs[s] = li * 128 + (((2 * s + kh) ^ sw) << 4);
+
+    issue(0, 0);
+    if (KT > 1) issue(1, 1);
+    if (KT > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // operand fragments are double-buffered in registers: the reads of k sub-step s+1 are in flight while
+    // the 8 MFMAs of sub-step s issue
+    half8 fa[2][4], fb[2][2];
+#define FG2_LOAD_FRAGS(BUF, S, SLOT)                                                                       \
+    {                                                                                                        \
+        const unsigned char* As_ = fg2_smem + (BUF) * FG2_STAGE + wr * (128 * 128);                          \
+        const unsigned char* Bs_ = fg2_smem + (BUF) * FG2_STAGE + 32768 + wc * (64 * 128);                   \
+        _Pragma("unroll") for (int t = 0; t < 4; t++)                                                        \
+            fa[SLOT][t] = *reinterpret_cast<const half8*>(As_ + t * 4096 + offs[S]);                         \
+        _Pragma("unroll") for (int t = 0; t < 2; t++)                                                        \
+            fb[SLOT][t] = *reinterpret_cast<const half8*>(Bs_ + t * 4096 + offs[S]);                         \
+    }
+    FG2_LOAD_FRAGS(0, 0, 0)
+    for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s < 3) FG2_LOAD_FRAGS(kt & 1, s + 1, (s + 1) & 1)
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+                for (int tj = 0; tj < 2; tj++)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][ti], fb[s & 1][tj], acc[ti][tj], 0, 0, 0);
+        }
+        if (kt + 1 < KT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of stage kt+1 have landed
+            __syncthreads();                                    // everyone: done with stage kt, stage kt+1 complete
+            if (kt + 2 < KT) issue(kt + 2, kt & 1);
+            FG2_LOAD_FRAGS((kt + 1) & 1, 0, 0)
+        }
+    }
+#undef FG2_LOAD_FRAGS
+
+    // A index i = query, B index j = db row
+    const int lj = lane & 31, lh = lane >> 5;
+    if (!FILTER) {
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            int64_t col = vt0 + wc * 64 + tj * 32 + lj;
+            float bv = (bias && col < nv) ? bias[v0 + col] : 0.0f;
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int64_t qrow = q0 + wr * 128 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (col < nv && qrow < nq_pad) temp[qrow * tstride + col] = acc[ti][tj][r] + bv;
+                }
+        }
+    } else {
+        float bv[2]; int64_t colv[2];
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            colv[tj] = vt0 + wc * 64 + tj * 32 + lj;
+            bv[tj] = (bias && colv[tj] < nv) ? bias[v0 + colv[tj]] : 0.0f;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ql = wr * 128 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // query inside the tile
+                const uint64_t tau = s_tau[ql];          // ~0 for padding queries: nothing passes
+                const float tf = key_score(tau);
+#pragma unroll
+                for (int tj = 0; tj < 2; tj++) {
+                    const float sc = acc[ti][tj][r] + bv[tj];
+                    if (!__any(sc >= tf && colv[tj] < nv)) continue;
+                    const uint64_t key = (colv[tj] < nv) ? make_key(sc, (uint32_t)(v0 + colv[tj])) : 0ull;
+                    const bool pass = key > tau;
+                    const uint64_t mask = __ballot(pass);
+                    const uint64_t mine = lh ? (mask >> 32) : (mask & 0xffffffffull);   // my half-wave = my query
+                    if (mine) {
+                        unsigned long long base = 0;
+                        const int leader = (__ffsll((unsigned long long)mine) - 1) + 32 * lh;
+                        if (lane == leader) base = atomicAdd(&F.cand_cnt[q0 + ql], (unsigned long long)__popcll(mine));
+                        base = __shfl(base, leader);
+                        const unsigned long long slot = base + __popcll(mine & ((1ull << lj) - 1ull));
+                        if (pass && slot < (unsigned long long)F.cand_cap) F.cand[(q0 + ql) * F.cand_cap + slot] = key;
+                    }
+                }
+            }
+    }
+}
+
+static const size_t FG2_SHM = 2 * FG2_STAGE + 256 * 8;
+template <bool FILTER>
+static bool fg2_ready() {
+    static int ok = -1;
+    if (ok < 0) ok = hipFuncSetAttribute((const void*)k_flat_gemm2<FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FG2_SHM) == hipSuccess;
+    return ok == 1;
+}
+// the 256 x 256 LDS-DMA kernel needs fp16 storage, K a multiple of 64 and enough queries to fill its tile
+static bool fg2_applies(int nq_pad, int x_f16, int ld) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("RSX_FLAT_GEMM_V1"); off = (e && atoi(e)) ? 1 : 0; }
+    return !off && x_f16 && nq_pad > 128 && ld % 64 == 0;
+}
+
 void launch_flat_gemm(const __half* Q16, int nq_pad, const void* X, int x_f16, int64_t v0, int64_t nv, int ld,
                       const float* bias, float* temp, int64_t tstride, hipStream_t st) {
     if (nv <= 0 || nq_pad <= 0) return;
-    dim3 grid(nq_pad / 128, (unsigned)((nv + 127) / 128));
     FlatFilterArgs F{};
+    if (fg2_applies(nq_pad, x_f16, ld) && fg2_ready<false>()) {
+        dim3 g2((unsigned)((nq_pad + 255) / 256), (unsigned)((nv + 255) / 256));
+        hipLaunchKernelGGL((k_flat_gemm2<false>), g2, dim3(512), FG2_SHM, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias, temp, tstride, F);
+        return;
+    }
+    dim3 grid(nq_pad / 128, (unsigned)((nv + 127) / 128));
     if (x_f16) hipLaunchKernelGGL((k_flat_gemm<true, false>), grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, temp, tstride, F);
     else hipLaunchKernelGGL((k_flat_gemm<false, false>), grid, dim3(256), 0, st, Q16, X, v0, nv, ld, bias, temp, tstride, F);
 }
@@ -354,6 +539,13 @@ void launch_flat_gemm_filter(const __half* Q16, int nq_pad, int nq, const void* 
     if (nv <= 0 || nq_pad <= 0) return;
     FlatFilterArgs F{};
     F.tau = tau; F.tau_stride = tau_stride; F.cand = cand; F.cand_cnt = cand_cnt; F.cand_cap = cand_cap;
+    if (fg2_applies(nq_pad, x_f16, ld) && fg2_ready<true>()) {
+        F.nq = nq; F.qt = (nq_pad + 255) / 256; F.ntiles = (nv + 255) / 256;
+        int64_t blocks2 = ((F.ntiles + 7) / 8) * F.qt * 8;
+        hipLaunchKernelGGL((k_flat_gemm2<true>), dim3((unsigned)blocks2), dim3(512), FG2_SHM, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias,
+                           (float*)nullptr, (int64_t)0, F);
+        return;
+    }
     F.nq = nq; F.qt = nq_pad / 128; F.ntiles = (nv + 127) / 128;
     int64_t groups = (F.ntiles + 7) / 8;                 // 8 db tiles (one per XCD) x qt query tiles each
     int64_t blocks = groups * F.qt * 8;

@@ -30,7 +30,7 @@ def test_golden(gpu, name):
 
 
 @pytest.mark.parametrize("metric", [0, 1])
-@pytest.mark.parametrize("nq", [3, 200])        # 3 -> streaming small-batch kernel, 200 -> MFMA GEMM tiles
+@pytest.mark.parametrize("nq", [3, 100, 200, 300])   # 3 -> streaming small-batch kernel, 100 -> 128x128 MFMA tiles, 200/300 -> 256x256 LDS-DMA tiles
 def test_vs_oracle_both_kernels(gpu, orc, metric, nq):
     d, n, k = 768, 5000, 10
     x = orc.synth_vectors(d, 12, 21, 22, 0.5, 0, n)
