@@ -359,22 +359,21 @@ template <bool FILTER>
 __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pad, const __half* X, int64_t v0, int64_t nv,
                                                     int ld, const float* bias, float* temp, int64_t tstride,
                                                     FlatFilterArgs F) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char fg2_smem[];   // 2 stages x (A 32 KiB | B 32 KiB), tau[256]
+    extern __shared__ __attribute__((aligned(16))) unsigned char fg2_smem[];   // 2 stages x (A 32 KiB | B 32 KiB), tau[2][256]
     uint64_t* s_tau = reinterpret_cast<uint64_t*>(fg2_smem + 2 * FG2_STAGE);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 2, wc = w & 3;
-    int64_t q0, vt0;
-    if (FILTER) {
-        const int64_t b = blockIdx.x;
-        const int64_t i = b >> 3;
-        const int64_t vt = (b & 7) + 8 * (i / F.qt);
-        if (vt >= F.ntiles) return;
-        q0 = (i % F.qt) * 256;
-        vt0 = vt * 256;
-        if (tid < 256) s_tau[tid] = (q0 + tid < F.nq) ? F.tau[(q0 + tid) * F.tau_stride] : ~0ull;
-    } else {
-        q0 = (int64_t)blockIdx.x * 256;
-        vt0 = (int64_t)blockIdx.y * 256;
+    const int wr0 = __builtin_amdgcn_readfirstlane(w >> 2), wc0 = __builtin_amdgcn_readfirstlane(w & 3);
+    // FILTER: the workgroup owns ONE db tile and passes every query tile over it (the db tile comes from HBM
+    // once, for the first pass; each CU streams a different tile, so the HBM requests in flight are all
+    // distinct).  !FILTER: one (query tile, db tile) pair per workgroup.
+    const int64_t vt0 = (FILTER ? (int64_t)blockIdx.x : (int64_t)blockIdx.y) * 256;
+    const int qi0 = FILTER ? 0 : (int)blockIdx.x;
+    const int npass = FILTER ? F.qt : 1;
+    float* s_tf = reinterpret_cast<float*>(s_tau + 512);                        // tf[2][256]: the thresholds as floats
+    if (FILTER && tid < 256) {
+        const uint64_t t = (tid < F.nq) ? F.tau[(int64_t)tid * F.tau_stride] : ~0ull;
+        s_tau[tid] = t;
+        s_tf[tid] = (tid < F.nq) ? key_score(t) : __builtin_inff();
     }
 
     // DMA sources: wave w copies blocks [4w, 4w + 4) (8 rows each) of both operands, every stage
@@ -385,20 +384,28 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
         for (int j = 0; j < 4; j++) {
             const int R = (4 * w + j) * 8 + r8;
             const int c = p ^ ((R >> 1) & 7);
-            int64_t qrow = q0 + R; if (qrow > nq_pad - 1) qrow = nq_pad - 1;
             int64_t xrow = vt0 + R; if (xrow > nv - 1) xrow = nv - 1;
-            srcA[j] = reinterpret_cast<const char*>(Q16 + qrow * ld) + c * 16;
+            srcA[j] = reinterpret_cast<const char*>(Q16 + ((int64_t)qi0 * 256 + R) * ld) + c * 16;   // nq_pad % 256 == 0
             srcB[j] = reinterpret_cast<const char*>(X + (v0 + xrow) * ld) + c * 16;
         }
     }
-    auto issue = [&](int kt, int buf) {
+    const int KT = ld / 64;
+    const int G = npass * KT;                    // K steps of all passes, one software pipeline
+    const int64_t pass_bytes = (int64_t)256 * ld * 2;
+    int i_kt = 0; int64_t i_aoff = 0;            // position of the next stage to issue
+    auto issue = [&](int buf, bool advance) {
         unsigned char* sa = fg2_smem + buf * FG2_STAGE + (4 * w) * 1024;
         unsigned char* sb = sa + 32768;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            fg2_dma16(srcA[j] + (int64_t)kt * 128, sa + j * 1024);
-            fg2_dma16(srcB[j] + (int64_t)kt * 128, sb + j * 1024);
+            fg2_dma16(srcA[j] + i_aoff + (int64_t)i_kt * 128, sa + j * 1024);
+            fg2_dma16(srcB[j] + (int64_t)i_kt * 128, sb + j * 1024);
         }
+        // branch-free advance (a branch here would split the scheduling region the interleave below pins)
+        i_kt += advance ? 1 : 0;
+        const bool wrap = i_kt == KT;
+        i_kt = wrap ? 0 : i_kt;
+        i_aoff += wrap ? pass_bytes : 0;
     };
 
     floatx16 acc[4][2];
@@ -409,17 +416,14 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
 
-    const int KT = ld / 64;
     const int li = lane & 31, kh = lane >> 5;
     const int sw = (li >> 1) & 7;
     int offs[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) offs[s] = li * 128 + (((2 * s + kh) ^ sw) << 4);
 
-    issue(0, 0);
-    if (KT > 1) issue(1, 1);
-    if (KT > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(0, G > 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // operand fragments are double-buffered in registers: the reads of k sub-step s+1 are in flight while
@@ -427,84 +431,143 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
     half8 fa[2][4], fb[2][2];
 #define FG2_LOAD_FRAGS(BUF, S, SLOT)                                                                       \
     {                                                                                                        \
-        const unsigned char* As_ = fg2_smem + (BUF) * FG2_STAGE + wr * (128 * 128);                          \
-        const unsigned char* Bs_ = fg2_smem + (BUF) * FG2_STAGE + 32768 + wc * (64 * 128);                   \
+        const unsigned char* As_ = fg2_smem + (BUF) * FG2_STAGE + wr0 * (128 * 128);                         \
+        const unsigned char* Bs_ = fg2_smem + (BUF) * FG2_STAGE + 32768 + wc0 * (64 * 128);                  \
         _Pragma("unroll") for (int t = 0; t < 4; t++)                                                        \
             fa[SLOT][t] = *reinterpret_cast<const half8*>(As_ + t * 4096 + offs[S]);                         \
         _Pragma("unroll") for (int t = 0; t < 2; t++)                                                        \
             fb[SLOT][t] = *reinterpret_cast<const half8*>(Bs_ + t * 4096 + offs[S]);                         \
     }
+#define FG2_MFMAS(SLOT)                                                                                     \
+    _Pragma("unroll") for (int ti = 0; ti < 4; ti++)                                                         \
+        _Pragma("unroll") for (int tj = 0; tj < 2; tj++)                                                     \
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][ti], fb[SLOT][tj], acc[ti][tj], 0, 0, 0);
     FG2_LOAD_FRAGS(0, 0, 0)
-    for (int kt = 0; kt < KT; kt++) {
+    const int lj0 = lane & 31, lh0 = lane >> 5;
+    int kt = 0, qi = qi0;
+    for (int g = 0; g < G; g++) {
+        // sub-step 0 carries the DMA of the NEXT stage (into the buffer every wave left at the last barrier);
+        // the last step re-fetches its own stage into the idle buffer so the body stays branch-free.
+        issue((g + 1) & 1, g + 2 < G);
+        FG2_LOAD_FRAGS(g & 1, 1, 1)
+        FG2_MFMAS(0)
+        // pin the interleave: 1 MFMA : 1 DMA (+ 1 fragment read) — each DMA issue and LDS latency is then
+        // covered by a 32-cycle matrix-pipe slot instead of stalling in front of the MFMAs
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            if (s < 3) FG2_LOAD_FRAGS(kt & 1, s + 1, (s + 1) & 1)
-#pragma unroll
-            for (int ti = 0; ti < 4; ti++)
-#pragma unroll
-                for (int tj = 0; tj < 2; tj++)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][ti], fb[s & 1][tj], acc[ti][tj], 0, 0, 0);
+        for (int i = 0; i < 6; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        if (kt + 1 < KT) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of stage kt+1 have landed
-            __syncthreads();                                    // everyone: done with stage kt, stage kt+1 complete
-            if (kt + 2 < KT) issue(kt + 2, kt & 1);
-            FG2_LOAD_FRAGS((kt + 1) & 1, 0, 0)
-        }
-    }
-#undef FG2_LOAD_FRAGS
-
-    // A index i = query, B index j = db row
-    const int lj = lane & 31, lh = lane >> 5;
-    if (!FILTER) {
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
-            int64_t col = vt0 + wc * 64 + tj * 32 + lj;
-            float bv = (bias && col < nv) ? bias[v0 + col] : 0.0f;
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        FG2_LOAD_FRAGS(g & 1, 2, 0)
+        FG2_MFMAS(1)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+        FG2_LOAD_FRAGS(g & 1, 3, 1)
+        FG2_MFMAS(0)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+        FG2_MFMAS(1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of stage g+1 have landed
+        __syncthreads();                                    // everyone: done with stage g, stage g+1 complete
+        if (++kt < KT) {
+            FG2_LOAD_FRAGS((g + 1) & 1, 0, 0)
+            continue;
+        }
+        kt = 0;
+        // ---- end of a pass: the 256 x 256 scores of query tile qi are complete
+        const int64_t q0 = (int64_t)qi * 256;
+        // launder the lane coordinates: everything derived from them below would otherwise be hoisted out of
+        // the K loop as loop-invariant and held in ~70 VGPRs across the MFMA phase (-> spills)
+        int lj = lj0, lh = lh0, wr = wr0, wc = wc0;
+        asm volatile("" : "+v"(lj), "+v"(lh), "+s"(wr), "+s"(wc));
+        if (!FILTER) {
+#pragma unroll
+            for (int tj = 0; tj < 2; tj++) {
+                int64_t col = vt0 + wc * 64 + tj * 32 + lj;
+                float bv = (bias && col < nv) ? bias[v0 + col] : 0.0f;
+#pragma unroll
+                for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        int64_t qrow = q0 + wr * 128 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (col < nv && qrow < nq_pad) temp[qrow * tstride + col] = acc[ti][tj][r] + bv;
+                    }
+            }
+        } else {
+            const uint64_t* taus = s_tau + (qi & 1) * 256;
+            const float* tfs = s_tf + (qi & 1) * 256;
+            float bv[2]; int64_t colv[2];
+#pragma unroll
+            for (int tj = 0; tj < 2; tj++) {
+                colv[tj] = vt0 + wc * 64 + tj * 32 + lj;
+                bv[tj] = (bias && colv[tj] < nv) ? bias[v0 + colv[tj]] : 0.0f;
+            }
+            const bool in0 = colv[0] < nv, in1 = colv[1] < nv;
 #pragma unroll
             for (int ti = 0; ti < 4; ti++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    int64_t qrow = q0 + wr * 128 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (col < nv && qrow < nq_pad) temp[qrow * tstride + col] = acc[ti][tj][r] + bv;
-                }
-        }
-    } else {
-        float bv[2]; int64_t colv[2];
+                    const int ql = wr * 128 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // query inside the tile
+                    // fast reject of the row pair on the float threshold (+inf for padding queries);
+                    // the exact decision below is on the full key
+                    const float s0 = acc[ti][0][r] + bv[0], s1 = acc[ti][1][r] + bv[1];
+                    const float tf = tfs[ql];
+                    if (!__any((in0 && s0 >= tf) || (in1 && s1 >= tf))) continue;
+                    const uint64_t tau = taus[ql];
 #pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
-            colv[tj] = vt0 + wc * 64 + tj * 32 + lj;
-            bv[tj] = (bias && colv[tj] < nv) ? bias[v0 + colv[tj]] : 0.0f;
-        }
-#pragma unroll
-        for (int ti = 0; ti < 4; ti++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int ql = wr * 128 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // query inside the tile
-                const uint64_t tau = s_tau[ql];          // ~0 for padding queries: nothing passes
-                const float tf = key_score(tau);
-#pragma unroll
-                for (int tj = 0; tj < 2; tj++) {
-                    const float sc = acc[ti][tj][r] + bv[tj];
-                    if (!__any(sc >= tf && colv[tj] < nv)) continue;
-                    const uint64_t key = (colv[tj] < nv) ? make_key(sc, (uint32_t)(v0 + colv[tj])) : 0ull;
-                    const bool pass = key > tau;
-                    const uint64_t mask = __ballot(pass);
-                    const uint64_t mine = lh ? (mask >> 32) : (mask & 0xffffffffull);   // my half-wave = my query
-                    if (mine) {
-                        unsigned long long base = 0;
-                        const int leader = (__ffsll((unsigned long long)mine) - 1) + 32 * lh;
-                        if (lane == leader) base = atomicAdd(&F.cand_cnt[q0 + ql], (unsigned long long)__popcll(mine));
-                        base = __shfl(base, leader);
-                        const unsigned long long slot = base + __popcll(mine & ((1ull << lj) - 1ull));
-                        if (pass && slot < (unsigned long long)F.cand_cap) F.cand[(q0 + ql) * F.cand_cap + slot] = key;
+                    for (int tj = 0; tj < 2; tj++) {
+                        const float sc = tj ? s1 : s0;
+                        const uint64_t key = (colv[tj] < nv) ? make_key(sc, (uint32_t)(v0 + colv[tj])) : 0ull;
+                        const bool pass = key > tau;
+                        const uint64_t mask = __ballot(pass);
+                        const uint64_t mine = lh ? (mask >> 32) : (mask & 0xffffffffull);   // my half-wave = my query
+                        if (mine) {
+                            unsigned long long base = 0;
+                            const int leader = (__ffsll((unsigned long long)mine) - 1) + 32 * lh;
+                            if (lane == leader) base = atomicAdd(&F.cand_cnt[q0 + ql], (unsigned long long)__popcll(mine));
+                            base = __shfl(base, leader);
+                            const unsigned long long slot = base + __popcll(mine & ((1ull << lj) - 1ull));
+                            if (pass && slot < (unsigned long long)F.cand_cap) F.cand[(q0 + ql) * F.cand_cap + slot] = key;
+                        }
                     }
                 }
+            // thresholds of the next pass (read after at least one more barrier)
+            if (qi + 1 < npass && tid < 256) {
+                const int64_t qn = (int64_t)(qi + 1) * 256 + tid;
+                const uint64_t t = (qn < F.nq) ? F.tau[qn * F.tau_stride] : ~0ull;
+                s_tau[((qi + 1) & 1) * 256 + tid] = t;
+                s_tf[((qi + 1) & 1) * 256 + tid] = (qn < F.nq) ? key_score(t) : __builtin_inff();
             }
+            if (KT == 1) __syncthreads();            // no K-loop barrier would order them before the next epilogue
+        }
+        qi++;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+        if (g + 1 < G) FG2_LOAD_FRAGS((g + 1) & 1, 0, 0)
     }
+#undef FG2_MFMAS
+#undef FG2_LOAD_FRAGS
 }
 
-static const size_t FG2_SHM = 2 * FG2_STAGE + 256 * 8;
+static const size_t FG2_SHM = 2 * FG2_STAGE + 2 * 256 * 8 + 2 * 256 * 4;
 template <bool FILTER>
 static bool fg2_ready() {
     static int ok = -1;
@@ -515,7 +578,7 @@ static bool fg2_ready() {
 static bool fg2_applies(int nq_pad, int x_f16, int ld) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("RSX_FLAT_GEMM_V1"); off = (e && atoi(e)) ? 1 : 0; }
-    return !off && x_f16 && nq_pad > 128 && ld % 64 == 0;
+    return !off && x_f16 && nq_pad % 256 == 0 && ld % 64 == 0;
 }
 
 void launch_flat_gemm(const __half* Q16, int nq_pad, const void* X, int x_f16, int64_t v0, int64_t nv, int ld,
@@ -523,7 +586,7 @@ void launch_flat_gemm(const __half* Q16, int nq_pad, const void* X, int x_f16, i
     if (nv <= 0 || nq_pad <= 0) return;
     FlatFilterArgs F{};
     if (fg2_applies(nq_pad, x_f16, ld) && fg2_ready<false>()) {
-        dim3 g2((unsigned)((nq_pad + 255) / 256), (unsigned)((nv + 255) / 256));
+        dim3 g2((unsigned)(nq_pad / 256), (unsigned)((nv + 255) / 256));
         hipLaunchKernelGGL((k_flat_gemm2<false>), g2, dim3(512), FG2_SHM, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias, temp, tstride, F);
         return;
     }
@@ -540,9 +603,9 @@ void launch_flat_gemm_filter(const __half* Q16, int nq_pad, int nq, const void* 
     FlatFilterArgs F{};
     F.tau = tau; F.tau_stride = tau_stride; F.cand = cand; F.cand_cnt = cand_cnt; F.cand_cap = cand_cap;
     if (fg2_applies(nq_pad, x_f16, ld) && fg2_ready<true>()) {
-        F.nq = nq; F.qt = (nq_pad + 255) / 256; F.ntiles = (nv + 255) / 256;
-        int64_t blocks2 = ((F.ntiles + 7) / 8) * F.qt * 8;
-        hipLaunchKernelGGL((k_flat_gemm2<true>), dim3((unsigned)blocks2), dim3(512), FG2_SHM, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias,
+        F.nq = nq; F.qt = nq_pad / 256; F.ntiles = (nv + 255) / 256;
+
+        hipLaunchKernelGGL((k_flat_gemm2<true>), dim3((unsigned)F.ntiles), dim3(512), FG2_SHM, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias,
                            (float*)nullptr, (int64_t)0, F);
         return;
     }

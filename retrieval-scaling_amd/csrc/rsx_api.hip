@@ -665,7 +665,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     // queries: fp32 copy (exact re-rank, coarse quantiser, LUT) [nq, ld]; fp16 copy for the scans
     h->w_q32.ensure((size_t)nq * ld * 4);
     launch_convert_to_f32(dq, dtype == RSX_F16, d, nq, d, h->w_q32.as<float>(), ld, h->st);
-    int64_t nq_pad = round_up(nq, 128);
+    int64_t nq_pad = nq > 128 ? round_up(nq, 256) : 128;   // query tiles: 128 (k_flat_gemm) or 256 (k_flat_gemm2)
     if (h->kind != KIND_IVFPQ) {
         h->w_q16.ensure((size_t)nq_pad * ld * 2);
         launch_convert_to_f16(dq, dtype == RSX_F16, nq, d, h->w_q16.as<__half>(), ld, nq_pad, nullptr, h->st);

@@ -42,6 +42,8 @@ for s in $STAGES; do
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_flat.json" 2> "$OLDPWD/gpurun_out/prof_flat.log" ); echo "exit $?" >> gpurun_out/prof_flat.log ;;
     variants)
       for v in 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
+    fg2dbg)
+      for v in 0 1 2 4 8 9; do RSX_FG2_DBG=$v timeout 300 python tools/bench_configs.py flat --check 0 --steps 3 > gpurun_out/fg2_dbg$v.json 2> gpurun_out/fg2_dbg$v.log; done ;;
     bench_diag)
       timeout 900 python bench.py --diag --no-recall --cpu-queries 0 > gpurun_out/bench_diag.json 2> gpurun_out/bench_diag.log; echo "exit $?" >> gpurun_out/bench_diag.log ;;
     prof)
