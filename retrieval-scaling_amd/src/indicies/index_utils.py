@@ -5,6 +5,7 @@ rows a5, a9, a10).  Same function names, arguments and on-disk names; the implem
 `cfg` may be an OmegaConf node (reference) or any attribute/dict container (`cfg_get`).
 """
 import glob
+import collections
 import json
 import os
 import pickle
@@ -170,13 +171,33 @@ class BackendBase:
             return self.load_embeds(shard_id)
         raise AttributeError("get_embs(indices=...) needs resident embeddings, which no backend keeps")
 
-    # ---- id -> passage (reference flat.py:115-136)
+    # ---- id -> passage (reference flat.py:115-136).  The reference opens the passage file once per
+    # retrieved id (nq * k open() calls per search — the wall-clock bottleneck once the search itself is
+    # fast); here the files stay open in a small LRU and a line is fetched by seek +
+    # readline on the cached handle.  Same bytes, same json, same return value.
+    _MAX_OPEN_PASSAGE_FILES = 64
+
+    def _passage_file(self, filename):
+        cache = self.__dict__.setdefault("_psg_files", collections.OrderedDict())
+        f = cache.get(filename)
+        if f is None:
+            f = open(filename, "rb")
+            cache[filename] = f
+            if len(cache) > self._MAX_OPEN_PASSAGE_FILES:
+                cache.popitem(last=False)[1].close()
+        else:
+            cache.move_to_end(filename)
+        return f
+
+    def close_passage_files(self):
+        for f in self.__dict__.pop("_psg_files", {}).values():
+            f.close()
+
     def _id2psg(self, shard_id, chunk_id):
         filename, position = self.psg_pos_id_map[shard_id][chunk_id]
-        with open(filename, "r") as f:
-            f.seek(position)
-            line = f.readline()
-        return json.loads(line)
+        f = self._passage_file(filename)
+        f.seek(position)
+        return json.loads(f.readline().decode("utf-8"))
 
     def _db_id(self, index_id):
         # NOTE reference quirk kept: index_id == -1 (fewer than k hits) indexes the LAST element.
@@ -192,8 +213,15 @@ class BackendBase:
 
     def get_retrieved_passages(self, all_indices):
         passages, db_ids = [], []
+        texts = {}                      # a passage retrieved for several queries of the batch is read once
         for query_indices in all_indices:
-            passages.append([self._get_passage(int(i))["text"] for i in query_indices])
+            row = []
+            for i in query_indices:
+                i = int(i)
+                if i not in texts:
+                    texts[i] = self._get_passage(i)["text"]
+                row.append(texts[i])
+            passages.append(row)
             db_ids.append([self._db_id(int(i)) for i in query_indices])
         return passages, db_ids
 

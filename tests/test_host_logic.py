@@ -110,6 +110,38 @@ def test_indexer_facade_contract(tmp_path, orc, fake, index_type):
         assert ix2.datastore.index.nprobe == 4     # probe applied at load (ivf_flat.py:73)
 
 
+def test_passage_fetch_matches_reference_reads(tmp_path, orc, fake, monkeypatch):
+    """get_retrieved_passages keeps files open (LRU) instead of the reference's open() per id
+    (flat.py:115-121): the strings must be what open/seek/readline/json.loads gives, non-ASCII
+    text included, and repeated ids must not re-open anything."""
+    import builtins, json
+    from src.indicies.base import Indexer
+    tmp = str(tmp_path)
+    write_datastore(tmp, orc)
+    ds = Indexer(make_cfg(tmp, "Flat", [0, 1])).datastore
+    ids = [[0, 399, 400, 799, 5], [5, 5, 400, 0, 799]]
+    opened = []
+    real_open = builtins.open
+    monkeypatch.setattr(builtins, "open", lambda f, *a, **k: (opened.append(f), real_open(f, *a, **k))[1])
+    passages, db_ids = ds.get_retrieved_passages(ids)
+    monkeypatch.undo()
+    assert len([f for f in opened if str(f).endswith(".jsonl")]) == 2          # one handle per passage file
+    for row_ids, row_txt, row_db in zip(ids, passages, db_ids):
+        for i, txt, db in zip(row_ids, row_txt, row_db):
+            shard, chunk = ds.index_id_to_db_id[i]
+            fname, pos = ds.psg_pos_id_map[shard][chunk]
+            with open(fname, "r") as f:                                           # the reference's read
+                f.seek(pos)
+                assert txt == json.loads(f.readline())["text"]
+            assert db == [shard, chunk]
+    ds.close_passage_files()
+    ds._MAX_OPEN_PASSAGE_FILES = 1                                                # LRU bound holds
+    assert ds.get_retrieved_passages(ids) == (passages, db_ids)
+    assert len(ds._psg_files) == 1
+    ds.close_passage_files()
+    assert "_psg_files" not in ds.__dict__
+
+
 def test_unknown_index_type_raises(tmp_path, orc, fake):
     from src.indicies.base import Indexer
     write_datastore(str(tmp_path), orc)
