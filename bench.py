@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-recall", action="store_true", help="skip the exact ground truth (recall = null)")
     ap.add_argument("--diag", action="store_true", help="print a fast-vs-exact comparison of the first timed batch and exit")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine parameter for an experiment (rsx_set_param), e.g. pq_filter=0; not for the reported line")
     ap.add_argument("--ab", action="store_true", help="also time the per-pair v1 scan kernel (same process, same index)")
     args = ap.parse_args()
 
@@ -104,6 +106,9 @@ def main():
         fresh.set_centroids(cen.cpu().numpy()); fresh.set_codebooks(cb.cpu().numpy())
         index = fresh
     index.nprobe = args.nprobe
+    for kv in args.param:
+        name, val = kv.split("=")
+        index.set_param(name, int(val))
 
     # ---------------- queries (all steps resident in HBM)
     nsteps = args.warmup + args.steps

@@ -41,13 +41,8 @@ for s in $STAGES; do
     prof_flat)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_flat.json" 2> "$OLDPWD/gpurun_out/prof_flat.log" ); echo "exit $?" >> gpurun_out/prof_flat.log ;;
     variants)
-      for v in 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
-    pmc_flat)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d "$OLDPWD/gpurun_out/pmc_sq_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --n 4000000 --check 0 --steps 2 > "$OLDPWD/gpurun_out/pmc_sq_flat.json" 2> "$OLDPWD/gpurun_out/pmc_sq_flat.log" ); echo "exit $?" >> gpurun_out/pmc_sq_flat.log
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_MFMA -d "$OLDPWD/gpurun_out/pmc_sq_flat2" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --n 4000000 --check 0 --steps 2 > "$OLDPWD/gpurun_out/pmc_sq_flat2.json" 2> "$OLDPWD/gpurun_out/pmc_sq_flat2.log" ); echo "exit $?" >> gpurun_out/pmc_sq_flat2.log
-      rm -f gpurun_out/pmc_flat_summary.txt
-      for d in pmc_sq_flat pmc_sq_flat2; do python tools/pmc_summary.py gpurun_out/$d/r01_results.db gpurun_out/pmc_flat_summary.txt '%k_flat_gemm%'; done
-      rm -rf gpurun_out/pmc_sq_flat gpurun_out/pmc_sq_flat2 ;;
+      # cost split of k_pq_scan8 (unfiltered form): 0 = real kernel, 1 = gathers + ONE add, 2 = no LDS gather
+      for v in 0 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall --param pq_filter=0 > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
     bench_diag)
       timeout 900 python bench.py --diag --no-recall --cpu-queries 0 > gpurun_out/bench_diag.json 2> gpurun_out/bench_diag.log; echo "exit $?" >> gpurun_out/bench_diag.log ;;
     prof)
