@@ -642,6 +642,7 @@ static int launch_pq_scan8_t(const PQScan8Args& A, hipStream_t st) {
 template <int NCH, bool FILTER = false>
 static int launch_pq_scan8_v(const PQScan8Args& A, int vpl, hipStream_t st) {
     switch (vpl) {
+        case 16: return launch_pq_scan8_t<NCH, 16, 0, FILTER>(A, st);
         case 8: return launch_pq_scan8_t<NCH, 8, 0, FILTER>(A, st);
         case 4: return launch_pq_scan8_t<NCH, 4, 0, FILTER>(A, st);
         case 2: return launch_pq_scan8_t<NCH, 2, 0, FILTER>(A, st);

@@ -832,9 +832,9 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             tm.mark("lut8");
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             int vpl = 8;
-            if (h->scan_chunk > 0) vpl = std::max(1, std::min(8, h->scan_chunk / 1024));
+            if (h->scan_chunk > 0) vpl = std::max(1, std::min(16, h->scan_chunk / 1024));
             else while (vpl > 1 && (pairs / 4 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
-            if (vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
+            if (vpl != 16 && vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
             const int tile_rows = 64 * 16 * vpl;
             h->w_pairs.ensure((size_t)(pairs + 5 * (size_t)(nlist + 1) + 8) * 4);
             int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
