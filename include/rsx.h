@@ -152,7 +152,8 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out);
  * v1 kernel, 2 = exact list-major kernel; non-zero disables the fast scan), "pq_fast" (IVFPQ: 1 = 8-bit-table
  * fast scan with certified exact re-rank [default], 0 = exact scan only), "pq_fast_kp" (candidates kept by the
  * fast scan, 0 = auto), "pq_filter" (fast scan: 1 = candidates filtered inside the scan kernel [default], 0 = full
- * score buffer), "flat_filter" (Flat: 1 = one filtered GEMM launch after the first chunk [default], 0 = score buffer
+ * score buffer), "pq_pre_rows" (filtered fast scan: vectors of each query's closest list scored by the threshold
+ * pre-pass, default 2048, 0 = one scan tile), "flat_filter" (Flat: 1 = one filtered GEMM launch after the first chunk [default], 0 = score buffer
  * per chunk), "profile" (1 = record stage timings with HIP
  * events on the library's stream; 2 = additionally count the vectors each search scanned). */
 int rsx_set_param(rsx_index_t* h, const char* key, double value);

@@ -64,6 +64,19 @@ void launch_fill_u64(uint64_t* p, int64_t n, uint64_t v, hipStream_t st) {
     int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, st, p, n, v);
 }
+// rows of `len` keys: keep only the last key of each row (a selection state reduced to its threshold)
+__global__ void k_keep_last_u64(uint64_t* p, int64_t rows, int len) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = rows * len;
+    for (; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (i % len != len - 1) p[i] = 0;
+}
+void launch_keep_last_u64(uint64_t* p, int64_t rows, int len, hipStream_t st) {
+    if (rows <= 0 || len <= 1) return;
+    int64_t n = rows * len;
+    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_keep_last_u64, dim3(blocks), dim3(256), 0, st, p, rows, len);
+}
 __global__ void k_fill_f32(float* p, int64_t n, float v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;

@@ -501,7 +501,6 @@ struct PQScan8Args {
     int nlist; int max_items;
     // filtered output (FILTER = true): keys > tau_key[q] are appended to cand[q][0..cap)
     const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
-    int skip_rank0_tile0;   // the (closest list, first tile) piece of each query was scored by the pre-pass
 };
 
 // VAR != 0 are MEASUREMENT-ONLY variants (wrong results; selected with RSX_SCAN8_VARIANT for the cost split
@@ -563,7 +562,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
         PQQParam p = A.qp[qq[i]];
         const int64_t col = a.seg_start[qq[i] * (a.nprobe + 1) + (pidx[i] - (int)qq[i] * a.nprobe)];
         prm_f[i * 4 + 0] = a.probe_dis0[pidx[i]]; prm_f[i * 4 + 1] = p.scale; prm_f[i * 4 + 2] = p.bias;
-        prm_f[i * 4 + 3] = (FILTER && A.skip_rank0_tile0 && tile == 0 && (pidx[i] - (int)qq[i] * a.nprobe) == 0) ? 1.0f : 0.0f;
+        prm_f[i * 4 + 3] = 0.0f;
         prm_o[i * 2 + 0] = FILTER ? col : qq[i] * a.tstride + col;
         prm_o[i * 2 + 1] = qq[i];
         prm_t[i] = FILTER ? A.tau_key[qq[i] * A.tau_stride] : 0ull;
@@ -607,7 +606,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (i >= np) continue;
-            if (FILTER && prm_f[i * 4 + 3] != 0.0f) continue;   // scored by the pre-pass
             const float sc = prm_f[i * 4] + __fmaf_rn(prm_f[i * 4 + 1], (float)A4[i], prm_f[i * 4 + 2]);
             if (!FILTER) {
                 a.temp[prm_o[i * 2] + pos] = (pos < len) ? sc : -__builtin_inff();
@@ -661,7 +659,6 @@ int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
     A.tau_key = nullptr; A.tau_stride = 0; A.cand = nullptr; A.cand_cnt = nullptr; A.cand_cap = 0;
-    A.skip_rank0_tile0 = 0;
     if (a.Mpad == 96 && vpl == 8) {
         static int var = -1;
         if (var < 0) { const char* e = getenv("RSX_SCAN8_VARIANT"); var = e ? atoi(e) : 0; }
@@ -683,7 +680,7 @@ int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void*
                            const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                            const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                            const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                           int cand_cap, int skip_rank0_tile0, hipStream_t st) {
+                           int cand_cap, hipStream_t st) {
     if (a.CB != 16 || max_items <= 0 || max_items > 0x7fffff00 || a.M * 255 >= 65536) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8; A.qp = (const PQQParam*)qparam;
@@ -691,7 +688,6 @@ int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void*
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
     A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap;
-    A.skip_rank0_tile0 = skip_rank0_tile0;
     switch (a.Mpad / 16) {
         case 1: return launch_pq_scan8_v<1, true>(A, vpl, st);
         case 2: return launch_pq_scan8_v<2, true>(A, vpl, st);

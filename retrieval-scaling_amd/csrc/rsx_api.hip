@@ -147,6 +147,7 @@ struct rsx_index {
     int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
     int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
     int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
+    int pq_pre_rows = 2048;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int flat_filter = 1;  // Flat: one filtered GEMM launch after the first chunk (0 = score buffer per chunk)
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
@@ -854,19 +855,31 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             //           (wave-aggregated atomics); a final select merges them with state0.
             // A full candidate buffer marks the query uncertain (-> exact fallback), so this is always exact.
             filtered = (nprobe > 1) && (h->pq_filter != 0);
+            // the pre-pass only has to produce a threshold: it scores a (smaller) prefix of the closest list
+            int pre_vpl = vpl;
+            if (filtered && h->pq_pre_rows > 0) {
+                while (pre_vpl > 1 && 64 * 16 * pre_vpl > h->pq_pre_rows) pre_vpl /= 2;
+                while (pre_vpl > 1 && 64 * 16 * pre_vpl < KP * 4) pre_vpl *= 2;   // ... but well above K' candidates
+                if (pre_vpl > vpl) pre_vpl = vpl;
+            }
+            const int pre_rows = filtered ? 64 * 16 * pre_vpl : tile_rows;
             launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0,
+                               pairs_sorted, h->d_len.as<int64_t>(), pre_rows, item_off, total_items, nprobe, 0,
                                filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
             tm.mark("group");
             done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                    total_groups, item_off, total_items, nlist,
-                                   filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows), vpl,
-                                   h->st) == 0;
+                                   filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows),
+                                   filtered ? pre_vpl : vpl, h->st) == 0;
             if (done && filtered) {
                 tm.mark("scan0");
-                // top-K' of the first tile of the closest list: row prefix [0, min(seg_start[q][1], tile_rows))
+                // top-K' of the scored prefix of the closest list: row prefix [0, min(seg_start[q][1], pre_rows))
                 select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
-                            std::min<int64_t>(maxlen, tile_rows), 0, nq, KP, BUF, KP, state, false);
+                            std::min<int64_t>(maxlen, pre_rows), 0, nq, KP, BUF, KP, state, false);
+                // The pre-pass is only a threshold: keep its K'-th key and let the main scan score EVERYTHING (the
+                // prefix included), so the scan kernel carries no per-slab "already scored" test and no key can
+                // arrive twice (the prefix keys above the threshold come back through the candidate buffer).
+                launch_keep_last_u64(state, nq, KP, h->st);
                 tm.mark("select0");
                 cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
@@ -879,7 +892,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 done = launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist,
                                               max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
-                                              h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap, 1,
+                                              h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
                                               h->st) == 0;
             }
             if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
@@ -1484,6 +1497,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_fast") h->pq_fast = (int)value;
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
         else if (s == "pq_filter") h->pq_filter = (int)value;
+        else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;

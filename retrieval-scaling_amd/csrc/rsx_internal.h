@@ -53,6 +53,7 @@ void launch_write_ids(const int64_t* dest_row, const int64_t* ids_in, int64_t id
 void launch_widen_storage(const __half* src, float* dst, int64_t count, hipStream_t st);
 void launch_residuals(const float* x, int64_t n, int d, const float* centroids, const int32_t* assign, float* out, hipStream_t st);
 void launch_fill_u64(uint64_t* p, int64_t n, uint64_t v, hipStream_t st);
+void launch_keep_last_u64(uint64_t* p, int64_t rows, int len, hipStream_t st);   // zero all but the last key of each row
 void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void launch_synth_vectors(int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t i0,
                           int64_t n, __half* out, hipStream_t st);
@@ -143,7 +144,7 @@ int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void*
                            const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                            const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                            const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                           int cand_cap, int skip_rank0_tile0, hipStream_t st);
+                           int cand_cap, hipStream_t st);
 // codes for rows of a batch: residual vs centroid[assign] (centroids may be null -> no residual).
 // plain_out != null: write [n, Mpad] row-major instead of the slab layout (training / export).
 void launch_pq_encode(const void* x, int x_f16, int64_t n, int ldx, int d, int M, int Mpad, int CB,

@@ -31,7 +31,7 @@ METRIC_L2 = 1
 _F32, _F16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIB_PATH = os.path.join(_CSRC, "librsx.so")
+_LIB_PATH = os.environ.get("RSX_LIB", os.path.join(_CSRC, "librsx.so"))   # RSX_LIB: another build, for A/B measurements
 _lib = None
 
 #: every symbol include/rsx.h declares (checked by tests/test_abi.py against the header)

@@ -43,6 +43,12 @@ for s in $STAGES; do
     variants)
       # cost split of k_pq_scan8 (unfiltered form): 0 = real kernel, 1 = gathers + ONE add, 2 = no LDS gather
       for v in 0 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall --param pq_filter=0 > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
+    ab_lib)
+      # same-box A/B of two builds: retrieval-scaling_amd/csrc/librsx_head.so (copied there by hand) vs the current one
+      for r in 1 2; do
+        RSX_LIB=$PWD/retrieval-scaling_amd/csrc/librsx_head.so timeout 600 python bench.py --steps 10 --warmup 3 --cpu-queries 0 --no-recall > gpurun_out/bench_ab_head$r.json 2> gpurun_out/bench_ab_head$r.log
+        timeout 600 python bench.py --steps 10 --warmup 3 --cpu-queries 0 --no-recall > gpurun_out/bench_ab_new$r.json 2> gpurun_out/bench_ab_new$r.log
+      done ;;
     bench_diag)
       timeout 900 python bench.py --diag --no-recall --cpu-queries 0 > gpurun_out/bench_diag.json 2> gpurun_out/bench_diag.log; echo "exit $?" >> gpurun_out/bench_diag.log ;;
     prof)
