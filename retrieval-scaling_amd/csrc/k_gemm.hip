@@ -706,9 +706,173 @@ __global__ __launch_bounds__(256) void k_list_scan(ListScanArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_list_scan2: the same list-major scan for fp16 rows with the row stream staged through LDS by LDS-DMA.
+// k_list_scan pulls 16 rows x 64 B per load instruction (half a cache line per row) through VGPRs and tops out
+// at ~4.5 TB/s; here every wave owns a ring of LS2_D stages of 16 rows x 128 B (two 1 KiB DMA pieces, 8 rows x
+// one full line each, XOR-swizzled like k_flat_gemm2's tiles) that runs LS2_D - 1 K steps ahead of the MFMAs,
+// across the 16-row blocks of its chunk.  Waves never synchronise with each other after the queries are staged;
+// the scores wait in registers (8 blocks x 4) and are stored once the DMA stream has drained, because loads and
+// stores retire out of order with each other and would break the counted vmcnt waits.
+// ---------------------------------------------------------------------------------------
+#define LS2_D 6
+#define LS2_NB 8            // 16-row blocks per wave per chunk -> chunk_rows = 4 waves x 16 x 8 = 512
+
+__global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
+    const int qstride = (a.ld + 8) * 2;
+    unsigned char* Qs = ls_smem;
+    int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + 16 * qstride);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* ring = ls_smem + 16 * qstride + 128 + w * (LS2_D * 2048);
+    const int g = blockIdx.x;
+    const int chunk = blockIdx.y;
+
+    int64_t base, len;
+    int np;
+    int pair0 = 0;
+    if (a.flat_mode) {
+        base = 0; len = a.flat_n;
+        np = a.nq - 16 * g; if (np > 16) np = 16;
+        if (np <= 0) return;
+    } else {
+        if (g >= *a.total_groups) return;
+        int lo = 0, hi = a.nlist;  // largest l with group_off[l] <= g
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.group_off[mid] <= g) lo = mid; else hi = mid; }
+        const int l = lo;
+        int gi = g - a.group_off[l];
+        int cnt = a.pair_off[l + 1] - a.pair_off[l];
+        np = cnt - 16 * gi; if (np > 16) np = 16;
+        pair0 = a.pair_off[l] + 16 * gi;
+        base = a.list_base[l]; len = a.list_len[l];
+    }
+    const int64_t len_pad = (len + 15) & ~15ll;
+    const int64_t c0 = (int64_t)chunk * (64 * LS2_NB);
+    if (c0 >= len_pad) return;
+    int64_t c1 = c0 + 64 * LS2_NB; if (c1 > len_pad) c1 = len_pad;
+
+    // stage the group's queries (16 rows of ld halfs) and their score-buffer offsets
+    for (int i = 0; i < 16; i++) {
+        int64_t q = -1;
+        if (i < np) {
+            if (a.flat_mode) q = 16 * (int64_t)g + i;
+            else q = a.pairs_sorted[pair0 + i] / a.nprobe;
+        }
+        for (int t = tid * 8; t < a.ld; t += 256 * 8) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q >= 0) v = *reinterpret_cast<const uint4*>(a.Q16 + q * a.ld + t);
+            *reinterpret_cast<uint4*>(Qs + i * qstride + t * 2) = v;
+        }
+    }
+    if (tid < 16) {
+        int64_t off = 0;
+        if (tid < np) {
+            if (a.flat_mode) off = (16 * (int64_t)g + tid) * a.tstride;
+            else {
+                int pidx = a.pairs_sorted[pair0 + tid];
+                int64_t q = pidx / a.nprobe; int j = pidx % a.nprobe;
+                off = q * a.tstride + a.seg_start[q * (a.nprobe + 1) + j];
+            }
+        }
+        segoff[tid] = off;
+    }
+    __syncthreads();
+
+    // this wave's blocks: rows c0 + 16 w + 64 i, i < nb
+    const int64_t r0 = c0 + 16 * w;
+    const int nb = r0 < c1 ? (int)((c1 - r0 + 63) >> 6) : 0;
+    if (nb == 0) return;
+    const int KT = a.ld >> 6;
+    const int T = nb * KT;
+    // DMA source: uniform block base + per-lane offset.  Piece j (0/1) = rows 8j..8j+7 of the block, one 128-B line each.
+    const char* xb = reinterpret_cast<const char*>(reinterpret_cast<const __half*>(a.X) + (base + r0) * a.ld);
+    uint32_t off0, off1;
+    {
+        const int r8 = lane >> 3, p = lane & 7;
+        const int R0 = r8, R1 = 8 + r8;
+        off0 = (uint32_t)R0 * (uint32_t)(a.ld * 2) + ((p ^ ((R0 >> 1) & 7)) << 4);
+        off1 = (uint32_t)R1 * (uint32_t)(a.ld * 2) + ((p ^ ((R1 >> 1) & 7)) << 4);
+    }
+    const int64_t blk_bytes = (int64_t)64 * a.ld * 2;       // the wave's next block is 64 rows further
+    int i_kt = 0, i_slot = 0; int64_t i_boff = 0; int i_left = T;   // issue position
+    auto issue = [&]() {
+        const char* gsrc = xb + i_boff + (int64_t)i_kt * 128;
+        unsigned char* dst = ring + i_slot * 2048;
+        fg2_dma16(gsrc + off0, dst);
+        fg2_dma16(gsrc + off1, dst + 1024);
+        // branch-free advance; past the last step the last (valid) piece is fetched again into a slot nobody reads
+        const bool adv = i_left > 1;
+        i_left -= adv ? 1 : 0;
+        i_kt += adv ? 1 : 0;
+        const bool wrap = i_kt == KT;
+        i_kt = wrap ? 0 : i_kt;
+        i_boff += wrap ? blk_bytes : 0;
+        i_slot = (i_slot + 1 == LS2_D) ? 0 : i_slot + 1;
+    };
+#pragma unroll
+    for (int d = 0; d < LS2_D - 1; d++) issue();
+
+    const int lr = lane & 15, kg = lane >> 4;
+    const int swz = (lr >> 1) & 7;
+    const int boff0 = lr * 128 + (((0 + kg) ^ swz) << 4), boff1 = lr * 128 + (((4 + kg) ^ swz) << 4);
+    const unsigned char* qa_base = Qs + lr * qstride + (8 * kg) * 2;
+    floatx4 acc[LS2_NB];
+#pragma unroll
+    for (int i = 0; i < LS2_NB; i++) acc[i] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    int slot = 0;
+#pragma unroll
+    for (int i = 0; i < LS2_NB; i++) {
+        if (i < nb) {
+            for (int kt = 0; kt < KT; kt++) {
+                issue();
+                // all but the newest LS2_D - 1 stages (2 pieces each) have landed -> this stage is in LDS
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                static_assert(2 * (LS2_D - 1) == 10, "the vmcnt literal above");
+                const unsigned char* bs = ring + slot * 2048;
+                half8 x0 = *reinterpret_cast<const half8*>(bs + boff0);
+                half8 x1 = *reinterpret_cast<const half8*>(bs + boff1);
+                half8 q0 = *reinterpret_cast<const half8*>(qa_base + (kt * 64) * 2);
+                half8 q1 = *reinterpret_cast<const half8*>(qa_base + (kt * 64 + 32) * 2);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0, x0, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q1, x1, acc[i], 0, 0, 0);
+                slot = (slot + 1 == LS2_D) ? 0 : slot + 1;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail pieces before any store
+    // C/D layout of 16x16 MFMA: reg r of lane l holds (row i = 4*(l>>4) + r, col j = l&15): i = query, j = db row
+#pragma unroll
+    for (int i = 0; i < LS2_NB; i++) {
+        if (i < nb) {
+            const int64_t rloc = r0 + 64 * i + lr;
+            const float bv = (a.bias && rloc < len) ? a.bias[base + rloc] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int qi = kg * 4 + r;
+                if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[i][r] + bv : -__builtin_inff();
+            }
+        }
+    }
+}
+
+// rows per work item k_list_scan2 is built for (0: it does not apply to this storage)
+int list_scan2_chunk_rows(int x_f16, int ld) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("RSX_LIST_SCAN_V1"); off = (e && atoi(e)) ? 1 : 0; }
+    return (!off && x_f16 && ld % 64 == 0) ? 64 * LS2_NB : 0;
+}
+
 void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     if (a.max_groups <= 0 || a.max_chunks <= 0) return;
     dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
+    if (a.chunk_rows == list_scan2_chunk_rows(a.x_f16, a.ld)) {
+        size_t shm2 = (size_t)16 * (a.ld + 8) * 2 + 128 + 4 * LS2_D * 2048;
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute((const void*)k_list_scan2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(k_list_scan2, grid, dim3(256), shm2, st, a);
+        return;
+    }
     size_t shm = (size_t)16 * (a.ld + 8) * 2 + 16 * sizeof(int64_t);
     if (a.x_f16) {
         if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_list_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

@@ -961,6 +961,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int64_t chunk_rows = h->scan_chunk > 0 ? round_up(h->scan_chunk, 64) : 2048;
         int64_t want = 2048;  // work items
         while (chunk_rows > 256 && (int64_t)a.max_groups * ((maxlen + chunk_rows - 1) / chunk_rows) < want) chunk_rows /= 2;
+        if (h->scan_chunk <= 0 && list_scan2_chunk_rows(h->storage_f16, ld) > 0) chunk_rows = list_scan2_chunk_rows(h->storage_f16, ld);
         a.chunk_rows = (int)chunk_rows;
         a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
         launch_list_scan(a, h->st);

@@ -109,6 +109,7 @@ struct ListScanArgs {
     int chunk_rows;                         // rows per work item (multiple of 64)
     int max_groups; int max_chunks;
 };
+int list_scan2_chunk_rows(int x_f16, int ld);   // work-item rows of the LDS-DMA list scan, 0 if it does not apply
 void launch_list_scan(const ListScanArgs& a, hipStream_t st);
 
 // k_pq.hip
