@@ -718,14 +718,17 @@ __global__ __launch_bounds__(256) void k_list_scan(ListScanArgs a) {
 #define LS2_D 6
 #define LS2_NB 8            // 16-row blocks per wave per chunk -> chunk_rows = 4 waves x 16 x 8 = 512
 
+template <bool FILTER>
 __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
     const int qstride = (a.ld + 8) * 2;
     unsigned char* Qs = ls_smem;
-    int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + 16 * qstride);
+    int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + 16 * qstride);   // [16] score-buffer offset | (FILTER) row column
+    int64_t* sq = segoff + 16;                                              // [16] query            (FILTER)
+    uint64_t* stau = reinterpret_cast<uint64_t*>(sq + 16);                  // [16] threshold key    (FILTER)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* ring = ls_smem + 16 * qstride + 128 + w * (LS2_D * 2048);
+    unsigned char* ring = ls_smem + 16 * qstride + 384 + w * (LS2_D * 2048);
     const int g = blockIdx.x;
     const int chunk = blockIdx.y;
 
@@ -776,6 +779,15 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
             }
         }
         segoff[tid] = off;
+        if (FILTER) {
+            int64_t q = 0; uint64_t t = ~0ull;      // padding slot: nothing passes
+            if (tid < np) {
+                q = a.flat_mode ? 16 * (int64_t)g + tid : a.pairs_sorted[pair0 + tid] / a.nprobe;
+                t = a.tau_key[q * a.tau_stride];
+                segoff[tid] = off - q * a.tstride;  // the column inside the query's row = the candidate's index
+            }
+            sq[tid] = q; stau[tid] = t;
+        }
     }
     __syncthreads();
 
@@ -850,7 +862,24 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int qi = kg * 4 + r;
-                if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[i][r] + bv : -__builtin_inff();
+                if (!FILTER) {
+                    if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[i][r] + bv : -__builtin_inff();
+                } else {
+                    // lanes 16 kg .. 16 kg + 15 hold query qi's scores of the block's 16 rows
+                    const uint64_t key = (rloc < len && qi < np) ? make_key(acc[i][r] + bv, (uint32_t)(segoff[qi] + rloc)) : 0ull;
+                    const bool pass = key > stau[qi];
+                    const uint64_t mask = __ballot(pass);
+                    const uint64_t mine = (mask >> (16 * kg)) & 0xffffull;
+                    if (mine) {   // one atomic per query per block
+                        const int64_t q = sq[qi];
+                        unsigned long long slot0 = 0;
+                        const int leader = (__ffsll((unsigned long long)mine) - 1) + 16 * kg;
+                        if (lane == leader) slot0 = atomicAdd(&a.cand_cnt[q], (unsigned long long)__popcll(mine));
+                        slot0 = __shfl(slot0, leader);
+                        const unsigned long long slot = slot0 + __popcll(mine & ((1ull << lr) - 1ull));
+                        if (pass && slot < (unsigned long long)a.cand_cap) a.cand[q * a.cand_cap + slot] = key;
+                    }
+                }
             }
         }
     }
@@ -867,10 +896,15 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     if (a.max_groups <= 0 || a.max_chunks <= 0) return;
     dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
     if (a.chunk_rows == list_scan2_chunk_rows(a.x_f16, a.ld)) {
-        size_t shm2 = (size_t)16 * (a.ld + 8) * 2 + 128 + 4 * LS2_D * 2048;
+        size_t shm2 = (size_t)16 * (a.ld + 8) * 2 + 384 + 4 * LS2_D * 2048;
         static bool attr = false;
-        if (!attr) { hipFuncSetAttribute((const void*)k_list_scan2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL(k_list_scan2, grid, dim3(256), shm2, st, a);
+        if (!attr) {
+            hipFuncSetAttribute((const void*)k_list_scan2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)k_list_scan2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        if (a.tau_key) hipLaunchKernelGGL(k_list_scan2<true>, grid, dim3(256), shm2, st, a);
+        else hipLaunchKernelGGL(k_list_scan2<false>, grid, dim3(256), shm2, st, a);
         return;
     }
     size_t shm = (size_t)16 * (a.ld + 8) * 2 + 16 * sizeof(int64_t);

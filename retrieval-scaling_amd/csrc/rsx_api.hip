@@ -149,6 +149,7 @@ struct rsx_index {
     int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
     int pq_pre_rows = 2048;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int flat_filter = 1;  // Flat: one filtered GEMM launch after the first chunk (0 = score buffer per chunk)
+    int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
 
@@ -964,8 +965,47 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         if (h->scan_chunk <= 0 && list_scan2_chunk_rows(h->storage_f16, ld) > 0) chunk_rows = list_scan2_chunk_rows(h->storage_f16, ld);
         a.chunk_rows = (int)chunk_rows;
         a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
-        launch_list_scan(a, h->st);
-        tm.mark("scan");
+        // Same two-stage shape as the IVF-PQ fast path when the LDS-DMA kernel applies: score a prefix of every
+        // query's closest list, take its K'-th key as the query's threshold, then scan everything with the keys
+        // above it going to a small per-query candidate buffer instead of a full score row.  A full buffer
+        // (never seen at the bench sizes) falls back to the score-buffer path, so the result is always exact.
+        // (ivf_filter: 1 = when the score rows would exceed ~2 GB — below that the second grouping pass and the
+        //  count read-back cost more than the row traffic they save; 2 = always; 0 = never)
+        bool want_filter = h->ivf_filter != 0 && nprobe > 1 && chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld) &&
+                           (int64_t)KP * 4 <= chunk_rows && (h->ivf_filter > 1 || nq * tmax >= (int64_t)500000000);
+        if (want_filter) {
+            a.max_chunks = 1;                                      // the first chunk of ...
+            launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
+                               pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, 1, 0, h->st);   // ... the closest list only
+            launch_list_scan(a, h->st);
+            tm.mark("scan0");
+            select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
+                        std::min<int64_t>(maxlen, chunk_rows), 0, nq, KP, BUF, KP, state, false);
+            launch_keep_last_u64(state, nq, KP, h->st);           // the pre-pass is only a threshold (see the IVF-PQ path)
+            tm.mark("select0");
+            cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
+            h->w_cand.ensure((size_t)nq * cand_cap * 8);
+            h->w_candcnt.ensure((size_t)nq * 8);
+            HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8, h->st));
+            launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
+                               pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, 0, h->st);
+            tm.mark("group");
+            a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
+            a.tau_key = state + (KP - 1); a.tau_stride = KP;
+            a.cand = h->w_cand.as<uint64_t>(); a.cand_cnt = h->w_candcnt.as<unsigned long long>(); a.cand_cap = cand_cap;
+            launch_list_scan(a, h->st);
+            tm.mark("scan");
+            std::vector<unsigned long long> cnts((size_t)nq);
+            HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipStreamSynchronize(h->st));
+            filtered = true;
+            for (auto c : cnts) if (c > (unsigned long long)cand_cap) { filtered = false; break; }
+            a.tau_key = nullptr; a.cand = nullptr; a.cand_cnt = nullptr; a.cand_cap = 0;
+        }
+        if (!filtered) {
+            launch_list_scan(a, h->st);
+            tm.mark("scan");
+        }
     }
     // 3. per-query k-selection over the score rows
     if (filtered) {
@@ -1498,6 +1538,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_fast") h->pq_fast = (int)value;
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
         else if (s == "pq_filter") h->pq_filter = (int)value;
+        else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }

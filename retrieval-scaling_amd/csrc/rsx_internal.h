@@ -108,6 +108,9 @@ struct ListScanArgs {
     float* temp; int64_t tstride;
     int chunk_rows;                         // rows per work item (multiple of 64)
     int max_groups; int max_chunks;
+    // filtered output (k_list_scan2 only; tau_key != null): keys > tau_key[q * tau_stride] are appended to
+    // cand[q][0..cand_cap) (count in cand_cnt[q]) instead of storing every score
+    const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
 };
 int list_scan2_chunk_rows(int x_f16, int ld);   // work-item rows of the LDS-DMA list scan, 0 if it does not apply
 void launch_list_scan(const ListScanArgs& a, hipStream_t st);

@@ -38,6 +38,14 @@ def test_golden_ivfflat(gpu, orc):
     ix.nprobe = g["nprobe"]
     D, I = ix.search(q, g["k"])
     assert_same_results(D, I, g["D"], g["I"], "ivfflat golden")
+    ix.set_param("ivf_filter", 2)          # in-kernel candidate filtering (auto-enabled only for multi-GB score rows)
+    Du, Iu = ix.search(q, g["k"])
+    assert_same_results(Du, Iu, g["D"], g["I"], "ivfflat golden, filtered")
+    ix.set_param("ivf_filter", 0)
+    ix.set_param("scan_chunk", 256)        # ... and through the VGPR-staged kernel (k_list_scan)
+    Dv, Iv = ix.search(q, g["k"])
+    assert_same_results(Dv, Iv, g["D"], g["I"], "ivfflat golden, k_list_scan")
+    ix.set_param("scan_chunk", 0); ix.set_param("ivf_filter", 1)
     # nprobe = nlist must reproduce the exhaustive search (and hence the Flat index)
     ix.nprobe = g["nlist"]
     D, I = ix.search(q, g["k"])
@@ -181,6 +189,23 @@ def test_ivfflat_skewed_lists_and_l2(gpu, orc):
             Dr, Ir = orc.ivfflat_search(metric, cen, lm, q, nprobe, 10)
             assert np.array_equal(I, Ir), f"metric={metric} nprobe={nprobe}"
             assert np.allclose(D, Dr, rtol=0, atol=max(1e-30, np.abs(Dr[np.isfinite(Dr)]).max() * 2 ** -22))
+    # the same shape with fp16 rows: LDS-DMA list scan (k_list_scan2), plain and with in-kernel candidate filtering
+    x16 = x.astype(np.float16); x16f = x16.astype(np.float32)
+    a16, _ = orc.assign_ip(cen, x16f)
+    lm16 = orc.ListMajor(a16, np.arange(n), x16f, nlist)
+    for metric in (0, 1):
+        ix = gpu.IndexIVFFlat(None, d, nlist, metric)
+        ix.set_centroids(cen)
+        ix.add(x16)
+        assert ix.storage_dtype == "float16"
+        for filt in (0, 2):
+            ix.set_param("ivf_filter", filt)
+            for nprobe in (2, nlist):
+                ix.nprobe = nprobe
+                D, I = ix.search(q, 10)
+                Dr, Ir = orc.ivfflat_search(metric, cen, lm16, q, nprobe, 10)
+                assert np.array_equal(I, Ir), f"fp16 rows metric={metric} nprobe={nprobe} filter={filt}"
+                assert np.allclose(D, Dr, rtol=0, atol=max(1e-30, np.abs(Dr[np.isfinite(Dr)]).max() * 2 ** -22))
 
 
 def test_train_matches_oracle(gpu, orc):
