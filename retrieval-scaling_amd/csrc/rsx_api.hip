@@ -704,6 +704,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             a.flat_mode = 1; a.flat_n = N; a.nq = (int)nq; a.nprobe = 1; a.nlist = 1;
             a.temp = h->w_temp.as<float>(); a.tstride = tstride;
             a.chunk_rows = 1024;
+            if (list_scan2_chunk_rows(h->storage_f16, ld) > 0 && round_up(N, 16) / list_scan2_chunk_rows(h->storage_f16, ld) < 65535)
+                a.chunk_rows = list_scan2_chunk_rows(h->storage_f16, ld);     // LDS-DMA streaming kernel
             a.max_groups = (int)((nq + 15) / 16);
             a.max_chunks = (int)((round_up(N, 16) + a.chunk_rows - 1) / a.chunk_rows);
             if (a.max_chunks > 65535) { a.chunk_rows = (int)round_up((round_up(N, 16) + 65534) / 65535, 64); a.max_chunks = (int)((round_up(N, 16) + a.chunk_rows - 1) / a.chunk_rows); }

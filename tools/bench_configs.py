@@ -81,6 +81,18 @@ def main():
         res["roofline"] = {"bound": "hbm", "achieved": round(by / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(by / (scan_ms * 1e-3) / 8e12, 4), "algorithmic_bytes_per_batch": by,
                            "note": "algorithmic = sum over (query, probed list) of len*d*2 B; list-major grouping reads a list once per group of <=16 queries"}
+    if a.which == "flat":
+        # small batches stream the database once through the list-scan kernel (HBM-bound): 16 queries per pass
+        small = {}
+        for b in (1, 16):
+            ix.search(Q[:b], k)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for s in range(5):
+                ix.search(Q[s * b:(s + 1) * b], k)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 5 * 1e3
+            small[f"batch{b}"] = {"ms": round(ms, 3), "db_GBps": round(n * D * 2 / (ms * 1e-3) / 1e9, 1)}
+        res["small_batch"] = small
     # parity spot check against the oracle (exact arithmetic) on a few queries of the last batch
     if a.check:
         qs = Q[a.steps * nq:a.steps * nq + a.check].cpu().numpy().astype(np.float32)
