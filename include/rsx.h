@@ -140,6 +140,17 @@ int rsx_search(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, floa
 int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
                    float* D_out, int64_t* I_out, int device);
 
+/* The same merge for the in-node multi-GPU exchange (replaces the HTTP fan-in of api/serve_main_node.py:281-323):
+ * rsx_pack_topk turns one rank's (D, I) [nq, k] into its packed [2, nq, k] int64 block (plane 0 = the score's
+ * bits in the low word, plane 1 = ids + id_offset, padding ids < 0 kept) — ONE buffer per rank, so ONE
+ * all-gather; rsx_merge_packed merges the gathered [nshards, 2, nq, k] buffer with rsx_merge_topk's rule.
+ * Device pointers; both calls run on `stream` (a hipStream_t, NULL = the default stream) and do NOT
+ * synchronise, so they can sit between the search and the collective on the caller's stream. */
+int rsx_pack_topk(int64_t nq, int k, const float* D, const int64_t* I, int64_t id_offset, int64_t* packed,
+                  int device, void* stream);
+int rsx_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed, float* D_out,
+                     int64_t* I_out, int device, void* stream);
+
 /* ---- introspection / knobs --------------------------------------------------------- */
 
 /* Integer properties: "ntotal", "nlist", "d", "is_trained", "nprobe", "M", "nbits", "kind",

@@ -429,8 +429,12 @@ void launch_finalize(const FinalizeArgs& a, hipStream_t st) {
 // Multi-shard merge (src/search.py:362-367): concatenate the shards' top-k in shard order and
 // stable-sort by score; ties keep the earlier shard, then the within-shard order.
 // ---------------------------------------------------------------------------------------
+// Inputs are addressed as D32[sh * d_sstride + (q * k + j) * d_estride] (32-bit words) and
+// I[sh * i_sstride + q * k + j]: plain [nshards, nq, k] arrays, or the packed [nshards, 2, nq, k] int64
+// buffer an all-gather of rsx_pack_topk outputs produces (score bits in the low word).
 __global__ __launch_bounds__(64) void k_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D,
-                                                   const int64_t* I, float* Do, int64_t* Io, int NP) {
+                                                   int64_t d_sstride, int d_estride, const int64_t* I, int64_t i_sstride,
+                                                   float* Do, int64_t* Io, int NP) {
     extern __shared__ __attribute__((aligned(16))) uint64_t mg_buf[];
     const int lane = threadIdx.x;
     const int64_t q = blockIdx.x;
@@ -439,9 +443,9 @@ __global__ __launch_bounds__(64) void k_merge_topk(int nshards, int64_t nq, int 
         uint64_t key = 0;
         if (p < n) {
             int sh = p / k, j = p % k;
-            int64_t src = ((int64_t)sh * nq + q) * k + j;
-            if (I[src] >= 0) {
-                float s = D[src];
+            const int64_t e = q * k + j;
+            if (I[sh * i_sstride + e] >= 0) {
+                float s = D[sh * d_sstride + e * d_estride];
                 s = (metric == 0 ? s : 0.0f - s) + 0.0f;
                 if (s == s) key = ((uint64_t)f2ord(s) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)p);
             }
@@ -455,9 +459,9 @@ __global__ __launch_bounds__(64) void k_merge_topk(int nshards, int64_t nq, int 
         if (key) {
             int p = (int)key_idx(key);
             int sh = p / k, jj = p % k;
-            int64_t src = ((int64_t)sh * nq + q) * k + jj;
-            Do[q * k + j] = D[src];
-            Io[q * k + j] = I[src];
+            const int64_t e = q * k + jj;
+            Do[q * k + j] = D[sh * d_sstride + e * d_estride];
+            Io[q * k + j] = I[sh * i_sstride + e];
         } else {
             Do[q * k + j] = metric == 0 ? -__builtin_inff() : __builtin_inff();
             Io[q * k + j] = -1;
@@ -465,14 +469,38 @@ __global__ __launch_bounds__(64) void k_merge_topk(int nshards, int64_t nq, int 
     }
 }
 
-void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do,
-                       int64_t* Io, hipStream_t st) {
+static void launch_merge_strided(int nshards, int64_t nq, int k, int metric, const float* D, int64_t d_sstride, int d_estride,
+                                 const int64_t* I, int64_t i_sstride, float* Do, int64_t* Io, hipStream_t st) {
     if (nq <= 0) return;
     int NP = 64;
     while (NP < nshards * k) NP <<= 1;
     size_t shm = (size_t)NP * 8;
     if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)nq), dim3(64), shm, st, nshards, nq, k, metric, D, I, Do, Io, NP);
+    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)nq), dim3(64), shm, st, nshards, nq, k, metric, D, d_sstride, d_estride, I,
+                       i_sstride, Do, Io, NP);
+}
+void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do,
+                       int64_t* Io, hipStream_t st) {
+    launch_merge_strided(nshards, nq, k, metric, D, nq * k, 1, I, nq * k, Do, Io, st);
+}
+// packed: [nshards, 2, nq, k] int64 — plane 0 = score bits (low word), plane 1 = ids
+void launch_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed, float* Do, int64_t* Io,
+                         hipStream_t st) {
+    launch_merge_strided(nshards, nq, k, metric, reinterpret_cast<const float*>(packed), 4 * nq * k, 2, packed + nq * k,
+                         2 * nq * k, Do, Io, st);
+}
+
+// one rank's (D, I) -> the packed [2, nq, k] int64 block it contributes to the all-gather; ids get the shard's offset
+__global__ void k_pack_topk(int64_t n, const float* D, const int64_t* I, int64_t id_offset, int64_t* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (int64_t)(uint64_t)__float_as_uint(D[i]);
+    const int64_t id = I[i];
+    out[n + i] = id >= 0 ? id + id_offset : id;
+}
+void launch_pack_topk(int64_t n, const float* D, const int64_t* I, int64_t id_offset, int64_t* out, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pack_topk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, D, I, id_offset, out);
 }
 
 }  // namespace rsx

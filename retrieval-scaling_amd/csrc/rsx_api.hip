@@ -1509,6 +1509,31 @@ int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, c
     });
 }
 
+int rsx_pack_topk(int64_t nq, int k, const float* D, const int64_t* I, int64_t id_offset, int64_t* packed, int device,
+                  void* stream) {
+    return guarded([&] {
+        if (nq < 0 || k <= 0 || !D || !I || !packed) RSX_THROW(RSX_ERR_INVALID, "pack_topk: bad arguments");
+        if (nq == 0) return;
+        if (!is_device_ptr(D) || !is_device_ptr(I) || !is_device_ptr(packed)) RSX_THROW(RSX_ERR_INVALID, "pack_topk: device pointers only");
+        HIPCHECK(hipSetDevice(device));
+        launch_pack_topk(nq * k, D, I, id_offset, packed, (hipStream_t)stream);
+        HIPCHECK(hipGetLastError());
+    });
+}
+
+int rsx_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed, float* Do, int64_t* Io, int device,
+                     void* stream) {
+    return guarded([&] {
+        if (nshards <= 0 || nq < 0 || k <= 0 || !packed || !Do || !Io) RSX_THROW(RSX_ERR_INVALID, "merge_packed: bad arguments");
+        if ((int64_t)nshards * k > 16384) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_packed: nshards*k = %lld exceeds 16384", (long long)nshards * k);
+        if (nq == 0) return;
+        if (!is_device_ptr(packed) || !is_device_ptr(Do) || !is_device_ptr(Io)) RSX_THROW(RSX_ERR_INVALID, "merge_packed: device pointers only");
+        HIPCHECK(hipSetDevice(device));
+        launch_merge_packed(nshards, nq, k, metric, packed, Do, Io, (hipStream_t)stream);
+        HIPCHECK(hipGetLastError());
+    });
+}
+
 int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
     return guarded([&] {
         if (!h || !key || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");

@@ -198,5 +198,8 @@ struct FinalizeArgs {
 void launch_finalize(const FinalizeArgs& a, hipStream_t st);
 void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
                        float* Do, int64_t* Io, hipStream_t st);
+void launch_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed /* [nshards,2,nq,k] */, float* Do,
+                         int64_t* Io, hipStream_t st);
+void launch_pack_topk(int64_t n, const float* D, const int64_t* I, int64_t id_offset, int64_t* out /* [2,n] */, hipStream_t st);
 
 }  // namespace rsx

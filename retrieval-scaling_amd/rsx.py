@@ -39,7 +39,8 @@ ABI_SYMBOLS = [
     "rsx_last_error", "rsx_version", "rsx_device_count", "rsx_flat_create", "rsx_ivfflat_create",
     "rsx_ivfpq_create", "rsx_destroy", "rsx_train", "rsx_set_centroids", "rsx_set_codebooks",
     "rsx_get_centroids", "rsx_get_codebooks", "rsx_add", "rsx_assign", "rsx_reset", "rsx_reserve_lists", "rsx_add_list",
-    "rsx_get_list", "rsx_set_nprobe", "rsx_search", "rsx_merge_topk", "rsx_get", "rsx_set_param",
+    "rsx_get_list", "rsx_set_nprobe", "rsx_search", "rsx_merge_topk", "rsx_pack_topk", "rsx_merge_packed", "rsx_get",
+    "rsx_set_param",
     "rsx_get_timing", "rsx_save", "rsx_load", "rsx_synth_vectors", "rsx_synth_queries",
 ]
 
@@ -392,6 +393,33 @@ def merge_topk(D, I, metric=METRIC_INNER_PRODUCT, device=None):
     _check(lib().rsx_merge_topk(ns, ctypes.c_int64(nq), k, int(metric), D.ctypes.data_as(ctypes.c_void_p),
                                 I.ctypes.data_as(ctypes.c_void_p), Do.ctypes.data_as(ctypes.c_void_p),
                                 Io.ctypes.data_as(ctypes.c_void_p), dev))
+    return Do, Io
+
+
+def pack_topk(D, I, id_offset=0):
+    """One rank's CUDA (D, I) [nq, k] -> packed [2, nq, k] int64 (score bits | ids + id_offset) on torch's current stream."""
+    import torch
+    D = D.contiguous().float(); I = I.contiguous().to(torch.int64)
+    nq, k = D.shape
+    out = torch.empty((2, nq, k), dtype=torch.int64, device=D.device)
+    _check(lib().rsx_pack_topk(ctypes.c_int64(nq), k, ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                               ctypes.c_int64(int(id_offset)), ctypes.c_void_p(out.data_ptr()), D.device.index or 0,
+                               ctypes.c_void_p(torch.cuda.current_stream(D.device).cuda_stream)))
+    return out
+
+
+def merge_packed(gathered, metric=METRIC_INNER_PRODUCT):
+    """gathered: CUDA int64 [nshards, 2, nq, k] (an all-gather of pack_topk blocks) -> merged (D, I) [nq, k], same rule as
+    merge_topk; runs on torch's current stream without a host synchronisation."""
+    import torch
+    gathered = gathered.contiguous()
+    ns, two, nq, k = gathered.shape
+    assert two == 2 and gathered.dtype == torch.int64 and gathered.is_cuda
+    Do = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
+    Io = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
+    _check(lib().rsx_merge_packed(ns, ctypes.c_int64(nq), k, int(metric), ctypes.c_void_p(gathered.data_ptr()),
+                                  ctypes.c_void_p(Do.data_ptr()), ctypes.c_void_p(Io.data_ptr()), gathered.device.index or 0,
+                                  ctypes.c_void_p(torch.cuda.current_stream(gathered.device).cuda_stream)))
     return Do, Io
 
 

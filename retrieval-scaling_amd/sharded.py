@@ -61,11 +61,20 @@ class ShardedSearcher:
         as_numpy = not torch.is_tensor(D)
         if as_numpy:
             D, I = torch.from_numpy(np.ascontiguousarray(D)), torch.from_numpy(np.ascontiguousarray(I))
+        if D.is_cuda and not as_numpy and (self.world_size > 1 or self.force_collective):
+            # GPU results: one pack kernel (adds the shard's id offset), one collective, one merge kernel,
+            # all on the current stream
+            import rsx
+            nq = D.shape[0]
+            packed = rsx.pack_topk(D, I, self.id_offset)
+            gathered = torch.empty((self.world_size, 2, nq, k), dtype=torch.int64, device=D.device)
+            dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+            return rsx.merge_packed(gathered, metric=self.metric)
         I = torch.where(I >= 0, I + self.id_offset, I)
         if self.world_size == 1 and not self.force_collective:
             return (D.numpy(), I.numpy()) if as_numpy else (D, I)
         nq = D.shape[0]
-        # one packed buffer -> one collective: [2, nq, k] int64 (scores as raw bits in the low word)
+        # host results (or a gloo group): the same exchange with torch ops — one packed buffer -> one collective: [2, nq, k] int64 (scores as raw bits in the low word)
         backend = dist.get_backend(self.group)
         dev = D.device
         if backend == "nccl" and not D.is_cuda:

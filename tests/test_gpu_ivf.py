@@ -272,6 +272,15 @@ def test_merge_kernel_matches_reference_rule(gpu, orc):
     import torch
     Dt, It = gpu.merge_topk(torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda())
     assert np.array_equal(It.cpu().numpy(), Ir) and np.array_equal(Dt.cpu().numpy(), Dr)
+    # the multi-GPU exchange form: per-shard pack (adds the shard's id offset, keeps -1 padding) -> [ns, 2, nq, k] -> merge
+    D[2, :, 0] = -3.5                                       # a negative score: its sign bit must survive the packing
+    D[2] = np.sort(D[2], axis=1)[:, ::-1]
+    offs = [7 * s for s in range(8)]
+    packed = torch.stack([gpu.pack_topk(torch.from_numpy(D[s]).cuda(), torch.from_numpy(I[s]).cuda(), offs[s]) for s in range(8)])
+    Dp, Ip = gpu.merge_packed(packed)
+    Ioff = np.stack([np.where(I[s] >= 0, I[s] + offs[s], I[s]) for s in range(8)])
+    Dr2, Ir2 = orc.merge_topk(D, Ioff, 0)
+    assert np.array_equal(Ip.cpu().numpy(), Ir2) and np.array_equal(Dp.cpu().numpy(), Dr2)
 
 
 def test_sharded_searcher_over_rccl_single_rank(gpu, orc):
