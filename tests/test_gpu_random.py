@@ -1,0 +1,84 @@
+"""Randomised parity sweep: many small (shape, nprobe, k, batch) draws per index type against the oracle.
+Sizes are chosen to cross the engine's internal switches: pre-pass prefix shorter/longer than the closest
+list, K' above/below the filter guards, one-query batches, empty lists, k > candidates (padding)."""
+import numpy as np
+import pytest
+
+from util import assert_same_results
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(orc, rng, d, n, nq, ncent):
+    x = orc.synth_vectors(d, ncent, int(rng.randint(1, 1 << 20)), int(rng.randint(1, 1 << 20)), 0.5, 0, n)
+    q = orc.synth_queries(d, ncent, 11, 12, 0.5, n, int(rng.randint(1, 1 << 20)), 0.1, 0, nq)
+    return x, q
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_ivfpq(gpu, orc, seed):
+    rng = np.random.RandomState(100 + seed)
+    d, M = [(768, 96), (96, 96), (128, 16), (64, 32)][seed]
+    nlist = int(rng.choice([3, 8, 32]))
+    n = int(rng.choice([700, 5000, 16000]))
+    nq = int(rng.choice([1, 5, 70]))
+    x, q = _data(orc, rng, d, n, nq, nlist)
+    x32 = x.astype(np.float32)
+    cen = orc.kmeans(0, x32, nlist, 2, 7)
+    a, _ = orc.assign_ip(cen, x32)
+    res = orc.residuals(cen, x32, a)
+    cb = orc.pq_train(res[:2000], M, 1, 7)
+    lm = orc.ListMajor(a, np.arange(n), orc.pq_encode(cb, res), nlist)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    ix.set_centroids(cen); ix.set_codebooks(cb)
+    for c0 in range(0, n, 7001):                      # several add calls: list growth / re-layout
+        ix.add(x[c0:c0 + 7001])
+    for nprobe, k in [(1, 1), (2, 10), (nlist, 10), (max(2, nlist // 2), 300), (nlist, 2048)]:
+        ix.nprobe = nprobe
+        D, I = ix.search(q, k)
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q.astype(np.float32), nprobe, k)
+        assert_same_results(D, I, Dr, Ir, f"ivfpq seed={seed} d={d} M={M} nlist={nlist} n={n} nq={nq} nprobe={nprobe} k={k}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_ivfflat(gpu, orc, seed):
+    rng = np.random.RandomState(200 + seed)
+    d = int(rng.choice([64, 128, 768, 100]))          # 100: row stride padded to 128
+    nlist = int(rng.choice([2, 8, 16]))
+    n = int(rng.choice([600, 4000, 20000]))
+    nq = int(rng.choice([1, 17, 90]))
+    metric = seed % 2
+    x, q = _data(orc, rng, d, n, nq, nlist)
+    x32 = x.astype(np.float32)
+    cen = orc.kmeans(0, x32, nlist, 3, 7)
+    a, _ = orc.assign_ip(cen, x32)
+    lm = orc.ListMajor(a, np.arange(n), x32, nlist)
+    ix = gpu.IndexIVFFlat(None, d, nlist, metric)
+    ix.set_centroids(cen)
+    ix.add(x)
+    for filt in (1, 2):
+        ix.set_param("ivf_filter", filt)
+        for nprobe, k in [(1, 1), (2, 10), (nlist, 100), (nlist, 1000)]:
+            ix.nprobe = nprobe
+            D, I = ix.search(q, k)
+            Dr, Ir = orc.ivfflat_search(metric, cen, lm, q.astype(np.float32), nprobe, k)
+            what = f"ivfflat seed={seed} d={d} nlist={nlist} n={n} nq={nq} metric={metric} nprobe={nprobe} k={k} filter={filt}"
+            assert np.array_equal(I, Ir), what
+            fin = np.isfinite(Dr)
+            assert np.array_equal(np.isfinite(D), fin) and np.allclose(D[fin], Dr[fin], rtol=0, atol=max(1e-30, np.abs(Dr[fin]).max() * 2 ** -22)), what
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_flat(gpu, orc, seed):
+    rng = np.random.RandomState(300 + seed)
+    d = int(rng.choice([64, 768, 200]))
+    n = int(rng.choice([50, 3000, 70000]))            # 70000 > 65536: the filtered single-launch GEMM path
+    nq = int(rng.choice([1, 40, 129, 300]))
+    metric = seed % 2
+    x, q = _data(orc, rng, d, n, nq, 9)
+    ix = gpu.IndexFlat(d, metric)
+    ix.add(x)
+    for k in (1, 10, 200):
+        D, I = ix.search(q, k)
+        Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), k, metric)
+        assert_same_results(D, I, Dr, Ir, f"flat seed={seed} d={d} n={n} nq={nq} metric={metric} k={k}")
