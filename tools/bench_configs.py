@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--nlist", type=int, default=4096)
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--check", type=int, default=4, help="queries verified against the CPU oracle")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="latency: engine parameter A/B")
     a = ap.parse_args()
     import torch, rsx
     from oracle import oracle as orc
@@ -141,16 +142,30 @@ def latency(a):
         ix.add(buf[:nb])
     q = rsx.synth_queries(D, NC, SC, SX, 0.5, n, SQ, 0.1, 0, 30)   # numpy fp16 on the host
     res = {"config": f"single-query latency, {n}x{D} IVF-PQ M=96 nlist={a.nlist} nprobe={a.nprobe} k=10, host query/result"}
-    for name, k in (("k10", 10), ("k100", 100)):
-        ts = []
-        for i in range(30):
-            t0 = time.perf_counter(); ix.search(q[i:i + 1], k); ts.append(time.perf_counter() - t0)
-        res[f"mean_ms_{name}"] = round(float(np.mean(ts[10:])) * 1e3, 4)
-        res[f"min_ms_{name}"] = round(float(np.min(ts[10:])) * 1e3, 4)
-    ts = []
-    for i in range(30):
-        t0 = time.perf_counter(); ix.search(q[:16], 10); ts.append(time.perf_counter() - t0)
-    res["mean_ms_batch16_k10"] = round(float(np.mean(ts[10:])) * 1e3, 4)
+
+    def run(tag):
+        for name, k in (("k10", 10), ("k100", 100)):
+            ts = []
+            for i in range(30):
+                t0 = time.perf_counter(); ix.search(q[i:i + 1], k); ts.append(time.perf_counter() - t0)
+            res[f"mean_ms_{name}{tag}"] = round(float(np.mean(ts[10:])) * 1e3, 4)
+            res[f"min_ms_{name}{tag}"] = round(float(np.min(ts[10:])) * 1e3, 4)
+        for b in (16, 64):
+            ts = []
+            for i in range(30):
+                t0 = time.perf_counter(); ix.search(q[:b] if b <= 30 else np.concatenate([q, q, q])[:b], 10); ts.append(time.perf_counter() - t0)
+            res[f"mean_ms_batch{b}_k10{tag}"] = round(float(np.mean(ts[10:])) * 1e3, 4)
+
+    run("")
+    for kv in a.param:            # A/B of engine parameters, e.g. --param pq_filter=0
+        name, val = kv.split("=")
+        ix.set_param(name, int(val))
+    if a.param:
+        run("_" + ",".join(a.param))
+    ix.set_param("profile", 1)
+    ix.search(q[:1], 10)
+    res["stage_ms_single_query"] = {s: round(ix.get_timing(s), 4) for s in
+                                    ("convert", "coarse", "select_probe", "lut8", "group", "scan0", "select0", "scan", "select", "finalize", "total")}
     print(json.dumps(res), flush=True)
 
 

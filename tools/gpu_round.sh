@@ -27,6 +27,8 @@ for s in $STAGES; do
       timeout 900 python tools/bench_configs.py ivfflat > gpurun_out/cfg_ivfflat.json 2> gpurun_out/cfg_ivfflat.log; echo "exit $?" >> gpurun_out/cfg_ivfflat.log ;;
     ivfflat100m)
       timeout 1500 python tools/bench_configs.py ivfflat --n 100000000 > gpurun_out/cfg_ivfflat100m.json 2> gpurun_out/cfg_ivfflat100m.log; echo "exit $?" >> gpurun_out/cfg_ivfflat100m.log ;;
+    latency_ab)
+      timeout 900 python tools/bench_configs.py latency --param pq_filter=0 > gpurun_out/cfg_latency_ab.json 2> gpurun_out/cfg_latency_ab.log; echo "exit $?" >> gpurun_out/cfg_latency_ab.log ;;
     latency)
       timeout 900 python tools/bench_configs.py latency > gpurun_out/cfg_latency.json 2> gpurun_out/cfg_latency.log; echo "exit $?" >> gpurun_out/cfg_latency.log ;;
     pmc_sq)
