@@ -147,6 +147,7 @@ struct rsx_index {
     int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
     int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
     int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
+    int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_pre_rows = 2048;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int flat_filter = 1;  // Flat: one filtered GEMM launch after the first chunk (0 = score buffer per chunk)
     int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
@@ -154,7 +155,7 @@ struct rsx_index {
     int64_t temp_budget = (int64_t)16 << 30;
 
     // workspace
-    DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_state,
+    DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
         w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt;
     std::map<std::string, double> timing;
 
@@ -831,8 +832,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
             h->w_qparam.ensure((size_t)nq * 16);
             h->w_uncertain.ensure((size_t)nq * 4);
+            void* lut_ws = nullptr;
+            if (fused_lut && h->dsub == 8 && h->lut_tiled != 0) { h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad)); lut_ws = h->w_lutws.p; }
             launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
-                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->st);
+                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, h->st);
             tm.mark("lut8");
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             int vpl = 8;
@@ -1567,6 +1570,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_filter") h->pq_filter = (int)value;
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
+        else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;

@@ -138,7 +138,9 @@ int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int3
 size_t pq_lut8_fused_lds(int M, int Mpad, int dsub);
 void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
                     int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
-                    void* qparam /* [nq] {scale, bias, eps, pad} */, hipStream_t st);
+                    void* qparam /* [nq] {scale, bias, eps, pad} */,
+                    void* ws /* pq_lut8_tiled_ws(nq, Mpad) bytes -> tiled build (dsub 8), or null */, hipStream_t st);
+size_t pq_lut8_tiled_ws(int64_t nq, int Mpad);
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
                     const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                     const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
