@@ -452,9 +452,10 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
 }
 
 // Tiled form of the same table build for dsub = 8 (what k_pq_lut8f computes, bit for bit).  k_pq_lut8f reads the whole
-// 786 KB codebook per query through one CU's L2 path (~47 GB/s): 4 rounds of ~30 us.  Here a workgroup keeps the
-// codebook slice of LT_MB sub-quantisers (64 KiB) in LDS and serves LT_QC queries with it, so the codebook is read
-// 32x less often; the global maximum range a query's quantisation scale needs is taken between two passes:
+// 786 KB codebook per query through one CU's L2 path (~47 GB/s): 4 rounds of ~30 us.  Here a workgroup takes the
+// codebook slice of LT_MB sub-quantisers (each wave two of them, 4 codewords per lane in registers) and streams
+// LT_QC queries past it, so the codebook is read 32x less often; the global maximum range a query's quantisation
+// scale needs is taken between two passes:
 //   pass 0: per (query, m) min / max of the entries        -> mnmx [nq][Mpad][2]
 //   pass 1: entries again, quantised with the query's scale -> lut8, per (query, m) max error -> err [nq][Mpad]
 //   k_pq_qparam: per query, the sums over m in m order      -> {scale, bias, eps}
@@ -463,21 +464,13 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
 template <int PASS>
 __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq, const float* codebooks, int M, int Mpad,
                                                       int64_t nq, float* mnmx, float* errb, uint8_t* lut8) {
-    extern __shared__ __attribute__((aligned(16))) float lt_s[];
-    float* s_cb = lt_s;                          // [LT_MB][256][8]
-    float* s_q = s_cb + LT_MB * 2048;            // [LT_QC][LT_MB * 8]
-    float* s_scale = s_q + LT_QC * LT_MB * 8;    // [LT_QC] scale, [LT_QC] 1 / scale
-    float* s_mn = s_scale + 2 * LT_QC;           // [LT_QC][LT_MB]
+    __shared__ float s_q[LT_QC * LT_MB * 8];     // the tile's query slices
+    __shared__ float s_scale[2 * LT_QC];         // scale, 1 / scale
+    __shared__ float s_mn[LT_QC * LT_MB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.x * LT_MB;
     const int64_t q0 = (int64_t)blockIdx.y * LT_QC;
     const int nqc = (int)((nq - q0) < LT_QC ? (nq - q0) : LT_QC);
-    for (int i = tid; i < LT_MB * 512; i += 256) {
-        const int m = m0 + i / 512;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M) v = reinterpret_cast<const float4*>(codebooks)[(int64_t)m0 * 512 + i];
-        reinterpret_cast<float4*>(s_cb)[i] = v;
-    }
     for (int i = tid; i < LT_QC * LT_MB * 8; i += 256) {
         const int qi = i / (LT_MB * 8), t = i % (LT_MB * 8);
         const int m = m0 + t / 8;
@@ -497,66 +490,84 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
         }
     }
     __syncthreads();
-    // a wave owns whole (query, sub-quantiser) pairs: 4 codewords per lane, reductions by shuffles only
-    for (int p = w; p < nqc * LT_MB; p += 4) {
-        const int qi = p / LT_MB, mi = p % LT_MB;
+    // a wave owns sub-quantisers mi = w, w + 4 of the tile: its 4 codewords per lane stay in registers while the tile's
+    // queries stream past (query values are LDS broadcasts); reductions over the 256 codewords are shuffles only
+    for (int mi = w; mi < LT_MB; mi += 4) {
         const int m = m0 + mi;
-        if (m >= Mpad) continue;
-        const int64_t q = q0 + qi;
-        const float* qs = s_q + qi * (LT_MB * 8) + mi * 8;
-        float v[4];
+        if (m >= Mpad) break;
+        float4 cx[4], cy[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const float4* cw = reinterpret_cast<const float4*>(s_cb + (mi * 256 + lane + 64 * j) * 8);
-            const float4 x = cw[0], y = cw[1];
-            float t = 0.0f;
-            t = __fmaf_rn(qs[0], x.x, t); t = __fmaf_rn(qs[1], x.y, t); t = __fmaf_rn(qs[2], x.z, t); t = __fmaf_rn(qs[3], x.w, t);
-            t = __fmaf_rn(qs[4], y.x, t); t = __fmaf_rn(qs[5], y.y, t); t = __fmaf_rn(qs[6], y.z, t); t = __fmaf_rn(qs[7], y.w, t);
-            v[j] = t;
+            cx[j] = make_float4(0.f, 0.f, 0.f, 0.f); cy[j] = cx[j];
+            if (m < M) {
+                const float4* cw = reinterpret_cast<const float4*>(codebooks + ((int64_t)m * 256 + lane + 64 * j) * 8);
+                cx[j] = cw[0]; cy[j] = cw[1];
+            }
         }
-        if (PASS == 0) {
-            float mn = fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
-            if (lane == 0) { mnmx[(q * Mpad + m) * 2] = mn; mnmx[(q * Mpad + m) * 2 + 1] = mx; }
-        } else {
-            const float mn = s_mn[qi * LT_MB + mi], scale = s_scale[qi], inv = s_scale[LT_QC + qi];
-            float err = 0.0f;
-            uint8_t* o = lut8 + (q * Mpad + m) * 256 + lane;
+        for (int qi = 0; qi < nqc; qi++) {
+            const int64_t q = q0 + qi;
+            const float* qs = s_q + qi * (LT_MB * 8) + mi * 8;
+            const float q0_ = qs[0], q1_ = qs[1], q2_ = qs[2], q3_ = qs[3], q4_ = qs[4], q5_ = qs[5], q6_ = qs[6], q7_ = qs[7];
+            float v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                float u = rintf((v[j] - mn) * inv);
-                u = fminf(fmaxf(u, 0.0f), 255.0f);
-                o[64 * j] = (uint8_t)u;
-                err = fmaxf(err, fabsf(v[j] - (mn + scale * u)));
+                float t = 0.0f;
+                t = __fmaf_rn(q0_, cx[j].x, t); t = __fmaf_rn(q1_, cx[j].y, t); t = __fmaf_rn(q2_, cx[j].z, t); t = __fmaf_rn(q3_, cx[j].w, t);
+                t = __fmaf_rn(q4_, cy[j].x, t); t = __fmaf_rn(q5_, cy[j].y, t); t = __fmaf_rn(q6_, cy[j].z, t); t = __fmaf_rn(q7_, cy[j].w, t);
+                v[j] = t;
             }
+            if (PASS == 0) {
+                float mn = fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
-            if (lane == 0) errb[q * Mpad + m] = err;
+                for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+                if (lane == 0) { mnmx[(q * Mpad + m) * 2] = mn; mnmx[(q * Mpad + m) * 2 + 1] = mx; }
+            } else {
+                const float mn = s_mn[qi * LT_MB + mi], scale = s_scale[qi], inv = s_scale[LT_QC + qi];
+                float err = 0.0f;
+                uint8_t* o = lut8 + (q * Mpad + m) * 256 + lane;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float u = rintf((v[j] - mn) * inv);
+                    u = fminf(fmaxf(u, 0.0f), 255.0f);
+                    o[64 * j] = (uint8_t)u;
+                    err = fmaxf(err, fabsf(v[j] - (mn + scale * u)));
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
+                if (lane == 0) errb[q * Mpad + m] = err;
+            }
         }
     }
 }
 
-__global__ void k_pq_qparam(int64_t nq, int M, int Mpad, const float* mnmx, const float* errb, const float* probe_dis0,
-                            int nprobe, PQQParam* qp) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
+// one wave per query: the per-query sums over m (lanes over m, tree order — any fixed order is fine: scale, bias and
+// eps only have to be the values the scan and the certificate both use)
+__global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, const float* mnmx, const float* errb,
+                                                  const float* probe_dis0, int nprobe, PQQParam* qp) {
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
     const float* mm = mnmx + q * Mpad * 2;
-    float absmax_sum = 0.0f, maxrange = 0.0f, e_quant = 0.0f, bias = 0.0f;
-    for (int m = 0; m < Mpad; m++) {
+    float absmax_sum = 0.0f, maxrange = 0.0f, e_quant = 0.0f, bias = 0.0f, d0 = 0.0f;
+    for (int m = lane; m < Mpad; m += 64) {
         const float mn = mm[2 * m], mx = mm[2 * m + 1];
         absmax_sum += fmaxf(fabsf(mn), fabsf(mx));
         maxrange = fmaxf(maxrange, mx - mn);
         e_quant += errb[q * Mpad + m];
         bias += mn;
     }
-    const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
-    float d0 = 0.0f;
-    for (int j = 0; j < nprobe; j++) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
-    // fp32 slack: < 300 roundings of relative size 2^-24 on magnitudes bounded by B
-    const float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
-    PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 0.0f;
-    qp[q] = r;
+    for (int j = lane; j < nprobe; j += 64) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        absmax_sum += __shfl_xor(absmax_sum, off); e_quant += __shfl_xor(e_quant, off); bias += __shfl_xor(bias, off);
+        maxrange = fmaxf(maxrange, __shfl_xor(maxrange, off)); d0 = fmaxf(d0, __shfl_xor(d0, off));
+    }
+    if (lane == 0) {
+        const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
+        // fp32 slack: < 300 roundings of relative size 2^-24 on magnitudes bounded by B
+        const float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 0.0f;
+        qp[q] = r;
+    }
 }
 
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad) { return (size_t)nq * Mpad * 3 * 4; }   // mnmx + err
@@ -574,18 +585,11 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
     if (ws && dsub == 8) {   // tiled: codebook slices shared by 32 queries
         float* mnmx = reinterpret_cast<float*>(ws);
         float* errb = mnmx + (size_t)nq * Mpad * 2;
-        const size_t lds2 = (size_t)(LT_MB * 2048 + LT_QC * LT_MB * 8 + 2 * LT_QC + LT_QC * LT_MB) * 4;
-        static bool attr = false;
-        if (!attr) {
-            hipFuncSetAttribute((const void*)k_pq_lut_tiled<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            attr = true;
-        }
         dim3 grid((unsigned)((Mpad + LT_MB - 1) / LT_MB), (unsigned)((nq + LT_QC - 1) / LT_QC));
-        hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), lds2, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8);
-        hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), lds2, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8);
-        hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0,
-                           nprobe, (PQQParam*)qparam);
+        hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8);
+        hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8);
+        hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)nq), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0, nprobe,
+                           (PQQParam*)qparam);
         return;
     }
     const size_t lds = pq_lut8_fused_lds(M, Mpad, dsub);
