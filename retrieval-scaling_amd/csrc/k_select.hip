@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     if (start >= end && !a.init) {  // segment beyond the row's length: no candidates
         uint64_t* o = a.out + row * a.out_row_stride + (int64_t)seg * KP;
         for (int i = lane; i < KP; i += 64) o[i] = 0;
+        if (a.zero_cnt && lane == 0 && seg == 0) a.zero_cnt[row] = 0ull;
         return;
     }
 
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     __syncthreads();
     bitonic_sort_desc(buf, BUF, lane);
     uint64_t* o = a.out + row * a.out_row_stride + (int64_t)seg * KP;
-    for (int i = lane; i < KP; i += 64) o[i] = buf[i];
+    for (int i = lane; i < KP; i += 64) o[i] = (a.keep_last && i != KP - 1) ? 0ull : buf[i];
+    if (a.zero_cnt && lane == 0 && seg == 0) a.zero_cnt[row] = 0ull;
 }
 
 void launch_select(const SelectArgs& a, hipStream_t st) {

@@ -603,7 +603,7 @@ static void kp_for(const rsx_index* h, int k, bool fast, int& KP, int& BUF) {
 // top-k of `nrows` rows of fp32 scores (row r valid length: row_n or n_uniform) into state [nrows, KP]
 static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, const int64_t* row_n, int64_t row_n_stride,
                         int64_t n_max, uint32_t idx_base, int64_t nrows, int KP, int BUF, int k, uint64_t* state,
-                        bool merge_state) {
+                        bool merge_state, unsigned long long* threshold_only_cnt = nullptr) {
     int64_t seg_len = std::max<int64_t>(4096, (int64_t)8 * BUF);
     seg_len = round_up(seg_len, 256);
     int nseg = (int)std::max<int64_t>(1, (n_max + seg_len - 1) / seg_len);
@@ -615,6 +615,7 @@ static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, c
     if (nseg == 1) {
         a.init = merge_state ? state : nullptr;
         a.out = state; a.out_row_stride = KP;
+        if (threshold_only_cnt) { a.keep_last = 1; a.zero_cnt = threshold_only_cnt; }
         launch_select(a, h->st);
         return;
     }
@@ -639,6 +640,7 @@ static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, c
     b.init = merge_state ? state : nullptr;
     b.out = state; b.out_row_stride = KP;
     b.nrows = nrows; b.KP = KP; b.BUF = BUF; b.k = k;
+    if (threshold_only_cnt) { b.keep_last = 1; b.zero_cnt = threshold_only_cnt; }
     launch_select(b, h->st);
 }
 
@@ -880,17 +882,17 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             if (done && filtered) {
                 tm.mark("scan0");
                 // top-K' of the scored prefix of the closest list: row prefix [0, min(seg_start[q][1], pre_rows))
-                select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
-                            std::min<int64_t>(maxlen, pre_rows), 0, nq, KP, BUF, KP, state, false);
-                // The pre-pass is only a threshold: keep its K'-th key and let the main scan score EVERYTHING (the
-                // prefix included), so the scan kernel carries no per-slab "already scored" test and no key can
-                // arrive twice (the prefix keys above the threshold come back through the candidate buffer).
-                launch_keep_last_u64(state, nq, KP, h->st);
-                tm.mark("select0");
                 cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8);
-                HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8, h->st));
+                select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
+                            std::min<int64_t>(maxlen, pre_rows), 0, nq, KP, BUF, KP, state, false,
+                            h->w_candcnt.as<unsigned long long>());
+                // The pre-pass is only a threshold: keep its K'-th key and let the main scan score EVERYTHING (the
+                // prefix included), so the scan kernel carries no per-slab "already scored" test and no key can
+                // arrive twice (the prefix keys above the threshold come back through the candidate buffer).
+                // (the selection wrote only the K'-th key of each query and reset the query's candidate counter)
+                tm.mark("select0");
                 launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
                                    pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                    h->st);
@@ -984,14 +986,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, 1, 0, h->st);   // ... the closest list only
             launch_list_scan(a, h->st);
             tm.mark("scan0");
-            select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
-                        std::min<int64_t>(maxlen, chunk_rows), 0, nq, KP, BUF, KP, state, false);
-            launch_keep_last_u64(state, nq, KP, h->st);           // the pre-pass is only a threshold (see the IVF-PQ path)
-            tm.mark("select0");
             cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
             h->w_cand.ensure((size_t)nq * cand_cap * 8);
             h->w_candcnt.ensure((size_t)nq * 8);
-            HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8, h->st));
+            // the pre-pass is only a threshold (see the IVF-PQ path): the K'-th key, candidate counters reset
+            select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
+                        std::min<int64_t>(maxlen, chunk_rows), 0, nq, KP, BUF, KP, state, false,
+                        h->w_candcnt.as<unsigned long long>());
+            tm.mark("select0");
             launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
                                pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, 0, h->st);
             tm.mark("group");

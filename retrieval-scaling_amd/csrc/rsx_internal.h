@@ -170,6 +170,9 @@ struct SelectArgs {
     int seg_base;                           // first segment index handled by this launch
     uint64_t* out; int64_t out_row_stride;  // out[row*out_row_stride + seg*KP + i]
     int64_t nrows; int KP; int BUF; int k;
+    // threshold pre-pass form (nseg == 1): write only the row's KP-th key (the other KP-1 slots zero) and reset
+    // the row's candidate counter, so no extra launches sit between the pre-pass and the filtered scan
+    int keep_last; unsigned long long* zero_cnt;
 };
 void launch_select(const SelectArgs& a, hipStream_t st);
 void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
