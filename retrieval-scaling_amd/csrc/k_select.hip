@@ -111,8 +111,130 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     if (a.zero_cnt && lane == 0 && seg == 0) a.zero_cnt[row] = 0ull;
 }
 
+// ---------------------------------------------------------------------------------------
+// Radix selection for short rows (a few thousand elements: the threshold pre-pass, the filtered scans'
+// candidate buffers).  k_select keeps a sorted LDS buffer and re-sorts 2*KP..512 keys whenever it fills —
+// ~9 us per sort on one wave, 4-5 sorts per row.  Here the row's KP-th largest key is found exactly by an
+// 8-bit MSB-first radix walk over the 64-bit keys (8 counting passes over data that sits in L1/L2), the keys
+// >= it are compacted (keys are distinct: the index is part of the key) and only those KP are sorted.
+// Same output contract as k_select with nseg == 1: KP keys descending, zero padded.
+// ---------------------------------------------------------------------------------------
+__device__ inline void bitonic_sort_desc_wg(uint64_t* buf, int n, int tid, int nt) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (n >> 1); t += nt) {
+                int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                int j = i + stride;
+                bool desc = ((i & size) == 0);
+                uint64_t x = buf[i], y = buf[j];
+                if ((x < y) == desc) { buf[i] = y; buf[j] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t rs_obuf[];   // [KP] output keys, then hist[256], ctl[4]
+    const int KP = a.KP;
+    int32_t* hist = reinterpret_cast<int32_t*>(rs_obuf + KP);
+    int32_t* ctl = hist + 256;          // [0] digit, [1] remaining, [2] valid count, [3] output cursor
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t row = blockIdx.x;
+    int64_t n = a.row_n ? a.row_n[row * a.row_n_stride] : a.n_uniform;
+    if (a.row_n && a.n_uniform > 0 && n > a.n_uniform) n = a.n_uniform;
+    const int nin = (int)n;
+    const int N = nin + (a.init ? KP : 0);      // the running state's keys are just more elements
+    const float* sf = (const float*)a.in + row * a.row_stride;
+    const uint64_t* sk = (const uint64_t*)a.in + row * a.row_stride;
+    auto key_at = [&](int i) -> uint64_t {
+        if (i >= nin) return a.init[row * KP + (i - nin)];
+        return MODE == 0 ? make_key(sf[i], a.idx_base + (uint32_t)i) : sk[i];
+    };
+    if (tid < 4) ctl[tid] = 0;
+    for (int i = tid; i < KP; i += 256) rs_obuf[i] = 0;
+    __syncthreads();
+    int myvalid = 0;
+    for (int i = tid; i < N; i += 256) myvalid += key_at(i) != 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) myvalid += __shfl_xor(myvalid, off);
+    if (lane == 0 && myvalid) atomicAdd(&ctl[2], myvalid);
+    __syncthreads();
+    const int V = ctl[2];
+    uint64_t kth = 1;                   // fewer than KP valid keys: take every valid one
+    if (V > KP) {
+        uint64_t prefix = 0;
+        if (tid == 0) ctl[1] = KP;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < N; i += 256) {
+                const uint64_t key = key_at(i);
+                if (key != 0ull && (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8))))
+                    atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {             // wave 0: 4 bins per lane, suffix sums from the top
+                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const int sum4 = h0 + h1 + h2 + h3;
+                int suf = sum4;         // inclusive suffix sum over lanes >= lane
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { int y = __shfl_down(suf, off); if (lane + off < 64) suf += y; }
+                const int remaining = ctl[1];
+                const uint64_t m = __ballot(suf >= remaining);
+                const int L = 63 - __clzll((unsigned long long)m);      // m != 0: suf[0] = matching count >= remaining
+                if (lane == L) {
+                    int run = suf - sum4;                               // count in bins above this lane's
+                    const int hb[4] = {h0, h1, h2, h3};
+                    int d = 4 * L, rem = remaining;
+                    for (int b = 3; b >= 0; b--) {
+                        if (run + hb[b] >= remaining) { d = 4 * L + b; rem = remaining - run; break; }
+                        run += hb[b];
+                    }
+                    ctl[0] = d; ctl[1] = rem;
+                }
+            }
+            __syncthreads();
+            prefix |= (uint64_t)(uint32_t)ctl[0] << shift;
+            __syncthreads();
+        }
+        kth = prefix;
+    }
+    for (int i = tid; i < N; i += 256) {
+        const uint64_t key = key_at(i);
+        if (key != 0ull && key >= kth) { const int pos = atomicAdd(&ctl[3], 1); if (pos < KP) rs_obuf[pos] = key; }
+    }
+    __syncthreads();
+    bitonic_sort_desc_wg(rs_obuf, KP, tid, 256);
+    uint64_t* o = a.out + row * a.out_row_stride;
+    for (int i = tid; i < KP; i += 256) o[i] = (a.keep_last && i != KP - 1) ? 0ull : rs_obuf[i];
+    if (a.zero_cnt && tid == 0) a.zero_cnt[row] = 0ull;
+}
+
+// rows short enough for the radix form (single segment; the counting passes re-read the row 9 times from L1/L2)
+static bool select_radix_applies(const SelectArgs& a) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("RSX_SELECT_V1"); off = (e && atoi(e)) ? 1 : 0; }
+    // measured: wins for the threshold pre-pass (2048 scores -> K' = 128) and the candidate merge, loses for the
+    // probe selection (4096 scores -> 32 keys: k_select's buffer hardly ever needs a second sort there)
+    return !off && (a.keep_last || a.in_is_keys) && a.nseg == 1 && a.seg_base == 0 && !a.tau_ptr && a.n_uniform > 0 &&
+           a.n_uniform <= 16384 && a.KP <= 4096;
+}
+
 void launch_select(const SelectArgs& a, hipStream_t st) {
     if (a.nrows <= 0 || a.nseg - a.seg_base <= 0) return;
+    if (select_radix_applies(a)) {
+        size_t shm2 = (size_t)a.KP * 8 + 260 * 4;
+        if (a.in_is_keys) {
+            if (shm2 > 48 * 1024) hipFuncSetAttribute((const void*)k_select_radix<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+            hipLaunchKernelGGL(k_select_radix<1>, dim3((unsigned)a.nrows), dim3(256), shm2, st, a);
+        } else {
+            if (shm2 > 48 * 1024) hipFuncSetAttribute((const void*)k_select_radix<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+            hipLaunchKernelGGL(k_select_radix<0>, dim3((unsigned)a.nrows), dim3(256), shm2, st, a);
+        }
+        return;
+    }
     dim3 grid((unsigned)a.nrows, (unsigned)(a.nseg - a.seg_base));
     size_t shm = (size_t)a.BUF * sizeof(uint64_t);
     if (a.in_is_keys) {
