@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t rs_obuf[];   // [KP] output keys, then hist[256], ctl[4]
     const int KP = a.KP;
     int32_t* hist = reinterpret_cast<int32_t*>(rs_obuf + KP);
-    int32_t* ctl = hist + 256;          // [0] digit, [1] remaining, [2] valid count, [3] output cursor
+    int32_t* ctl = hist + 256;          // [0] digit, [1] remaining, [2] valid count, [3] output cursor, [4] keys in the digit's bin
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t row = blockIdx.x;
     int64_t n = a.row_n ? a.row_n[row * a.row_n_stride] : a.n_uniform;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
         if (i >= nin) return a.init[row * KP + (i - nin)];
         return MODE == 0 ? make_key(sf[i], a.idx_base + (uint32_t)i) : sk[i];
     };
-    if (tid < 4) ctl[tid] = 0;
+    if (tid < 8) ctl[tid] = 0;
     for (int i = tid; i < KP; i += 256) rs_obuf[i] = 0;
     __syncthreads();
     int myvalid = 0;
@@ -188,18 +188,21 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
                     int run = suf - sum4;                               // count in bins above this lane's
                     const int hb[4] = {h0, h1, h2, h3};
                     int d = 4 * L, rem = remaining;
+                    int inbin = 0;
                     for (int b = 3; b >= 0; b--) {
-                        if (run + hb[b] >= remaining) { d = 4 * L + b; rem = remaining - run; break; }
+                        if (run + hb[b] >= remaining) { d = 4 * L + b; rem = remaining - run; inbin = hb[b]; break; }
                         run += hb[b];
                     }
-                    ctl[0] = d; ctl[1] = rem;
+                    ctl[0] = d; ctl[1] = rem; ctl[4] = inbin;
                 }
             }
             __syncthreads();
             prefix |= (uint64_t)(uint32_t)ctl[0] << shift;
+            const bool all_in = ctl[1] == ctl[4];      // every key under this prefix is selected: no need to refine it
             __syncthreads();
+            if (all_in) break;                          // (typically after 4 of the 8 rounds: the score bits are distinct)
         }
-        kth = prefix;
+        kth = prefix;                                   // low bits zero after an early exit: a lower bound of those keys
     }
     for (int i = tid; i < N; i += 256) {
         const uint64_t key = key_at(i);
@@ -225,7 +228,7 @@ static bool select_radix_applies(const SelectArgs& a) {
 void launch_select(const SelectArgs& a, hipStream_t st) {
     if (a.nrows <= 0 || a.nseg - a.seg_base <= 0) return;
     if (select_radix_applies(a)) {
-        size_t shm2 = (size_t)a.KP * 8 + 260 * 4;
+        size_t shm2 = (size_t)a.KP * 8 + 264 * 4;
         if (a.in_is_keys) {
             if (shm2 > 48 * 1024) hipFuncSetAttribute((const void*)k_select_radix<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
             hipLaunchKernelGGL(k_select_radix<1>, dim3((unsigned)a.nrows), dim3(256), shm2, st, a);
