@@ -42,6 +42,8 @@ for s in $STAGES; do
       timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log ;;
     prof_flat)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_flat.json" 2> "$OLDPWD/gpurun_out/prof_flat.log" ); echo "exit $?" >> gpurun_out/prof_flat.log ;;
+    prof_ivfflat)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_ivfflat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" ivfflat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_ivfflat.json" 2> "$OLDPWD/gpurun_out/prof_ivfflat.log" ); echo "exit $?" >> gpurun_out/prof_ivfflat.log ;;
     variants)
       # cost split of k_pq_scan8 (unfiltered form): 0 = real kernel, 1 = gathers + ONE add, 2 = no LDS gather
       for v in 0 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall --param pq_filter=0 > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
