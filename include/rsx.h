@@ -165,7 +165,8 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out);
  * fast scan, 0 = auto), "pq_filter" (fast scan: 1 = candidates filtered inside the scan kernel [default], 0 = full
  * score buffer), "pq_pre_rows" (filtered fast scan: vectors of each query's closest list scored by the threshold
  * pre-pass, default 2048, 0 = one scan tile), "ivf_filter" (IVF-Flat: candidates filtered inside the list scan: 1 = when
- * the score rows of the batch would exceed ~2 GB [default], 2 = always, 0 = never = full score rows), "lut_tiled" (IVFPQ fast scan, dsub = 8: 1 = 8-bit tables built by
+ * the score rows of the batch would exceed ~2 GB [default], 2 = always, 0 = never = full score rows), "pq_prepass_fused" (filtered fast scan: 1 = threshold pre-pass in one launch [default], 0 = grouping +
+ * scan + selection launches), "lut_tiled" (IVFPQ fast scan, dsub = 8: 1 = 8-bit tables built by
  * codebook-slice tiles shared by 32 queries [default], 0 = one workgroup per query), "flat_filter" (Flat: 1 = one filtered GEMM launch after the first chunk [default], 0 = score buffer
  * per chunk), "profile" (1 = record stage timings with HIP
  * events on the library's stream; 2 = additionally count the vectors each search scanned). */

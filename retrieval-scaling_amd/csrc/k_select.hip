@@ -134,29 +134,16 @@ __device__ inline void bitonic_sort_desc_wg(uint64_t* buf, int n, int tid, int n
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t rs_obuf[];   // [KP] output keys, then hist[256], ctl[4]
-    const int KP = a.KP;
-    int32_t* hist = reinterpret_cast<int32_t*>(rs_obuf + KP);
-    int32_t* ctl = hist + 256;          // [0] digit, [1] remaining, [2] valid count, [3] output cursor, [4] keys in the digit's bin
+// Top-KP (sorted descending into obuf, zero padded) of the N keys key_at(0..N-1) by a workgroup of NT threads.
+// hist: 256 ints, ctl: 8 ints of LDS.  Zero keys are "no element".
+template <int NT, class KeyAt>
+__device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf, int32_t* hist, int32_t* ctl) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t row = blockIdx.x;
-    int64_t n = a.row_n ? a.row_n[row * a.row_n_stride] : a.n_uniform;
-    if (a.row_n && a.n_uniform > 0 && n > a.n_uniform) n = a.n_uniform;
-    const int nin = (int)n;
-    const int N = nin + (a.init ? KP : 0);      // the running state's keys are just more elements
-    const float* sf = (const float*)a.in + row * a.row_stride;
-    const uint64_t* sk = (const uint64_t*)a.in + row * a.row_stride;
-    auto key_at = [&](int i) -> uint64_t {
-        if (i >= nin) return a.init[row * KP + (i - nin)];
-        return MODE == 0 ? make_key(sf[i], a.idx_base + (uint32_t)i) : sk[i];
-    };
-    if (tid < 8) ctl[tid] = 0;
-    for (int i = tid; i < KP; i += 256) rs_obuf[i] = 0;
+    if (tid < 8) ctl[tid] = 0;          // [0] digit, [1] remaining, [2] valid count, [3] output cursor, [4] keys in the digit's bin
+    for (int i = tid; i < KP; i += NT) obuf[i] = 0;
     __syncthreads();
     int myvalid = 0;
-    for (int i = tid; i < N; i += 256) myvalid += key_at(i) != 0ull;
+    for (int i = tid; i < N; i += NT) myvalid += key_at(i) != 0ull;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) myvalid += __shfl_xor(myvalid, off);
     if (lane == 0 && myvalid) atomicAdd(&ctl[2], myvalid);
@@ -167,9 +154,9 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
         uint64_t prefix = 0;
         if (tid == 0) ctl[1] = KP;
         for (int shift = 56; shift >= 0; shift -= 8) {
-            hist[tid] = 0;
+            for (int i = tid; i < 256; i += NT) hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < N; i += 256) {
+            for (int i = tid; i < N; i += NT) {
                 const uint64_t key = key_at(i);
                 if (key != 0ull && (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8))))
                     atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
@@ -204,15 +191,95 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
         }
         kth = prefix;                                   // low bits zero after an early exit: a lower bound of those keys
     }
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += NT) {
         const uint64_t key = key_at(i);
-        if (key != 0ull && key >= kth) { const int pos = atomicAdd(&ctl[3], 1); if (pos < KP) rs_obuf[pos] = key; }
+        if (key != 0ull && key >= kth) { const int pos = atomicAdd(&ctl[3], 1); if (pos < KP) obuf[pos] = key; }
     }
     __syncthreads();
-    bitonic_sort_desc_wg(rs_obuf, KP, tid, 256);
+    bitonic_sort_desc_wg(obuf, KP, tid, NT);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t rs_obuf[];   // [KP] output keys, then hist[256], ctl[8]
+    const int KP = a.KP;
+    int32_t* hist = reinterpret_cast<int32_t*>(rs_obuf + KP);
+    int32_t* ctl = hist + 256;
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    int64_t n = a.row_n ? a.row_n[row * a.row_n_stride] : a.n_uniform;
+    if (a.row_n && a.n_uniform > 0 && n > a.n_uniform) n = a.n_uniform;
+    const int nin = (int)n;
+    const int N = nin + (a.init ? KP : 0);      // the running state's keys are just more elements
+    const float* sf = (const float*)a.in + row * a.row_stride;
+    const uint64_t* sk = (const uint64_t*)a.in + row * a.row_stride;
+    auto key_at = [&](int i) -> uint64_t {
+        if (i >= nin) return a.init[row * KP + (i - nin)];
+        return MODE == 0 ? make_key(sf[i], a.idx_base + (uint32_t)i) : sk[i];
+    };
+    radix_topk_wg<256>(key_at, N, KP, rs_obuf, hist, ctl);
     uint64_t* o = a.out + row * a.out_row_stride;
     for (int i = tid; i < KP; i += 256) o[i] = (a.keep_last && i != KP - 1) ? 0ull : rs_obuf[i];
     if (a.zero_cnt && tid == 0) a.zero_cnt[row] = 0ull;
+}
+
+// ---------------------------------------------------------------------------------------
+// IVF-PQ threshold pre-pass in ONE launch: a workgroup per query scores the first pre_rows vectors of the
+// query's closest list with the query's 8-bit table (24 KiB in LDS, byte gathers; the SAME integer sums and
+// the same fp32 expression as k_pq_scan8, hence the same keys), selects their K'-th largest key in LDS and
+// writes it as the query's threshold (state[q][KP-1], the other slots zero) and resets the candidate counter.
+// Replaces pair grouping + k_pq_scan8<unfiltered> + selection (5 launches) for that step.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t pp_smem[];
+    uint64_t* keys = pp_smem;                                        // [pre_rows]
+    uint64_t* obuf = keys + a.pre_rows;                              // [KP]
+    int32_t* hist = reinterpret_cast<int32_t*>(obuf + a.KP);         // [256]
+    int32_t* ctl = hist + 256;                                       // [8]
+    uint8_t* tab = reinterpret_cast<uint8_t*>(ctl + 8);              // [Mpad][256]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t q = blockIdx.x;
+    const int32_t l = a.probe_list[q * a.nprobe];
+    const int64_t len = l >= 0 ? a.list_len[l] : 0;
+    const int n = (int)(len < a.pre_rows ? len : a.pre_rows);
+    const int nslab = (n + 63) >> 6;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.lut8 + q * a.Mpad * 256);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (int i = tid; i < a.Mpad * 16; i += 1024) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float scale = a.qparam[q * 4 + 0], bias = a.qparam[q * 4 + 1];
+    const float dis0 = a.probe_dis0[q * a.nprobe];
+    const int64_t col = a.seg_start[q * (a.nprobe + 1)];
+    const int nch = a.Mpad >> 4;
+    for (int s = w; s < nslab; s += 16) {
+        const uint8_t* sp = a.codes + ((a.list_base[l] >> 6) + s) * (int64_t)(64 * a.Mpad) + lane * 16;
+        uint32_t acc = 0;
+        for (int g = 0; g < nch; g++) {
+            const uint4 c = *reinterpret_cast<const uint4*>(sp + g * 1024);
+            const uint32_t wds[4] = {c.x, c.y, c.z, c.w};
+            const uint8_t* tg = tab + g * 16 * 256;
+#pragma unroll
+            for (int b = 0; b < 16; b++) acc += tg[b * 256 + ((wds[b >> 2] >> (8 * (b & 3))) & 255u)];
+        }
+        const int64_t pos = (int64_t)s * 64 + lane;
+        const float sc = dis0 + __fmaf_rn(scale, (float)acc, bias);
+        keys[pos] = (pos < len) ? make_key(sc, (uint32_t)(col + pos)) : 0ull;
+    }
+    __syncthreads();
+    auto key_at = [&](int i) -> uint64_t { return keys[i]; };
+    radix_topk_wg<1024>(key_at, nslab * 64, a.KP, obuf, hist, ctl);
+    uint64_t* o = a.state + q * a.KP;
+    for (int i = tid; i < a.KP; i += 1024) o[i] = (i == a.KP - 1) ? obuf[i] : 0ull;
+    if (tid == 0) a.cand_cnt[q] = 0ull;
+}
+void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
+    if (nq <= 0) return;
+    size_t shm = (size_t)a.pre_rows * 8 + (size_t)a.KP * 8 + 264 * 4 + (size_t)a.Mpad * 256;
+    static size_t attr = 0;
+    if (shm > attr) { hipFuncSetAttribute((const void*)k_pq_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
+    hipLaunchKernelGGL(k_pq_prepass, dim3((unsigned)nq), dim3(1024), shm, st, a);
 }
 
 // rows short enough for the radix form (single segment; the counting passes re-read the row 9 times from L1/L2)

@@ -148,6 +148,7 @@ struct rsx_index {
     int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
     int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
+    int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
     int pq_pre_rows = 2048;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int flat_filter = 1;  // Flat: one filtered GEMM launch after the first chunk (0 = score buffer per chunk)
     int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
@@ -871,6 +872,24 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 if (pre_vpl > vpl) pre_vpl = vpl;
             }
             const int pre_rows = filtered ? 64 * 16 * pre_vpl : tile_rows;
+            // one-launch pre-pass (k_pq_prepass: score the prefix with byte gathers on the query's own 24 KiB table,
+            // select the K'-th key in LDS) when its LDS footprint allows; else grouping + k_pq_scan8 + selection
+            const bool fused_pre = filtered && h->pq_prepass_fused != 0 &&
+                                   (size_t)pre_rows * 8 + (size_t)KP * 8 + (size_t)h->Mpad * 256 + 2048 <= 150 * 1024;
+            if (fused_pre) {
+                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
+                h->w_cand.ensure((size_t)nq * cand_cap * 8);
+                h->w_candcnt.ensure((size_t)nq * 8);
+                PQPrepassArgs pa{};
+                pa.codes = h->data.as<uint8_t>(); pa.list_base = h->d_base.as<int64_t>(); pa.list_len = h->d_len.as<int64_t>();
+                pa.probe_list = h->w_probelist.as<int32_t>(); pa.probe_dis0 = h->w_dis0.as<float>();
+                pa.seg_start = h->w_segstart.as<int64_t>();
+                pa.lut8 = h->w_lut8.as<uint8_t>(); pa.qparam = h->w_qparam.as<float>();
+                pa.nprobe = nprobe; pa.Mpad = h->Mpad; pa.pre_rows = pre_rows; pa.KP = KP;
+                pa.state = state; pa.cand_cnt = h->w_candcnt.as<unsigned long long>();
+                launch_pq_prepass(pa, nq, h->st);
+                done = true;
+            } else {
             launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
                                pairs_sorted, h->d_len.as<int64_t>(), pre_rows, item_off, total_items, nprobe, 0,
                                filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
@@ -879,12 +898,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    total_groups, item_off, total_items, nlist,
                                    filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows),
                                    filtered ? pre_vpl : vpl, h->st) == 0;
+            }
             if (done && filtered) {
                 tm.mark("scan0");
                 // top-K' of the scored prefix of the closest list: row prefix [0, min(seg_start[q][1], pre_rows))
                 cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8);
+                if (!fused_pre)
                 select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
                             std::min<int64_t>(maxlen, pre_rows), 0, nq, KP, BUF, KP, state, false,
                             h->w_candcnt.as<unsigned long long>());
@@ -1572,6 +1593,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_filter") h->pq_filter = (int)value;
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
+        else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }

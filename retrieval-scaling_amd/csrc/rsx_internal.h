@@ -175,6 +175,15 @@ struct SelectArgs {
     int keep_last; unsigned long long* zero_cnt;
 };
 void launch_select(const SelectArgs& a, hipStream_t st);
+// IVF-PQ threshold pre-pass in one launch (k_pq_prepass): needs the 16-byte-granule code layout
+struct PQPrepassArgs {
+    const uint8_t* codes; const int64_t* list_base; const int64_t* list_len;
+    const int32_t* probe_list; const float* probe_dis0; const int64_t* seg_start;
+    const uint8_t* lut8; const float* qparam;   // [nq][Mpad][256] u8 tables; [nq] {scale, bias, eps, pad}
+    int nprobe; int Mpad; int pre_rows; int KP;
+    uint64_t* state; unsigned long long* cand_cnt;
+};
+void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
 void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
                         int pad_to, int32_t* probe_list, float* probe_dis0, int64_t* seg_start, hipStream_t st);
 // tile_rows > 0: also build the (list, tile, group) work-item table: item_off[nlist+1], total_items

@@ -121,6 +121,10 @@ def test_golden_ivfpq(gpu, orc, name):
     D8, I8 = ix.search(q, g["k"])
     assert_same_results(D8, I8, g["D"], g["I"], name + " unfiltered fast scan")
     ix.set_param("pq_filter", 1)
+    ix.set_param("pq_prepass_fused", 0)     # threshold pre-pass as grouping + k_pq_scan8 + selection launches
+    Da, Ia = ix.search(q, g["k"])
+    assert_same_results(Da, Ia, g["D"], g["I"], name + " multi-launch pre-pass")
+    ix.set_param("pq_prepass_fused", 1)
     ix.set_param("lut_tiled", 0)            # one workgroup per query builds its table (the tiled build is the dsub = 8 default)
     D9, I9 = ix.search(q, g["k"])
     assert_same_results(D9, I9, g["D"], g["I"], name + " per-query table build")
