@@ -44,6 +44,11 @@ for s in $STAGES; do
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_flat.json" 2> "$OLDPWD/gpurun_out/prof_flat.log" ); echo "exit $?" >> gpurun_out/prof_flat.log ;;
     prof_ivfflat)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_ivfflat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" ivfflat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_ivfflat.json" 2> "$OLDPWD/gpurun_out/prof_ivfflat.log" ); echo "exit $?" >> gpurun_out/prof_ivfflat.log ;;
+    pmc_ivfflat)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_ivfflat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" ivfflat --check 0 --steps 2 > "$OLDPWD/gpurun_out/pmc_ivfflat.json" 2> "$OLDPWD/gpurun_out/pmc_ivfflat.log" ); echo "exit $?" >> gpurun_out/pmc_ivfflat.log
+      rm -f gpurun_out/pmc_ivfflat_summary.txt
+      python tools/pmc_summary.py gpurun_out/pmc_ivfflat/r01_results.db gpurun_out/pmc_ivfflat_summary.txt '%k_list_scan%' '%k_select%' '%k_finalize%'
+      rm -rf gpurun_out/pmc_ivfflat ;;
     variants)
       # cost split of k_pq_scan8 (unfiltered form): 0 = real kernel, 1 = gathers + ONE add, 2 = no LDS gather
       for v in 0 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall --param pq_filter=0 > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
