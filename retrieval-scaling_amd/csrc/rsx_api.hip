@@ -890,25 +890,26 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 launch_pq_prepass(pa, nq, h->st);
                 done = true;
             } else {
-            launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, h->d_len.as<int64_t>(), pre_rows, item_off, total_items, nprobe, 0,
-                               filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
-            tm.mark("group");
-            done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                   total_groups, item_off, total_items, nlist,
-                                   filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows),
-                                   filtered ? pre_vpl : vpl, h->st) == 0;
+                launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
+                                   pairs_sorted, h->d_len.as<int64_t>(), pre_rows, item_off, total_items, nprobe, 0,
+                                   filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
+                tm.mark("group");
+                done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
+                                       total_groups, item_off, total_items, nlist,
+                                       filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows),
+                                       filtered ? pre_vpl : vpl, h->st) == 0;
             }
             if (done && filtered) {
                 tm.mark("scan0");
-                // top-K' of the scored prefix of the closest list: row prefix [0, min(seg_start[q][1], pre_rows))
                 cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8);
+                // multi-launch form: top-K' of the scored prefix of the closest list, row prefix
+                // [0, min(seg_start[q][1], pre_rows)), written as the threshold key + counter reset
                 if (!fused_pre)
-                select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
-                            std::min<int64_t>(maxlen, pre_rows), 0, nq, KP, BUF, KP, state, false,
-                            h->w_candcnt.as<unsigned long long>());
+                    select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
+                                std::min<int64_t>(maxlen, pre_rows), 0, nq, KP, BUF, KP, state, false,
+                                h->w_candcnt.as<unsigned long long>());
                 // The pre-pass is only a threshold: keep its K'-th key and let the main scan score EVERYTHING (the
                 // prefix included), so the scan kernel carries no per-slab "already scored" test and no key can
                 // arrive twice (the prefix keys above the threshold come back through the candidate buffer).
