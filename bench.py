@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-recall", action="store_true", help="skip the exact ground truth (recall = null)")
     ap.add_argument("--diag", action="store_true", help="print a fast-vs-exact comparison of the first timed batch and exit")
+    ap.add_argument("--shard", choices=["lists", "vectors"], default="lists",
+                    help="multi-GPU partition of the index: by inverted lists (rank r owns lists l %% N == r; every rank scans "
+                         "whole lists for 1/N of the (query, probe) pairs) or by contiguous id ranges (the reference's shards)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
                     help="engine parameter for an experiment (rsx_set_param), e.g. pq_filter=0; not for the reported line")
     ap.add_argument("--ab", action="store_true", help="also time the per-pair v1 scan kernel (same process, same index)")
@@ -106,6 +109,10 @@ def main():
         fresh.set_centroids(cen.cpu().numpy()); fresh.set_codebooks(cb.cpu().numpy())
         index = fresh
     index.nprobe = args.nprobe
+    list_shards = world > 1 and args.shard == "lists"
+    if list_shards:   # this rank keeps the lists l % world == rank of the whole add stream (same ids as a single index)
+        index.set_param("add_list_mod", world)
+        index.set_param("add_list_rem", rank)
     for kv in args.param:
         name, val = kv.split("=")
         index.set_param(name, int(val))
@@ -121,10 +128,17 @@ def main():
     buf = torch.empty((args.chunk, D), dtype=torch.float16, device=dev)
     flat = None if args.no_recall else rsx.IndexFlatIP(D, device=local_rank)
     gtD = gtI = None
+    if list_shards:   # every rank streams the whole id range through add (assignment + its own lists' codes)
+        for c0 in range(0, n_total, args.chunk):
+            nb = min(args.chunk, n_total - c0)
+            rsx.synth_vectors(D, NCENTRES, SEED_C, SEED_X, SIGMA, c0, nb, out=buf[:nb])
+            index.add(buf[:nb])
     for c0 in range(lo, hi, args.chunk):
         nb = min(args.chunk, hi - c0)
-        rsx.synth_vectors(D, NCENTRES, SEED_C, SEED_X, SIGMA, c0, nb, out=buf[:nb])
-        index.add(buf[:nb])
+        if not list_shards or flat is not None:
+            rsx.synth_vectors(D, NCENTRES, SEED_C, SEED_X, SIGMA, c0, nb, out=buf[:nb])
+        if not list_shards:
+            index.add(buf[:nb])
         if flat is not None:
             flat.reset()
             flat.add(buf[:nb])
@@ -136,11 +150,13 @@ def main():
                 gtD, gtI = rsx.merge_topk(torch.stack([gtD, Dc]), torch.stack([gtI, Ic]))
     del buf, flat
     torch.cuda.synchronize()
+    if list_shards:
+        n_local = index.ntotal      # the vectors of this rank's lists
     if rank == 0:
         log(f"add: {time.time() - t0:.1f}s for {n_local} vectors/rank; setup total {time.time() - t_setup:.1f}s")
     assert index.ntotal == n_local
 
-    searcher = ShardedSearcher(index, id_offset=lo) if world > 1 else None
+    searcher = ShardedSearcher(index, id_offset=0 if list_shards else lo) if world > 1 else None
 
     def step(i):
         q = Q[i * nq:(i + 1) * nq]
@@ -299,7 +315,8 @@ def main():
             "recall_at_10": recall,
             "config": {"workload": f"{n_total}x{D} IVF-PQ M={args.m} nbits=8 nlist={args.nlist} nprobe={args.nprobe} "
                                    f"batch={nq} k={k}, inner product, by_residual",
-                       "vectors_per_gpu": n_local, "parallelism": f"index sharded by id range over {world} GPU(s)"},
+                       "vectors_per_gpu": n_local, "parallelism": (f"index sharded by inverted lists (l % {world} == rank) over {world} GPU(s)" if list_shards
+                                       else f"index sharded by id range over {world} GPU(s)")},
             "roofline": {"bound": "hbm", "kernel": "k_pq_scan8", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(ms_per_launch, 4),

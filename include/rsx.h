@@ -170,6 +170,11 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out);
  * codebook-slice tiles shared by 32 queries [default], 0 = one workgroup per query), "flat_filter" (Flat: 1 = one filtered GEMM launch after the first chunk [default], 0 = score buffer
  * per chunk), "profile" (1 = record stage timings with HIP
  * events on the library's stream; 2 = additionally count the vectors each search scanned). */
+/* Build-time knob (IVF indexes, before the first add): "add_list_mod" = N, "add_list_rem" = r make this handle a LIST
+ * shard of an N-way multi-GPU index: rsx_add assigns every vector of the stream (sequential ids keep counting all
+ * of them) but stores only those whose inverted list l has l % N == r.  N handles fed the same stream, searched with
+ * the same queries and merged (rsx_merge_topk / rsx_merge_packed) return the single index's result; unlike vector
+ * shards, every rank then scans whole lists for 1/N of the (query, probe) pairs. */
 int rsx_set_param(rsx_index_t* h, const char* key, double value);
 
 /* HIP-event timings (ms) of the stages of the last rsx_search on this handle when

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const void* x, int x_f16, 
     int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     int64_t dst = dest_row ? dest_row[i] : i;
+    if (dst < 0) return;                         // the vector's list belongs to another shard
     for (int t = lane; t < ld; t += 64) {
         float v = 0.0f;
         if (t < d) v = x_f16 ? __half2float(((const __half*)x)[i * d + t]) : ((const float*)x)[i * d + t];
@@ -290,7 +291,7 @@ void launch_check_f16(const float* x, int64_t count, int* flag, hipStream_t st) 
 }
 __global__ void k_write_ids(const int64_t* dest_row, const int64_t* ids_in, int64_t id0, int64_t n, int64_t* ids_storage) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ids_storage[dest_row[i]] = ids_in ? ids_in[i] : id0 + i;
+    if (i < n && dest_row[i] >= 0) ids_storage[dest_row[i]] = ids_in ? ids_in[i] : id0 + i;   // dest < 0: dropped (other shard's list)
 }
 void launch_write_ids(const int64_t* dest_row, const int64_t* ids_in, int64_t id0, int64_t n, int64_t* ids_storage, hipStream_t st) {
     if (n <= 0) return;

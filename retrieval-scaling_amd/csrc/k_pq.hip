@@ -842,10 +842,10 @@ __global__ __launch_bounds__(256) void k_pq_encode(const void* x, int x_f16, int
     const int dsub = DSUB > 0 ? DSUB : dsub_rt;
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-    const bool valid = i < n;
-    const int64_t ii = valid ? i : n - 1;
+    const int64_t ii = i < n ? i : n - 1;
+    const int64_t drow = (dest_row && i < n) ? dest_row[ii] : 0;
+    const bool valid = i < n && drow >= 0;       // dest < 0: the vector's list belongs to another shard (rsx_set_param "add_list_mod")
     const float* cen = centroids ? centroids + (int64_t)assign[ii] * d : nullptr;
-    const int64_t drow = (dest_row && valid) ? dest_row[ii] : 0;
     uint32_t packed = 0;
     for (int m = 0; m < Mpad; m++) {
         uint32_t code = 0;

@@ -150,6 +150,8 @@ struct rsx_index {
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
     int pq_pre_rows = 2048;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
+    int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
+    int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
     int flat_filter = 1;  // Flat: one filtered GEMM launch after the first chunk (0 = score buffer per chunk)
     int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
     int profile = 0;
@@ -377,9 +379,18 @@ static void add_batch(rsx_index* h, int64_t n, const void* x, int dtype, const i
 
     std::vector<int64_t> need(h->h_len);
     std::vector<int64_t> pos((size_t)n);
-    for (int64_t i = 0; i < n; i++) pos[(size_t)i] = need[(size_t)assign[(size_t)i]]++;  // insertion order inside a list
+    // list-sharded multi-GPU index: this handle keeps only the lists l with l % add_list_mod == add_list_rem; the other
+    // vectors of the stream are assigned (they advance the sequential ids) and dropped
+    const int lmod = std::max(1, h->add_list_mod), lrem = h->add_list_rem;
+    int64_t nkept = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t l = assign[(size_t)i];
+        if (lmod > 1 && l % lmod != lrem) { pos[(size_t)i] = -1; continue; }
+        pos[(size_t)i] = need[(size_t)l]++;  // insertion order inside a list
+        nkept++;
+    }
     ensure_capacity(h, need, false);
-    for (int64_t i = 0; i < n; i++) pos[(size_t)i] += h->h_base[(size_t)assign[(size_t)i]];
+    for (int64_t i = 0; i < n; i++) if (pos[(size_t)i] >= 0) pos[(size_t)i] += h->h_base[(size_t)assign[(size_t)i]];
     h->w_dest.ensure((size_t)n * 8);
     HIPCHECK(hipMemcpyAsync(h->w_dest.p, pos.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
 
@@ -387,14 +398,15 @@ static void add_batch(rsx_index* h, int64_t n, const void* x, int dtype, const i
         launch_pq_encode(dx, dtype == RSX_F16, n, h->d, h->d, h->M, h->Mpad, h->CB, h->d_centroids.as<float>(),
                          h->w_assign.as<int32_t>(), h->d_codebooks.as<float>(), h->w_dest.as<int64_t>(),
                          h->data.as<uint8_t>(), nullptr, h->st);
-        launch_write_ids(h->w_dest.as<int64_t>(), dids, h->ntotal, n, h->ids.as<int64_t>(), h->st);
+        launch_write_ids(h->w_dest.as<int64_t>(), dids, h->ntotal + h->ndropped, n, h->ids.as<int64_t>(), h->st);
     } else {
         launch_scatter_rows(dx, dtype == RSX_F16, n, h->d, h->w_dest.as<int64_t>(), h->data.p, h->storage_f16, h->ld,
-                            h->norms.p ? h->norms.as<float>() : nullptr, dids, h->ntotal, h->ids.as<int64_t>(), h->st);
+                            h->norms.p ? h->norms.as<float>() : nullptr, dids, h->ntotal + h->ndropped, h->ids.as<int64_t>(), h->st);
     }
     HIPCHECK(hipStreamSynchronize(h->st));  // pos / staging buffers are reused by the next batch
     h->h_len = need;
-    h->ntotal += n;
+    h->ntotal += nkept;
+    h->ndropped += n - nkept;               // sequential ids count every vector of the add stream
     upload_dir(h);
 }
 
@@ -1463,7 +1475,7 @@ int rsx_reset(rsx_index_t* h) {
         use_device(h);
         HIPCHECK(hipStreamSynchronize(h->st));
         std::fill(h->h_len.begin(), h->h_len.end(), 0);
-        h->ntotal = 0;
+        h->ntotal = 0; h->ndropped = 0;
         if (h->d_len.p) upload_dir(h);
     });
 }
@@ -1592,6 +1604,12 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_fast") h->pq_fast = (int)value;
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
         else if (s == "pq_filter") h->pq_filter = (int)value;
+        else if (s == "add_list_mod" || s == "add_list_rem") {
+            if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_UNSUPPORTED, "%s: IVF indexes only", key);
+            if (h->ntotal + h->ndropped > 0) RSX_THROW(RSX_ERR_INVALID, "%s must be set before the first add", key);
+            if (s == "add_list_mod") { if (value < 1) RSX_THROW(RSX_ERR_INVALID, "add_list_mod >= 1"); h->add_list_mod = (int)value; h->add_list_rem = 0; }
+            else { if (value < 0 || value >= h->add_list_mod) RSX_THROW(RSX_ERR_INVALID, "0 <= add_list_rem < add_list_mod"); h->add_list_rem = (int)value; }
+        }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
