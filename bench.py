@@ -154,6 +154,8 @@ def main():
         n_local = index.ntotal      # the vectors of this rank's lists
     if rank == 0:
         log(f"add: {time.time() - t0:.1f}s for {n_local} vectors/rank; setup total {time.time() - t_setup:.1f}s")
+    if any(kv.startswith("add_list_mod=") for kv in args.param):
+        n_local = index.ntotal      # experiment: one list shard of an N-way index measured on a single GPU
     assert index.ntotal == n_local
 
     searcher = ShardedSearcher(index, id_offset=0 if list_shards else lo) if world > 1 else None

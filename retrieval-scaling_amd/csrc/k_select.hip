@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
 
 // ---------------------------------------------------------------------------------------
 // IVF-PQ threshold pre-pass in ONE launch: a workgroup per query scores the first pre_rows vectors of the
-// query's closest list with the query's 8-bit table (24 KiB in LDS, byte gathers; the SAME integer sums and
+// query's closest NON-EMPTY probed list with the query's 8-bit table (24 KiB in LDS, byte gathers; the SAME integer sums and
 // the same fp32 expression as k_pq_scan8, hence the same keys), selects their K'-th largest key in LDS and
 // writes it as the query's threshold (state[q][KP-1], the other slots zero) and resets the candidate counter.
 // Replaces pair grouping + k_pq_scan8<unfiltered> + selection (5 launches) for that step.
@@ -239,8 +239,12 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
     uint8_t* tab = reinterpret_cast<uint8_t*>(ctl + 8);              // [Mpad][256]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t q = blockIdx.x;
-    const int32_t l = a.probe_list[q * a.nprobe];
-    const int64_t len = l >= 0 ? a.list_len[l] : 0;
+    // the closest probed list that holds vectors HERE (in a list-sharded index most probes hit other ranks' lists)
+    int32_t l = -1; int64_t len = 0; int j0 = 0;
+    for (int j = 0; j < a.nprobe; j++) {
+        const int32_t lj = a.probe_list[q * a.nprobe + j];
+        if (lj >= 0 && a.list_len[lj] > 0) { l = lj; len = a.list_len[lj]; j0 = j; break; }
+    }
     const int n = (int)(len < a.pre_rows ? len : a.pre_rows);
     const int nslab = (n + 63) >> 6;
     {
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
     }
     __syncthreads();
     const float scale = a.qparam[q * 4 + 0], bias = a.qparam[q * 4 + 1];
-    const float dis0 = a.probe_dis0[q * a.nprobe];
-    const int64_t col = a.seg_start[q * (a.nprobe + 1)];
+    const float dis0 = a.probe_dis0[q * a.nprobe + j0];
+    const int64_t col = a.seg_start[q * (a.nprobe + 1) + j0];
     const int nch = a.Mpad >> 4;
     for (int s = w; s < nslab; s += 16) {
         const uint8_t* sp = a.codes + ((a.list_base[l] >> 6) + s) * (int64_t)(64 * a.Mpad) + lane * 16;

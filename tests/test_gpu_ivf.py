@@ -325,7 +325,11 @@ def test_list_sharded_index_equals_single_index(gpu, orc, kind):
     for r, s in enumerate(shards):
         assert s.ntotal == counts[r::3].sum()
     Df, If = full.search(q, k)
+    for s in shards:
+        s.set_param("profile", 1)
     Ds, Is = zip(*[s.search(q, k) for s in shards])
+    if kind == "ivfpq":   # a shard whose lists do not include a query's closest list must still get a threshold (no mass fallback)
+        assert sum(s.get_timing("fallback_queries") for s in shards) <= 2
     Dm, Im = gpu.merge_topk(np.stack(Ds), np.stack(Is))
     # exact cross-shard score ties may come back in shard order instead of id order; none in this data
     assert_same_results(Dm, Im, Df, If, f"list-sharded {kind}")
