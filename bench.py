@@ -54,9 +54,10 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-recall", action="store_true", help="skip the exact ground truth (recall = null)")
     ap.add_argument("--diag", action="store_true", help="print a fast-vs-exact comparison of the first timed batch and exit")
-    ap.add_argument("--shard", choices=["lists", "vectors"], default="lists",
-                    help="multi-GPU partition of the index: by inverted lists (rank r owns lists l %% N == r; every rank scans "
-                         "whole lists for 1/N of the (query, probe) pairs) or by contiguous id ranges (the reference's shards)")
+    ap.add_argument("--shard", choices=["vectors", "lists"], default="vectors",
+                    help="multi-GPU partition of the index: by contiguous id ranges (the reference's shards; default) or by "
+                         "inverted lists (rank r owns lists l %% N == r) — experimental: measured slower until the ranks "
+                         "exchange their pre-pass thresholds, see DESIGN.md section 6")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
                     help="engine parameter for an experiment (rsx_set_param), e.g. pq_filter=0; not for the reported line")
     ap.add_argument("--ab", action="store_true", help="also time the per-pair v1 scan kernel (same process, same index)")
