@@ -9,6 +9,11 @@
 //  k_flat_gemm  : Flat scan Q · Xᵀ, fp16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16),
 //                 128x128 tiles staged through padded LDS (IndexFlatIP::search, flat.py:139).
 //                 Candidates only — exact scores come from the fp64 re-rank in k_finalize.
+//  k_flat_gemm2 : the same contraction for batches > 128 over fp16 rows: 256 x 256 tiles, LDS-DMA staging
+//                 (global_load_lds_dwordx4) into XOR-swizzled unpadded LDS, one barrier per K step, one db tile per
+//                 workgroup with every query tile passed over it.
+//  k_list_scan2 : k_list_scan for fp16 rows with the row stream staged through per-wave LDS-DMA rings (full
+//                 128-byte lines per row, five K steps ahead, no barriers), optional in-kernel candidate filter.
 //  k_list_scan  : IVF-Flat list scan, list-major: one work item = (list, <=16 probing queries,
 //                 row chunk); the list's fp16 rows stream from HBM straight into MFMA B fragments
 //                 (16-byte loads, 64 B contiguous per row per instruction) and are dotted against

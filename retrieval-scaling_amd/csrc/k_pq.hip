@@ -11,6 +11,15 @@
 //                fp32 sum of FAISS's generic IVFPQ scanner; the score goes to the query's row of the
 //                score buffer (coalesced fp32 stores).  Integer/byte work bounded by HBM and the LDS
 //                gather rate — deliberately NOT reshaped into a GEMM.
+//  k_pq_scan2  : exact list-major scan (two queries per ds_read_b64 of an interleaved float2 table): the
+//                certified fast path's fallback and the A/B reference.
+//  k_pq_lut8 / k_pq_lut8f / k_pq_lut_tiled + k_pq_qparam : the fast path's 8-bit affine-quantised tables with a
+//                rigorous per-query error bound (from an fp32 table in HBM / built in LDS per query / built by
+//                codebook-slice tiles shared by 32 queries — all three give the same bits).
+//  k_pq_scan8  : THE hot kernel: list-major fast scan, four queries' 8-bit tables interleaved as one dword per
+//                (code, m) in 97 KiB of LDS, one ds_read_b32 per (vector, m) serves four queries, exact integer
+//                sums in 16-bit fields, candidates beating the query's threshold key appended from the kernel.
+//                (k_pq_prepass, the one-launch threshold pre-pass, lives in k_select.hip next to the radix select.)
 //  k_pq_encode : ProductQuantizer::compute_code on residuals: nearest codeword per subspace by
 //                squared L2 (fmaf chain, first minimum), written straight into the slab layout.
 #include <cstdlib>

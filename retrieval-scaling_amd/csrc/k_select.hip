@@ -3,6 +3,9 @@
 // popcounts give lane-private append slots with no LDS atomics, and the workgroup barrier of a
 // single-wave group is free, so many independent selections share a CU.
 //
+// k_select_radix (short rows: exact K'-th key by an MSB-first radix walk + one small sort) and k_pq_prepass (the IVF-PQ
+// threshold pre-pass in one launch) use 256 / 1024 threads per row instead.
+//
 // Replaces, inside faiss.Index*.search (reference call sites flat.py:139, ivf_flat.py:225,
 // ivf_pq.py:230): the per-query heap / reservoir top-k, quantizer->search top-nprobe, and
 // heap_reorder; and src/search.py:362-367 (multi-shard merge).
