@@ -137,6 +137,84 @@ def paths_golden():
     print("paths_golden ok")
 
 
+def search_golden():
+    """Golden vectors for the pure-Python driver pieces the host mirror restates, produced by
+    RUNNING the reference's own function definitions: the five functions below are taken from
+    /root/reference/src/search.py with `ast` (the module itself cannot be imported here: faiss, omegaconf,
+    sentence_transformers, pyserini are not installed) and executed against small inputs.  The only name supplied
+    from outside is `ListConfig = list` (the reference uses it solely in isinstance tests on `index_shard_ids`)."""
+    import ast, logging, tempfile
+    ref = "/root/reference/src/search.py"
+    if not os.path.exists(ref):
+        print("reference absent: search_golden.json left as is")
+        return
+    want = {"add_passages_to_eval_data", "get_search_output_path", "get_merged_search_output_path",
+            "post_hoc_merge_topk", "safe_write_jsonl"}
+    tree = ast.parse(open(ref).read())
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    ns = {"os": os, "json": json, "logging": logging, "ListConfig": list}
+    exec(compile(mod, ref, "exec"), ns)
+    assert want <= set(ns)
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    out = {"generated_by": "tests/golden/make_golden.py executing the function definitions of /root/reference/src/search.py"}
+
+    # 1. ctxs records (src/search.py:126-146)
+    data = [{"raw_query": f"q{i}"} for i in range(4)]
+    passages = [["p a", "p b é"], ["p c", "p d"]]
+    scores = [[0.75, 0.5], [1.25, -0.125]]
+    db_ids = [[[0, 3], [1, 9]], [[2, 1], [0, 0]]]
+    inp = {"data": json.loads(json.dumps(data)), "passages": passages, "scores": scores, "db_ids": db_ids,
+           "valid_query_idx": [1, 3], "domain": "unit"}
+    ns["add_passages_to_eval_data"](data, passages, scores, db_ids, [1, 3], domain="unit")
+    out["add_passages"] = {"in": inp, "out": data}
+
+    # 2. output paths (src/search.py:156-183)
+    paths = []
+    for shard_ids in ([0], [2, 0, 1], [[1], [0]], [[3, 4], [0, 1, 2]]):
+        cfg = NS(datastore=NS(index=NS(index_shard_ids=shard_ids)),
+                 evaluation=NS(eval_output_dir="/out/eval", data=NS(eval_data="/data/eval/nq_open.jsonl")))
+        first = shard_ids[0] if isinstance(shard_ids[0], list) else shard_ids
+        paths.append({"index_shard_ids": shard_ids, "per_index": ns["get_search_output_path"](cfg, first),
+                      "merged": ns["get_merged_search_output_path"](cfg)})
+    out["paths"] = paths
+
+    # 3. multi-index merge (src/search.py:312-373): string scores, cross-shard ties, a query-less first example
+    def ctx(shard, j, score):
+        return {"id": [shard, j], "source": "unit", "retrieval text": f"s{shard} c{j}", "retrieval score": score}
+    shard_results = {
+        0: [{"raw_query": "", "ctxs": [None]},
+            {"raw_query": "a", "ctxs": [ctx(0, 0, "0.9"), ctx(0, 1, "0.5"), ctx(0, 2, "0.25")]},
+            {"raw_query": "b", "ctxs": [ctx(0, 3, "1.5"), ctx(0, 4, "1.5"), ctx(0, 5, "-2.0")]}],
+        1: [{"raw_query": "", "ctxs": [None]},
+            {"raw_query": "a", "ctxs": [ctx(1, 0, "0.9"), ctx(1, 1, "0.6"), ctx(1, 2, "0.1")]},
+            {"raw_query": "b", "ctxs": [ctx(1, 3, "1.5"), ctx(1, 4, "1e-3"), ctx(1, 5, "-3")]}],
+        2: [{"raw_query": "", "ctxs": [None]},
+            {"raw_query": "a", "ctxs": [ctx(2, 0, "0.95"), ctx(2, 1, "0.5"), ctx(2, 2, "0.5")]},
+            {"raw_query": "b", "ctxs": [ctx(2, 3, "2"), ctx(2, 4, "1.5"), ctx(2, 5, "1.5")]}],
+    }
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = NS(datastore=NS(index=NS(index_shard_ids=[[0], [1], [2]])),
+                 evaluation=NS(eval_output_dir=os.path.join(tmp, "eval"), data=NS(eval_data="/data/eval/unit.jsonl"),
+                               search=NS(overwrite=True, n_docs=3)))
+        for sid, exs in shard_results.items():
+            pth = ns["get_search_output_path"](cfg, [sid])
+            os.makedirs(os.path.dirname(pth), exist_ok=True)
+            with open(pth, "w") as f:
+                for ex in exs:
+                    f.write(json.dumps(ex) + "\n")
+        ns["post_hoc_merge_topk"](cfg)
+        merged_path = ns["get_merged_search_output_path"](cfg)
+        merged = [json.loads(l) for l in open(merged_path)]
+        out["merge"] = {"n_docs": 3, "index_shard_ids": [[0], [1], [2]], "shard_results": {str(k): v for k, v in shard_results.items()},
+                        "merged_relpath": os.path.relpath(merged_path, tmp), "merged": merged}
+    with open(os.path.join(OUT, "search_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+    print("search_golden ok:", [c["id"] for c in out["merge"]["merged"][2]["ctxs"]])
+
+
 if __name__ == "__main__":
     flat_case("flat_ip_d768", 768, 16, 4096, 32, 10, 0)
     flat_case("flat_l2_d64", 64, 16, 2048, 16, 5, 1)
@@ -146,3 +224,4 @@ if __name__ == "__main__":
     ivf_case("ivfpq_d64_m16", 64, 16, 8192, 32, 10, 32, 8, M=16)
     edge_cases()
     paths_golden()
+    search_golden()

@@ -183,6 +183,41 @@ def test_search_driver_and_merge(tmp_path, orc, fake):
     assert os.path.getmtime(merged_path) == before
 
 
+def test_search_driver_matches_reference_golden(tmp_path, fake):
+    """tests/golden/search_golden.json was produced by RUNNING the reference's own add_passages_to_eval_data,
+    get_search_output_path, get_merged_search_output_path and post_hoc_merge_topk (tests/golden/make_golden.py):
+    the host mirror must give the same records, paths and merged files (ties: earlier shard first)."""
+    import copy, json
+    from src import search as S
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "search_golden.json")) as f:
+        g = json.load(f)
+    a = g["add_passages"]
+    data = copy.deepcopy(a["in"]["data"])
+    S.add_passages_to_eval_data(data, a["in"]["passages"], a["in"]["scores"], a["in"]["db_ids"], a["in"]["valid_query_idx"],
+                                domain=a["in"]["domain"])
+    assert data == a["out"]
+    for c in g["paths"]:
+        cfg = NS(datastore=NS(index=NS(index_shard_ids=c["index_shard_ids"])),
+                 evaluation=NS(eval_output_dir="/out/eval", data=NS(eval_data="/data/eval/nq_open.jsonl")))
+        first = c["index_shard_ids"][0] if isinstance(c["index_shard_ids"][0], list) else c["index_shard_ids"]
+        assert S.get_search_output_path(cfg, first) == c["per_index"]
+        assert S.get_merged_search_output_path(cfg) == c["merged"]
+    m = g["merge"]
+    cfg = NS(datastore=NS(index=NS(index_shard_ids=m["index_shard_ids"])),
+             evaluation=NS(eval_output_dir=os.path.join(str(tmp_path), "eval"), data=NS(eval_data="/data/eval/unit.jsonl"),
+                           search=NS(overwrite=True, n_docs=m["n_docs"])))
+    for sid, exs in m["shard_results"].items():
+        pth = S.get_search_output_path(cfg, [int(sid)])
+        os.makedirs(os.path.dirname(pth), exist_ok=True)
+        with open(pth, "w") as f:
+            for ex in exs:
+                f.write(json.dumps(ex) + "\n")
+    out = S.post_hoc_merge_topk(cfg)
+    assert os.path.relpath(out, str(tmp_path)) == m["merged_relpath"]
+    with open(out) as f:
+        assert [json.loads(line) for line in f] == m["merged"]
+
+
 def test_merge_ctxs_is_stable():
     from src.search import merge_ctxs
     mk = lambda tag, s: {"id": tag, "retrieval score": str(s)}
