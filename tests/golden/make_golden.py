@@ -215,6 +215,139 @@ def search_golden():
     print("search_golden ok:", [c["id"] for c in out["merge"]["merged"][2]["ctxs"]])
 
 
+def flat_indexer_golden():
+    """Host behaviour of the reference's OWN FlatIndexer class (src/indicies/flat.py), executed here with the test
+    double tests/fake_engine.py registered as the `faiss` module (the one import the file needs that the image
+    lacks; its surface is the subset of FAISS the class calls: IndexFlatIP / add / search / read_index / write_index,
+    arithmetic by the oracle).  Recorded: files written, the id map, the passage position map, search() returns, and
+    that a second construction loads instead of rebuilding.  Pins SURVEY 8 rows a1, a2, a5, a8 (Flat) of the host
+    mirror to the reference's behaviour, not to a reading of it."""
+    import pickle, tempfile
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        print("reference absent: flat_indexer_golden.json left as is")
+        return
+    tests_dir = os.path.dirname(OUT)
+    sys.path.insert(0, tests_dir)
+    import fake_engine
+    sys.modules["faiss"] = fake_engine
+    for m in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        sys.modules.pop(m)
+    sys.path.insert(0, ref)
+    import importlib
+    ref_flat = importlib.import_module("src.indicies.flat")
+    assert ref_flat.__file__.startswith(ref)
+    n_shards, per, d = 2, 400, 32
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "emb")); os.makedirs(os.path.join(tmp, "psg")); os.makedirs(os.path.join(tmp, "index"))
+        embs = []
+        for sh in range(n_shards):   # the same datastore tests/test_host_logic.py::write_datastore builds
+            e = o.synth_vectors(d, 6, 11, 100 + sh, 0.5, 0, per)
+            embs.append(e)
+            with open(os.path.join(tmp, "emb", f"passages_{sh:02d}.pkl"), "wb") as f:
+                pickle.dump((list(range(per)), e), f)
+            with open(os.path.join(tmp, "psg", f"raw_passages-{sh}-of-{n_shards}.pkl"), "wb") as f:
+                pickle.dump([{"text": f"shard {sh} chunk {c} é", "id": c} for c in range(per)], f)
+        kw = dict(embed_paths=[os.path.join(tmp, "emb", f"passages_{sh:02d}.pkl") for sh in (1, 0)],   # given order = id order
+                  index_path=os.path.join(tmp, "index", "index_Flat.faiss"),
+                  meta_file=os.path.join(tmp, "index", "index_Flat.faiss.meta"),
+                  passage_dir=os.path.join(tmp, "psg"),
+                  pos_map_save_path=os.path.join(tmp, "index", "passage_pos_id_map.pkl"), dimension=d)
+        ix = ref_flat.FlatIndexer(**kw)
+        q = np.concatenate([embs[0][5:6], embs[1][7:8], embs[1][399:400]], 0)
+        scores, passages, db_ids = ix.search(q, k=3)
+        files = sorted(os.listdir(os.path.join(tmp, "index")))
+        meta = pickle.load(open(kw["meta_file"], "rb"))
+        pos = pickle.load(open(kw["pos_map_save_path"], "rb"))
+        pos_rel = {str(sh): {str(c): [os.path.relpath(v[0], tmp), v[1]] for c, v in m.items() if c in (0, 1, 2, 399)} for sh, m in pos.items()}
+        mtime = os.path.getmtime(kw["index_path"])
+        ix2 = ref_flat.FlatIndexer(**kw)
+        s2, p2, d2 = ix2.search(q, k=3)
+        assert os.path.getmtime(kw["index_path"]) == mtime and (s2, p2, d2) == (scores, passages, db_ids)
+        psg_files = sorted(os.listdir(os.path.join(tmp, "psg")))
+    out = {"generated_by": "tests/golden/make_golden.py running /root/reference/src/indicies/flat.py::FlatIndexer with tests/fake_engine.py as `faiss`",
+           "datastore": {"n_shards": n_shards, "per": per, "d": d, "embed_order": [1, 0], "query_rows": [[0, 5], [1, 7], [1, 399]]},
+           "index_dir_files": files, "passage_dir_files": psg_files,
+           "meta_len": len(meta), "meta_head": meta[:3], "meta_at_400": meta[400], "meta_sha": sha(np.asarray(meta, dtype=np.int64)),
+           "pos_map_sample": pos_rel, "k": 3, "scores": scores, "passages": passages, "db_ids": db_ids,
+           "attrs": {"cuda": ix.cuda, "ntotal": int(ix.index.ntotal)}}
+    with open(os.path.join(OUT, "flat_indexer_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+    print("flat_indexer_golden ok:", db_ids[0], files)
+
+
+def indexer_facade_golden():
+    """The reference's OWN facade and backends — src/indicies/base.py::Indexer dispatching to FlatIndexer,
+    IVFFlatIndexer and IVFPQIndexer — executed on a small datastore with tests/fake_engine.py registered as `faiss`
+    and a two-line `omegaconf` module (ListConfig = list; the backends import the name, the code paths used here
+    never touch it).  numpy's global RNG is seeded before each construction so that the reference's
+    np.random.choice training sample (ivf_flat.py:132, ivf_pq.py:135) is reproducible; the mirror draws the same
+    sample under the same seed, so the whole pipeline — sample, train, add, file names, id maps, search() returns —
+    must coincide.  Pins SURVEY 8 rows a1-a5, a8, a9."""
+    import pickle, tempfile, types
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        print("reference absent: indexer_facade_golden.json left as is")
+        return
+    sys.path.insert(0, os.path.dirname(OUT))
+    import fake_engine
+    sys.modules["faiss"] = fake_engine
+    om = types.ModuleType("omegaconf"); om.ListConfig = list
+    sys.modules.setdefault("omegaconf", om)
+    for m in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        sys.modules.pop(m)
+    if ref in sys.path:
+        sys.path.remove(ref)
+    sys.path.insert(0, ref)
+    import importlib
+    ref_base = importlib.import_module("src.indicies.base")
+    assert ref_base.__file__.startswith(ref)
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    n_shards, per, d = 2, 400, 32
+    out = {"generated_by": "tests/golden/make_golden.py running /root/reference/src/indicies/base.py::Indexer (+ flat.py, ivf_flat.py, "
+                           "ivf_pq.py) with tests/fake_engine.py as `faiss`",
+           "datastore": {"n_shards": n_shards, "per": per, "d": d, "query_rows": [[0, 5], [1, 7], [1, 399]]},
+           "index_args": {"projection_size": d, "sample_train_size": 600, "ncentroids": 4, "probe": 4, "n_subquantizers": 4, "n_bits": 8},
+           "np_random_seed": 4242, "k": 3, "cases": []}
+    for index_type, shard_ids in (("Flat", [1, 0]), ("IVFFlat", [1, 0]), ("IVFPQ", [0, 1])):
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(os.path.join(tmp, "emb")); os.makedirs(os.path.join(tmp, "psg"))
+            embs = []
+            for sh in range(n_shards):   # = tests/test_host_logic.py::write_datastore
+                e = o.synth_vectors(d, 6, 11, 100 + sh, 0.5, 0, per)
+                embs.append(e)
+                with open(os.path.join(tmp, "emb", f"passages_{sh:02d}.pkl"), "wb") as f:
+                    pickle.dump((list(range(per)), e), f)
+                with open(os.path.join(tmp, "psg", f"raw_passages-{sh}-of-{n_shards}.pkl"), "wb") as f:
+                    pickle.dump([{"text": f"shard {sh} chunk {c} é", "id": c} for c in range(per)], f)
+            cfg = NS(datastore=NS(domain="unit",
+                                  embedding=NS(embedding_dir=os.path.join(tmp, "emb"), prefix="passages", passages_dir=os.path.join(tmp, "psg")),
+                                  index=NS(index_type=index_type, index_shard_ids=shard_ids, **out["index_args"])))
+            np.random.seed(out["np_random_seed"])
+            ix = ref_base.Indexer(cfg)
+            q = np.concatenate([embs[0][5:6], embs[1][7:8], embs[1][399:400]], 0)
+            scores, passages, db_ids = ix.search(q, k=3)
+            index_dir = None
+            for root, dirs, files in os.walk(os.path.join(tmp, "emb")):
+                if any(f.endswith(".faiss") for f in files):
+                    index_dir = root
+            meta_name = [f for f in os.listdir(index_dir) if f.endswith(".meta")][0]
+            meta = pickle.load(open(os.path.join(index_dir, meta_name), "rb"))
+            ds = ix.datastore
+            out["cases"].append({
+                "index_type": index_type, "index_shard_ids": shard_ids,
+                "index_dir": os.path.relpath(index_dir, tmp), "index_dir_files": sorted(os.listdir(index_dir)),
+                "meta_len": len(meta), "meta_head": meta[:2], "meta_at_400": meta[400], "meta_sha": sha(np.asarray(meta, dtype=np.int64)),
+                "ntotal": int(ds.index.ntotal), "nprobe": int(getattr(ds.index, "nprobe", 0)), "probe_attr": getattr(ds, "probe", None),
+                "scores": scores, "passages": passages, "db_ids": db_ids})
+            print("indexer_facade_golden", index_type, db_ids[0], sorted(os.listdir(index_dir)))
+    with open(os.path.join(OUT, "indexer_facade_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+
+
 if __name__ == "__main__":
     flat_case("flat_ip_d768", 768, 16, 4096, 32, 10, 0)
     flat_case("flat_l2_d64", 64, 16, 2048, 16, 5, 1)
@@ -225,3 +358,5 @@ if __name__ == "__main__":
     edge_cases()
     paths_golden()
     search_golden()
+    flat_indexer_golden()
+    indexer_facade_golden()

@@ -183,6 +183,83 @@ def test_search_driver_and_merge(tmp_path, orc, fake):
     assert os.path.getmtime(merged_path) == before
 
 
+def test_flat_indexer_matches_reference_class_golden(tmp_path, orc, fake):
+    """tests/golden/flat_indexer_golden.json records what the reference's own FlatIndexer class does on this datastore
+    (run with the same test-double engine standing in for faiss — tests/golden/make_golden.py).  The mirror class must
+    write the same files, build the same id map and position map, and return the same search() triple."""
+    import json
+    from src.indicies.flat import FlatIndexer
+    with open(os.path.join(GOLDEN, "flat_indexer_golden.json")) as f:
+        g = json.load(f)
+    tmp = str(tmp_path)
+    ds = g["datastore"]
+    embs = write_datastore(tmp, orc, n_shards=ds["n_shards"], per=ds["per"], d=ds["d"])
+    os.makedirs(os.path.join(tmp, "index"))
+    kw = dict(embed_paths=[os.path.join(tmp, "emb", f"passages_{s:02d}.pkl") for s in ds["embed_order"]],
+              index_path=os.path.join(tmp, "index", "index_Flat.faiss"),
+              meta_file=os.path.join(tmp, "index", "index_Flat.faiss.meta"),
+              passage_dir=os.path.join(tmp, "psg"),
+              pos_map_save_path=os.path.join(tmp, "index", "passage_pos_id_map.pkl"), dimension=ds["d"])
+    ix = FlatIndexer(**kw)
+    assert sorted(os.listdir(os.path.join(tmp, "index"))) == g["index_dir_files"]
+    assert sorted(os.listdir(os.path.join(tmp, "psg"))) == g["passage_dir_files"]
+    with open(kw["meta_file"], "rb") as f:
+        meta = pickle.load(f)
+    assert len(meta) == g["meta_len"] and meta[:3] == g["meta_head"] and meta[400] == g["meta_at_400"]
+    from util import sha
+    assert sha(np.asarray(meta, dtype=np.int64)) == g["meta_sha"]
+    with open(kw["pos_map_save_path"], "rb") as f:
+        pos = pickle.load(f)
+    for sh, m in g["pos_map_sample"].items():
+        for c, (rel, off) in m.items():
+            fn, got_off = pos[int(sh)][int(c)]
+            assert os.path.relpath(fn, tmp) == rel and got_off == off
+    q = np.concatenate([embs[s][r:r + 1] for s, r in ds["query_rows"]], 0)
+    scores, passages, db_ids = ix.search(q, k=g["k"])
+    assert passages == g["passages"] and db_ids == g["db_ids"]
+    assert np.allclose(scores, g["scores"], rtol=0, atol=1e-5)
+    assert int(ix.index.ntotal) == g["attrs"]["ntotal"]
+    mtime = os.path.getmtime(kw["index_path"])
+    ix2 = FlatIndexer(**kw)                                # loads, does not rebuild
+    assert os.path.getmtime(kw["index_path"]) == mtime
+    assert ix2.search(q, k=g["k"])[1:] == (passages, db_ids)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_indexer_matches_reference_facade_golden(tmp_path, orc, fake, case):
+    """tests/golden/indexer_facade_golden.json = the reference's own Indexer facade + FlatIndexer / IVFFlatIndexer /
+    IVFPQIndexer run on this datastore with the same test-double engine as `faiss` and numpy's RNG seeded (so the
+    unseeded training sample of ivf_flat.py:132 is reproducible).  The mirror, seeded the same way, must derive the same
+    index directory and file names, id map, engine state and search() triple."""
+    import json
+    from src.indicies.base import Indexer
+    with open(os.path.join(GOLDEN, "indexer_facade_golden.json")) as f:
+        g = json.load(f)
+    c = g["cases"][case]
+    tmp = str(tmp_path)
+    ds = g["datastore"]
+    embs = write_datastore(tmp, orc, n_shards=ds["n_shards"], per=ds["per"], d=ds["d"])
+    cfg = make_cfg(tmp, c["index_type"], c["index_shard_ids"], **g["index_args"])
+    np.random.seed(g["np_random_seed"])
+    ix = Indexer(cfg)
+    index_dir = os.path.join(tmp, c["index_dir"])
+    assert sorted(os.listdir(index_dir)) == c["index_dir_files"]
+    meta_name = [f for f in c["index_dir_files"] if f.endswith(".meta")][0]
+    with open(os.path.join(index_dir, meta_name), "rb") as f:
+        meta = pickle.load(f)
+    from util import sha
+    assert len(meta) == c["meta_len"] and meta[:2] == c["meta_head"] and meta[400] == c["meta_at_400"]
+    assert sha(np.asarray(meta, dtype=np.int64)) == c["meta_sha"]
+    d_ = ix.datastore
+    assert int(d_.index.ntotal) == c["ntotal"]
+    if c["index_type"] != "Flat":
+        assert int(d_.index.nprobe) == c["nprobe"] and d_.probe == c["probe_attr"]
+    q = np.concatenate([embs[s][r:r + 1] for s, r in ds["query_rows"]], 0)
+    scores, passages, db_ids = ix.search(q, k=g["k"])
+    assert db_ids == c["db_ids"] and passages == c["passages"]
+    assert np.allclose(scores, c["scores"], rtol=0, atol=1e-5)
+
+
 def test_search_driver_matches_reference_golden(tmp_path, fake):
     """tests/golden/search_golden.json was produced by RUNNING the reference's own add_passages_to_eval_data,
     get_search_output_path, get_merged_search_output_path and post_hoc_merge_topk (tests/golden/make_golden.py):
