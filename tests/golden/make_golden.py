@@ -210,9 +210,24 @@ def search_golden():
         merged = [json.loads(l) for l in open(merged_path)]
         out["merge"] = {"n_docs": 3, "index_shard_ids": [[0], [1], [2]], "shard_results": {str(k): v for k, v in shard_results.items()},
                         "merged_relpath": os.path.relpath(merged_path, tmp), "merged": merged}
+    # 4. the serving twin of the merge: api/serve_main_node.py:109-165 rerank_elements (pure Python), 3 shards x 4 queries
+    #    x 5 results with many equal scores: the order the GPU merge kernel / merge_topk_host must reproduce
+    api = "/root/reference/api/serve_main_node.py"
+    tree2 = ast.parse(open(api).read())
+    ns2 = {}
+    exec(compile(ast.Module(body=[n for n in tree2.body if isinstance(n, ast.FunctionDef) and n.name == "rerank_elements"],
+                            type_ignores=[]), api, "exec"), ns2)
+    rng = np.random.RandomState(7)
+    D = np.sort(rng.randint(0, 6, size=(3, 4, 5)).astype(np.float32) * 0.5, axis=2)[:, :, ::-1].copy()
+    I = rng.randint(0, 10 ** 6, size=(3, 4, 5)).astype(np.int64)
+    elems = [{"IDs": I[s_].tolist(), "passages": [[f"p{i}" for i in row] for row in I[s_].tolist()], "scores": D[s_].tolist()}
+             for s_ in range(3)]
+    rr = ns2["rerank_elements"](elems, k=5)
+    out["rerank_elements"] = {"D": D.tolist(), "I": I.tolist(), "k": 5, "IDs": rr["IDs"], "scores": rr["scores"],
+                              "passages_first_row": rr["passages"][0]}
     with open(os.path.join(OUT, "search_golden.json"), "w") as f:
         json.dump(out, f, indent=1, ensure_ascii=False)
-    print("search_golden ok:", [c["id"] for c in out["merge"]["merged"][2]["ctxs"]])
+    print("search_golden ok:", [c["id"] for c in out["merge"]["merged"][2]["ctxs"]], rr["scores"][0])
 
 
 def flat_indexer_golden():

@@ -270,6 +270,12 @@ def test_merge_kernel_matches_reference_rule(gpu, orc):
     e = load_golden("edge_cases")
     Do, Io = gpu.merge_topk(e["Dm"], e["Im"])
     assert np.array_equal(Io, e["Imo"]) and np.array_equal(Do, e["Dmo"])
+    import json, os
+    from util import GOLDEN
+    with open(os.path.join(GOLDEN, "search_golden.json")) as f:   # output of the reference's own rerank_elements
+        r = json.load(f)["rerank_elements"]
+    Dg, Ig = gpu.merge_topk(np.asarray(r["D"], np.float32), np.asarray(r["I"], np.int64))
+    assert Ig.tolist() == r["IDs"] and Dg.tolist() == r["scores"]
     rng = np.random.RandomState(0)
     D = np.sort(rng.randint(0, 9, size=(8, 33, 10)).astype(np.float32), axis=2)[:, :, ::-1].copy()
     I = rng.randint(0, 10 ** 9, size=(8, 33, 10)).astype(np.int64)

@@ -295,6 +295,21 @@ def test_search_driver_matches_reference_golden(tmp_path, fake):
         assert [json.loads(line) for line in f] == m["merged"]
 
 
+def test_merge_matches_reference_rerank_elements_golden(orc):
+    """search_golden.json["rerank_elements"] = output of the reference's own api/serve_main_node.py::rerank_elements on
+    3 shards x 4 queries x 5 results full of equal scores.  The oracle merge (what the GPU kernel is tested against) and
+    the host merge must give exactly that order."""
+    import json
+    sys.path.insert(0, os.path.join(REPO, "retrieval-scaling_amd"))
+    from sharded import merge_topk_host
+    with open(os.path.join(GOLDEN, "search_golden.json")) as f:
+        g = json.load(f)["rerank_elements"]
+    D, I = np.asarray(g["D"], np.float32), np.asarray(g["I"], np.int64)
+    for fn in (lambda: orc.merge_topk(D, I, 0), lambda: merge_topk_host(D, I, 0)):
+        Dm, Im = fn()
+        assert Im.tolist() == g["IDs"] and Dm.tolist() == g["scores"]
+
+
 def test_merge_ctxs_is_stable():
     from src.search import merge_ctxs
     mk = lambda tag, s: {"id": tag, "retrieval score": str(s)}
