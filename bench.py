@@ -241,6 +241,9 @@ def main():
     index.set_param("profile", 2)
     step(args.warmup)
     scanned = index.get_timing("scanned_vectors")
+    cand_keys = index.get_timing("cand_keys")          # keys that passed the in-kernel filter (this one step)
+    cand_keys_max = index.get_timing("cand_keys_max")
+    dbg_vals = {k: index.get_timing("dbg_" + k) for k in ("hit_blocks", "hit_clk", "loop_clk", "blocks")}
     index.set_param("profile", 0)
     launches_per_step = max(1.0, scan_launches / args.steps)
     scan_bytes = scanned * args.m / launches_per_step          # algorithmic bytes of ONE launch
@@ -332,6 +335,8 @@ def main():
                                  "kernel is bound by LDS table gathers, not HBM (DESIGN.md 4.1)"},
             "stage_ms_per_step": stage_ms,
             "certificate_fallback_fraction": fallbacks,
+            "filter_survivors_per_query": {"mean": round(cand_keys / max(1, nq), 1), "max": cand_keys_max},
+            "dbg": dbg_vals,
             "ab_exact_kernels_same_process": ab,
             "cpu_baseline": cpu,
             "cpu_parity_ids_and_scores_bit_exact": parity,

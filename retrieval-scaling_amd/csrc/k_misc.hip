@@ -235,11 +235,8 @@ void launch_copy_lists(int nlist, const int64_t* old_base, const int64_t* new_ba
 //   byte(slab s, granule g, lane v, b) = codes[(s*Mpad/CB + g) * 64*CB + v*CB + b],  m = g*CB + b
 // so that the scan's lane v reads CB contiguous bytes and the wave reads 64*CB contiguous bytes.
 // ---------------------------------------------------------------------------------------
-__device__ inline int64_t pq_byte_addr(int64_t row, int m, int Mpad, int CB) {
-    int64_t slab = row >> 6; int v = (int)(row & 63);
-    int g = m / CB, b = m - g * CB;
-    return (slab * (Mpad / CB) + g) * (int64_t)(64 * CB) + v * CB + b;
-}
+// (CB = 0: the rotated 16-vector-block layout — both are pq_code_addr in rsx_internal.h)
+__device__ inline int64_t pq_byte_addr(int64_t row, int m, int Mpad, int CB) { return pq_code_addr(row, m, Mpad, CB); }
 __global__ void k_pq_export(const uint8_t* codes, int64_t base_row, int64_t n, int M, int Mpad, int CB, uint8_t* out) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = n * M;

@@ -158,28 +158,6 @@ struct PQScan2Args {
     int nlist; int max_items;
 };
 
-// Work-item decode shared by the list-major scans.  Items are ordered (list, tile, group) so that the
-// query groups of one list-tile (same codes) are adjacent; XCD c takes the contiguous item range
-// [c*TI/8, (c+1)*TI/8) (workgroups are dispatched round-robin over the 8 XCDs, block b -> XCD b % 8, each
-// with a private 4 MiB L2), so those groups run on ONE XCD close together in time and the tile is
-// fetched from HBM once.  Placement only affects speed, never results.
-__device__ inline bool pq_decode_item(const int32_t* item_off, const int32_t* group_off, int total_items, int nlist,
-                                      int& l, int& gi, int& tile) {
-    const int per_xcd = (total_items + 7) >> 3;
-    const int ix = (int)(blockIdx.x >> 3);
-    if (ix >= per_xcd) return false;
-    const int item = (int)(blockIdx.x & 7) * per_xcd + ix;
-    if (item >= total_items) return false;
-    int lo = 0, hi = nlist;  // largest l with item_off[l] <= item
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (item_off[mid] <= item) lo = mid; else hi = mid; }
-    l = lo;
-    const int ng = group_off[l + 1] - group_off[l];
-    const int r = item - item_off[l];
-    tile = r / ng;
-    gi = r - tile * ng;
-    return true;
-}
-
 template <int NCH, int VPL>
 __global__ __launch_bounds__(1024) void k_pq_scan2(PQScan2Args A) {
     extern __shared__ __attribute__((aligned(16))) float2 pq_lut2_s[];
@@ -322,11 +300,10 @@ int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int3
 // by a(.), k_finalize re-scores them EXACTLY (sequential fp32 table sum, = oracle) and certifies:
 // if a(K'-th candidate) + eps_q < s(k-th best candidate) no excluded vector can reach the top k, so
 // the result equals the exact search; otherwise the query is flagged and re-run with k_pq_scan2.
-struct PQQParam { float scale, bias, eps, pad; };
 
 // Unfused form (tables too large for LDS): quantises an fp32 table k_pq_lut already wrote to HBM.
 __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int Mpad, const float* probe_dis0, int nprobe,
-                                                 uint8_t* lut8, PQQParam* qp) {
+                                                 uint8_t* lut8, PQQParam* qp, int transposed) {
     __shared__ float s_mn[256], s_red[8];
     const int64_t q = blockIdx.x;
     const int c = threadIdx.x, lane = c & 63, w = c >> 6;
@@ -355,7 +332,8 @@ __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int 
         float mn = s_mn[m];
         float u = rintf((v - mn) * inv);
         u = fminf(fmaxf(u, 0.0f), 255.0f);
-        lut8[(q * Mpad + m) * 256 + c] = (uint8_t)u;
+        if (transposed) lut8[(q * 256 + c) * Mpad + m] = (uint8_t)u;   // [q][code][m]: the rotated-layout scans
+        else lut8[(q * Mpad + m) * 256 + c] = (uint8_t)u;
         float err = fabsf(v - (mn + scale * u));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
@@ -383,7 +361,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int 
 template <int DSUB>   // 8: two float4 loads per codeword; 0: generic dsub
 __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, const float* codebooks, int dsub, int M,
                                                   int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
-                                                  PQQParam* qp) {
+                                                  PQQParam* qp, int transposed) {
     extern __shared__ float sm_lut8f[];
     float* T = sm_lut8f;                 // [Mpad][256]
     float* s_q = T + Mpad * 256;         // [M*dsub]
@@ -439,7 +417,10 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
             pk |= (uint32_t)u << (8 * j);
             err = fmaxf(err, fabsf(vv[j] - (mn + scale * u)));
         }
-        *(uint32_t*)&lut8[(q * Mpad + m) * 256 + lane * 4] = pk;
+        if (transposed) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) lut8[(q * 256 + lane * 4 + j) * Mpad + m] = (uint8_t)(pk >> (8 * j));
+        } else *(uint32_t*)&lut8[(q * Mpad + m) * 256 + lane * 4] = pk;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
         if (lane == 0) s_err[m] = err;
@@ -472,7 +453,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
 #define LT_QC 32
 template <int PASS>
 __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq, const float* codebooks, int M, int Mpad,
-                                                      int64_t nq, float* mnmx, float* errb, uint8_t* lut8) {
+                                                      int64_t nq, float* mnmx, float* errb, uint8_t* lut8, int transposed) {
     __shared__ float s_q[LT_QC * LT_MB * 8];     // the tile's query slices
     __shared__ float s_scale[2 * LT_QC];         // scale, 1 / scale
     __shared__ float s_mn[LT_QC * LT_MB];
@@ -533,12 +514,13 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
             } else {
                 const float mn = s_mn[qi * LT_MB + mi], scale = s_scale[qi], inv = s_scale[LT_QC + qi];
                 float err = 0.0f;
-                uint8_t* o = lut8 + (q * Mpad + m) * 256 + lane;
+                uint8_t* o = transposed ? lut8 + (q * 256 + lane) * Mpad + m : lut8 + (q * Mpad + m) * 256 + lane;
+                const int ostep = transposed ? 64 * Mpad : 64;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float u = rintf((v[j] - mn) * inv);
                     u = fminf(fmaxf(u, 0.0f), 255.0f);
-                    o[64 * j] = (uint8_t)u;
+                    o[ostep * j] = (uint8_t)u;
                     err = fmaxf(err, fabsf(v[j] - (mn + scale * u)));
                 }
 #pragma unroll
@@ -584,19 +566,20 @@ size_t pq_lut8_tiled_ws(int64_t nq, int Mpad) { return (size_t)nq * Mpad * 3 * 4
 size_t pq_lut8_fused_lds(int M, int Mpad, int dsub) { return ((size_t)Mpad * 256 + (size_t)M * dsub + 3 * (size_t)Mpad) * 4; }
 
 void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
-                    int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8, void* qparam, void* ws, hipStream_t st) {
+                    int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8, void* qparam, void* ws, int transposed,
+                    hipStream_t st) {
     if (nq <= 0) return;
     if (lut32) {
         hipLaunchKernelGGL(k_pq_lut8, dim3((unsigned)nq), dim3(256), 0, st, lut32, M, Mpad, probe_dis0, nprobe, lut8,
-                           (PQQParam*)qparam);
+                           (PQQParam*)qparam, transposed);
         return;
     }
     if (ws && dsub == 8) {   // tiled: codebook slices shared by 32 queries
         float* mnmx = reinterpret_cast<float*>(ws);
         float* errb = mnmx + (size_t)nq * Mpad * 2;
         dim3 grid((unsigned)((Mpad + LT_MB - 1) / LT_MB), (unsigned)((nq + LT_QC - 1) / LT_QC));
-        hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8);
-        hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8);
+        hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
+        hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
         hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)nq), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0, nprobe,
                            (PQQParam*)qparam);
         return;
@@ -607,7 +590,7 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
     bool& done = dsub == 8 ? attr8 : attr0;
     if (!done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), lds, st, Q32, ldq, codebooks, dsub, M, Mpad, probe_dis0, nprobe,
-                       lut8, (PQQParam*)qparam);
+                       lut8, (PQQParam*)qparam, transposed);
 }
 
 // LDS byte offset (code * 4) of byte K of w in ONE instruction: the SDWA form of v_lshlrev selects the
@@ -632,16 +615,6 @@ __device__ __forceinline__ uint32_t code_mul(uint32_t w, uint32_t stride) {
     if (K == 3) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(stride), "v"(w));
     return r;
 }
-
-struct PQScan8Args {
-    PQScanArgs b;
-    const uint8_t* lut8; const PQQParam* qp;
-    const int32_t* pairs_sorted; const int32_t* pair_off; const int32_t* group_off; const int32_t* total_groups;
-    const int32_t* item_off; const int32_t* total_items;
-    int nlist; int max_items;
-    // filtered output (FILTER = true): keys > tau_key[q] are appended to cand[q][0..cap)
-    const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
-};
 
 // VAR != 0 are MEASUREMENT-ONLY variants (wrong results; selected with RSX_SCAN8_VARIANT for the cost split
 // in DESIGN.md): 1 = gathers kept, mask/shift accumulate replaced by one add; 2 = no LDS gather at all.
@@ -891,6 +864,8 @@ __global__ __launch_bounds__(256) void k_pq_encode(const void* x, int x_f16, int
         }
         if (plain_out) {
             if (valid) plain_out[i * Mpad + m] = (uint8_t)code;
+        } else if (CB == 0) {      // rotated layout: consecutive m of a vector are not contiguous
+            if (valid) codes[pq_code_addr(drow, m, Mpad, 0)] = (uint8_t)code;
         } else {
             packed |= code << (8 * (m & 3));
             if ((m & 3) == 3) {

@@ -260,6 +260,42 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
     const float dis0 = a.probe_dis0[q * a.nprobe + j0];
     const int64_t col = a.seg_start[q * (a.nprobe + 1) + j0];
     const int nch = a.Mpad >> 4;
+    if (a.CB == 0) {
+        // rotated layout: lut8 is [q][code][M]; lane (g, i) of a wave sums the entries of its 16 (+8) bytes of
+        // vector i of a 16-vector block, the four lanes of a vector are added with two shuffles
+        const int M = a.Mpad, NF = M >> 6, NH = (M >> 5) & 1;
+        const int g = lane >> 4, i = lane & 15;
+        const int nblk = nslab * 4;
+        for (int b = w; b < nblk; b += 16) {
+            const uint8_t* bp = a.codes + ((a.list_base[l] >> 4) + b) * (int64_t)(16 * M);
+            uint32_t acc = 0;
+            for (int p = 0; p < NF; p++) {
+                const uint4 c = *reinterpret_cast<const uint4*>(bp + p * 1024 + lane * 16);
+                const uint32_t wds[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int s2 = 0; s2 < 16; s2++) {
+                    const int m = 64 * p + 16 * g + ((i + s2) & 15);
+                    acc += tab[((wds[s2 >> 2] >> (8 * (s2 & 3))) & 255u) * M + m];
+                }
+            }
+            if (NH) {
+                const uint2 c = *reinterpret_cast<const uint2*>(bp + NF * 1024 + lane * 8);
+                const uint32_t wds[2] = {c.x, c.y};
+#pragma unroll
+                for (int s2 = 0; s2 < 8; s2++) {
+                    const int m = 64 * NF + 16 * (g & 1) + ((i + s2 + 8 * (g >> 1)) & 15);
+                    acc += tab[((wds[s2 >> 2] >> (8 * (s2 & 3))) & 255u) * M + m];
+                }
+            }
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            if (g == 0) {
+                const int64_t pos = (int64_t)b * 16 + i;
+                const float sc = dis0 + __fmaf_rn(scale, (float)acc, bias);
+                keys[pos] = (pos < len) ? make_key(sc, (uint32_t)(col + pos)) : 0ull;
+            }
+        }
+    } else
     for (int s = w; s < nslab; s += 16) {
         const uint8_t* sp = a.codes + ((a.list_base[l] >> 6) + s) * (int64_t)(64 * a.Mpad) + lane * 16;
         uint32_t acc = 0;
@@ -578,6 +614,41 @@ __device__ inline float pq_exact_sum(const uint8_t* sp, int v, int M, const floa
     return sum;
 }
 
+// Rotated layout (CB = 0): the M code bytes of a vector through pq_code_addr, eight at a time so that the
+// byte -> table-entry loads of different m overlap; summed in m order like the granule form.
+__device__ inline float pq_exact_sum_rot(const uint8_t* codes, int64_t row, int M, const float* T, const float* qv,
+                                         const float* codebooks, int dsub) {
+    float sum = 0.0f;
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        uint32_t code[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) code[j] = codes[pq_code_addr(row, m0 + j, M, 0)];
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int m = m0 + j;
+            if (T) {
+                t[j] = T[m * 256 + code[j]];
+            } else {
+                const float* qs = qv + m * dsub;
+                const float* cw = codebooks + ((int64_t)m * 256 + code[j]) * dsub;
+                float e = 0.0f;
+                if (dsub == 8) {
+                    float4 x = ((const float4*)cw)[0], y = ((const float4*)cw)[1];
+                    e = __fmaf_rn(qs[0], x.x, e); e = __fmaf_rn(qs[1], x.y, e); e = __fmaf_rn(qs[2], x.z, e); e = __fmaf_rn(qs[3], x.w, e);
+                    e = __fmaf_rn(qs[4], y.x, e); e = __fmaf_rn(qs[5], y.y, e); e = __fmaf_rn(qs[6], y.z, e); e = __fmaf_rn(qs[7], y.w, e);
+                } else {
+                    for (int tt = 0; tt < dsub; tt++) e = __fmaf_rn(qs[tt], cw[tt], e);
+                }
+                t[j] = e;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) sum += t[j];
+    }
+    return sum;
+}
+
 __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t fin_buf[];
     const int KP = a.KP;
@@ -624,7 +695,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
             const float dis0 = a.probe_dis0[q * a.nprobe + lo];
             const int64_t slab = row >> 6; const int v = (int)(row & 63);
             const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-            const float sum = a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
+            const float sum = a.CB == 0 ? pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub)
+                            : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                          : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
             sord[c] = f2ord((dis0 + sum) + 0.0f);
         }

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -120,7 +121,8 @@ static void rand_perm(int64_t n, uint64_t seed, std::vector<int64_t>& perm) {
 // ---------------------------------------------------------------------------------------
 struct rsx_index {
     int kind = 0, d = 0, metric = 0, device = 0;
-    int nlist = 1, M = 0, nbits = 8, Mpad = 0, CB = 16, dsub = 0;
+    int nlist = 1, M = 0, nbits = 8, Mpad = 0, CB = 16, dsub = 0;   // CB: code layout (rsx_internal.h), 0 = rotated
+    int CB_granule = 16;
     int nprobe = 1;
     bool trained = false;
     int64_t ntotal = 0;
@@ -159,7 +161,7 @@ struct rsx_index {
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc;
     std::map<std::string, double> timing;
 
     int row_align() const { return kind == KIND_IVFPQ ? 64 : (kind == KIND_FLAT ? 128 : 64); }
@@ -307,6 +309,11 @@ static rsx_index* create_common(int kind, int d, int nlist, int M, int nbits, in
             int nch = h->Mpad / 16;
             if (!(nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8)) h->CB = 4;
         }
+        // M in {32, 64, 96, 128}: the rotated layout (conflict-free table gathers, k_pq_rot.hip) unless RSX_PQ_LAYOUT=0;
+        // rsx_set_param "pq_layout" switches an EMPTY index between the two
+        h->CB_granule = h->CB;
+        const char* e = getenv("RSX_PQ_LAYOUT");
+        if (pq_rot_applies(M) && !(e && atoi(e) == 0)) h->CB = 0;
         if ((size_t)h->Mpad * 1024 > 160 * 1024) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: M = %d needs more than 160 KiB of LDS for the look-up table", M);
     }
     HIPCHECK(hipSetDevice(device));
@@ -674,7 +681,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     StageTimer tm(h, allow_fast ? "" : "fb_");
     const int d = h->d, ld = h->ld;
     // IVFPQ fast path: needs the 16-byte-granule layout, 16-bit integer sums, and K' <= 4096
-    bool fast = allow_fast && h->kind == KIND_IVFPQ && h->pq_fast != 0 && h->scan_kernel == 0 && h->CB == 16 &&
+    const bool rot = h->kind == KIND_IVFPQ && h->CB == 0;
+    bool fast = allow_fast && h->kind == KIND_IVFPQ && h->pq_fast != 0 && h->scan_kernel == 0 && (h->CB == 16 || rot) &&
                 h->M * 255 < 65536;
     int KP, BUF;
     kp_for(h, k, fast, KP, BUF);
@@ -850,13 +858,17 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             void* lut_ws = nullptr;
             if (fused_lut && h->dsub == 8 && h->lut_tiled != 0) { h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad)); lut_ws = h->w_lutws.p; }
             launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
-                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, h->st);
+                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st);
             tm.mark("lut8");
+            auto rot_desc = [&](int64_t items) -> void* {   // work-item descriptors of the rotated-layout scan
+                h->w_itemdesc.ensure((size_t)pq_scan_rot_grid(items) * sizeof(PQItemDesc));
+                return h->w_itemdesc.p;
+            };
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             int vpl = 8;
-            if (h->scan_chunk > 0) vpl = std::max(1, std::min(16, h->scan_chunk / 1024));
+            if (h->scan_chunk > 0) vpl = std::max(1, std::min(rot ? 64 : 16, h->scan_chunk / 1024));
             else while (vpl > 1 && (pairs / 4 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
-            if (vpl != 16 && vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
+            if (vpl != 64 && vpl != 32 && vpl != 16 && vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
             const int tile_rows = 64 * 16 * vpl;
             h->w_pairs.ensure((size_t)(pairs + 5 * (size_t)(nlist + 1) + 8) * 4);
             int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
@@ -891,13 +903,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             if (fused_pre) {
                 cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
-                h->w_candcnt.ensure((size_t)nq * 8);
+                h->w_candcnt.ensure((size_t)nq * 8 + 64);
+                HIPCHECK(hipMemsetAsync((char*)h->w_candcnt.p + (size_t)nq * 8, 0, 64, h->st));
                 PQPrepassArgs pa{};
                 pa.codes = h->data.as<uint8_t>(); pa.list_base = h->d_base.as<int64_t>(); pa.list_len = h->d_len.as<int64_t>();
                 pa.probe_list = h->w_probelist.as<int32_t>(); pa.probe_dis0 = h->w_dis0.as<float>();
                 pa.seg_start = h->w_segstart.as<int64_t>();
                 pa.lut8 = h->w_lut8.as<uint8_t>(); pa.qparam = h->w_qparam.as<float>();
-                pa.nprobe = nprobe; pa.Mpad = h->Mpad; pa.pre_rows = pre_rows; pa.KP = KP;
+                pa.nprobe = nprobe; pa.Mpad = h->Mpad; pa.pre_rows = pre_rows; pa.KP = KP; pa.CB = h->CB;
                 pa.state = state; pa.cand_cnt = h->w_candcnt.as<unsigned long long>();
                 launch_pq_prepass(pa, nq, h->st);
                 done = true;
@@ -906,10 +919,12 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    pairs_sorted, h->d_len.as<int64_t>(), pre_rows, item_off, total_items, nprobe, 0,
                                    filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
                 tm.mark("group");
-                done = launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                       total_groups, item_off, total_items, nlist,
-                                       filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows),
-                                       filtered ? pre_vpl : vpl, h->st) == 0;
+                const int64_t mi = filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows);
+                done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
+                                                 total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
+                                                 nullptr, 0, nullptr, nullptr, 0, rot_desc(mi), h->st)
+                            : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
+                                              total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
             }
             if (done && filtered) {
                 tm.mark("scan0");
@@ -931,11 +946,16 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                    h->st);
                 tm.mark("group");
-                done = launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                              total_groups, item_off, total_items, nlist,
-                                              max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
-                                              h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                              h->st) == 0;
+                done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
+                                                 total_groups, item_off, total_items, nlist,
+                                                 max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
+                                                 h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
+                                                 rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows)), h->st)
+                            : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
+                                                     total_groups, item_off, total_items, nlist,
+                                                     max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
+                                                     h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
+                                                     h->st)) == 0;
             }
             if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
         }
@@ -973,7 +993,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             }
             a.slabs_per_chunk = (int)spc;
             a.max_chunks = (int)((max_slabs + spc - 1) / spc);
-            if (launch_pq_scan(a, h->st) != 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ scan: no kernel for M=%d", h->M);
+            if ((rot ? launch_pq_scan_rot_exact(a, h->st) : launch_pq_scan(a, h->st)) != 0)
+                RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ scan: no kernel for M=%d", h->M);
         }
         h->timing[allow_fast ? "scan_launches" : "fb_scan_launches"] += 1;
         tm.mark("scan");
@@ -1047,6 +1068,18 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             launch_list_scan(a, h->st);
             tm.mark("scan");
         }
+    }
+    if (filtered && h->profile >= 2) {   // diagnostics: keys that passed the in-kernel filter
+        std::vector<unsigned long long> cnts((size_t)nq);
+        HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));
+        double tot = 0, mx = 0;
+        for (auto c : cnts) { tot += (double)c; mx = std::max(mx, (double)c); }
+        h->timing["cand_keys"] += tot; h->timing["cand_keys_max"] = std::max(h->timing["cand_keys_max"], mx);
+        unsigned long long dbg[8];
+        HIPCHECK(hipMemcpy(dbg, (char*)h->w_candcnt.p + (size_t)nq * 8, 64, hipMemcpyDeviceToHost));
+        h->timing["dbg_hit_blocks"] = (double)dbg[0]; h->timing["dbg_hit_clk"] = (double)dbg[1];
+        h->timing["dbg_loop_clk"] = (double)dbg[2]; h->timing["dbg_blocks"] = (double)dbg[3];
     }
     // 3. per-query k-selection over the score rows
     if (filtered) {
@@ -1590,6 +1623,7 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
         else if (s == "code_size") *out = (h->kind == KIND_IVFPQ) ? h->M : (int64_t)h->d * (h->storage_f16 ? 2 : 4);
         else if (s == "device") *out = h->device;
         else if (s == "max_k") *out = 2048;
+        else if (s == "pq_layout") *out = (h->kind == KIND_IVFPQ && h->CB == 0) ? 1 : 0;
         else if (s == "hbm_bytes") *out = (int64_t)(h->data.bytes + h->ids.bytes + h->norms.bytes);
         else RSX_THROW(RSX_ERR_INVALID, "unknown property '%s'", key);
     });
@@ -1609,6 +1643,12 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
             if (h->ntotal + h->ndropped > 0) RSX_THROW(RSX_ERR_INVALID, "%s must be set before the first add", key);
             if (s == "add_list_mod") { if (value < 1) RSX_THROW(RSX_ERR_INVALID, "add_list_mod >= 1"); h->add_list_mod = (int)value; h->add_list_rem = 0; }
             else { if (value < 0 || value >= h->add_list_mod) RSX_THROW(RSX_ERR_INVALID, "0 <= add_list_rem < add_list_mod"); h->add_list_rem = (int)value; }
+        }
+        else if (s == "pq_layout") {
+            if (h->kind != KIND_IVFPQ) RSX_THROW(RSX_ERR_UNSUPPORTED, "pq_layout: IVFPQ only");
+            if (h->ntotal + h->ndropped > 0) RSX_THROW(RSX_ERR_INVALID, "pq_layout must be set before the first add");
+            if ((int)value == 1 && !pq_rot_applies(h->M)) RSX_THROW(RSX_ERR_UNSUPPORTED, "pq_layout=1 (rotated) needs M in {32, 64, 96, 128}");
+            h->CB = (int)value == 1 ? 0 : h->CB_granule;
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;

@@ -31,6 +31,35 @@ __host__ __device__ inline float key_score(uint64_t k) { return ord2f((uint32_t)
 
 enum { KIND_FLAT = 0, KIND_IVFFLAT = 1, KIND_IVFPQ = 2 };
 
+// ---------------------------------------------------------------------------------------
+// IVF-PQ code layouts (CB = bytes of one vector that sit together):
+//   CB = 16 / 4 ("granule"): slab of 64 vectors, byte(slab, granule g, lane v, b) = (slab*Mpad/CB + g)*64*CB + v*CB + b,
+//             m = g*CB + b — every lane of a wave holds the SAME sub-quantiser at each step.
+//   CB = 0 ("rotated", M % 32 == 0, M <= 128): block of 16 vectors = 16*M bytes; a wave lane (g, i) = (lane >> 4, lane & 15)
+//             owns vector i of the block and reads, per 64-sub-quantiser phase p, 16 contiguous bytes at
+//             p*1024 + lane*16 (byte s: m = 64p + 16g + ((i + s) & 15)) and, for a trailing 32-sub-quantiser phase, 8
+//             contiguous bytes at NF*1024 + lane*8 (byte s: m = 64NF + 16(g & 1) + ((i + s + 8(g >> 1)) & 15)).
+//             At every step the 32 lanes of a half-wave hold 32 different m % 32, so a table laid out [code][m]
+//             (bank = m % 32) is gathered without a single LDS bank conflict whatever the codes are (k_pq_scan_rot).
+// Lists start on 64-vector boundaries in both layouts and a 64-vector slab is 64*Mpad bytes in both.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline int64_t pq_code_addr(int64_t row, int m, int Mpad, int CB) {
+    if (CB != 0) {
+        const int64_t slab = row >> 6; const int v = (int)(row & 63);
+        const int g = m / CB, b = m - g * CB;
+        return (slab * (Mpad / CB) + g) * (int64_t)(64 * CB) + v * CB + b;
+    }
+    const int64_t base = (row >> 4) * (int64_t)(16 * Mpad);
+    const int i = (int)(row & 15), NF = Mpad >> 6;
+    if (m < 64 * NF) {
+        const int p = m >> 6, mm = m & 63, g = mm >> 4, s = ((mm & 15) - i) & 15;
+        return base + p * 1024 + (16 * g + i) * 16 + s;
+    }
+    const int mm = m - 64 * NF, t = ((mm & 15) - i) & 15, g = (mm >> 4) + 2 * (t >> 3), s = t & 7;
+    return base + NF * 1024 + (16 * g + i) * 8 + s;
+}
+__host__ __device__ inline bool pq_rot_applies(int M) { return M % 32 == 0 && M >= 32 && M <= 128; }
+
 // Inverted-list directory on the device (one entry per list; Flat uses a single list 0).
 //   base : first storage row of the list (PQ: multiple of 64 = slab aligned; flat rows: of 16)
 //   len  : vectors in the list
@@ -139,7 +168,8 @@ size_t pq_lut8_fused_lds(int M, int Mpad, int dsub);
 void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
                     int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
                     void* qparam /* [nq] {scale, bias, eps, pad} */,
-                    void* ws /* pq_lut8_tiled_ws(nq, Mpad) bytes -> tiled build (dsub 8), or null */, hipStream_t st);
+                    void* ws /* pq_lut8_tiled_ws(nq, Mpad) bytes -> tiled build (dsub 8), or null */,
+                    int transposed /* 0: lut8 [nq][Mpad][256]; 1: [nq][256][Mpad] (rotated-layout scans) */, hipStream_t st);
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad);
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
                     const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
@@ -151,6 +181,57 @@ int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void*
                            const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                            const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
                            int cand_cap, hipStream_t st);
+// shared by the list-major IVF-PQ scans (k_pq.hip, k_pq_rot.hip)
+struct PQQParam { float scale, bias, eps, pad; };
+struct PQScan8Args {
+    PQScanArgs b;
+    const uint8_t* lut8; const PQQParam* qp;
+    const int32_t* pairs_sorted; const int32_t* pair_off; const int32_t* group_off; const int32_t* total_groups;
+    const int32_t* item_off; const int32_t* total_items;
+    int nlist; int max_items;
+    // filtered output (FILTER = true): keys > tau_key[q] are appended to cand[q][0..cap)
+    const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
+    const struct PQItemDesc* item_desc;   // k_pq_scan_rot: one descriptor per launched workgroup (launch_pq_item_desc), or null
+};
+// Work item of a list-major scan, resolved ahead of the scan launch so that a workgroup starts from ONE 32-byte load
+// instead of a 12-step binary search over item_off and three more dependent loads (measured: ~4 us per work item with
+// one workgroup resident per CU).  Indexed by blockIdx.x, XCD placement (pq_decode_item's mapping) already applied.
+struct PQItemDesc { int32_t l, tile, pair0, np; int64_t len, base_row; };   // l < 0: no work for this workgroup
+void launch_pq_item_desc(const int32_t* item_off, const int32_t* group_off, const int32_t* pair_off, const int32_t* total_items,
+                         const int64_t* list_base, const int64_t* list_len, int nlist, int group_size, int64_t grid,
+                         PQItemDesc* desc, hipStream_t st);
+
+// Work-item decode shared by the list-major scans.  Items are ordered (list, tile, group) so that the
+// query groups of one list-tile (same codes) are adjacent; XCD c takes the contiguous item range
+// [c*TI/8, (c+1)*TI/8) (workgroups are dispatched round-robin over the 8 XCDs, block b -> XCD b % 8, each
+// with a private 4 MiB L2), so those groups run on ONE XCD close together in time and the tile is
+// fetched from HBM once.  Placement only affects speed, never results.
+__device__ inline bool pq_decode_item(const int32_t* item_off, const int32_t* group_off, int total_items, int nlist,
+                                      int& l, int& gi, int& tile) {
+    const int per_xcd = (total_items + 7) >> 3;
+    const int ix = (int)(blockIdx.x >> 3);
+    if (ix >= per_xcd) return false;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + ix;
+    if (item >= total_items) return false;
+    int lo = 0, hi = nlist;  // largest l with item_off[l] <= item
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (item_off[mid] <= item) lo = mid; else hi = mid; }
+    l = lo;
+    const int ng = group_off[l + 1] - group_off[l];
+    const int r = item - item_off[l];
+    tile = r / ng;
+    gi = r - tile * ng;
+    return true;
+}
+
+// rotated-layout (CB = 0) scans: k_pq_rot.hip.  lut8 is TRANSPOSED there: [nq][256][M] (see launch_pq_lut8's `transposed`)
+int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qparam, const int32_t* pairs_sorted,
+                       const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
+                       const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
+                       const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
+                       int cand_cap, void* item_desc_ws /* pq_scan_rot_grid(max_items) * sizeof(PQItemDesc) bytes */, hipStream_t st);
+inline int64_t pq_scan_rot_grid(int64_t max_items) { return (max_items + 7) & ~(int64_t)7; }
+// exact per-(query, list) scan of the rotated layout (fp32 table, sequential sums = oracle bits): fallback / A-B path
+int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st);
 // codes for rows of a batch: residual vs centroid[assign] (centroids may be null -> no residual).
 // plain_out != null: write [n, Mpad] row-major instead of the slab layout (training / export).
 void launch_pq_encode(const void* x, int x_f16, int64_t n, int ldx, int d, int M, int Mpad, int CB,
@@ -180,7 +261,7 @@ struct PQPrepassArgs {
     const uint8_t* codes; const int64_t* list_base; const int64_t* list_len;
     const int32_t* probe_list; const float* probe_dis0; const int64_t* seg_start;
     const uint8_t* lut8; const float* qparam;   // [nq][Mpad][256] u8 tables; [nq] {scale, bias, eps, pad}
-    int nprobe; int Mpad; int pre_rows; int KP;
+    int nprobe; int Mpad; int pre_rows; int KP; int CB;   // CB = 0: rotated layout, lut8 transposed
     uint64_t* state; unsigned long long* cand_cnt;
 };
 void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st);

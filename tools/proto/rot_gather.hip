@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t lds_rd(uint32_t addr) {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)addr);
 }
 
-template <int MODE, bool OUT>
+template <int MODE, bool OUT, int VAR = 0>
 __global__ __launch_bounds__(1024) void k_rot(const uint8_t* __restrict__ codes, int64_t ntiles_mod,
                                               const uint32_t* __restrict__ img /* LDS image */, int thr, int nblk,
                                               int* __restrict__ out /* optional [tile][512][16][4] */,
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void k_rot(const uint8_t* __restrict__ codes,
                 gv[16 + s] = __builtin_amdgcn_perm(cw[4 + (s >> 2)], RB[s / 3], sel);
             }
             __builtin_amdgcn_sched_barrier(0);
-            {   // the slot's code registers are dead now: refill them in place (clamped, branch-free)
+            if (!(VAR & 4)) {   // the slot's code registers are dead now: refill them in place (clamped, branch-free)
                 int bn = b + 16 * D; bn = bn < nblk ? bn : nblk - 1;
                 const uint8_t* bp = tp + (int64_t)bn * BLK_BYTES;
                 ca[dd] = *reinterpret_cast<const uint4*>(bp + lane * 16);
@@ -118,14 +118,118 @@ __global__ __launch_bounds__(1024) void k_rot(const uint8_t* __restrict__ codes,
             __builtin_amdgcn_sched_barrier(0);
             const int thr_b = b < nblk ? mythr : 0x7fffffff;
 #pragma unroll
-            for (int s = 0; s < 24; s++) gv[s] = lds_rd(gv[s]);
+            for (int s = 0; s < 24; s++) if (!(VAR & 2)) gv[s] = lds_rd(gv[s]);
             v4i C = {0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < 6; t++) {
                 const v4i A = {(int)gv[4 * t], (int)gv[4 * t + 1], (int)gv[4 * t + 2], (int)gv[4 * t + 3]};
-                C = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, Bm, C, 0, 0, 0);
+                if (VAR & 1) { C[0] += A[0]; C[1] += A[1]; C[2] += A[2]; C[3] += A[3]; }
+                else if (VAR & 8) { v4i Z = {0, 0, 0, 0}; v4i P = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, Bm, Z, 0, 0, 0); C[0] += P[0]; C[1] += P[1]; C[2] += P[2]; C[3] += P[3]; }
+                else C = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, Bm, C, 0, 0, 0);
             }
             if (OUT) {
+                if (n < 4 && b < nblk) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) out[(((int64_t)blockIdx.x * BLOCKS_PER_TILE + b) * 16 + (4 * g + r)) * 4 + n] = C[r];
+                }
+            } else {
+                const bool hit = (C[0] >= thr_b) | (C[1] >= thr_b) | (C[2] >= thr_b) | (C[3] >= thr_b);
+                if (__builtin_amdgcn_ballot_w64(hit)) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) nh += (C[r] >= thr_b) ? 1 : 0;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) nh += __shfl_xor(nh, off);
+    if (lane == 0 && nh) atomicAdd(hits + (blockIdx.x & 255), nh);
+}
+
+
+// ---- software-pipelined form: block j's MFMAs are interleaved with block j+1's address perms and LDS gathers, so every
+// wave's own instruction stream keeps VALU, LDS and the matrix core busy together (waves of a SIMD run in lockstep
+// after the barrier; without this the three units take turns).
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+template <int PIN, int NOLOAD = 0>
+__global__ __launch_bounds__(1024) void k_rot2(const uint8_t* __restrict__ codes, int64_t ntiles_mod,
+                                               const uint32_t* __restrict__ img, int thr, int nblk,
+                                               int* __restrict__ out, unsigned long long* __restrict__ hits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    for (int e = tid; e < TAB_BYTES / 16; e += 1024)
+        reinterpret_cast<uint4*>(lds)[e] = reinterpret_cast<const uint4*>(img)[e];
+    uint32_t RA[4], RB[3];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) v |= (uint32_t)(64 * g + 4 * ((i + r * 4 + b) & 15)) << (8 * b);
+        RA[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        uint32_t v = 0x01000000u;
+#pragma unroll
+        for (int b = 0; b < 3; b++) { const int s = r * 3 + b; if (s < 8) v |= (uint32_t)(64 * (g & 1) + 4 * ((i + s + 8 * (g >> 1)) & 15)) << (8 * b); }
+        RB[r] = v;
+    }
+    const int n = lane & 15;
+    const int bsel = n < 4 ? (1 << (8 * n)) : 0;
+    const v4i Bm = {bsel, bsel, bsel, bsel};
+    const int mythr = n < 4 ? thr : 0x7fffffff;
+    __syncthreads();
+    const int64_t tile = (int64_t)blockIdx.x % ntiles_mod;
+    const uint8_t* tp = codes + tile * (int64_t)BLOCKS_PER_TILE * BLK_BYTES;
+    unsigned long long nh = 0;
+    constexpr int D = 4;
+    uint4 ca[D]; uint2 cb[D];
+#pragma unroll
+    for (int dd = 0; dd < D; dd++) {
+        int b = w + 16 * dd; b = b < nblk ? b : nblk - 1;
+        const uint8_t* bp = tp + (int64_t)b * BLK_BYTES;
+        ca[dd] = *reinterpret_cast<const uint4*>(bp + lane * 16);
+        cb[dd] = *reinterpret_cast<const uint2*>(bp + 1024 + lane * 8);
+    }
+    uint32_t G[2][24];
+    auto addr = [&](int dd, int s) -> uint32_t {   // LDS address of gather s of the block in slot dd
+        if (s < 16) return __builtin_amdgcn_perm(((const uint32_t*)&ca[dd])[s >> 2], RA[s >> 2], 0x0c0c0000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s & 3));
+        const int s2 = s - 16;
+        return __builtin_amdgcn_perm(((const uint32_t*)&cb[dd])[s2 >> 2], RB[s2 / 3], 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
+    };
+    // prologue: gathers of block 0 (slot 0), then refill slot 0
+#pragma unroll
+    for (int s = 0; s < 24; s++) G[0][s] = lds_rd(addr(0, s));
+    {
+        int bn = w + 16 * D; bn = bn < nblk ? bn : nblk - 1;
+        const uint8_t* bp = tp + (int64_t)bn * BLK_BYTES;
+        ca[0] = *reinterpret_cast<const uint4*>(bp + lane * 16);
+        cb[0] = *reinterpret_cast<const uint2*>(bp + 1024 + lane * 8);
+    }
+#pragma unroll 1
+    for (int b0 = w; b0 < nblk; b0 += 16 * D) {
+#pragma unroll
+        for (int dd = 0; dd < D; dd++) {
+            const int b = b0 + 16 * dd;             // block whose gathers sit in G[dd & 1]
+            const int nd = (dd + 1) & 3;            // slot of block b + 16
+            v4i C = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                uint32_t a0 = addr(nd, 4 * t), a1 = addr(nd, 4 * t + 1), a2 = addr(nd, 4 * t + 2), a3 = addr(nd, 4 * t + 3);
+                G[(dd + 1) & 1][4 * t] = lds_rd(a0); G[(dd + 1) & 1][4 * t + 1] = lds_rd(a1);
+                G[(dd + 1) & 1][4 * t + 2] = lds_rd(a2); G[(dd + 1) & 1][4 * t + 3] = lds_rd(a3);
+                const v4i A = {(int)G[dd & 1][4 * t], (int)G[dd & 1][4 * t + 1], (int)G[dd & 1][4 * t + 2], (int)G[dd & 1][4 * t + 3]};
+                C = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, Bm, C, 0, 0, 0);
+                if (PIN) { SGB(0x002, 4); SGB(0x100, 4); SGB(0x008, 1); }
+            }
+            if (!NOLOAD) {   // slot nd is consumed: refill it with block b + 16 + 16 D
+                int bn = b + 16 + 16 * D; bn = bn < nblk ? bn : nblk - 1;
+                const uint8_t* bp = tp + (int64_t)bn * BLK_BYTES;
+                ca[nd] = *reinterpret_cast<const uint4*>(bp + lane * 16);
+                cb[nd] = *reinterpret_cast<const uint2*>(bp + 1024 + lane * 8);
+            }
+            const int thr_b = b < nblk ? mythr : 0x7fffffff;
+            if (out) {
                 if (n < 4 && b < nblk) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) out[(((int64_t)blockIdx.x * BLOCKS_PER_TILE + b) * 16 + (4 * g + r)) * 4 + n] = C[r];
@@ -203,9 +307,46 @@ int main(int argc, char** argv) {
     }
     // ---- timing
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    {
+        int64_t tmod = (int64_t)ntiles * REP;
+        auto run = [&](const char* nm, void (*kern)(const uint8_t*, int64_t, const uint32_t*, int, int, int*, unsigned long long*)) {
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TAB_BYTES));
+            float best = 1e9;
+            for (int rep = 0; rep < 3; rep++) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), TAB_BYTES, 0, dc, tmod, dt, 2200, 512, nullptr, dh);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+            }
+            printf("variant %-28s %.3f ms  (%.2f clk/CU per wave-gather @2.4GHz)\n", nm, best, best * 1e-3 * 2.4e9 * 256 / ((double)grid * 8192 * 96 / 64));
+        };
+        for (int64_t tm : {(int64_t)32, (int64_t)256, (int64_t)ntiles * REP}) {
+            tmod = tm; printf("-- %lld distinct tiles (%.0f MB)\n", (long long)tm, tm * 0.786432);
+            run("full", k_rot<0, false, 0>);
+            run("pipelined", k_rot2<0>);
+            run("pipelined+pinned", k_rot2<1>);
+            run("no-mfma (v_add)", k_rot<0, false, 1>);
+            run("no-lds-read", k_rot<0, false, 2>);
+            run("no-mfma, no-lds", k_rot<0, false, 3>);
+        }
+        tmod = (int64_t)ntiles * REP;
+        run("full", k_rot<0, false, 0>);
+        run("pipelined", k_rot2<0>);
+        run("pipelined+pinned", k_rot2<1>);
+        run("pipelined, no-global", k_rot2<0, 1>);
+        run("pipelined+pinned, no-global", k_rot2<1, 1>);
+        run("no-mfma (v_add)", k_rot<0, false, 1>);
+        run("no-lds-read", k_rot<0, false, 2>);
+        run("no-global-reload", k_rot<0, false, 4>);
+        run("independent mfma + v_add", k_rot<0, false, 8>);
+        run("no-mfma, no-lds", k_rot<0, false, 3>);
+        run("no-global, no-mfma", k_rot<0, false, 5>);
+        run("no-global, no-lds", k_rot<0, false, 6>);
+        run("nothing but perms", k_rot<0, false, 7>);
+    }
     const int nblks[4] = {512, 0, 256, 512};
-    for (int mode = 0; mode < 2; mode++) {
-        for (int rep = 0; rep < 4; rep++) {
+    for (int mode = 0; mode < 1; mode++) {
+        for (int rep = 0; rep < 1; rep++) {
             const int nblk = nblks[rep];
             CK(hipMemset(dh, 0, 8 * 256));
             CK(hipEventRecord(e0));
