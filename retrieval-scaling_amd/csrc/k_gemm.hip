@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_flat_gemm(const __half* Q16, const void
                     if (mine) {
                         unsigned long long base = 0;
                         const int leader = (__ffsll((unsigned long long)mine) - 1) + 32 * lh;
-                        if (lane == leader) base = atomicAdd(&F.cand_cnt[q0 + ql], (unsigned long long)__popcll(mine));
+                        if (lane == leader) base = atomicAdd(&F.cand_cnt[(int64_t)(q0 + ql) * CCS], (unsigned long long)__popcll(mine));
                         base = __shfl(base, leader);
                         const unsigned long long slot = base + __popcll(mine & ((1ull << lj) - 1ull));
                         if (pass && slot < (unsigned long long)F.cand_cap) F.cand[(q0 + ql) * F.cand_cap + slot] = key;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
                         if (mine) {
                             unsigned long long base = 0;
                             const int leader = (__ffsll((unsigned long long)mine) - 1) + 32 * lh;
-                            if (lane == leader) base = atomicAdd(&F.cand_cnt[q0 + ql], (unsigned long long)__popcll(mine));
+                            if (lane == leader) base = atomicAdd(&F.cand_cnt[(int64_t)(q0 + ql) * CCS], (unsigned long long)__popcll(mine));
                             base = __shfl(base, leader);
                             const unsigned long long slot = base + __popcll(mine & ((1ull << lj) - 1ull));
                             if (pass && slot < (unsigned long long)F.cand_cap) F.cand[(q0 + ql) * F.cand_cap + slot] = key;
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
                         const int64_t q = sq[qi];
                         unsigned long long slot0 = 0;
                         const int leader = (__ffsll((unsigned long long)mine) - 1) + 16 * kg;
-                        if (lane == leader) slot0 = atomicAdd(&a.cand_cnt[q], (unsigned long long)__popcll(mine));
+                        if (lane == leader) slot0 = atomicAdd(&a.cand_cnt[(int64_t)q * CCS], (unsigned long long)__popcll(mine));
                         slot0 = __shfl(slot0, leader);
                         const unsigned long long slot = slot0 + __popcll(mine & ((1ull << lr) - 1ull));
                         if (pass && slot < (unsigned long long)a.cand_cap) a.cand[q * a.cand_cap + slot] = key;

@@ -731,7 +731,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
                     const int64_t q = prm_o[i * 2 + 1];
                     unsigned long long base = 0;
                     const int leader = __ffsll((unsigned long long)mask) - 1;
-                    if (lane == leader) base = atomicAdd(&A.cand_cnt[q], (unsigned long long)__popcll(mask));
+                    if (lane == leader) base = atomicAdd(&A.cand_cnt[q * CCS], (unsigned long long)__popcll(mask));
                     base = __shfl(base, leader);
                     const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
                     if (pass && slot < (unsigned long long)A.cand_cap) A.cand[q * A.cand_cap + slot] = key;

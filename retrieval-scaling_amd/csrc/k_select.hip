@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     if (start >= end && !a.init) {  // segment beyond the row's length: no candidates
         uint64_t* o = a.out + row * a.out_row_stride + (int64_t)seg * KP;
         for (int i = lane; i < KP; i += 64) o[i] = 0;
-        if (a.zero_cnt && lane == 0 && seg == 0) a.zero_cnt[row] = 0ull;
+        if (a.zero_cnt && lane == 0 && seg == 0) a.zero_cnt[row * CCS] = 0ull;
         return;
     }
 
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     bitonic_sort_desc(buf, BUF, lane);
     uint64_t* o = a.out + row * a.out_row_stride + (int64_t)seg * KP;
     for (int i = lane; i < KP; i += 64) o[i] = (a.keep_last && i != KP - 1) ? 0ull : buf[i];
-    if (a.zero_cnt && lane == 0 && seg == 0) a.zero_cnt[row] = 0ull;
+    if (a.zero_cnt && lane == 0 && seg == 0) a.zero_cnt[row * CCS] = 0ull;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
     radix_topk_wg<256>(key_at, N, KP, rs_obuf, hist, ctl);
     uint64_t* o = a.out + row * a.out_row_stride;
     for (int i = tid; i < KP; i += 256) o[i] = (a.keep_last && i != KP - 1) ? 0ull : rs_obuf[i];
-    if (a.zero_cnt && tid == 0) a.zero_cnt[row] = 0ull;
+    if (a.zero_cnt && tid == 0) a.zero_cnt[row * CCS] = 0ull;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
     radix_topk_wg<1024>(key_at, nslab * 64, a.KP, obuf, hist, ctl);
     uint64_t* o = a.state + q * a.KP;
     for (int i = tid; i < a.KP; i += 1024) o[i] = (i == a.KP - 1) ? obuf[i] : 0ull;
-    if (tid == 0) a.cand_cnt[q] = 0ull;
+    if (tid == 0) a.cand_cnt[q * CCS] = 0ull;
 }
 void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
     if (nq <= 0) return;
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
             float s_k = have_k ? ord2f(sord[a.k - 1]) : -__builtin_inff();
             if (!(a_last + eps < s_k)) bad = 1;
         }
-        if (a.cand_cnt && a.cand_cnt[q] > (unsigned long long)a.cand_cap) bad = 1;   // candidates were dropped
+        if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad = 1;   // candidates were dropped
         a.uncertain[q] = bad;
     }
     for (int j = tid; j < a.k; j += nt) {

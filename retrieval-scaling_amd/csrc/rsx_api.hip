@@ -758,20 +758,20 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // the rest in ONE GEMM launch whose epilogue keeps only keys beating the running K'-th key
                 const int cap = 32768;
                 h->w_cand.ensure((size_t)nq * cap * 8);
-                h->w_candcnt.ensure((size_t)nq * 8);
-                HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8, h->st));
+                h->w_candcnt.ensure((size_t)nq * 8 * CCS);
+                HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8 * CCS, h->st));
                 launch_flat_gemm_filter(h->w_q16.as<__half>(), (int)nq_pad, (int)nq, h->data.p, h->storage_f16, done_rows,
                                         N - done_rows, ld, bias, state + (KP - 1), KP, h->w_cand.as<uint64_t>(),
                                         h->w_candcnt.as<unsigned long long>(), cap, h->st);
                 tm.mark("scan");
-                std::vector<unsigned long long> cnts((size_t)nq);
-                HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, h->st));
+                std::vector<unsigned long long> cnts((size_t)nq * CCS);
+                HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
                 HIPCHECK(hipStreamSynchronize(h->st));
-                for (auto c : cnts) if (c > (unsigned long long)cap) { filtered_ok = false; break; }
+                for (int64_t qi = 0; qi < nq; qi++) if (cnts[(size_t)qi * CCS] > (unsigned long long)cap) { filtered_ok = false; break; }
                 if (filtered_ok) {
                     SelectArgs b{};
                     b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cap;
-                    b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = 1; b.n_uniform = cap;
+                    b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cap;
                     b.seg_len = cap; b.nseg = 1; b.idx_base = 0;
                     b.init = state; b.out = state; b.out_row_stride = KP;
                     b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;
@@ -860,8 +860,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
                            h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st);
             tm.mark("lut8");
-            auto rot_desc = [&](int64_t items) -> void* {   // work-item descriptors of the rotated-layout scan
-                h->w_itemdesc.ensure((size_t)pq_scan_rot_grid(items) * sizeof(PQItemDesc));
+            auto rot_desc = [&](int64_t items, int v) -> void* {   // work-item records + survivor segments of the rotated-layout scan
+                h->w_itemdesc.ensure(pq_scan_rot_ws(items, 1024 * v));
                 return h->w_itemdesc.p;
             };
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
@@ -903,8 +903,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             if (fused_pre) {
                 cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
-                h->w_candcnt.ensure((size_t)nq * 8 + 64);
-                HIPCHECK(hipMemsetAsync((char*)h->w_candcnt.p + (size_t)nq * 8, 0, 64, h->st));
+                h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 PQPrepassArgs pa{};
                 pa.codes = h->data.as<uint8_t>(); pa.list_base = h->d_base.as<int64_t>(); pa.list_len = h->d_len.as<int64_t>();
                 pa.probe_list = h->w_probelist.as<int32_t>(); pa.probe_dis0 = h->w_dis0.as<float>();
@@ -922,7 +921,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 const int64_t mi = filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows);
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
-                                                 nullptr, 0, nullptr, nullptr, 0, rot_desc(mi), h->st)
+                                                 nullptr, 0, nullptr, nullptr, 0, rot_desc(mi, filtered ? pre_vpl : vpl), h->st)
                             : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
             }
@@ -930,7 +929,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 tm.mark("scan0");
                 cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
-                h->w_candcnt.ensure((size_t)nq * 8);
+                h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 // multi-launch form: top-K' of the scored prefix of the closest list, row prefix
                 // [0, min(seg_start[q][1], pre_rows)), written as the threshold key + counter reset
                 if (!fused_pre)
@@ -950,7 +949,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                                  total_groups, item_off, total_items, nlist,
                                                  max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows)), h->st)
+                                                 rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows), vpl), h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
                                                      max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
@@ -1043,7 +1042,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             tm.mark("scan0");
             cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
             h->w_cand.ensure((size_t)nq * cand_cap * 8);
-            h->w_candcnt.ensure((size_t)nq * 8);
+            h->w_candcnt.ensure((size_t)nq * 8 * CCS);
             // the pre-pass is only a threshold (see the IVF-PQ path): the K'-th key, candidate counters reset
             select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
                         std::min<int64_t>(maxlen, chunk_rows), 0, nq, KP, BUF, KP, state, false,
@@ -1057,11 +1056,11 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             a.cand = h->w_cand.as<uint64_t>(); a.cand_cnt = h->w_candcnt.as<unsigned long long>(); a.cand_cap = cand_cap;
             launch_list_scan(a, h->st);
             tm.mark("scan");
-            std::vector<unsigned long long> cnts((size_t)nq);
-            HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, h->st));
+            std::vector<unsigned long long> cnts((size_t)nq * CCS);
+            HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
             HIPCHECK(hipStreamSynchronize(h->st));
             filtered = true;
-            for (auto c : cnts) if (c > (unsigned long long)cand_cap) { filtered = false; break; }
+            for (int64_t qi = 0; qi < nq; qi++) if (cnts[(size_t)qi * CCS] > (unsigned long long)cand_cap) { filtered = false; break; }
             a.tau_key = nullptr; a.cand = nullptr; a.cand_cnt = nullptr; a.cand_cap = 0;
         }
         if (!filtered) {
@@ -1070,23 +1069,19 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         }
     }
     if (filtered && h->profile >= 2) {   // diagnostics: keys that passed the in-kernel filter
-        std::vector<unsigned long long> cnts((size_t)nq);
-        HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, h->st));
+        std::vector<unsigned long long> cnts((size_t)nq * CCS);
+        HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
         HIPCHECK(hipStreamSynchronize(h->st));
         double tot = 0, mx = 0;
-        for (auto c : cnts) { tot += (double)c; mx = std::max(mx, (double)c); }
+        for (int64_t qi = 0; qi < nq; qi++) { const double c = (double)cnts[(size_t)qi * CCS]; tot += c; mx = std::max(mx, c); }
         h->timing["cand_keys"] += tot; h->timing["cand_keys_max"] = std::max(h->timing["cand_keys_max"], mx);
-        unsigned long long dbg[8];
-        HIPCHECK(hipMemcpy(dbg, (char*)h->w_candcnt.p + (size_t)nq * 8, 64, hipMemcpyDeviceToHost));
-        h->timing["dbg_hit_blocks"] = (double)dbg[0]; h->timing["dbg_hit_clk"] = (double)dbg[1];
-        h->timing["dbg_loop_clk"] = (double)dbg[2]; h->timing["dbg_blocks"] = (double)dbg[3];
     }
     // 3. per-query k-selection over the score rows
     if (filtered) {
         // merge the filtered candidates (keys) into state0: one wave per query, the whole buffer in one segment
         SelectArgs b{};
         b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cand_cap;
-        b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = 1; b.n_uniform = cand_cap;
+        b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cand_cap;
         b.seg_len = round_up(cand_cap, 256); b.nseg = 1; b.idx_base = 0;
         b.init = state; b.out = state; b.out_row_stride = KP;
         b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;

@@ -5,5 +5,6 @@ import json; d=json.load(open('gpurun_out/bench_p_$tag.json')); s=d['stage_ms_pe
 run base
 run chunk16k --param scan_chunk=16384
 run chunk32k --param scan_chunk=32768
-RSX_ROT_VARIANT=1 run chunk32k_nohit --param scan_chunk=32768
 RSX_ROT_VARIANT=2 run chunk32k_noloop --param scan_chunk=32768
+RSX_ROT_VARIANT=2 run base_noloop
+RSX_ROT_VARIANT=6 run base_noloop_nostage
