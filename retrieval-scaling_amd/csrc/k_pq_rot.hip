@@ -61,9 +61,10 @@ struct __attribute__((aligned(16))) PQRotItem {
 static_assert(sizeof(PQRotItem) == 176, "PQRotItem is copied as 11 x 16 bytes");
 
 template <int M, bool FILTER>
-__global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* items) {
+__global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* items, uint32_t* xcd_ctr) {
     const PQScanArgs& a = A.b;
     const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item < 8) xcd_ctr[item * 32] = 0u;     // the scan's per-XCD work counters (one per 128-byte line)
     const int ti = *A.total_items;
     if (item >= ti) return;
     int lo = 0, hi = A.nlist;   // largest l with item_off[l] <= item
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
 // ---------------------------------------------------------------------------------------
 template <int NF, int NH, bool FILTER>
 __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ seg_keys,
-                                                      uint32_t* __restrict__ seg_cnt, int seg_cap, int bpw, int var) {
+                                                      uint32_t* __restrict__ seg_cnt, uint32_t* xcd_ctr, int seg_cap, int bpw, int var) {
     constexpr int M = 64 * NF + 32 * NH;
     constexpr int NPH = NF + NH;               // phases = table planes
     constexpr int TAB = NPH * 65536;           // plane p at p * 64 KiB; row = code * 256; a half phase uses 128 B of the row
@@ -136,14 +137,17 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15, n = lane & 15, nq4 = n & 3;
 
-    // ---- the workgroup's items
+    // ---- the workgroup's items: XCD b % 8 owns the contiguous item range [xlo, xhi) of the list-major order (the query groups
+    // of a list tile stay on one XCD, close together in time); its workgroups draw items from one counter.  Only wave 0
+    // talks to the counter, one item ahead, and publishes each item's record (or an end marker) through LDS.
     const int ti = *A.total_items;
     const int per_xcd = (ti + 7) >> 3;
-    const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
-    int item = xcd * per_xcd + (int)(blockIdx.x >> 3);
-    int item_hi = (xcd + 1) * per_xcd; if (item_hi > ti) item_hi = ti;
-    if (item >= item_hi) return;
-
+    const int xcd = blockIdx.x & 7;
+    const int xlo = xcd * per_xcd;
+    int xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
+    if (xlo >= xhi) return;
+    uint32_t* ctr = xcd_ctr + xcd * 32;
+    unsigned drawn = 0;          // wave 0, lane 0: the counter value of the last draw (consumed one item later)
     // ---- per-lane constants, once per workgroup: rotation bytes, the one-hot B operand, the survivor-queue geometry
     uint32_t R0[NR0 > 0 ? NR0 : 1], R1[NR1 > 0 ? NR1 : 1];
 #pragma unroll
@@ -181,12 +185,23 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     // table loads (measured: 0.6 ms of a 3.8 ms scan for 1.9 M survivors).
     const uint64_t QM = n < 4 ? (0x0001000100010001ull << n) : 0ull;   // the four lanes that own query n
 
-    if (w == 0 && lane < 11) reinterpret_cast<uint4*>(&islot[0])[lane] = reinterpret_cast<const uint4*>(&items[item])[lane];
+    int item = 0;
+    if (w == 0) {
+        if (lane == 0) { drawn = atomicAdd(ctr, 1u); }
+        item = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+        if (lane == 0) drawn = atomicAdd(ctr, 1u);
+        uint4 r0 = make_uint4(0xffffffffu, 0, 0, 0);       // l = -1: end marker
+        if (lane < 11 && item < xhi) r0 = reinterpret_cast<const uint4*>(&items[item])[lane];
+        if (lane < 11) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
+        if (lane == 0) islot[0].pad0 = item;
+    }
     int buf = 0;
 #pragma unroll 1
-    for (; item < item_hi; item += stride, buf ^= 1) {
+    for (;; buf ^= 1) {
         __syncthreads();    // #1: every wave has left the previous item's scan (table free), the item record is in LDS
         const PQRotItem* it = &islot[buf];
+        if (__builtin_amdgcn_readfirstlane(it->l) < 0) break;
+        item = __builtin_amdgcn_readfirstlane(it->pad0);
         const int np = __builtin_amdgcn_readfirstlane(it->np);
         const int64_t len = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->len >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->len);
         const int64_t base_row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->base_row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->base_row);
@@ -205,10 +220,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
             if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
         }
-        // ---- next item's record: requested now by wave 0, parked in LDS after the scan
-        const int nxt = item + stride;
-        uint4 pre = make_uint4(0, 0, 0, 0);
-        if (w == 0 && lane < 11 && nxt < item_hi) pre = reinterpret_cast<const uint4*>(&items[nxt])[lane];
 
         // ---- stage the group's table: work unit = (code, 4 consecutive m) -> 4 dwords (one per m: byte k = query k, as int8 = u8 - 128)
         {
@@ -234,6 +245,14 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             }
         }
         uint64_t* myseg = seg_keys + (((size_t)item * 16 + w) * 4 + nq4) * seg_cap;
+        // ---- next item's record: requested now by wave 0 (its index was drawn during the previous item: the counter's answer
+        // has had a barrier wait and a table staging to arrive), parked in LDS after the scan
+        uint4 pre = make_uint4(0xffffffffu, 0, 0, 0);
+        int i1 = 0;
+        if (w == 0) {
+            i1 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+            if (lane < 11 && i1 < xhi) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
+        }
         // ---- the lane's share of the item record: accumulator init, score parameters of the query it owns (n < 4)
         const int cinit = FILTER ? (n < 4 ? it->cinit[nq4] : -(1 << 30)) : 0;
         const v4i Ci = {cinit, cinit, cinit, cinit};
@@ -322,9 +341,13 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 }
             }
         }
-        // ---- item epilogue: park the next record; the wave's four survivor counts leave with one store (lanes 0..3 own queries 0..3)
-        if (w == 0 && lane < 11 && nxt < item_hi) reinterpret_cast<uint4*>(&islot[buf ^ 1])[lane] = pre;
+        // ---- item epilogue: the wave's four survivor counts leave with one store (lanes 0..3 own queries 0..3); wave 0 parks
+        // the next record (or the end marker) and draws the index of the item after it
         if (FILTER && lane < 4) seg_cnt[((size_t)item * 16 + w) * 4 + lane] = qcnt;
+        if (w == 0) {
+            if (lane < 11) reinterpret_cast<uint4*>(&islot[buf ^ 1])[lane] = pre;
+            if (lane == 0) { islot[buf ^ 1].pad0 = i1; drawn = atomicAdd(ctr, 1u); }
+        }
     }
 }
 
@@ -376,14 +399,15 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, hi
     PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
     uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(desc_ws) + (size_t)(A.max_items + 8) * 176);
     uint64_t* seg_keys = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(seg_cnt) + (size_t)(A.max_items + 8) * 256);
-    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items);
+    uint32_t* xcd_ctr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(seg_keys) + (size_t)(A.max_items + 8) * 64 * seg_cap * 8);
+    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr);
     static int var = -1;
     if (var < 0) { const char* e = getenv("RSX_ROT_VARIANT"); var = e ? atoi(e) : 0; }
     // one persistent workgroup per CU (a multiple of 8: workgroup b serves XCD b % 8); never more than the work items
     int64_t grid = (ncu + 7) & ~7;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
-    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, seg_cap,
-                       bpw, var);
+    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, xcd_ctr,
+                       seg_cap, bpw, var);
     if (FILTER)
         hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)A.max_items), dim3(64), 0, st, items, A.total_items, seg_keys, seg_cnt, seg_cap,
                            A.cand, A.cand_cnt, A.cand_cap);

@@ -865,7 +865,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 return h->w_itemdesc.p;
             };
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
+            // rotated layout: persistent workgroups draw items dynamically, so the tile is the whole (average) list — one table
+            // staging per (list, query group) — as long as that leaves a few thousand items to balance over 256 CUs
             int vpl = 8;
+            if (rot) { vpl = 32; while (vpl > 8 && 16 * (vpl / 2) >= avg_slabs) vpl /= 2; }
             if (h->scan_chunk > 0) vpl = std::max(1, std::min(rot ? 64 : 16, h->scan_chunk / 1024));
             else while (vpl > 1 && (pairs / 4 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
             if (vpl != 64 && vpl != 32 && vpl != 16 && vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;

@@ -228,7 +228,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
 // survivor segment capacity per (item, wave, query): ~3x the mean a query's CLOSEST list yields at the default pre-pass
 inline int pq_scan_rot_seg_cap(int tile_rows) { int c = tile_rows / 64; return c < 128 ? 128 : c; }
 inline size_t pq_scan_rot_ws(int64_t max_items, int tile_rows) {   // item records + segment counts + segment keys
-    return (size_t)(max_items + 8) * (176 + 256 + (size_t)64 * pq_scan_rot_seg_cap(tile_rows) * 8);
+    return (size_t)(max_items + 8) * (176 + 256 + (size_t)64 * pq_scan_rot_seg_cap(tile_rows) * 8) + 1024;   // + per-XCD counters
 }
 // exact per-(query, list) scan of the rotated layout (fp32 table, sequential sums = oracle bits): fallback / A-B path
 int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st);
