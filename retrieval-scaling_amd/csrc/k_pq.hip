@@ -457,6 +457,7 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
     __shared__ float s_q[LT_QC * LT_MB * 8];     // the tile's query slices
     __shared__ float s_scale[2 * LT_QC];         // scale, 1 / scale
     __shared__ float s_mn[LT_QC * LT_MB];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lt_obuf[];   // transposed output: [LT_QC][256][LT_MB] bytes (64 KiB)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.x * LT_MB;
     const int64_t q0 = (int64_t)blockIdx.y * LT_QC;
@@ -514,8 +515,10 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
             } else {
                 const float mn = s_mn[qi * LT_MB + mi], scale = s_scale[qi], inv = s_scale[LT_QC + qi];
                 float err = 0.0f;
-                uint8_t* o = transposed ? lut8 + (q * 256 + lane) * Mpad + m : lut8 + (q * Mpad + m) * 256 + lane;
-                const int ostep = transposed ? 64 * Mpad : 64;
+                // transposed ([q][code][m], the rotated-layout scans): bytes collect in LDS and leave as 8-byte runs of the
+                // tile's 8 sub-quantisers (a byte store per entry at stride M costs 0.1 ms per batch)
+                uint8_t* o = transposed ? lt_obuf + ((size_t)qi * 256 + lane) * LT_MB + mi : lut8 + (q * Mpad + m) * 256 + lane;
+                const int ostep = transposed ? 64 * LT_MB : 64;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float u = rintf((v[j] - mn) * inv);
@@ -527,6 +530,16 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
                 for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
                 if (lane == 0) errb[q * Mpad + m] = err;
             }
+        }
+    }
+    if (PASS == 1 && transposed) {
+        __syncthreads();
+        for (int e = tid; e < nqc * 256; e += 256) {
+            const int qi = e >> 8, c = e & 255;
+            const uint2 v8 = *reinterpret_cast<const uint2*>(lt_obuf + (size_t)e * LT_MB);
+            uint8_t* dst = lut8 + ((q0 + qi) * 256 + c) * Mpad + m0;
+            if (m0 + LT_MB <= Mpad) *reinterpret_cast<uint2*>(dst) = v8;
+            else for (int t = 0; m0 + t < Mpad; t++) dst[t] = lt_obuf[(size_t)e * LT_MB + t];
         }
     }
 }
@@ -578,8 +591,11 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
         float* mnmx = reinterpret_cast<float*>(ws);
         float* errb = mnmx + (size_t)nq * Mpad * 2;
         dim3 grid((unsigned)((Mpad + LT_MB - 1) / LT_MB), (unsigned)((nq + LT_QC - 1) / LT_QC));
+        const size_t osm = transposed ? (size_t)LT_QC * 256 * LT_MB : 0;
+        static bool attr = false;
+        if (osm && !attr) { hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm); attr = true; }
         hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
-        hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
+        hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), osm, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
         hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)nq), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0, nprobe,
                            (PQQParam*)qparam);
         return;
