@@ -4,7 +4,14 @@
 Workload (BASELINE.json metric / configs[3]): 100M x 768 IVF-PQ, M = 96, nbits = 8, nlist = 4096,
 nprobe = 32, batch = 1024 queries, k = 10, synthetic Gaussian-mixture fp16 embeddings.
 One "step" = one rsx_search call over one batch of 1024 queries that is already resident in HBM,
-results left in HBM.
+results left in HBM (`value`); the same loop with host-resident queries/results is reported beside it as
+`pcie_inclusive`, never as `value`.
+
+At N = 1 the line also carries (rank 0, after the timed region, each on its own index): `configs` = BASELINE configs 2
+and 3 (Flat 10M batch 1024; IVF-Flat 100M nlist 4096 nprobe 32) with ms/step, roofline and an oracle spot check,
+`recall_informative` = recall@10 on a second mixture whose neighbours PQ can resolve, the list-length histogram and
+the CPU baseline (the oracle on all host cores, all 1024 queries, three repeats).  --no-configs / --cpu-queries 0 /
+--no-recall switch the extras off for experiments.
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -51,8 +58,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--chunk", type=int, default=1_000_000, help="vectors synthesised per add call")
-    ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=1024, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-recall", action="store_true", help="skip the exact ground truth (recall = null)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2/3 and the second recall figure")
     ap.add_argument("--diag", action="store_true", help="print a fast-vs-exact comparison of the first timed batch and exit")
     ap.add_argument("--shard", choices=["vectors", "lists"], default="vectors",
                     help="multi-GPU partition of the index: by contiguous id ranges (the reference's shards; default) or by "
@@ -185,12 +193,22 @@ def main():
         log(f"diag: fallback queries {nfb}; queries differing fast vs exact: {len(badq)} of {nq}: {badq[:20].tolist()}")
         for qi in badq[:6]:
             log(f" q={qi}\n  exact I {Ie[qi].tolist()}\n  fast  I {If[qi].tolist()}\n  exact D {De[qi].tolist()}\n  fast  D {Df[qi].tolist()}")
-        for kp in (128, 512):
+        for kp in (128, 512, 1024):
             index.set_param("pq_fast_kp", kp); index.set_param("profile", 1)
             Dg, Ig = index.search(q, k)
             Dg, Ig = Dg.cpu().numpy(), Ig.cpu().numpy()
-            nb = int(((Ie != Ig).any(1) | (De != Dg).any(1)).sum())
-            log(f"diag: K'={kp}: fallbacks {index.get_timing('fallback_queries')}, differing queries {nb}")
+            bq = np.nonzero((Ie != Ig).any(1) | (De != Dg).any(1))[0]
+            nb = len(bq)
+            log(f"diag: K'={kp}: fallbacks {index.get_timing('fallback_queries')}, differing queries {nb}: {bq[:8].tolist()}")
+            for qi in bq[:3]:
+                log(f" q={qi}\n  exact I {Ie[qi].tolist()}\n  K'    I {Ig[qi].tolist()}\n  exact D {De[qi].tolist()}\n  K'    D {Dg[qi].tolist()}")
+            if nb:
+                index.set_param("pq_fast_kp", kp); index.set_param("profile", 2)
+                index.search(q, k)
+                log(f"diag: K'={kp}: survivors/query mean {index.get_timing('cand_keys') / nq:.0f} max {index.get_timing('cand_keys_max'):.0f}")
+                for qi in bq[:3]:
+                    D1_, I1_ = index.search(q[qi:qi + 1], k)
+                    log(f"diag: K'={kp} q={qi} alone: equal to exact = {np.array_equal(I1_.cpu().numpy()[0], Ie[qi]) and np.array_equal(D1_.cpu().numpy()[0], De[qi])}")
         index.set_param("pq_fast_kp", 0)
         # each query alone through the fast path
         nb1 = 0
@@ -217,12 +235,27 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
     fallbacks = index.get_timing("fallback_queries") / max(1.0, index.get_timing("fast_queries"))
+    index.set_param("profile", 0)
+
+    # ---- the same loop with host-resident queries and results (H2D of Q, D2H of D, I inside the timed region)
+    pcie = None
+    if world == 1:
+        Qh = Q.cpu().numpy()
+        for i in range(min(2, args.warmup)):
+            index.search(Qh[i * nq:(i + 1) * nq], k)
+        t1 = time.perf_counter()
+        for i in range(args.warmup, nsteps):
+            index.search(Qh[i * nq:(i + 1) * nq], k)
+        el_h = time.perf_counter() - t1
+        pcie = {"value": round(args.steps * nq / el_h, 2), "unit": "queries/s", "ms_per_step": round(el_h / args.steps * 1e3, 4),
+                "note": "numpy fp16 queries in, numpy D/I out: 1.57 MB H2D + 0.12 MB D2H per step inside the timed loop"}
+        del Qh
+
     ab = None
     if args.ab:
         ab = {}
-        for name, sk in (("exact_list_major_scan2", 2), ("exact_per_pair_scan", 1)):
+        for name, sk in (("exact_scan_kernel_2", 2), ("exact_scan_kernel_1", 1)):
             index.set_param("scan_kernel", sk)
             for i in range(args.warmup):
                 step(i)
@@ -236,19 +269,27 @@ def main():
                         "scan_ms_per_step": round(index.get_timing("scan") / args.steps, 4)}
         index.set_param("scan_kernel", 0)
 
-    # algorithmic bytes of the dominant kernel (k_pq_scan2): every (query, probed list) pair reads the
-    # list's codes once = M bytes per scanned vector (SURVEY §8d / DESIGN.md).
+    # ---- work of one scan launch, counted from the actual probe lists of one step (profile 2 reads them back)
     index.set_param("profile", 2)
     step(args.warmup)
-    scanned = index.get_timing("scanned_vectors")
-    cand_keys = index.get_timing("cand_keys")          # keys that passed the in-kernel filter (this one step)
+    scanned = index.get_timing("scanned_vectors")               # sum over (query, probed list) of len
+    scanned_unique = index.get_timing("scanned_unique_vectors")  # vectors of every list probed at least once
+    scanned_group = index.get_timing("scanned_group_vectors")    # vectors x groups of <= 4 probing queries
+    cand_keys = index.get_timing("cand_keys")                    # keys that passed the in-kernel filter
     cand_keys_max = index.get_timing("cand_keys_max")
-    dbg_vals = {k: index.get_timing("dbg_" + k) for k in ("hit_blocks", "hit_clk", "loop_clk", "blocks")}
     index.set_param("profile", 0)
     launches_per_step = max(1.0, scan_launches / args.steps)
-    scan_bytes = scanned * args.m / launches_per_step          # algorithmic bytes of ONE launch
     ms_per_launch = scan_ms / max(1.0, scan_launches)
-    achieved = scan_bytes / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+    sec = ms_per_launch * 1e-3
+    rot = index._get("pq_layout") == 1
+    kernel = "k_pq_scan_rot" if rot else "k_pq_scan8"
+    # HBM roofline: the codes of every list probed at least once must cross HBM once per batch (list-major scan) — that is the
+    # kernel's algorithmic HBM traffic; PMC FETCH_SIZE (`traffic`) shows what actually crossed.
+    alg_bytes = scanned_unique * args.m / launches_per_step
+    achieved = alg_bytes / sec / 1e9 if sec > 0 else 0.0
+    # LDS side: one 4-byte table gather per lane per (vector, sub-quantiser, group of 4 queries); ds_read_b32 peak = 128 B/clk/CU
+    lds_bytes = scanned_group * args.m * 4 / launches_per_step
+    lds_peak = 128.0 * 256 * 2.4e9 / 1e9
 
     # recall@k of the first timed batch against the exact streaming ground truth (all shards merged)
     D1, I1 = step(args.warmup)
@@ -262,8 +303,13 @@ def main():
         a, b = I1.cpu().numpy(), gtI.cpu().numpy()
         recall = float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a, b)]))
 
-    # ---------------- CPU baseline (rank 0, N = 1): the oracle's FAISS-structured IVFPQ search on the
-    # host cores over a bounded sample of the same queries and the same index.
+    ls = index.list_sizes()
+    hist = {"lists": int(len(ls)), "empty": int((ls == 0).sum()), "min": int(ls.min()), "p5": int(np.percentile(ls, 5)),
+            "p25": int(np.percentile(ls, 25)), "p50": int(np.percentile(ls, 50)), "p75": int(np.percentile(ls, 75)),
+            "p95": int(np.percentile(ls, 95)), "max": int(ls.max()), "mean": round(float(ls.mean()), 1)}
+
+    # ---------------- CPU baseline (rank 0, N = 1): the oracle's FAISS-structured IVFPQ search on all host cores over the
+    # queries of the first timed batch and the same index (probed lists copied to the host), three repeats.
     cpu = None
     parity = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
@@ -273,40 +319,74 @@ def main():
         cen, cb = index.get_centroids(), index.get_codebooks()
         pid, _ = orc.coarse_probe(cen, qs, min(args.nprobe, args.nlist))
         need = np.unique(pid[pid >= 0])
-        off = np.zeros(args.nlist + 1, dtype=np.int64)
-        payload, ids = [], []
         lens = np.zeros(args.nlist, dtype=np.int64)
-        for l in need:
-            c, i = index.get_list(int(l))
-            payload.append(c); ids.append(i); lens[l] = len(i)
+        lens[need] = ls[need]
+        off = np.zeros(args.nlist + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
 
         class LM:
             pass
         lm = LM()
         lm.list_off = off
-        lm.payload = np.concatenate(payload) if payload else np.zeros((0, args.m), np.uint8)
-        lm.ids = np.concatenate(ids) if ids else np.zeros(0, np.int64)
-        orc.ivfpq_search(cen, cb, lm, qs[:2], args.nprobe, k, heap=True)  # page in
-        t0 = time.perf_counter()
-        Dc, Ic = orc.ivfpq_search(cen, cb, lm, qs, args.nprobe, k, heap=True)
-        cpu_s = time.perf_counter() - t0
-        cpu = {"value": round(ns / cpu_s, 3), "unit": "queries/s", "cores": orc.num_threads(), "kind": "port",
-               "sample": f"{ns} of the {nq} queries of the first timed batch, same {n_total}-vector index "
-                         f"(probed lists copied to host), oracle orc_ivfpq_search_heap, OpenMP over queries"}
-        parity = bool(np.array_equal(Ic, I1[:ns].cpu().numpy()) and np.array_equal(Dc, D1[:ns].cpu().numpy()))
-        log(f"cpu baseline: {ns} queries in {cpu_s:.2f}s on {orc.num_threads()} threads; parity with GPU ids+scores: {parity}")
+        lm.payload = np.empty((int(off[-1]), args.m), np.uint8)
+        lm.ids = np.empty(int(off[-1]), np.int64)
+        for l in need:
+            c, i = index.get_list(int(l))
+            lm.payload[off[l]:off[l + 1]] = c; lm.ids[off[l]:off[l + 1]] = i
+        orc.ivfpq_search(cen, cb, lm, qs[:min(ns, 2 * orc.num_threads())], args.nprobe, k, heap=True)  # page in
+        times = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            Dc, Ic = orc.ivfpq_search(cen, cb, lm, qs, args.nprobe, k, heap=True)
+            times.append(time.perf_counter() - t0)
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            model = "unknown"
+        cpu = {"value": round(ns / float(np.mean(times)), 3), "unit": "queries/s", "best": round(ns / min(times), 3),
+               "repeats_s": [round(t, 3) for t in times], "cores": orc.num_threads(), "cpu_model": model, "kind": "port",
+               "sample": f"all {ns} queries of the first timed batch, same {n_total}-vector index ({len(need)} probed lists copied to "
+                         f"host), oracle orc_ivfpq_search_heap, OpenMP over queries, mean of 3 repeats"}
+        # parity against the oracle's CANONICAL order (score desc, id asc — what the GPU path emits).  The timed variant above is
+        # the FAISS-structured heap, whose order among EXACTLY equal scores is heap mechanics (unpinned): queries
+        # where it differs from the canonical result by such a tie are counted, not failed.
+        Dk, Ik = orc.ivfpq_search(cen, cb, lm, qs, args.nprobe, k)
+        Ig, Dg = I1[:ns].cpu().numpy(), D1[:ns].cpu().numpy()
+        parity = bool(np.array_equal(Ik, Ig) and np.array_equal(Dk, Dg))
+        heap_tie_queries = int(((Ic != Ik).any(1)).sum())
+        heap_scores_equal = bool(np.array_equal(Dc, Dk))
+        if not parity:
+            badq = np.nonzero((Ik != Ig).any(1) | (Dk != Dg).any(1))[0]
+            log(f"cpu/gpu differ on {len(badq)} of {ns} queries: {badq[:16].tolist()}")
+            for qi in badq[:4]:
+                log(f" q={qi}\n  cpu I {Ik[qi].tolist()}\n  gpu I {Ig[qi].tolist()}\n  cpu D {Dk[qi].tolist()}\n  gpu D {Dg[qi].tolist()}")
+        cpu["heap_variant_vs_canonical"] = {"queries_with_a_tie_in_different_order": heap_tie_queries, "scores_identical": heap_scores_equal}
+        log(f"cpu baseline: {ns} queries x3 in {[round(t, 2) for t in times]} s on {orc.num_threads()} threads; parity with GPU ids+scores: {parity}")
+        del lm
+
+    # ---------------- extras on their own indexes (N = 1): BASELINE configs 2 / 3, a second recall figure
+    configs = None
+    recall2 = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        index = Q = Qgt = out = D1 = I1 = gtD = gtI = None   # the 100M index leaves HBM before the next ones are built
+        import gc
+        gc.collect(); torch.cuda.synchronize()
+        recall2 = recall_informative(args, log)
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import bench_configs
+        configs = {}
+        for name, kw in (("flat_10M_batch1024", dict(which="flat", n=10_000_000, steps=5, check=4, small_batches=False)),
+                         ("ivfflat_100M_nlist4096_nprobe32", dict(which="ivfflat", n=100_000_000, steps=5, check=2))):
+            t0 = time.time()
+            try:
+                configs[name] = bench_configs.measure(**kw)
+            except Exception as e:   # a config that cannot run (e.g. a smaller GPU) must not lose the headline line
+                configs[name] = {"error": repr(e)}
+            log(f"config {name}: {time.time() - t0:.1f}s -> {json.dumps(configs[name])[:300]}")
+            gc.collect()
 
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                t = json.load(open(tpath))
-                if t.get("n") == n_total and t.get("n_gpus") == world:
-                    traffic = t.get("k_pq_scan8_hbm_bytes_per_launch")
-            except Exception:
-                pass
+        traffic, traffic_note = load_pmc_traffic(n_total, world, kernel)
         res = {
             "metric": "queries/sec + recall@10, 100M x 768 IVF-PQ nprobe=32 batch=1024",
             "value": round(args.steps * nq / elapsed, 2),
@@ -316,28 +396,41 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "u8 codes; u8-table integer scan, exact f32-table re-rank (certified)",
+            "dtype": "u8 codes; i8-table integer scan (MFMA-i8 adder tree), exact f32-table re-rank (certified)",
             "data": "synthetic",
             "recall_at_10": recall,
+            "recall_informative": recall2,
             "config": {"workload": f"{n_total}x{D} IVF-PQ M={args.m} nbits=8 nlist={args.nlist} nprobe={args.nprobe} "
                                    f"batch={nq} k={k}, inner product, by_residual",
-                       "vectors_per_gpu": n_local, "parallelism": (f"index sharded by inverted lists (l % {world} == rank) over {world} GPU(s)" if list_shards
+                       "vectors_per_gpu": n_local, "code_layout": "rotated" if rot else "granule",
+                       "parallelism": (f"index sharded by inverted lists (l % {world} == rank) over {world} GPU(s)" if list_shards
                                        else f"index sharded by id range over {world} GPU(s)")},
-            "roofline": {"bound": "hbm", "kernel": "k_pq_scan8", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(ms_per_launch, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms_per_launch, 4),
                          "launches_per_step": launches_per_step,
-                         "traffic_gbs": (round(traffic / (ms_per_launch * 1e-3) / 1e9, 2) if traffic else None),
-                         "note": "achieved = scanned code bytes (sum over (query, probed list) of len*M) / HIP-event "
-                                 "duration of the scan launch on the library stream, rank 0. frac > 1 is possible: the "
-                                 "list-major kernel reads each code byte from HBM once for up to 24 grouped queries, so "
-                                 "the algorithmic bytes exceed the measured HBM traffic (`traffic`, PMC FETCH_SIZE); the "
-                                 "kernel is bound by LDS table gathers, not HBM (DESIGN.md 4.1)"},
+                         "traffic_gbs": (round(traffic / sec / 1e9, 2) if traffic and sec > 0 else None),
+                         "traffic_over_algorithmic": (round(traffic / alg_bytes, 3) if traffic and alg_bytes > 0 else None),
+                         "traffic_note": traffic_note,
+                         "lds": {"achieved": round(lds_bytes / sec / 1e9, 1) if sec > 0 else None, "peak": round(lds_peak, 1), "unit": "GB/s",
+                                 "frac": round(lds_bytes / sec / 1e9 / lds_peak, 4) if sec > 0 else None,
+                                 "note": "4-byte ds_read_b32 table gathers: one per lane per (vector, sub-quantiser, group of <= 4 "
+                                         "queries); peak = 128 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS)"},
+                         "logical": {"bytes_per_launch": scanned * args.m / launches_per_step,
+                                     "effective_GBs": round(scanned * args.m / launches_per_step / sec / 1e9, 1) if sec > 0 else None,
+                                     "note": "SURVEY 8(d): sum over (query, probed list) of len*M; an EFFECTIVE rate (one HBM read serves "
+                                             "every query group of the list), not a fraction of any peak"},
+                         "note": "achieved = M bytes x vectors of every inverted list probed by at least one query of the batch (the bytes a "
+                                 "list-major scan must pull from HBM once) / HIP-event duration of the scan launch on the library "
+                                 "stream, rank 0; traffic = PMC FETCH_SIZE x 2 of the same kernel (profiles/pmc_traffic.json, refused when "
+                                 "the kernel sources changed since it was measured)"},
+            "pcie_inclusive": pcie,
+            "list_length_histogram": hist,
             "stage_ms_per_step": stage_ms,
             "certificate_fallback_fraction": fallbacks,
             "filter_survivors_per_query": {"mean": round(cand_keys / max(1, nq), 1), "max": cand_keys_max},
-            "dbg": dbg_vals,
             "ab_exact_kernels_same_process": ab,
+            "configs": configs,
             "cpu_baseline": cpu,
             "cpu_parity_ids_and_scores_bit_exact": parity,
         }
@@ -345,6 +438,75 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_source_hash():
+    """sha256 over the sources that decide the scan kernel's HBM traffic (kernel, grouping, tile choice)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("k_pq_rot.hip", "k_pq.hip", "k_select.hip", "rsx_api.hip", "rsx_internal.h"):
+        h.update(open(os.path.join(REPO, "retrieval-scaling_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def load_pmc_traffic(n_total, world, kernel):
+    """HBM bytes per scan launch from the committed rocprofv3 --pmc FETCH_SIZE pass (tools/update_pmc_traffic.py writes the
+    file with the hash of the sources it measured) — null when it does not describe THIS build / workload."""
+    tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        return None, "profiles/pmc_traffic.json missing"
+    if t.get("n") != n_total or t.get("n_gpus") != world:
+        return None, "pmc_traffic.json describes another workload"
+    if t.get("kernel") != kernel:
+        return None, f"pmc_traffic.json was measured on {t.get('kernel')}, this run used {kernel}"
+    if t.get("source_sha256") != kernel_source_hash():
+        return None, "pmc_traffic.json is stale: the kernel sources changed since the PMC pass"
+    return t.get("hbm_bytes_per_launch"), f"PMC pass of {t.get('date', '?')}, FETCH_SIZE x 2 (gfx950 correction), same sources"
+
+
+def recall_informative(args, log):
+    """recall@10 on a mixture whose neighbours a 96-byte PQ can resolve: N/8 centres (about 8 vectors each), sigma 0.1, so a
+    query's exact top-10 is its centre's handful of vectors plus the nearest strangers; 10M x 768, same index parameters."""
+    import torch, rsx
+    dev = torch.device("cuda", 0)
+    n, nq, k = 10_000_000, args.batch, args.k
+    nc, sig, sigq = n // 8, 0.1, 0.02
+    t0 = time.time()
+    ix = rsx.IndexIVFPQ(rsx.IndexFlatIP(D), D, args.nlist, args.m, 8, rsx.METRIC_INNER_PRODUCT, device=0)
+    nt = 256 * args.nlist
+    xt = torch.empty((nt, D), dtype=torch.float16, device=dev)
+    blk, stride = 4096, n // nt
+    for b in range(0, nt, blk):
+        nb = min(blk, nt - b)
+        rsx.synth_vectors(D, nc, SEED_C, SEED_X, sig, (b * stride) % (n - nb), nb, out=xt[b:b + nb])
+    ix.train(xt); del xt
+    ix.nprobe = args.nprobe
+    Q = torch.empty((nq, D), dtype=torch.float16, device=dev)
+    rsx.synth_queries(D, nc, SEED_C, SEED_X, sig, n, SEED_Q, sigq, 0, nq, out=Q)
+    buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
+    flat = rsx.IndexFlatIP(D, device=0)
+    gD = gI = None
+    for c0 in range(0, n, buf.shape[0]):
+        nb = min(buf.shape[0], n - c0)
+        rsx.synth_vectors(D, nc, SEED_C, SEED_X, sig, c0, nb, out=buf[:nb])
+        ix.add(buf[:nb])
+        flat.reset(); flat.add(buf[:nb])
+        Dc, Ic = flat.search(Q, k); Ic = Ic + c0
+        gD, gI = (Dc, Ic) if gD is None else rsx.merge_topk(torch.stack([gD, Dc]), torch.stack([gI, Ic]))
+    out = {}
+    for npb in sorted({1, 8, args.nprobe}):
+        ix.nprobe = npb
+        _, I = ix.search(Q, k)
+        a, b = I.cpu().numpy(), gI.cpu().numpy()
+        out[f"nprobe{npb}"] = round(float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a, b)])), 4)
+    res = {"recall_at_10": out[f"nprobe{args.nprobe}"], "by_nprobe": out,
+           "data": f"{n}x{D} mixture of {nc} centres (sigma {sig}), queries = base vector + {sigq} noise; IVF-PQ M={args.m} nlist={args.nlist}",
+           "build_and_gt_s": round(time.time() - t0, 1)}
+    log(f"recall on the informative mixture: {res}")
+    del ix, flat, buf, Q
+    return res
 
 
 if __name__ == "__main__":

@@ -122,6 +122,10 @@ int rsx_add_list(rsx_index_t* h, int64_t list_no, int64_t n, const void* codes, 
 int rsx_get_list(rsx_index_t* h, int64_t list_no, int64_t* n_out, void* codes_out,
                  int64_t* ids_out);
 
+/* len(list l) for every inverted list: sizes int64 [nlist] (Flat: one entry = ntotal).  Host pointer.  Used for the
+ * list-length histogram SURVEY.md 8(d) asks the bench to report (FAISS: index.invlists.list_size(l)). */
+int rsx_get_list_sizes(rsx_index_t* h, int64_t* sizes);
+
 /* ---- search ------------------------------------------------------------------------ */
 
 /* index.nprobe = probe                         — ivf_flat.py:73,149; ivf_pq.py:77,154 */

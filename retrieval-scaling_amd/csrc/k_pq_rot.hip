@@ -367,12 +367,12 @@ __global__ __launch_bounds__(64) void k_pq_rot_compact(const PQRotItem* __restri
 #pragma unroll
     for (int off = 4; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off); if (lane >= off) incl += y; }
     const uint32_t total = __shfl(incl, 60 + k);
-    const uint32_t over = __builtin_amdgcn_ballot_w64(c0 > (uint32_t)seg_cap) != 0ull ? 1u : 0u;   // any segment overflowed
+    const uint64_t ovm = __builtin_amdgcn_ballot_w64(c0 > (uint32_t)seg_cap);     // segments that dropped keys (all 64 lanes vote)
+    const bool myover = (ovm & (0x1111111111111111ull << k)) != 0ull;              // ... any of them of MY query
     const int64_t q = items[item].q[k];
     unsigned long long base = 0;
-    if (w == 0 && (total > 0 || over)) {
+    if (w == 0 && (total > 0 || myover)) {
         // an overflowing segment dropped keys: push the row's count past its capacity so that k_finalize flags the query
-        const uint32_t myover = (uint32_t)((__builtin_amdgcn_ballot_w64(c0 > (uint32_t)seg_cap) & (0x1111111111111111ull << k)) != 0ull);
         base = atomicAdd(&cand_cnt[q * CCS], (unsigned long long)total + (myover ? (unsigned long long)cand_cap + 1ull : 0ull));
     }
     base = __shfl(base, k) + (incl - c);
@@ -384,8 +384,7 @@ __global__ __launch_bounds__(64) void k_pq_rot_compact(const PQRotItem* __restri
 }
 
 template <int NF, int NH, bool FILTER>
-static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, hipStream_t st) {
-    const int seg_cap = pq_scan_rot_seg_cap(bpw * 256);
+static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, int seg_cap, hipStream_t st) {
     constexpr int M = 64 * NF + 32 * NH;
     const size_t shm = (size_t)(NF + NH) * 65536 + 2 * 192;
     static int ncu = 0;
@@ -419,7 +418,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws, hipStream_t st) {
+                       int cand_cap, void* item_ws, int seg_cap, hipStream_t st) {
     if (a.CB != 0 || !item_ws || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8t; A.qp = (const PQQParam*)qparam;
@@ -430,10 +429,10 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
     switch (a.M) {
-        case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, st);
-        case 64: return f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, st);
-        case 96: return f ? launch_pq_scan_rot_t<1, 1, true>(A, bpw, item_ws, st) : launch_pq_scan_rot_t<1, 1, false>(A, bpw, item_ws, st);
-        case 128: return f ? launch_pq_scan_rot_t<2, 0, true>(A, bpw, item_ws, st) : launch_pq_scan_rot_t<2, 0, false>(A, bpw, item_ws, st);
+        case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, seg_cap, st);
+        case 64: return f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, seg_cap, st);
+        case 96: return f ? launch_pq_scan_rot_t<1, 1, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<1, 1, false>(A, bpw, item_ws, seg_cap, st);
+        case 128: return f ? launch_pq_scan_rot_t<2, 0, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<2, 0, false>(A, bpw, item_ws, seg_cap, st);
         default: return -1;
     }
 }

@@ -817,8 +817,15 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         HIPCHECK(hipMemcpyAsync(pl.data(), h->w_probelist.p, pl.size() * 4, hipMemcpyDeviceToHost, h->st));
         HIPCHECK(hipStreamSynchronize(h->st));
         double tot = 0;
-        for (int32_t l : pl) if (l >= 0) tot += (double)h->h_len[(size_t)l];
+        std::vector<int32_t> pc((size_t)nlist, 0);
+        for (int32_t l : pl) if (l >= 0) { tot += (double)h->h_len[(size_t)l]; pc[(size_t)l]++; }
         h->timing["scanned_vectors"] += tot;
+        // the same batch seen list-major: vectors of every list probed at least once (what HBM must deliver), and vectors x
+        // groups of 4 probing queries (what the IVF-PQ fast scan gathers)
+        double uniq = 0, grp = 0;
+        for (int l = 0; l < nlist; l++)
+            if (pc[(size_t)l]) { uniq += (double)h->h_len[(size_t)l]; grp += (double)h->h_len[(size_t)l] * ((pc[(size_t)l] + 3) / 4); }
+        h->timing["scanned_unique_vectors"] += uniq; h->timing["scanned_group_vectors"] += grp;
         tm.mark("count");
     }
     // host-side bound on a query's row of the score buffer: the nprobe longest (padded) lists
@@ -860,8 +867,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
                            h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st);
             tm.mark("lut8");
-            auto rot_desc = [&](int64_t items, int v) -> void* {   // work-item records + survivor segments of the rotated-layout scan
-                h->w_itemdesc.ensure(pq_scan_rot_ws(items, 1024 * v));
+            int rot_seg_cap = 128;
+            auto rot_desc = [&](int64_t items, int v, int pre_rows_) -> void* {   // work-item records + survivor segments of the rotated-layout scan
+                rot_seg_cap = pq_scan_rot_seg_cap(1024 * v, KP, pre_rows_);
+                h->w_itemdesc.ensure(pq_scan_rot_ws(items, rot_seg_cap));
                 return h->w_itemdesc.p;
             };
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
@@ -922,9 +931,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
                 tm.mark("group");
                 const int64_t mi = filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows);
+                void* rws0 = rot ? rot_desc(mi, filtered ? pre_vpl : vpl, 0) : nullptr;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
-                                                 nullptr, 0, nullptr, nullptr, 0, rot_desc(mi, filtered ? pre_vpl : vpl), h->st)
+                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, h->st)
                             : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
             }
@@ -948,11 +958,12 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                    h->st);
                 tm.mark("group");
+                void* rws1 = rot ? rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, pre_rows) : nullptr;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist,
                                                  max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows), vpl), h->st)
+                                                 rws1, rot_seg_cap, h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
                                                      max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
@@ -1531,6 +1542,13 @@ int rsx_get_list(rsx_index_t* h, int64_t list_no, int64_t* n_out, void* codes_ou
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         use_device(h);
         get_list_impl(h, list_no, n_out, codes_out, ids_out);
+    });
+}
+
+int rsx_get_list_sizes(rsx_index_t* h, int64_t* sizes) {
+    return guarded([&] {
+        if (!h || !sizes) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        for (int l = 0; l < h->nlist; l++) sizes[l] = h->h_len[(size_t)l];
     });
 }
 

@@ -224,11 +224,19 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, 1024 * vpl) bytes */, hipStream_t st);
-// survivor segment capacity per (item, wave, query): ~3x the mean a query's CLOSEST list yields at the default pre-pass
-inline int pq_scan_rot_seg_cap(int tile_rows) { int c = tile_rows / 64; return c < 128 ? 128 : c; }
-inline size_t pq_scan_rot_ws(int64_t max_items, int tile_rows) {   // item records + segment counts + segment keys
-    return (size_t)(max_items + 8) * (176 + 256 + (size_t)64 * pq_scan_rot_seg_cap(tile_rows) * 8) + 1024;   // + per-XCD counters
+                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, hipStream_t st);
+// survivor segment capacity per (item, wave, query): 4x what a query's CLOSEST list is expected to yield (a wave scans
+// tile/16 vectors of it, of which the pre-pass threshold lets about KP / pre_rows through), never less than 128 and never
+// more than the wave's whole share of the tile (at which point no overflow is possible)
+inline int pq_scan_rot_seg_cap(int tile_rows, int KP, int pre_rows) {
+    const int64_t share = tile_rows / 16;
+    int64_t c = pre_rows > 0 ? 4 * share * KP / pre_rows : share;
+    if (c < 128) c = 128;
+    if (c > share) c = share;
+    return (int)c;
+}
+inline size_t pq_scan_rot_ws(int64_t max_items, int seg_cap) {   // item records + segment counts + segment keys + per-XCD counters
+    return (size_t)(max_items + 8) * (176 + 256 + (size_t)64 * seg_cap * 8) + 1024;
 }
 // exact per-(query, list) scan of the rotated layout (fp32 table, sequential sums = oracle bits): fallback / A-B path
 int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st);

@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "rsx_last_error", "rsx_version", "rsx_device_count", "rsx_flat_create", "rsx_ivfflat_create",
     "rsx_ivfpq_create", "rsx_destroy", "rsx_train", "rsx_set_centroids", "rsx_set_codebooks",
     "rsx_get_centroids", "rsx_get_codebooks", "rsx_add", "rsx_assign", "rsx_reset", "rsx_reserve_lists", "rsx_add_list",
-    "rsx_get_list", "rsx_set_nprobe", "rsx_search", "rsx_merge_topk", "rsx_pack_topk", "rsx_merge_packed", "rsx_get",
+    "rsx_get_list", "rsx_get_list_sizes", "rsx_set_nprobe", "rsx_search", "rsx_merge_topk", "rsx_pack_topk", "rsx_merge_packed", "rsx_get",
     "rsx_set_param",
     "rsx_get_timing", "rsx_save", "rsx_load", "rsx_synth_vectors", "rsx_synth_queries",
 ]
@@ -117,6 +117,14 @@ def _as_matrix(x, d, what):
     return x, ctypes.c_void_p(x.ctypes.data), x.shape[0], (_F16 if x.dtype == np.float16 else _F32), False
 
 
+def _sync_producer(keep, on_dev):
+    """The library reads caller data on its OWN (non-blocking) stream: a CUDA tensor must be complete before the
+    call — including the .float()/.contiguous() copies _as_matrix may have enqueued on torch's current stream."""
+    if on_dev:
+        import torch
+        torch.cuda.current_stream(keep.device).synchronize()
+
+
 class Index:
     """Base handle.  Attributes follow faiss.Index: d, ntotal, is_trained, metric_type."""
 
@@ -163,18 +171,21 @@ class Index:
 
     # -- faiss.Index API
     def train(self, x):
-        keep, p, n, dt, _ = _as_matrix(x, self.d, "train")
+        keep, p, n, dt, on_dev = _as_matrix(x, self.d, "train")
+        _sync_producer(keep, on_dev)
         _check(lib().rsx_train(self._h, ctypes.c_int64(n), p, dt))
 
     def add(self, x):
-        keep, p, n, dt, _ = _as_matrix(x, self.d, "add")
+        keep, p, n, dt, on_dev = _as_matrix(x, self.d, "add")
+        _sync_producer(keep, on_dev)
         _check(lib().rsx_add(self._h, ctypes.c_int64(n), p, dt, None))
 
     def reset(self):
         _check(lib().rsx_reset(self._h))
 
     def add_with_ids(self, x, ids):
-        keep, p, n, dt, _ = _as_matrix(x, self.d, "add_with_ids")
+        keep, p, n, dt, on_dev = _as_matrix(x, self.d, "add_with_ids")
+        _sync_producer(keep, on_dev)
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         assert ids.shape == (n,), "ids must have one entry per vector"
         _check(lib().rsx_add(self._h, ctypes.c_int64(n), p, dt, ids.ctypes.data_as(ctypes.c_void_p)))
@@ -188,7 +199,7 @@ class Index:
             import torch
             D = torch.empty((n, k), dtype=torch.float32, device=keep.device)
             I = torch.empty((n, k), dtype=torch.int64, device=keep.device)
-            torch.cuda.current_stream(keep.device).synchronize()
+            _sync_producer(keep, on_dev)
             _check(lib().rsx_search(self._h, ctypes.c_int64(n), p, dt, k, ctypes.c_void_p(D.data_ptr()),
                                     ctypes.c_void_p(I.data_ptr())))
             return D, I
@@ -213,6 +224,12 @@ class Index:
             _check(lib().rsx_get_list(self._h, ctypes.c_int64(list_no), None, payload.ctypes.data_as(ctypes.c_void_p),
                                       ids.ctypes.data_as(ctypes.c_void_p)))
         return payload, ids
+
+    def list_sizes(self):
+        """int64 [nlist]: vectors per inverted list (Flat: one entry = ntotal) — the bench's list-length histogram."""
+        out = np.zeros(max(1, self._get("nlist")), dtype=np.int64)
+        _check(lib().rsx_get_list_sizes(self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     def reconstruct_n(self, i0, n):
         assert self._get("kind") == 0, "reconstruct_n is implemented for Flat indexes"
@@ -262,7 +279,8 @@ class _IndexIVF(Index):
 
     def assign(self, x):
         """index.quantizer.assign(x): list number of every vector (exact argmax-IP, as `add` computes it)."""
-        keep, p, n, dt, _ = _as_matrix(x, self.d, "assign")
+        keep, p, n, dt, on_dev = _as_matrix(x, self.d, "assign")
+        _sync_producer(keep, on_dev)
         labels = np.empty(n, dtype=np.int64)
         _check(lib().rsx_assign(self._h, ctypes.c_int64(n), p, dt, labels.ctypes.data_as(ctypes.c_void_p)))
         return labels

@@ -56,11 +56,17 @@ def test_golden_ivfflat(gpu, orc):
     assert_same_results(D2, I2, Dr, Ir, "nprobe>nlist")
 
 
-@pytest.mark.parametrize("name", ["ivfpq_d64_m16", "ivfpq_d768_m96"])
-def test_golden_ivfpq(gpu, orc, name):
+@pytest.mark.parametrize("name,layout", [("ivfpq_d64_m16", 0), ("ivfpq_d768_m96", 1), ("ivfpq_d768_m96", 0)])
+def test_golden_ivfpq(gpu, orc, name, layout):
+    """layout 1 = the rotated code layout (k_pq_rot.hip: conflict-free table gathers, default for M in {32, 64, 96, 128}),
+    layout 0 = the granule layout (k_pq.hip); both must give the oracle's bits through every scan variant."""
     g = load_golden(name)
     x, q = regen_gpu(gpu, g)
     ix = gpu.IndexIVFPQ(gpu.IndexFlatIP(g["d"]), g["d"], g["nlist"], g["M"], 8, gpu.METRIC_INNER_PRODUCT)
+    assert ix._get("pq_layout") == (1 if g["M"] % 32 == 0 else 0), "rotated layout is the default where it applies"
+    ix.set_param("pq_layout", layout)
+    assert ix._get("pq_layout") == layout
+    name = f"{name} layout={layout}"
     assert not ix.is_trained
     ix.set_centroids(g["centroids"])
     ix.set_codebooks(g["codebooks"])
@@ -131,10 +137,12 @@ def test_golden_ivfpq(gpu, orc, name):
     ix.set_param("lut_tiled", 1)
 
 
-@pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8), (64, 16, 7), (320, 160, 4)])
+@pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8), (64, 16, 7), (320, 160, 4),
+                                       (256, 32, 8), (256, 128, 4), (192, 96, 5), (384, 64, 6)])
 def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
     """Other (d, M): 16-byte-granule and 4-byte-granule code layouts, dsub 8/2/48; M=160 is too large for the
-    LDS-resident table build and takes the unfused table path."""
+    LDS-resident table build and takes the unfused table path; M = 32 / 64 / 96 / 128 take the rotated layout
+    (half phase only, one full phase, full + half, two full phases of k_pq_scan_rot)."""
     n, nq, k = 6000, 37, 20
     x = orc.synth_vectors(d, nlist, 61, 62, 0.5, 0, n)
     q = orc.synth_queries(d, nlist, 61, 62, 0.5, n, 63, 0.1, 0, nq)
@@ -152,6 +160,33 @@ def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
         D, I = ix.search(q, k)
         Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, nprobe, k)
         assert_same_results(D, I, Dr, Ir, f"d={d} M={M} nprobe={nprobe}")
+
+
+@pytest.mark.parametrize("layout", [1, 0])
+def test_ivfpq_many_survivors(gpu, orc, layout):
+    """Large K' (weak threshold): tens of thousands of keys pass the in-kernel filter, survivor segments and candidate rows
+    overflow — every query must then be flagged and repaired by the exact re-run, never silently lose a candidate."""
+    d, n, nlist, M, nq, k = 768, 120000, 8, 96, 96, 10
+    x = gpu.synth_vectors(d, 8, 1234, 10000, 0.5, 0, n)
+    q = gpu.synth_queries(d, 8, 1234, 10000, 0.5, n, 999, 0.1, 0, nq)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    ix.set_param("pq_layout", layout)
+    ix.train(x[:20000]); ix.add(x); ix.nprobe = 4
+    ix.set_param("scan_kernel", 2)
+    De, Ie = ix.search(q, k)
+    ix.set_param("scan_kernel", 0)
+    for kp in (0, 512, 2048):
+        for chunk in (0, 4096):
+            ix.set_param("pq_fast_kp", kp); ix.set_param("scan_chunk", chunk)
+            D, I = ix.search(q, k)
+            assert_same_results(D, I, De, Ie, f"layout={layout} K'={kp} scan_chunk={chunk}")
+    # k = 300 -> K' = 512 on its own
+    ix.set_param("pq_fast_kp", 0); ix.set_param("scan_chunk", 0)
+    ix.set_param("scan_kernel", 2)
+    De, Ie = ix.search(q[:16], 300)
+    ix.set_param("scan_kernel", 0)
+    D, I = ix.search(q[:16], 300)
+    assert_same_results(D, I, De, Ie, f"layout={layout} k=300")
 
 
 def test_ivfpq_large_k_and_ties(gpu, orc):

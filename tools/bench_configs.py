@@ -14,44 +14,33 @@ D, NC = 768, 4096
 SC, SX, SQ = 1234, 10000, 999
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("which", choices=["flat", "ivfflat", "latency"])
-    ap.add_argument("--n", type=int, default=0)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--nlist", type=int, default=4096)
-    ap.add_argument("--nprobe", type=int, default=32)
-    ap.add_argument("--check", type=int, default=4, help="queries verified against the CPU oracle")
-    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="latency: engine parameter A/B")
-    a = ap.parse_args()
+def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, small_batches=True):
+    """One non-headline config on cuda:0 -> result dict (the same object bench.py embeds under "configs")."""
     import torch, rsx
     from oracle import oracle as orc
     dev = torch.device("cuda", 0)
-    if a.which == "latency":
-        return latency(a)
-    n = a.n or (10_000_000 if a.which == "flat" else 20_000_000)
-    nq, k = a.batch, 10
-    Q = torch.empty((nq * (a.steps + 1), D), dtype=torch.float16, device=dev)
+    n = n or (10_000_000 if which == "flat" else 20_000_000)
+    nq, k = batch, 10
+    Q = torch.empty((nq * (steps + 1), D), dtype=torch.float16, device=dev)
     rsx.synth_queries(D, NC, SC, SX, 0.5, n, SQ, 0.1, 0, Q.shape[0], out=Q)
     buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
     t0 = time.time()
-    if a.which == "flat":
+    if which == "flat":
         ix = rsx.IndexFlatIP(D)
     else:
-        ix = rsx.IndexIVFFlat(None, D, a.nlist, rsx.METRIC_INNER_PRODUCT)
-        nt = min(n, 256 * a.nlist)
+        ix = rsx.IndexIVFFlat(None, D, nlist, rsx.METRIC_INNER_PRODUCT)
+        nt = min(n, 256 * nlist)
         xt = torch.empty((nt, D), dtype=torch.float16, device=dev)
         rsx.synth_vectors(D, NC, SC, SX, 0.5, 0, nt, out=xt)
         ix.train(xt); del xt
-        ix.nprobe = a.nprobe
+        ix.nprobe = nprobe
         # pass 1: count list sizes with quantizer.assign, reserve exactly (a re-layout of a 153.6 GB index
         # cannot hold two copies in 288 GB); pass 2: add
-        counts = np.zeros(a.nlist, dtype=np.int64)
+        counts = np.zeros(nlist, dtype=np.int64)
         for c0 in range(0, n, buf.shape[0]):
             nb = min(buf.shape[0], n - c0)
             rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb])
-            counts += np.bincount(ix.assign(buf[:nb]), minlength=a.nlist)
+            counts += np.bincount(ix.assign(buf[:nb]), minlength=nlist)
         ix.reserve_lists(counts)
     for c0 in range(0, n, buf.shape[0]):
         nb = min(buf.shape[0], n - c0)
@@ -60,29 +49,35 @@ def main():
     torch.cuda.synchronize()
     build_s = time.time() - t0
     ix.search(Q[:nq], k)
-    ix.set_param("profile", 2 if a.which == "ivfflat" else 1)
+    ix.set_param("profile", 2 if which == "ivfflat" else 1)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for s in range(1, a.steps + 1):
+    for s in range(1, steps + 1):
         Dq, Iq = ix.search(Q[s * nq:(s + 1) * nq], k)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
-    scan_ms = ix.get_timing("scan") / a.steps
-    res = {"config": f"{a.which} {n}x{D} batch={nq} k={k}" + (f" nlist={a.nlist} nprobe={a.nprobe}" if a.which == "ivfflat" else ""),
-           "queries_per_s": round(a.steps * nq / el, 1), "ms_per_batch": round(el / a.steps * 1e3, 3),
-           "scan_ms": round(scan_ms, 3), "select_ms": round(ix.get_timing("select") / a.steps, 3),
-           "finalize_ms": round(ix.get_timing("finalize") / a.steps, 3), "build_s": round(build_s, 1),
+    scan_ms = ix.get_timing("scan") / steps
+    res = {"config": f"{which} {n}x{D} batch={nq} k={k}" + (f" nlist={nlist} nprobe={nprobe}" if which == "ivfflat" else ""),
+           "queries_per_s": round(steps * nq / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+           "scan_ms": round(scan_ms, 3), "select_ms": round(ix.get_timing("select") / steps, 3),
+           "finalize_ms": round(ix.get_timing("finalize") / steps, 3), "build_s": round(build_s, 1),
            "storage_dtype": ix.storage_dtype}
-    if a.which == "flat":
+    if which == "flat":
         fl = 2.0 * nq * n * D
-        res["roofline"] = {"bound": "mfma", "achieved": round(fl / (scan_ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                           "frac": round(fl / (scan_ms * 1e-3) / 2.5e15, 4),
-                           "note": "scan stage = k_flat_gemm + per-chunk k_select launches (HIP events on the library stream)"}
+        res["roofline"] = {"bound": "mfma", "kernel": "k_flat_gemm2", "achieved": round(fl / (scan_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
+                           "unit": "TFLOP/s", "frac": round(fl / (scan_ms * 1e-3) / 2.5e15, 4),
+                           "note": "2*nq*N*d flop / scan stage (k_flat_gemm2 + the first chunk's k_select; HIP events on the library stream)"}
     else:
-        rows = ix.get_timing("scanned_vectors") / a.steps
-        by = rows * D * 2
-        res["roofline"] = {"bound": "hbm", "achieved": round(by / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(by / (scan_ms * 1e-3) / 8e12, 4), "algorithmic_bytes_per_batch": by,
-                           "note": "algorithmic = sum over (query, probed list) of len*d*2 B; list-major grouping reads a list once per group of <=16 queries"}
-    if a.which == "flat":
+        rows = ix.get_timing("scanned_vectors") / steps
+        uniq = ix.get_timing("scanned_unique_vectors") / steps
+        res["roofline"] = {"bound": "hbm", "kernel": "k_list_scan2", "achieved": round(uniq * D * 2 / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                           "unit": "GB/s", "frac": round(uniq * D * 2 / (scan_ms * 1e-3) / 8e12, 4),
+                           "algorithmic_bytes_per_step": uniq * D * 2, "logical_bytes_per_step": rows * D * 2,
+                           "effective_GBs": round(rows * D * 2 / (scan_ms * 1e-3) / 1e9, 1),
+                           "note": "achieved = rows of every list probed at least once x d x 2 B (each must cross HBM once per batch) / scan "
+                                   "stage; logical = sum over (query, probed list) of len*d*2 B (SURVEY 8d), served from one HBM read per "
+                                   "group of <=16 probing queries"}
+        ls = ix.list_sizes()
+        res["list_length"] = {"min": int(ls.min()), "p50": int(np.percentile(ls, 50)), "p95": int(np.percentile(ls, 95)), "max": int(ls.max())}
+    if which == "flat" and small_batches:
         # small batches stream the database once through the list-scan kernel (HBM-bound): 16 queries per pass
         small = {}
         for b in (1, 16):
@@ -95,9 +90,9 @@ def main():
             small[f"batch{b}"] = {"ms": round(ms, 3), "db_GBps": round(n * D * 2 / (ms * 1e-3) / 1e9, 1)}
         res["small_batch"] = small
     # parity spot check against the oracle (exact arithmetic) on a few queries of the last batch
-    if a.check:
-        qs = Q[a.steps * nq:a.steps * nq + a.check].cpu().numpy().astype(np.float32)
-        if a.which == "flat":
+    if check:
+        qs = Q[steps * nq:steps * nq + check].cpu().numpy().astype(np.float32)
+        if which == "flat":
             best = None
             for c0 in range(0, n, buf.shape[0]):
                 nb = min(buf.shape[0], n - c0)
@@ -105,22 +100,41 @@ def main():
                 Dc, Ic = orc.flat_search(qs, buf[:nb].cpu().numpy().astype(np.float32), k, 0)
                 Ic = Ic + c0
                 best = (Dc, Ic) if best is None else orc.merge_topk(np.stack([best[0], Dc]), np.stack([best[1], Ic]))
-            ok = bool(np.array_equal(best[1], Iq[:a.check].cpu().numpy()) and np.array_equal(best[0], Dq[:a.check].cpu().numpy()))
+            ok = bool(np.array_equal(best[1], Iq[:check].cpu().numpy()) and np.array_equal(best[0], Dq[:check].cpu().numpy()))
         else:
             cen = ix.get_centroids()
-            pid, _ = orc.coarse_probe(cen, qs, a.nprobe)
+            pid, _ = orc.coarse_probe(cen, qs, nprobe)
             need = np.unique(pid)
-            off = np.zeros(a.nlist + 1, np.int64); lens = np.zeros(a.nlist, np.int64); pay = []; ids = []
+            off = np.zeros(nlist + 1, np.int64); lens = np.zeros(nlist, np.int64); pay = []; ids = []
             for l in need:
                 v, i = ix.get_list(int(l)); pay.append(v); ids.append(i); lens[l] = len(i)
             np.cumsum(lens, out=off[1:])
 
             class LM: pass
             lm = LM(); lm.list_off = off; lm.payload = np.concatenate(pay); lm.ids = np.concatenate(ids)
-            Dr, Ir = orc.ivfflat_search(0, cen, lm, qs, a.nprobe, k)
-            ok = bool(np.array_equal(Ir, Iq[:a.check].cpu().numpy()) and np.array_equal(Dr, Dq[:a.check].cpu().numpy()))
+            Dr, Ir = orc.ivfflat_search(0, cen, lm, qs, nprobe, k)
+            ok = bool(np.array_equal(Ir, Iq[:check].cpu().numpy()) and np.array_equal(Dr, Dq[:check].cpu().numpy()))
         res["oracle_parity_ids_and_scores"] = ok
-    print(json.dumps(res), flush=True)
+        res["oracle_checked_queries"] = int(check)
+    del ix, buf, Q
+    torch.cuda.synchronize()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", choices=["flat", "ivfflat", "latency"])
+    ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--nlist", type=int, default=4096)
+    ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--check", type=int, default=4, help="queries verified against the CPU oracle")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="latency: engine parameter A/B")
+    a = ap.parse_args()
+    if a.which == "latency":
+        return latency(a)
+    print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check)), flush=True)
 
 
 def latency(a):

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Turn a `rocprofv3 --kernel-trace --pmc FETCH_SIZE` pass over bench.py into profiles-style pmc_traffic.json:
+HBM bytes per launch of the IVF-PQ scan kernel, stamped with the hash of the sources it was measured on (bench.py
+refuses the file when the hash no longer matches).  FETCH_SIZE is reported in KiB and, on gfx950, counts exactly half
+of the bytes of 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM) -> bytes = value * 1024 * 2.
+
+usage: update_pmc_traffic.py <results.db> <out.json> [n_vectors] [n_gpus]"""
+import datetime, json, os, sqlite3, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from bench import kernel_source_hash
+
+db, out = sys.argv[1], sys.argv[2]
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000_000
+ng = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+cur = sqlite3.connect(db).cursor()
+rows = cur.execute("select kernel_name, avg(value), count(*), avg(duration) from counters_collection "
+                   "where counter_name = 'FETCH_SIZE' and (kernel_name like '%k_pq_scan_rot%' or kernel_name like '%k_pq_scan8%') "
+                   "group by kernel_name order by avg(duration) desc").fetchall()
+assert rows, "no IVF-PQ scan kernel in the PMC pass"
+name, val, cnt, dur = rows[0]
+kernel = "k_pq_scan_rot" if "k_pq_scan_rot" in name else "k_pq_scan8"
+res = {"kernel": kernel, "kernel_name": name.split("(")[0].replace("void ", ""), "n": n, "n_gpus": ng,
+       "hbm_bytes_per_launch": val * 1024.0 * 2.0, "fetch_size_kib_avg": val, "dispatches": cnt, "avg_us_under_pmc": dur / 1e3,
+       "source_sha256": kernel_source_hash(), "date": datetime.date.today().isoformat(),
+       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --steps 2 --warmup 1 --cpu-queries 0 --no-recall --no-configs; "
+                 "bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 halves 16-B/lane streaming reads)"}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res))
