@@ -71,6 +71,22 @@ int rsx_ivfflat_create(int d, int nlist, int metric, int device, rsx_index_t** o
  * by_residual = true (FAISS default). nbits must be 8. */
 int rsx_ivfpq_create(int d, int nlist, int M, int nbits, int metric, int device, rsx_index_t** out);
 
+/* ONE handle over several GPUs of the node, single process — SURVEY.md 8(b)/(e).  The reference's offline driver makes one
+ * index.search(all_queries, k) call (src/search.py:296) and its serving tier fans a query out to shard workers over HTTP and
+ * re-sorts (api/serve_main_node.py:281-323); with this handle the same `Indexer(cfg).search` spans the node:
+ *   kind: rsx_kind; nlist / M / nbits as for the single-device constructors (ignored where they do not apply);
+ *   devices[ndev]: one shard per entry (an ordinal may repeat: several shards on one GPU).
+ * train trains the first shard and copies the parameters; every add call is cut into ndev contiguous pieces (piece r ->
+ * shard r) that keep the logical index's sequential ids, so the shards' lists are a partition of the single index's lists;
+ * search runs every shard from its own host thread on its own device, copies the [nq, k] blocks to devices[0] and merges
+ * them there by (score desc, id asc) — bit-identical to one index holding everything.  Every other entry point accepts the
+ * handle (rsx_get "ntotal" sums the shards, knobs apply to all shards, "nshards" tells them apart) except the per-list
+ * import / export calls.  rsx_save writes a manifest at `path` and one RSX1 file per shard beside it (path.shard<r>);
+ * rsx_load_sharded reads them back onto the given devices (shard r -> devices[r % ndev]). */
+int rsx_sharded_create(int kind, int d, int nlist, int M, int nbits, int metric, int ndev, const int* devices,
+                       rsx_index_t** out);
+int rsx_load_sharded(const char* path, int ndev, const int* devices, rsx_index_t** out);
+
 /* Python garbage collection of the SWIG object (implicit in the reference). */
 int rsx_destroy(rsx_index_t* h);
 
@@ -158,7 +174,8 @@ int rsx_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* 
 /* ---- introspection / knobs --------------------------------------------------------- */
 
 /* Integer properties: "ntotal", "nlist", "d", "is_trained", "nprobe", "M", "nbits", "kind",
- * "metric", "storage_dtype", "code_size", "device", "max_k".
+ * "metric", "storage_dtype", "code_size", "device", "max_k", "pq_layout" (IVFPQ: 1 = rotated code layout), "nshards"
+ * (0 = single-device handle), "hbm_bytes".
  * (index.ntotal / index.is_trained — ivf_flat.py:171; ivf_pq.py:175) */
 int rsx_get(rsx_index_t* h, const char* key, int64_t* out);
 

@@ -575,9 +575,10 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
 static const size_t FG2_SHM = 2 * FG2_STAGE + 2 * 256 * 8 + 2 * 256 * 4;
 template <bool FILTER>
 static bool fg2_ready() {
-    static int ok = -1;
-    if (ok < 0) ok = hipFuncSetAttribute((const void*)k_flat_gemm2<FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FG2_SHM) == hipSuccess;
-    return ok == 1;
+    static DevOnce once;
+    if (once.first() && hipFuncSetAttribute((const void*)k_flat_gemm2<FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FG2_SHM) != hipSuccess)
+        return false;
+    return true;
 }
 // the 256 x 256 LDS-DMA kernel needs fp16 storage, K a multiple of 64 and enough queries to fill its tile
 static bool fg2_applies(int nq_pad, int x_f16, int ld) {
@@ -902,11 +903,10 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
     if (a.chunk_rows == list_scan2_chunk_rows(a.x_f16, a.ld)) {
         size_t shm2 = (size_t)16 * (a.ld + 8) * 2 + 384 + 4 * LS2_D * 2048;
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce once;
+        if (once.first()) {
             hipFuncSetAttribute((const void*)k_list_scan2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)k_list_scan2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
         }
         if (a.tau_key) hipLaunchKernelGGL(k_list_scan2<true>, grid, dim3(256), shm2, st, a);
         else hipLaunchKernelGGL(k_list_scan2<false>, grid, dim3(256), shm2, st, a);

@@ -592,8 +592,8 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
         float* errb = mnmx + (size_t)nq * Mpad * 2;
         dim3 grid((unsigned)((Mpad + LT_MB - 1) / LT_MB), (unsigned)((nq + LT_QC - 1) / LT_QC));
         const size_t osm = transposed ? (size_t)LT_QC * 256 * LT_MB : 0;
-        static bool attr = false;
-        if (osm && !attr) { hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm); attr = true; }
+        static DevOnce once;
+        if (osm && once.first()) hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm);
         hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
         hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), osm, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
         hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)nq), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0, nprobe,
@@ -602,9 +602,8 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
     }
     const size_t lds = pq_lut8_fused_lds(M, Mpad, dsub);
     auto kern = dsub == 8 ? k_pq_lut8f<8> : k_pq_lut8f<0>;
-    static bool attr8 = false, attr0 = false;
-    bool& done = dsub == 8 ? attr8 : attr0;
-    if (!done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    static DevOnce once8, once0;
+    if ((dsub == 8 ? once8 : once0).first()) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), lds, st, Q32, ldq, codebooks, dsub, M, Mpad, probe_dis0, nprobe,
                        lut8, (PQQParam*)qparam, transposed);
 }

@@ -387,14 +387,17 @@ template <int NF, int NH, bool FILTER>
 static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, int seg_cap, hipStream_t st) {
     constexpr int M = 64 * NF + 32 * NH;
     const size_t shm = (size_t)(NF + NH) * 65536 + 2 * 192;
-    static int ncu = 0;
-    if (!ncu) {
+    static DevOnce once;
+    static int ncu_of[64] = {};
+    int& ncu = ncu_of[cur_device()];
+    if (once.first()) {
         if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return -1;
         int dev = 0; hipDeviceProp_t pr;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return -1;
         ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }
+    if (ncu <= 0) ncu = 256;
     PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
     uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(desc_ws) + (size_t)(A.max_items + 8) * 176);
     uint64_t* seg_keys = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(seg_cnt) + (size_t)(A.max_items + 8) * 256);
@@ -483,11 +486,9 @@ int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st) {
     if (pairs <= 0 || a.max_chunks <= 0) return 0;
     if (a.CB != 0 || !pq_rot_applies(a.M)) return -1;
     const size_t shm = (size_t)a.Mpad * 1024;
-    static size_t attr = 0;
-    if (shm > attr) {
-        if (hipFuncSetAttribute((const void*)k_pq_scan_rot_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return -1;
-        attr = shm;
-    }
+    static DevSize attr;
+    if (attr.need(shm) && hipFuncSetAttribute((const void*)k_pq_scan_rot_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+        return -1;
     hipLaunchKernelGGL(k_pq_scan_rot_exact, dim3((unsigned)pairs, (unsigned)a.max_chunks), dim3(1024), shm, st, a);
     return 0;
 }

@@ -320,8 +320,8 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
 void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
     if (nq <= 0) return;
     size_t shm = (size_t)a.pre_rows * 8 + (size_t)a.KP * 8 + 264 * 4 + (size_t)a.Mpad * 256;
-    static size_t attr = 0;
-    if (shm > attr) { hipFuncSetAttribute((const void*)k_pq_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
+    static DevSize attr;
+    if (attr.need(shm)) hipFuncSetAttribute((const void*)k_pq_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(k_pq_prepass, dim3((unsigned)nq), dim3(1024), shm, st, a);
 }
 
@@ -843,6 +843,65 @@ void launch_merge_packed(int nshards, int64_t nq, int k, int metric, const int64
                          hipStream_t st) {
     launch_merge_strided(nshards, nq, k, metric, reinterpret_cast<const float*>(packed), 4 * nq * k, 2, packed + nq * k,
                          2 * nq * k, Do, Io, st);
+}
+
+// Merge for the single-process multi-GPU handle (rsx_sharded_create): the shards are pieces of ONE logical index, so the
+// merged order is the single index's canonical order — score descending, ties by id ascending — not the reference's
+// shard-order rule above (which rsx_merge_topk keeps for its per-shard indexes).  One workgroup per query, bitonic sort of
+// (ordered score, id) pairs in LDS.
+__global__ __launch_bounds__(256) void k_merge_topk_byid(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
+                                                         float* Do, int64_t* Io, int NP) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t mb_buf[];
+    int64_t* sid = reinterpret_cast<int64_t*>(mb_buf);
+    uint32_t* sord = reinterpret_cast<uint32_t*>(sid + NP);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t q = blockIdx.x;
+    const int n = nshards * k;
+    for (int p = tid; p < NP; p += nt) {
+        uint32_t ord = 0; int64_t id = INT64_MAX;
+        if (p < n) {
+            const int sh = p / k, j = p - sh * k;
+            const int64_t e = ((int64_t)sh * nq + q) * k + j;
+            const int64_t ii = I[e];
+            if (ii >= 0) {
+                float sc = D[e];
+                sc = (metric == 0 ? sc : 0.0f - sc) + 0.0f;
+                if (sc == sc) { ord = f2ord(sc); id = ii; }
+            }
+        }
+        sord[p] = ord; sid[p] = id;
+    }
+    __syncthreads();
+    for (int size = 2; size <= NP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (NP >> 1); t += nt) {
+                const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                const int j = i + stride;
+                const bool desc = ((i & size) == 0);
+                const uint32_t oi = sord[i], oj = sord[j];
+                const int64_t ii = sid[i], ij = sid[j];
+                const bool i_worse = (oi < oj) || (oi == oj && ii > ij);
+                if (i_worse == desc) { sord[i] = oj; sord[j] = oi; sid[i] = ij; sid[j] = ii; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k; j += nt) {
+        const bool valid = sord[j] != 0 && sid[j] != INT64_MAX;
+        float sc = valid ? ord2f(sord[j]) : -__builtin_inff();
+        if (metric != 0) sc = valid ? (0.0f - sc) : __builtin_inff();
+        Do[q * k + j] = sc;
+        Io[q * k + j] = valid ? sid[j] : -1;
+    }
+}
+void launch_merge_topk_byid(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do,
+                            int64_t* Io, hipStream_t st) {
+    if (nq <= 0) return;
+    int NP = 64;
+    while (NP < nshards * k) NP <<= 1;
+    const size_t shm = (size_t)NP * 12;
+    if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_merge_topk_byid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(k_merge_topk_byid, dim3((unsigned)nq), dim3(256), shm, st, nshards, nq, k, metric, D, I, Do, Io, NP);
 }
 
 // one rank's (D, I) -> the packed [2, nq, k] int64 block it contributes to the all-gather; ids get the shard's offset

@@ -10,6 +10,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rsx.h"
@@ -163,6 +164,11 @@ struct rsx_index {
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
         w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc;
     std::map<std::string, double> timing;
+
+    // single-process multi-GPU handle (rsx_sharded_create): this object owns one child index per device and nothing else
+    std::vector<rsx_index*> shards;
+    DevBuf sh_D, sh_I, sh_q, sh_oD, sh_oI;      // parent-device gather / merge buffers
+    int64_t sh_next_id = 0;                      // next sequential id of the logical index
 
     int row_align() const { return kind == KIND_IVFPQ ? 64 : (kind == KIND_FLAT ? 128 : 64); }
     size_t row_bytes() const { return kind == KIND_IVFPQ ? (size_t)Mpad : (size_t)ld * (storage_f16 ? 2 : 4); }
@@ -1400,6 +1406,182 @@ static rsx_index* load_impl(const char* path, int device) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Single-process multi-GPU handle: N child indexes (one per device) behind one rsx_index_t.  The reference's driver makes
+// ONE index.search(all_queries, k) call (src/search.py:296) and its serving tier fans the query out to shard workers over
+// HTTP and re-sorts (api/serve_main_node.py:281-323); here the fan-out is N host threads driving N GPUs and the fan-in is
+// a device-to-device copy of each shard's [nq, k] block plus one merge kernel on the first device.
+//   * add: every call's rows are cut into N contiguous pieces, piece r -> shard r, ids = the logical index's sequential
+//     ids, so the union of the shards' lists IS the single index's lists and the merged result (score desc, id asc) is
+//     bit-identical to one index holding everything.
+//   * trained parameters are identical on every shard (trained once on the first, copied).
+// ---------------------------------------------------------------------------------------
+static bool is_sharded(const rsx_index* h) { return !h->shards.empty(); }
+
+template <typename F>
+static void for_each_shard_parallel(rsx_index* h, F&& f) {
+    const size_t n = h->shards.size();
+    std::vector<std::string> errs(n);
+    std::vector<int> codes(n, 0);
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < n; r++)
+        th.emplace_back([&, r] {
+            try { (void)hipSetDevice(h->shards[r]->device); f((int)r, h->shards[r]); }
+            catch (const RsxError& e) { errs[r] = e.what(); codes[r] = e.code; }
+            catch (const std::exception& e) { errs[r] = e.what(); codes[r] = RSX_ERR_INVALID; }
+        });
+    for (auto& t : th) t.join();
+    for (size_t r = 0; r < n; r++)
+        if (codes[r]) RSX_THROW(codes[r], "shard %zu (device %d): %s", r, h->shards[r]->device, errs[r].c_str());
+}
+
+static rsx_index* sharded_create(int kind, int d, int nlist, int M, int nbits, int metric, int ndev, const int* devices) {
+    if (ndev <= 0 || !devices) RSX_THROW(RSX_ERR_INVALID, "sharded_create: need at least one device");
+    if (ndev > 64) RSX_THROW(RSX_ERR_INVALID, "sharded_create: %d shards", ndev);
+    std::unique_ptr<rsx_index> p(new rsx_index());
+    try {
+        for (int r = 0; r < ndev; r++) p->shards.push_back(create_common(kind, d, nlist, M, nbits, metric, devices[r]));
+    } catch (...) {
+        for (auto* c : p->shards) { if (c->st) { (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->st); } delete c; }
+        throw;
+    }
+    rsx_index* c0 = p->shards[0];
+    p->kind = kind; p->d = d; p->metric = metric; p->device = devices[0];
+    p->nlist = c0->nlist; p->M = c0->M; p->nbits = c0->nbits; p->Mpad = c0->Mpad; p->CB = c0->CB; p->dsub = c0->dsub; p->ld = c0->ld;
+    p->trained = c0->trained;
+    HIPCHECK(hipSetDevice(p->device));
+    HIPCHECK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
+    return p.release();
+}
+
+static void sharded_sync_trained(rsx_index* h) {
+    rsx_index* c0 = h->shards[0];
+    for (size_t r = 1; r < h->shards.size(); r++) {
+        rsx_index* c = h->shards[r];
+        HIPCHECK(hipSetDevice(c->device));
+        if (!c0->h_centroids.empty()) set_centroids(c, c0->h_centroids.data());
+        if (!c0->h_codebooks.empty()) set_codebooks(c, c0->h_codebooks.data());
+        update_trained(c);
+    }
+    h->trained = c0->trained;
+}
+
+static int ptr_device(const void* p) {   // device ordinal of a device pointer, -1 for host memory
+    hipPointerAttribute_t at;
+    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) ? at.device : -1;
+}
+
+static void sharded_add(rsx_index* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
+    const int N = (int)h->shards.size();
+    const size_t esz = dtype == RSX_F16 ? 2 : 4;
+    const int xdev = ptr_device(x);
+    std::vector<int64_t> seq;
+    if (!ids) { seq.resize((size_t)n); for (int64_t i = 0; i < n; i++) seq[(size_t)i] = h->sh_next_id + i; }
+    std::vector<int64_t> hids;
+    if (ids && ptr_device(ids) >= 0) {   // device ids: bring them to the host once (children stage host ids themselves)
+        hids.resize((size_t)n);
+        HIPCHECK(hipMemcpy(hids.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    const int64_t* hid = ids ? (hids.empty() ? ids : hids.data()) : seq.data();
+    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
+        const int64_t lo = n * r / N, hi = n * (r + 1) / N;
+        if (hi <= lo) return;
+        const char* xp = (const char*)x + (size_t)lo * h->d * esz;
+        DevBuf tmp;
+        if (xdev >= 0 && xdev != c->device) {     // rows live on another GPU: one peer copy into this shard's staging buffer
+            tmp.ensure((size_t)(hi - lo) * h->d * esz);
+            HIPCHECK(hipMemcpy(tmp.p, xp, (size_t)(hi - lo) * h->d * esz, hipMemcpyDefault));
+            xp = (const char*)tmp.p;
+        }
+        add_all(c, hi - lo, xp, dtype, hid + lo);
+    });
+    h->ntotal += n;
+    if (!ids) h->sh_next_id += n;
+}
+
+static void sharded_search(rsx_index* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
+    const int N = (int)h->shards.size();
+    if (nq < 0 || k <= 0) RSX_THROW(RSX_ERR_INVALID, "search: nq=%lld k=%d", (long long)nq, k);
+    if ((int64_t)N * k > 8192) RSX_THROW(RSX_ERR_UNSUPPORTED, "sharded search: nshards * k = %lld exceeds 8192", (long long)N * k);
+    if (nq == 0) return;
+    if (!q || !D || !I) RSX_THROW(RSX_ERR_INVALID, "search: null pointer");
+    const bool o_dev = is_device_ptr(D);
+    if (o_dev != is_device_ptr(I)) RSX_THROW(RSX_ERR_INVALID, "search: D and I must both be host or both device pointers");
+    const size_t esz = dtype == RSX_F16 ? 2 : 4;
+    const int qdev = ptr_device(q);
+    const size_t blk = (size_t)nq * k;
+    HIPCHECK(hipSetDevice(h->device));
+    h->sh_D.ensure((size_t)N * blk * 4); h->sh_I.ensure((size_t)N * blk * 8);
+    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
+        const void* qp = q;
+        if (qdev >= 0 && qdev != c->device) {     // the caller's queries sit on another GPU
+            c->sh_q.ensure((size_t)nq * h->d * esz);
+            HIPCHECK(hipMemcpy(c->sh_q.p, q, (size_t)nq * h->d * esz, hipMemcpyDefault));
+            qp = c->sh_q.p;
+        }
+        c->sh_oD.ensure(blk * 4); c->sh_oI.ensure(blk * 8);
+        search_impl(c, nq, qp, dtype, k, c->sh_oD.as<float>(), c->sh_oI.as<int64_t>());   // synchronises c->st
+        // fan-in: this shard's [nq, k] block -> the parent device's gather buffers
+        HIPCHECK(hipMemcpy(h->sh_D.as<float>() + (size_t)r * blk, c->sh_oD.p, blk * 4, hipMemcpyDefault));
+        HIPCHECK(hipMemcpy(h->sh_I.as<int64_t>() + (size_t)r * blk, c->sh_oI.p, blk * 8, hipMemcpyDefault));
+    });
+    HIPCHECK(hipSetDevice(h->device));
+    float* dD = D; int64_t* dI = I;
+    if (!o_dev || ptr_device(D) != h->device) {
+        h->sh_oD.ensure(blk * 4); h->sh_oI.ensure(blk * 8);
+        dD = h->sh_oD.as<float>(); dI = h->sh_oI.as<int64_t>();
+    }
+    launch_merge_topk_byid(N, nq, k, h->metric, h->sh_D.as<float>(), h->sh_I.as<int64_t>(), dD, dI, h->st);
+    HIPCHECK(hipStreamSynchronize(h->st));
+    if (dD != D) {
+        HIPCHECK(hipMemcpy(D, dD, blk * 4, hipMemcpyDefault));
+        HIPCHECK(hipMemcpy(I, dI, blk * 8, hipMemcpyDefault));
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+static void sharded_save(rsx_index* h, const char* path) {
+    FILE* f = fopen(path, "wb");
+    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s for writing", path);
+    int32_t hdr[4] = {0, 1, (int32_t)h->shards.size(), 0};
+    memcpy(hdr, "RSXS", 4);
+    int64_t next = h->sh_next_id;
+    bool ok = fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr) && fwrite(&next, 1, 8, f) == 8;
+    if (fclose(f) != 0 || !ok) RSX_THROW(RSX_ERR_IO, "write failed for %s", path);
+    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
+        save_impl(c, (std::string(path) + ".shard" + std::to_string(r)).c_str());
+    });
+}
+
+static rsx_index* sharded_load(const char* path, int ndev, const int* devices) {
+    FILE* f = fopen(path, "rb");
+    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s", path);
+    int32_t hdr[4] = {0, 0, 0, 0}; int64_t next = 0;
+    bool ok = fread(hdr, 1, sizeof(hdr), f) == sizeof(hdr) && fread(&next, 1, 8, f) == 8;
+    fclose(f);
+    if (!ok || memcmp(hdr, "RSXS", 4) != 0) RSX_THROW(RSX_ERR_IO, "%s is not a sharded (RSXS) index manifest", path);
+    const int ns = hdr[2];
+    if (ns <= 0 || ns > 64) RSX_THROW(RSX_ERR_IO, "bad shard count in %s", path);
+    if (ndev <= 0 || !devices) RSX_THROW(RSX_ERR_INVALID, "load_sharded: need at least one device");
+    std::unique_ptr<rsx_index> p(new rsx_index());
+    try {
+        for (int r = 0; r < ns; r++)   // more shards than devices: several shards share a device
+            p->shards.push_back(load_impl((std::string(path) + ".shard" + std::to_string(r)).c_str(), devices[r % ndev]));
+    } catch (...) {
+        for (auto* c : p->shards) { if (c->st) { (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->st); } delete c; }
+        throw;
+    }
+    rsx_index* c0 = p->shards[0];
+    p->kind = c0->kind; p->d = c0->d; p->metric = c0->metric; p->device = c0->device;
+    p->nlist = c0->nlist; p->M = c0->M; p->nbits = c0->nbits; p->Mpad = c0->Mpad; p->CB = c0->CB; p->dsub = c0->dsub; p->ld = c0->ld;
+    p->trained = c0->trained; p->nprobe = c0->nprobe; p->sh_next_id = next;
+    for (auto* c : p->shards) p->ntotal += c->ntotal;
+    HIPCHECK(hipSetDevice(p->device));
+    HIPCHECK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
+    return p.release();
+}
+
+// ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
 extern "C" {
@@ -1426,9 +1608,28 @@ int rsx_ivfflat_create(int d, int nlist, int metric, int device, rsx_index_t** o
 int rsx_ivfpq_create(int d, int nlist, int M, int nbits, int metric, int device, rsx_index_t** out) {
     return guarded([&] { if (!out) RSX_THROW(RSX_ERR_INVALID, "null out"); *out = create_common(KIND_IVFPQ, d, nlist, M, nbits, metric, device); });
 }
+int rsx_sharded_create(int kind, int d, int nlist, int M, int nbits, int metric, int ndev, const int* devices, rsx_index_t** out) {
+    return guarded([&] {
+        if (!out) RSX_THROW(RSX_ERR_INVALID, "null out");
+        if (kind != KIND_FLAT && kind != KIND_IVFFLAT && kind != KIND_IVFPQ) RSX_THROW(RSX_ERR_INVALID, "unknown index kind %d", kind);
+        *out = sharded_create(kind, d, nlist, M, nbits, metric, ndev, devices);
+    });
+}
+int rsx_load_sharded(const char* path, int ndev, const int* devices, rsx_index_t** out) {
+    return guarded([&] {
+        if (!path || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        *out = sharded_load(path, ndev, devices);
+    });
+}
 int rsx_destroy(rsx_index_t* h) {
     return guarded([&] {
         if (!h) return;
+        for (auto* c : h->shards) {
+            (void)hipSetDevice(c->device);
+            if (c->st) { (void)hipStreamSynchronize(c->st); (void)hipStreamDestroy(c->st); }
+            delete c;
+        }
+        h->shards.clear();
         (void)hipSetDevice(h->device);
         if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
         delete h;
@@ -1439,6 +1640,12 @@ int rsx_train(rsx_index_t* h, int64_t n, const void* x, int dtype) {
     return guarded([&] {
         if (!h || (!x && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
+        if (is_sharded(h)) {     // train once on the first shard, copy the parameters to the others
+            HIPCHECK(hipSetDevice(h->shards[0]->device));
+            train_impl(h->shards[0], n, x, dtype);
+            sharded_sync_trained(h);
+            return;
+        }
         use_device(h);
         train_impl(h, n, x, dtype);
     });
@@ -1448,6 +1655,11 @@ int rsx_set_centroids(rsx_index_t* h, const float* c) {
         if (!h || !c) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "Flat has no centroids");
         if (h->ntotal) RSX_THROW(RSX_ERR_INVALID, "cannot replace centroids of a populated index");
+        if (is_sharded(h)) {
+            for (auto* s : h->shards) { HIPCHECK(hipSetDevice(s->device)); set_centroids(s, c); update_trained(s); }
+            h->trained = h->shards[0]->trained;
+            return;
+        }
         use_device(h); set_centroids(h, c); update_trained(h);
     });
 }
@@ -1456,12 +1668,18 @@ int rsx_set_codebooks(rsx_index_t* h, const float* c) {
         if (!h || !c) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         if (h->kind != KIND_IVFPQ) RSX_THROW(RSX_ERR_INVALID, "only IVFPQ has codebooks");
         if (h->ntotal) RSX_THROW(RSX_ERR_INVALID, "cannot replace codebooks of a populated index");
+        if (is_sharded(h)) {
+            for (auto* s : h->shards) { HIPCHECK(hipSetDevice(s->device)); set_codebooks(s, c); update_trained(s); }
+            h->trained = h->shards[0]->trained;
+            return;
+        }
         use_device(h); set_codebooks(h, c); update_trained(h);
     });
 }
 int rsx_get_centroids(rsx_index_t* h, float* out) {
     return guarded([&] {
         if (!h || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) h = h->shards[0];
         if (h->h_centroids.empty()) RSX_THROW(RSX_ERR_NOT_TRAINED, "no centroids");
         memcpy(out, h->h_centroids.data(), h->h_centroids.size() * 4);
     });
@@ -1469,6 +1687,7 @@ int rsx_get_centroids(rsx_index_t* h, float* out) {
 int rsx_get_codebooks(rsx_index_t* h, float* out) {
     return guarded([&] {
         if (!h || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) h = h->shards[0];
         if (h->h_codebooks.empty()) RSX_THROW(RSX_ERR_NOT_TRAINED, "no codebooks");
         memcpy(out, h->h_codebooks.data(), h->h_codebooks.size() * 4);
     });
@@ -1480,6 +1699,7 @@ int rsx_add(rsx_index_t* h, int64_t n, const void* x, int dtype, const int64_t* 
         if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
         if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "add before train");
         if (n <= 0) return;
+        if (is_sharded(h)) { sharded_add(h, n, x, dtype, ids); return; }
         use_device(h);
         add_all(h, n, x, dtype, ids);
     });
@@ -1489,6 +1709,7 @@ int rsx_assign(rsx_index_t* h, int64_t n, const void* x, int dtype, int64_t* lab
         if (!h || (!x && n > 0) || (!labels && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
         if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "Flat has no coarse quantiser");
+        if (is_sharded(h)) h = h->shards[0];
         if (h->h_centroids.empty()) RSX_THROW(RSX_ERR_NOT_TRAINED, "assign before train");
         use_device(h);
         const int64_t B = 262144;
@@ -1514,6 +1735,17 @@ int rsx_assign(rsx_index_t* h, int64_t n, const void* x, int dtype, int64_t* lab
 int rsx_reset(rsx_index_t* h) {
     return guarded([&] {
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) {
+            for (auto* s : h->shards) {
+                HIPCHECK(hipSetDevice(s->device));
+                HIPCHECK(hipStreamSynchronize(s->st));
+                std::fill(s->h_len.begin(), s->h_len.end(), 0);
+                s->ntotal = 0; s->ndropped = 0;
+                if (s->d_len.p) upload_dir(s);
+            }
+            h->ntotal = 0; h->sh_next_id = 0;
+            return;
+        }
         use_device(h);
         HIPCHECK(hipStreamSynchronize(h->st));
         std::fill(h->h_len.begin(), h->h_len.end(), 0);
@@ -1524,6 +1756,7 @@ int rsx_reset(rsx_index_t* h) {
 int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts) {
     return guarded([&] {
         if (!h || !counts) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) RSX_THROW(RSX_ERR_UNSUPPORTED, "reserve_lists: not available on a sharded handle");
         use_device(h);
         std::vector<int64_t> need(counts, counts + h->nlist);
         for (int l = 0; l < h->nlist; l++) need[(size_t)l] = std::max(need[(size_t)l], h->h_len[(size_t)l]);
@@ -1533,6 +1766,7 @@ int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts) {
 int rsx_add_list(rsx_index_t* h, int64_t list_no, int64_t n, const void* codes, int dtype, const int64_t* ids) {
     return guarded([&] {
         if (!h || (!codes && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) RSX_THROW(RSX_ERR_UNSUPPORTED, "add_list: not available on a sharded handle");
         use_device(h);
         add_list_impl(h, list_no, n, codes, dtype, ids);
     });
@@ -1540,6 +1774,7 @@ int rsx_add_list(rsx_index_t* h, int64_t list_no, int64_t n, const void* codes, 
 int rsx_get_list(rsx_index_t* h, int64_t list_no, int64_t* n_out, void* codes_out, int64_t* ids_out) {
     return guarded([&] {
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) RSX_THROW(RSX_ERR_UNSUPPORTED, "get_list: not available on a sharded handle (the lists are split over the shards)");
         use_device(h);
         get_list_impl(h, list_no, n_out, codes_out, ids_out);
     });
@@ -1548,6 +1783,10 @@ int rsx_get_list(rsx_index_t* h, int64_t list_no, int64_t* n_out, void* codes_ou
 int rsx_get_list_sizes(rsx_index_t* h, int64_t* sizes) {
     return guarded([&] {
         if (!h || !sizes) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) {
+            for (int l = 0; l < h->nlist; l++) { sizes[l] = 0; for (auto* s : h->shards) sizes[l] += s->h_len[(size_t)l]; }
+            return;
+        }
         for (int l = 0; l < h->nlist; l++) sizes[l] = h->h_len[(size_t)l];
     });
 }
@@ -1558,6 +1797,7 @@ int rsx_set_nprobe(rsx_index_t* h, int nprobe) {
         if (nprobe <= 0) RSX_THROW(RSX_ERR_INVALID, "nprobe must be positive (got %d)", nprobe);
         if (nprobe > 2048) RSX_THROW(RSX_ERR_UNSUPPORTED, "nprobe = %d exceeds this build's maximum of 2048", nprobe);
         h->nprobe = nprobe;
+        for (auto* s : h->shards) s->nprobe = nprobe;
     });
 }
 
@@ -1565,6 +1805,11 @@ int rsx_search(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, floa
     return guarded([&] {
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
+        if (is_sharded(h)) {
+            if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "search before train");
+            sharded_search(h, nq, q, dtype, k, D, I);
+            return;
+        }
         use_device(h);
         search_impl(h, nq, q, dtype, k, D, I);
     });
@@ -1626,6 +1871,14 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
     return guarded([&] {
         if (!h || !key || !out) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         std::string s(key);
+        if (s == "nshards") { *out = (int64_t)h->shards.size(); return; }
+        if (is_sharded(h)) {
+            if (s == "ntotal") { *out = h->ntotal; return; }
+            if (s == "nprobe") { *out = h->nprobe; return; }
+            if (s == "is_trained") { *out = h->trained; return; }
+            if (s == "hbm_bytes") { *out = 0; for (auto* c : h->shards) *out += (int64_t)(c->data.bytes + c->ids.bytes + c->norms.bytes); return; }
+            h = h->shards[0];
+        }
         if (s == "ntotal") *out = h->ntotal;
         else if (s == "nlist") *out = h->nlist;
         else if (s == "d") *out = h->d;
@@ -1648,6 +1901,10 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
     return guarded([&] {
         if (!h || !key) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         std::string s(key);
+        if (is_sharded(h)) {     // knobs apply to every shard
+            for (auto* c : h->shards) { int st_ = rsx_set_param(c, key, value); if (st_ != RSX_OK) throw RsxError(st_, g_err); }
+            return;
+        }
         if (s == "query_batch") h->query_batch = std::max(1, (int)value);
         else if (s == "scan_chunk") h->scan_chunk = std::max(0, (int)value);
         else if (s == "scan_kernel") h->scan_kernel = (int)value;
@@ -1679,6 +1936,13 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
 int rsx_get_timing(rsx_index_t* h, const char* key, double* ms) {
     return guarded([&] {
         if (!h || !key || !ms) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) {     // stage times: the slowest shard; counters: the sum
+            *ms = 0.0;
+            const std::string ks(key);
+            const bool sum = ks.find("queries") != std::string::npos || ks.find("launches") != std::string::npos || ks.find("vectors") != std::string::npos;
+            for (auto* c : h->shards) { auto it = c->timing.find(key); double v = it == c->timing.end() ? 0.0 : it->second; *ms = sum ? *ms + v : std::max(*ms, v); }
+            return;
+        }
         auto it = h->timing.find(key);
         *ms = (it == h->timing.end()) ? 0.0 : it->second;
     });
@@ -1687,6 +1951,7 @@ int rsx_get_timing(rsx_index_t* h, const char* key, double* ms) {
 int rsx_save(rsx_index_t* h, const char* path) {
     return guarded([&] {
         if (!h || !path) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (is_sharded(h)) { sharded_save(h, path); return; }
         use_device(h);
         save_impl(h, path);
     });

@@ -5,6 +5,8 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace rsx {
 
 // ---------------------------------------------------------------------------------------
@@ -30,6 +32,19 @@ __host__ __device__ inline uint32_t key_idx(uint64_t k) { return 0xFFFFFFFFu - (
 __host__ __device__ inline float key_score(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
 
 enum { KIND_FLAT = 0, KIND_IVFFLAT = 1, KIND_IVFPQ = 2 };
+
+// hipFuncSetAttribute (dynamic LDS above 64 KiB) is a per-DEVICE property of a kernel: with several GPUs driven from one
+// process (rsx_sharded_create) every device needs its own call.  first() is true once per device; need(bytes) is true when
+// this device has not yet been granted that many bytes.
+inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+struct DevOnce {
+    std::atomic<uint64_t> m{0};
+    bool first() { const uint64_t b = 1ull << cur_device(); return !(m.fetch_or(b) & b); }
+};
+struct DevSize {
+    size_t v[64] = {};
+    bool need(size_t bytes) { size_t& s = v[cur_device()]; if (bytes <= s) return false; s = bytes; return true; }
+};
 
 // Per-query candidate counters are atomically bumped from every CU: one counter per 128-byte line (8 B used), so that
 // the device-scope atomics of different queries never serialise on a shared line (measured: ~0.7 ms of a 3.8 ms scan).
@@ -301,6 +316,9 @@ struct FinalizeArgs {
 void launch_finalize(const FinalizeArgs& a, hipStream_t st);
 void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
                        float* Do, int64_t* Io, hipStream_t st);
+// single-index order (score desc, id asc) for the shards of ONE logical index (rsx_sharded_create); nshards * k <= 8192
+void launch_merge_topk_byid(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do,
+                            int64_t* Io, hipStream_t st);
 void launch_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed /* [nshards,2,nq,k] */, float* Do,
                          int64_t* Io, hipStream_t st);
 void launch_pack_topk(int64_t n, const float* D, const int64_t* I, int64_t id_offset, int64_t* out /* [2,n] */, hipStream_t st);

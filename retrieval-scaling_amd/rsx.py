@@ -37,7 +37,7 @@ _lib = None
 #: every symbol include/rsx.h declares (checked by tests/test_abi.py against the header)
 ABI_SYMBOLS = [
     "rsx_last_error", "rsx_version", "rsx_device_count", "rsx_flat_create", "rsx_ivfflat_create",
-    "rsx_ivfpq_create", "rsx_destroy", "rsx_train", "rsx_set_centroids", "rsx_set_codebooks",
+    "rsx_ivfpq_create", "rsx_sharded_create", "rsx_load_sharded", "rsx_destroy", "rsx_train", "rsx_set_centroids", "rsx_set_codebooks",
     "rsx_get_centroids", "rsx_get_codebooks", "rsx_add", "rsx_assign", "rsx_reset", "rsx_reserve_lists", "rsx_add_list",
     "rsx_get_list", "rsx_get_list_sizes", "rsx_set_nprobe", "rsx_search", "rsx_merge_topk", "rsx_pack_topk", "rsx_merge_packed", "rsx_get",
     "rsx_set_param",
@@ -63,6 +63,14 @@ def lib():
             raise RuntimeError(
                 f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the search path)")
+        # PyTorch-ROCm ships its own libamdhip64: whichever copy is mapped FIRST serves the whole process (same soname), and a
+        # process that maps /opt/rocm's through librsx and torch's afterwards ends up with two HIP runtimes — torch then
+        # reports "No HIP GPUs are available".  Load torch's first whenever torch is installed.
+        if not os.environ.get("RSX_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = ctypes.CDLL(_LIB_PATH)
         L.rsx_last_error.restype = ctypes.c_char_p
         for name in ABI_SYMBOLS:
@@ -88,6 +96,50 @@ def default_device():
         if key in os.environ:
             return int(os.environ[key])
     return 0
+
+
+_default_devices = None
+
+
+def set_default_devices(devices):
+    """Devices new indexes span when no `device` / `devices` argument is given: a list of ordinals (one shard per
+    entry, single process — rsx_sharded_create), "all", or None for one GPU.  The Indexer facade sets this from
+    cfg.datastore.index.devices; the RSX_DEVICES environment variable ("0,1,2,3" or "all") is the fallback."""
+    global _default_devices
+    _default_devices = devices
+
+
+def _resolve_devices(device, devices):
+    """-> None (single-GPU handle on `device`) or a list of device ordinals (sharded handle)."""
+    if devices is None and device is None:
+        devices = _default_devices
+        if devices is None and os.environ.get("RSX_DEVICES"):
+            devices = os.environ["RSX_DEVICES"]
+    if devices is None:
+        return None
+    if isinstance(devices, str):
+        devices = list(range(get_num_gpus())) if devices.strip().lower() == "all" else [int(t) for t in devices.split(",") if t.strip()]
+    devices = [int(t) for t in devices]
+    return devices if len(devices) > 1 else None
+
+
+def _create(kind, d, nlist, M, nbits, metric, device, devices):
+    h = ctypes.c_void_p()
+    devs = _resolve_devices(device, devices)
+    if devs is not None:
+        arr = (ctypes.c_int * len(devs))(*devs)
+        _check(lib().rsx_sharded_create(kind, int(d), int(nlist), int(M), int(nbits), int(metric), len(devs), arr, ctypes.byref(h)))
+        return h
+    if devices is not None and not isinstance(devices, str) and len(list(devices)) == 1:
+        device = list(devices)[0]
+    dev = default_device() if device is None else int(device)
+    if kind == 0:
+        _check(lib().rsx_flat_create(int(d), int(metric), dev, ctypes.byref(h)))
+    elif kind == 1:
+        _check(lib().rsx_ivfflat_create(int(d), int(nlist), int(metric), dev, ctypes.byref(h)))
+    else:
+        _check(lib().rsx_ivfpq_create(int(d), int(nlist), int(M), int(nbits), int(metric), dev, ctypes.byref(h)))
+    return h
 
 
 # ------------------------------------------------------------------------------------------
@@ -127,6 +179,11 @@ def _sync_producer(keep, on_dev):
 
 class Index:
     """Base handle.  Attributes follow faiss.Index: d, ntotal, is_trained, metric_type."""
+
+    @property
+    def nshards(self):
+        """0 for a single-GPU handle, else the number of per-device shards behind this (single-process) handle."""
+        return self._get("nshards")
 
     def __init__(self, handle, d, metric):
         self._h = handle
@@ -238,20 +295,18 @@ class Index:
 
 
 class IndexFlat(Index):
-    def __init__(self, d, metric=METRIC_L2, device=None):
-        h = ctypes.c_void_p()
-        _check(lib().rsx_flat_create(int(d), int(metric), default_device() if device is None else int(device), ctypes.byref(h)))
-        super().__init__(h, int(d), int(metric))
+    def __init__(self, d, metric=METRIC_L2, device=None, devices=None):
+        super().__init__(_create(0, d, 1, 0, 8, metric, device, devices), int(d), int(metric))
 
 
 class IndexFlatIP(IndexFlat):
-    def __init__(self, d, device=None):
-        super().__init__(d, METRIC_INNER_PRODUCT, device)
+    def __init__(self, d, device=None, devices=None):
+        super().__init__(d, METRIC_INNER_PRODUCT, device, devices)
 
 
 class IndexFlatL2(IndexFlat):
-    def __init__(self, d, device=None):
-        super().__init__(d, METRIC_L2, device)
+    def __init__(self, d, device=None, devices=None):
+        super().__init__(d, METRIC_L2, device, devices)
 
 
 class _IndexIVF(Index):
@@ -313,22 +368,16 @@ def _quantizer_metric(quantizer, metric):
 
 
 class IndexIVFFlat(_IndexIVF):
-    def __init__(self, quantizer, d, nlist, metric=METRIC_L2, device=None):
+    def __init__(self, quantizer, d, nlist, metric=METRIC_L2, device=None, devices=None):
         _quantizer_metric(quantizer, metric)
-        h = ctypes.c_void_p()
-        _check(lib().rsx_ivfflat_create(int(d), int(nlist), int(metric),
-                                        default_device() if device is None else int(device), ctypes.byref(h)))
-        super().__init__(h, int(d), int(metric))
+        super().__init__(_create(1, d, nlist, 0, 8, metric, device, devices), int(d), int(metric))
         self.quantizer = quantizer
 
 
 class IndexIVFPQ(_IndexIVF):
-    def __init__(self, quantizer, d, nlist, M, nbits, metric=METRIC_L2, device=None):
+    def __init__(self, quantizer, d, nlist, M, nbits, metric=METRIC_L2, device=None, devices=None):
         _quantizer_metric(quantizer, metric)
-        h = ctypes.c_void_p()
-        _check(lib().rsx_ivfpq_create(int(d), int(nlist), int(M), int(nbits), int(metric),
-                                      default_device() if device is None else int(device), ctypes.byref(h)))
-        super().__init__(h, int(d), int(metric))
+        super().__init__(_create(2, d, nlist, M, nbits, metric, device, devices), int(d), int(metric))
         self.quantizer = quantizer
         self.M = int(M)
         self.nbits = int(nbits)
@@ -370,11 +419,18 @@ def write_index(index, path):
     _check(lib().rsx_save(index._h, os.fspath(path).encode()))
 
 
-def read_index(path, device=None):
-    """faiss.read_index(path): loads an RSX1 container, or a FAISS-format file via rsx_faiss_io."""
+def read_index(path, device=None, devices=None):
+    """faiss.read_index(path): loads an RSX1 container (RSXS: the manifest of a sharded index, one shard per device), or
+    a FAISS-format file via rsx_faiss_io."""
     path = os.fspath(path)
     with open(path, "rb") as f:
         magic = f.read(4)
+    if magic == b"RSXS":
+        devs = _resolve_devices(device, devices) or [default_device() if device is None else int(device)]
+        arr = (ctypes.c_int * len(devs))(*devs)
+        h = ctypes.c_void_p()
+        _check(lib().rsx_load_sharded(path.encode(), len(devs), arr, ctypes.byref(h)))
+        return _wrap_handle(h)
     if magic != b"RSX1":
         from rsx_faiss_io import read_faiss_index
         return read_faiss_index(path, device=device)

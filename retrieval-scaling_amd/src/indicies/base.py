@@ -25,6 +25,16 @@ class Indexer(object):
         self.cfg = cfg
         self.args = cfg.datastore.index
         self.index_type = self.args.index_type
+        # optional key (absent in the reference's configs -> one GPU, unchanged behaviour): cfg.datastore.index.devices =
+        # [0, 1, ...] or "all" makes every engine object of this Indexer ONE handle over those GPUs (rsx_sharded_create):
+        # the single index.search(all_queries, k) call of src/search.py:296 then spans the node
+        try:
+            devices = self.args.get("devices", None) if hasattr(self.args, "get") else getattr(self.args, "devices", None)
+        except (KeyError, AttributeError):     # attribute-style config objects without the key
+            devices = None
+        if devices is not None:
+            import rsx
+            rsx.set_default_devices(devices if isinstance(devices, str) else list(devices))
 
         passage_dir = self.cfg.datastore.embedding.passages_dir
         index_dir, embedding_paths = get_index_dir_and_embedding_paths(cfg)
