@@ -171,11 +171,85 @@ class BackendBase:
             return self.load_embeds(shard_id)
         raise AttributeError("get_embs(indices=...) needs resident embeddings, which no backend keeps")
 
-    # ---- id -> passage (reference flat.py:115-136).  The reference opens the passage file once per
-    # retrieved id (nq * k open() calls per search — the wall-clock bottleneck once the search itself is
-    # fast); here the files stay open in a small LRU and a line is fetched by seek +
-    # readline on the cached handle.  Same bytes, same json, same return value.
+    # ---- id -> passage (reference flat.py:115-136).  The reference resolves every retrieved id through two Python
+    # containers (index_id_to_db_id list, {shard: {chunk: [file, offset]}} dict of dicts) and opens the passage file once
+    # per id: nq * k open() + seek + readline calls per search — the wall-clock bottleneck once the search itself takes
+    # milliseconds.  Here the two containers are flattened ONCE into integer arrays
+    #     index id -> (file number, byte offset, line length)
+    # and a batch is served by numpy indexing over its UNIQUE ids plus one os.pread per passage on a cached descriptor
+    # (no seek state, no text-mode decoding layer, each passage read once per batch).  Same bytes, same json, same return
+    # value.  The per-id helpers below (_id2psg, _get_passage) keep the reference's names for single look-ups.
+    #
+    # The -1 quirk (reference flat.py:124,133): an unfilled result slot carries id -1, which Python's negative indexing
+    # maps to the LAST stored passage.  It is kept on purpose — the driver asserts exactly n_docs contexts per example
+    # (src/search.py:367), so dropping the slot would change control flow — and it is explicit here: _row_of(-1) = n - 1.
     _MAX_OPEN_PASSAGE_FILES = 64
+
+    def _passage_table(self):
+        """(file names, file_no[idx], offset[idx], length[idx]) over index ids; built on first use, rebuilt when the id map
+        grows (index still being populated)."""
+        n = len(self.index_id_to_db_id)
+        tab = self.__dict__.get("_psg_table")
+        if tab is not None and tab[4] == n:
+            return tab
+        files, file_no_of = [], {}
+        per_shard = {}                              # shard -> (file_no[chunk], offset[chunk]) dense over chunk ids
+        for shard_id, chunks in self.psg_pos_id_map.items():
+            m = (max(chunks) + 1) if chunks else 0
+            fno = np.full(m, -1, dtype=np.int32); off = np.zeros(m, dtype=np.int64)
+            for chunk_id, (filename, position) in chunks.items():
+                k = file_no_of.get(filename)
+                if k is None:
+                    k = file_no_of[filename] = len(files)
+                    files.append(filename)
+                fno[chunk_id] = k; off[chunk_id] = position
+            per_shard[shard_id] = (fno, off)
+        # line length = distance to the next line start of the same file (the last line runs to the end of the file)
+        ends = {}
+        for fno, off in per_shard.values():
+            for k in np.unique(fno[fno >= 0]):
+                ends.setdefault(int(k), []).append(off[fno == k])
+        nxt = {}
+        for k, parts in ends.items():
+            starts = np.unique(np.concatenate(parts))
+            nxt[k] = (starts, np.append(starts[1:], os.path.getsize(files[k])))
+        file_no = np.full(n, -1, dtype=np.int32); offset = np.zeros(n, dtype=np.int64); length = np.zeros(n, dtype=np.int64)
+        if n:
+            first = self.index_id_to_db_id[0]
+            if isinstance(first, (list, tuple, np.ndarray)):
+                ids = np.asarray(self.index_id_to_db_id, dtype=np.int64).reshape(n, 2)
+                shard_of, chunk_of = ids[:, 0], ids[:, 1]
+            else:                                   # legacy metas hold a scalar chunk id (flat.py:123-126): shard 0
+                shard_of = np.zeros(n, dtype=np.int64); chunk_of = np.asarray(self.index_id_to_db_id, dtype=np.int64)
+            for shard_id in np.unique(shard_of):
+                sel = np.nonzero(shard_of == shard_id)[0]
+                fno, off = per_shard[int(shard_id)]
+                c = chunk_of[sel]
+                file_no[sel] = fno[c]; offset[sel] = off[c]
+            for k, (starts, stops) in nxt.items():
+                sel = np.nonzero(file_no == k)[0]
+                length[sel] = stops[np.searchsorted(starts, offset[sel])] - offset[sel]
+        tab = (files, file_no, offset, length, n)
+        self.__dict__["_psg_table"] = tab
+        return tab
+
+    def _passage_fd(self, file_no, files):
+        cache = self.__dict__.setdefault("_psg_fds", collections.OrderedDict())
+        fd = cache.get(file_no)
+        if fd is None:
+            fd = os.open(files[file_no], os.O_RDONLY)
+            cache[file_no] = fd
+            if len(cache) > self._MAX_OPEN_PASSAGE_FILES:
+                os.close(cache.popitem(last=False)[1])
+        else:
+            cache.move_to_end(file_no)
+        return fd
+
+    def close_passage_files(self):
+        for fd in self.__dict__.pop("_psg_fds", {}).values():
+            os.close(fd)
+        for f in self.__dict__.pop("_psg_files", {}).values():
+            f.close()
 
     def _passage_file(self, filename):
         cache = self.__dict__.setdefault("_psg_files", collections.OrderedDict())
@@ -188,10 +262,6 @@ class BackendBase:
         else:
             cache.move_to_end(filename)
         return f
-
-    def close_passage_files(self):
-        for f in self.__dict__.pop("_psg_files", {}).values():
-            f.close()
 
     def _id2psg(self, shard_id, chunk_id):
         filename, position = self.psg_pos_id_map[shard_id][chunk_id]
@@ -212,23 +282,36 @@ class BackendBase:
         return self._id2psg(shard_id, chunk_id)
 
     def get_retrieved_passages(self, all_indices):
-        passages, db_ids = [], []
-        texts = {}                      # a passage retrieved for several queries of the batch is read once
-        for query_indices in all_indices:
-            row = []
-            for i in query_indices:
-                i = int(i)
-                if i not in texts:
-                    texts[i] = self._get_passage(i)["text"]
-                row.append(texts[i])
-            passages.append(row)
-            db_ids.append([self._db_id(int(i)) for i in query_indices])
+        try:
+            idx = np.asarray(all_indices, dtype=np.int64)
+        except ValueError:                                     # ragged rows
+            idx = np.zeros(0, dtype=np.int64)
+        if idx.ndim != 2 or self.psg_pos_id_map is None:      # ragged input / no position map: the per-id path
+            passages = [[self._get_passage(int(i))["text"] for i in row] for row in all_indices]
+            return passages, [[self._db_id(int(i)) for i in row] for row in all_indices]
+        files, file_no, offset, length, n = self._passage_table()
+        rows = np.where(idx < 0, idx + n, idx)                 # Python's negative indexing, made explicit (see above)
+        uniq, inv = np.unique(rows, return_inverse=True)
+        order = np.lexsort((offset[uniq], file_no[uniq]))      # file by file, front to back
+        texts = [None] * len(uniq)
+        for u in order:
+            r = uniq[u]
+            raw = os.pread(self._passage_fd(int(file_no[r]), files), int(length[r]), int(offset[r]))
+            texts[u] = json.loads(raw.decode("utf-8"))["text"]
+        inv = inv.reshape(idx.shape)
+        passages = [[texts[j] for j in row] for row in inv]
+        id_map = self.index_id_to_db_id
+        db_ids = [[id_map[int(i)] for i in row] for row in idx]
         return passages, db_ids
 
     # ---- search (reference flat.py:138-141; the reference's astype(np.float32) is dropped: the
     # engine takes fp16 queries as they come out of the encoder)
     def search(self, query_embs, k=4096):
+        """query_embs: numpy array (the reference) or a CUDA tensor straight from the encoder (no host round trip of the
+        queries; D / I come back as tensors and only they cross PCIe)."""
         all_scores, all_indices = self.index.search(query_embs, k)
+        if hasattr(all_indices, "is_cuda"):
+            all_scores, all_indices = all_scores.cpu().numpy(), all_indices.cpu().numpy()
         all_passages, db_ids = self.get_retrieved_passages(all_indices)
         return all_scores.tolist(), all_passages, db_ids
 

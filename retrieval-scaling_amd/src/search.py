@@ -149,7 +149,8 @@ def search_dense_topk(cfg, data=None, questions_embedding=None, query_encoder_fn
             questions_embedding = query_encoder_fn(queries)
         if cfg_get(eval_args.search, "cache_query_embedding_only", False):
             return
-        questions_embedding = np.asarray(questions_embedding)
+        if not hasattr(questions_embedding, "is_cuda"):      # a CUDA tensor from the encoder goes to the engine as it is
+            questions_embedding = np.asarray(questions_embedding)
         for shard_ids in groups:
             output_path = get_search_output_path(cfg, shard_ids)
             if os.path.exists(output_path) and not eval_args.search.overwrite:

@@ -111,21 +111,24 @@ def test_indexer_facade_contract(tmp_path, orc, fake, index_type):
 
 
 def test_passage_fetch_matches_reference_reads(tmp_path, orc, fake, monkeypatch):
-    """get_retrieved_passages keeps files open (LRU) instead of the reference's open() per id
-    (flat.py:115-121): the strings must be what open/seek/readline/json.loads gives, non-ASCII
-    text included, and repeated ids must not re-open anything."""
-    import builtins, json
+    """get_retrieved_passages resolves ids through integer arrays and reads each passage with ONE os.pread on a cached
+    descriptor instead of the reference's open() per id (flat.py:115-121): the strings must be what
+    open/seek/readline/json.loads gives, non-ASCII text included, every passage file is opened once, and a repeated id is
+    read once."""
+    import json
     from src.indicies.base import Indexer
     tmp = str(tmp_path)
     write_datastore(tmp, orc)
     ds = Indexer(make_cfg(tmp, "Flat", [0, 1])).datastore
     ids = [[0, 399, 400, 799, 5], [5, 5, 400, 0, 799]]
-    opened = []
-    real_open = builtins.open
-    monkeypatch.setattr(builtins, "open", lambda f, *a, **k: (opened.append(f), real_open(f, *a, **k))[1])
+    opened, preads = [], []
+    real_open, real_pread = os.open, os.pread
+    monkeypatch.setattr(os, "open", lambda f, *a, **k: (opened.append(f), real_open(f, *a, **k))[1])
+    monkeypatch.setattr(os, "pread", lambda fd, n, off: (preads.append((fd, off)), real_pread(fd, n, off))[1])
     passages, db_ids = ds.get_retrieved_passages(ids)
     monkeypatch.undo()
-    assert len([f for f in opened if str(f).endswith(".jsonl")]) == 2          # one handle per passage file
+    assert len([f for f in opened if str(f).endswith(".jsonl")]) == 2          # one descriptor per passage file
+    assert len(preads) == 5                                                     # 5 distinct passages, each read once
     for row_ids, row_txt, row_db in zip(ids, passages, db_ids):
         for i, txt, db in zip(row_ids, row_txt, row_db):
             shard, chunk = ds.index_id_to_db_id[i]
@@ -134,12 +137,17 @@ def test_passage_fetch_matches_reference_reads(tmp_path, orc, fake, monkeypatch)
                 f.seek(pos)
                 assert txt == json.loads(f.readline())["text"]
             assert db == [shard, chunk]
+    # the reference's -1 quirk (an unfilled slot indexes the LAST passage) is kept, explicitly
+    p_neg, d_neg = ds.get_retrieved_passages(np.array([[-1, 0]]))
+    assert p_neg[0][0] == ds._get_passage(len(ds.index_id_to_db_id) - 1)["text"] and d_neg[0][0] == ds.index_id_to_db_id[-1]
+    # ragged input takes the per-id path and gives the same strings
+    assert ds.get_retrieved_passages([[0, 399], [5]])[0] == [passages[0][:2], [passages[0][4]]]
     ds.close_passage_files()
     ds._MAX_OPEN_PASSAGE_FILES = 1                                                # LRU bound holds
     assert ds.get_retrieved_passages(ids) == (passages, db_ids)
-    assert len(ds._psg_files) == 1
+    assert len(ds._psg_fds) == 1
     ds.close_passage_files()
-    assert "_psg_files" not in ds.__dict__
+    assert "_psg_fds" not in ds.__dict__ and "_psg_files" not in ds.__dict__
 
 
 def test_unknown_index_type_raises(tmp_path, orc, fake):
