@@ -188,6 +188,26 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const void* x, int x_f16, 
         if (ids_storage) ids_storage[dst] = ids_in ? ids_in[i] : id0 + i;
     }
 }
+// max over the batch rows of |x|^2 (fp32 wave sums: an upper-bound ingredient of the Flat / IVF-Flat certificate, not a
+// score), folded into *out with an atomic max on the (non-negative) float's bit pattern.
+__global__ __launch_bounds__(256) void k_max_norm2(const void* x, int x_f16, int64_t n, int d, unsigned int* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int t = lane; t < d; t += 64) {
+        const float v = x_f16 ? __half2float(((const __half*)x)[i * d + t]) : ((const float*)x)[i * d + t];
+        s = __fmaf_rn(v, v, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0 && s == s) atomicMax(out, __float_as_uint(s));
+}
+void launch_max_norm2(const void* x, int x_f16, int64_t n, int d, unsigned int* out_bits, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, x_f16, n, d, out_bits);
+}
+
 void launch_scatter_rows(const void* x, int x_f16, int64_t n, int d, const int64_t* dest_row, void* storage,
                          int storage_f16, int ld, float* norms, const int64_t* ids_in, int64_t id0,
                          int64_t* ids_storage, hipStream_t st) {

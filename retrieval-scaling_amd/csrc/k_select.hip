@@ -763,6 +763,30 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
         if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad = 1;   // candidates were dropped
         a.uncertain[q] = bad;
     }
+    if (a.kind != KIND_IVFPQ && a.uncertain) {
+        // certificate of the MFMA scan (see FinalizeArgs): wave 0 sums |q|^2, thread 0 decides
+        const float* qv = a.Q32 + q * a.ldq;
+        if (wv == 0) {
+            double q2 = 0.0;
+            for (int t = lane; t < a.d; t += 64) q2 += (double)qv[t] * (double)qv[t];
+            q2 = wave_sum_f64(q2);
+            if (lane == 0) {
+                const uint64_t last = a.state[q * KP + (KP - 1)];
+                int bad = 0;
+                if (last != 0) {     // K' candidates were kept: vectors were excluded on their approximate score
+                    const float qn = (float)sqrt(q2) * 1.0000002f;
+                    const float rel = a.cert_rel + ((a.cert_qflag && *a.cert_qflag) ? a.cert_rel_qlossy : 0.0f);
+                    const float eps = rel * qn * a.cert_xmax + a.cert_abs * (qn + a.cert_xmax);
+                    const float a_last = key_score(last);
+                    const bool have_k = sord[a.k - 1] != 0 && sid[a.k - 1] != INT64_MAX;
+                    const float s_k = have_k ? ord2f(sord[a.k - 1]) : -__builtin_inff();
+                    if (!(a_last + eps < s_k)) bad = 1;
+                }
+                if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad = 1;
+                a.uncertain[q] = bad;
+            }
+        }
+    }
     for (int j = tid; j < a.k; j += nt) {
         bool valid = (j < KP) && sord[j] != 0 && sid[j] != INT64_MAX;
         float s = valid ? ord2f(sord[j]) : -__builtin_inff();
@@ -770,6 +794,51 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
         a.D[q * a.k + j] = s;
         a.I[q * a.k + j] = valid ? sid[j] : -1;
     }
+}
+
+// one wave per score-buffer column; lanes over the dimensions; fp64 accumulation of exact products
+__global__ __launch_bounds__(256) void k_exact_scores(ExactScoreArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= a.tstride) return;
+    int64_t row = -1;
+    if (a.kind == KIND_FLAT) { if (c < a.flat_n) row = c; }
+    else {
+        const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+        if (c < ss[a.nprobe]) {
+            int lo = 0, hi = a.nprobe;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ss[mid] <= c) lo = mid; else hi = mid; }
+            const int32_t l = a.probe_list[q * a.nprobe + lo];
+            if (l >= 0 && c - ss[lo] < a.list_len[l]) row = a.list_base[l] + (c - ss[lo]);
+        }
+    }
+    float out = -__builtin_inff();
+    if (row >= 0) {      // wave-uniform
+        const float* qv = a.Q32 + q * a.ldq;
+        double acc = 0.0;
+        if (a.x_f16) {
+            const __half* xv = (const __half*)a.X + row * a.ld;
+            for (int t = lane; t < a.d; t += 64) {
+                const double qd = (double)qv[t], xd = (double)__half2float(xv[t]);
+                if (a.metric == 0) acc += qd * xd; else { const double df = qd - xd; acc += df * df; }
+            }
+        } else {
+            const float* xv = (const float*)a.X + row * a.ld;
+            for (int t = lane; t < a.d; t += 64) {
+                const double qd = (double)qv[t], xd = (double)xv[t];
+                if (a.metric == 0) acc += qd * xd; else { const double df = qd - xd; acc += df * df; }
+            }
+        }
+        acc = wave_sum_f64(acc);
+        const float s = (float)acc;
+        out = (a.metric == 0 ? s : 0.0f - s) + 0.0f;
+    }
+    if (lane == 0) a.temp[q * a.tstride + c] = out;
+}
+void launch_exact_scores(const ExactScoreArgs& a, hipStream_t st) {
+    if (a.nq <= 0 || a.tstride <= 0) return;
+    hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((a.tstride + 3) / 4), (unsigned)a.nq), dim3(256), 0, st, a);
 }
 
 void launch_finalize(const FinalizeArgs& a, hipStream_t st) {

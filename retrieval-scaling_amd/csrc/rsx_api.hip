@@ -11,6 +11,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rsx.h"
@@ -165,6 +166,16 @@ struct rsx_index {
         w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc;
     std::map<std::string, double> timing;
 
+    // Flat / IVF-Flat: largest |x|^2 ever added (certificate of the MFMA scan); device copy is the running atomic max
+    float max_norm2 = 0.0f;
+    DevBuf d_maxnorm;
+    int flat_cert = 1;        // 1 = certify the fp16-MFMA scan and re-run uncertified queries exactly (0 = round-1 behaviour)
+
+    // host-side bounds that only depend on the list lengths (top-nprobe sums of list / tile counts): computed once per
+    // directory generation instead of a partial_sort over nlist two to four times per search batch
+    uint64_t dir_gen = 0;
+    std::map<std::tuple<int, int, int>, std::pair<uint64_t, std::pair<int64_t, int64_t>>> bound_cache;
+
     // single-process multi-GPU handle (rsx_sharded_create): this object owns one child index per device and nothing else
     std::vector<rsx_index*> shards;
     DevBuf sh_D, sh_I, sh_q, sh_oD, sh_oI;      // parent-device gather / merge buffers
@@ -177,6 +188,7 @@ struct rsx_index {
 static void use_device(rsx_index* h) { HIPCHECK(hipSetDevice(h->device)); }
 
 static void upload_dir(rsx_index* h) {
+    h->dir_gen++;       // list lengths changed: the memoised host-side bounds below are stale
     size_t nb = (size_t)h->nlist * sizeof(int64_t);
     h->d_base.ensure(nb);
     h->d_len.ensure(nb);
@@ -348,6 +360,17 @@ static void decide_storage(rsx_index* h, const void* dx, int64_t n, int dtype) {
     h->storage_decided = true;
 }
 
+// fold the batch's largest |x|^2 into h->max_norm2 (read back here: every add path synchronises the stream anyway)
+static void track_max_norm(rsx_index* h, const void* dx, int64_t n, int dtype) {
+    if (!h->d_maxnorm.p) {
+        h->d_maxnorm.ensure(sizeof(unsigned int));
+        HIPCHECK(hipMemsetAsync(h->d_maxnorm.p, 0, sizeof(unsigned int), h->st));
+    }
+    launch_max_norm2(dx, dtype == RSX_F16, n, h->d, h->d_maxnorm.as<unsigned int>(), h->st);
+    HIPCHECK(hipMemcpyAsync(&h->max_norm2, h->d_maxnorm.p, sizeof(float), hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+}
+
 static void add_batch(rsx_index* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
     const void* dx = stage_rows(h, h->w_x, x, n, h->d, dtype);
     const int64_t* dids = nullptr;
@@ -360,6 +383,7 @@ static void add_batch(rsx_index* h, int64_t n, const void* x, int dtype, const i
         }
     }
     decide_storage(h, dx, n, dtype);
+    if (h->kind != KIND_IVFPQ) track_max_norm(h, dx, n, dtype);
 
     if (h->kind == KIND_FLAT) {
         if (ids && !h->custom_ids) {
@@ -672,18 +696,75 @@ static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, c
 
 // Upper bound on the number of (list, tile, group) work items of a list-major scan without a host round
 // trip: sum_l ceil(cnt_l/G)*tiles_l <= (nq * TQ)/G + sum_l tiles_l, TQ = tiles of the nprobe longest lists.
-static int64_t max_scan_items(const rsx_index* h, int64_t nq, int nprobe, int G, int tile_rows) {
+// (sum, max) of the nprobe largest values of ceil(len / unit) * scale over the lists (unit > 0), memoised per directory
+// generation.  tag distinguishes the callers' (unit, scale) families.
+static std::pair<int64_t, int64_t> top_probe_sum(rsx_index* h, int nprobe, int unit, int scale) {
+    const auto key = std::make_tuple(nprobe, unit, scale);
+    auto it = h->bound_cache.find(key);
+    if (it != h->bound_cache.end() && it->second.first == h->dir_gen) return it->second.second;
     std::vector<int64_t> t((size_t)h->nlist);
-    int64_t all = 0;
-    for (int l = 0; l < h->nlist; l++) { t[(size_t)l] = (h->h_len[(size_t)l] + tile_rows - 1) / tile_rows; all += t[(size_t)l]; }
-    std::partial_sort(t.begin(), t.begin() + nprobe, t.end(), std::greater<int64_t>());
-    int64_t tq = 0;
-    for (int j = 0; j < nprobe; j++) tq += t[(size_t)j];
+    for (int l = 0; l < h->nlist; l++) t[(size_t)l] = (h->h_len[(size_t)l] + unit - 1) / unit * scale;
+    const int np = std::min(nprobe, h->nlist);
+    std::partial_sort(t.begin(), t.begin() + np, t.end(), std::greater<int64_t>());
+    int64_t s = 0;
+    for (int j = 0; j < np; j++) s += t[(size_t)j];
+    const std::pair<int64_t, int64_t> r(s, np > 0 ? t[0] : 0);
+    h->bound_cache[key] = std::make_pair(h->dir_gen, r);
+    return r;
+}
+static int64_t max_scan_items(rsx_index* h, int64_t nq, int nprobe, int G, int tile_rows) {
+    const auto key = std::make_tuple(-1, tile_rows, 0);       // all tiles of all lists
+    int64_t all;
+    auto it = h->bound_cache.find(key);
+    if (it != h->bound_cache.end() && it->second.first == h->dir_gen) all = it->second.second.first;
+    else {
+        all = 0;
+        for (int l = 0; l < h->nlist; l++) all += (h->h_len[(size_t)l] + tile_rows - 1) / tile_rows;
+        h->bound_cache[key] = std::make_pair(h->dir_gen, std::make_pair(all, (int64_t)0));
+    }
+    const int64_t tq = top_probe_sum(h, nprobe, tile_rows, 1).first;
     return (nq * tq + G - 1) / G + all + 8;
 }
 
-static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI,
-                         bool allow_fast = true) {
+static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI, bool allow_fast = true);
+
+// Queries whose certificate failed (h->w_uncertain, written by k_finalize) are re-run through the exact path of their index
+// kind and their result rows replaced — rare, and what makes the fast paths EXACT rather than "almost always right".
+// temp_bytes_per_query > 0 bounds the exact path's score buffer (Flat / IVF-Flat): the re-run proceeds in chunks.
+static void rerun_uncertified(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI,
+                              size_t temp_bytes_per_query) {
+    std::vector<int32_t> bad((size_t)nq);
+    HIPCHECK(hipMemcpyAsync(bad.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+    const int d = h->d;
+    const size_t esz = dtype == RSX_F16 ? 2 : 4;
+    std::vector<int64_t> badq;
+    for (int64_t q = 0; q < nq; q++) if (bad[(size_t)q]) badq.push_back(q);
+    const int64_t nbad = (int64_t)badq.size();
+    h->timing["fallback_queries"] += (double)nbad;
+    h->timing["fast_queries"] += (double)nq;
+    if (nbad == 0) return;
+    int64_t chunk = nbad;
+    if (temp_bytes_per_query > 0) chunk = std::max<int64_t>(1, std::min<int64_t>(nbad, (int64_t)(((size_t)2 << 30) / temp_bytes_per_query)));
+    const size_t qrow = (size_t)d * esz;
+    h->w_fbq.ensure((size_t)chunk * qrow);
+    h->w_fbD.ensure((size_t)chunk * k * 4);
+    h->w_fbI.ensure((size_t)chunk * k * 8);
+    for (int64_t c0 = 0; c0 < nbad; c0 += chunk) {
+        const int64_t nb = std::min(chunk, nbad - c0);
+        // gather the uncertified queries into one contiguous batch, search it exactly, scatter the rows back
+        for (int64_t i = 0; i < nb; i++)
+            HIPCHECK(hipMemcpyAsync((char*)h->w_fbq.p + (size_t)i * qrow, (const char*)dq + (size_t)badq[(size_t)(c0 + i)] * qrow, qrow,
+                                    hipMemcpyDeviceToDevice, h->st));
+        search_batch(h, nb, h->w_fbq.p, dtype, k, h->w_fbD.as<float>(), h->w_fbI.as<int64_t>(), false);
+        for (int64_t i = 0; i < nb; i++) {
+            HIPCHECK(hipMemcpyAsync(dD + badq[(size_t)(c0 + i)] * k, h->w_fbD.as<float>() + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, h->st));
+            HIPCHECK(hipMemcpyAsync(dI + badq[(size_t)(c0 + i)] * k, h->w_fbI.as<int64_t>() + i * k, (size_t)k * 8, hipMemcpyDeviceToDevice, h->st));
+        }
+    }
+}
+
+static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI, bool allow_fast) {
     StageTimer tm(h, allow_fast ? "" : "fb_");
     const int d = h->d, ld = h->ld;
     // IVFPQ fast path: needs the 16-byte-granule layout, 16-bit integer sums, and K' <= 4096
@@ -698,9 +779,12 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     h->w_q32.ensure((size_t)nq * ld * 4);
     launch_convert_to_f32(dq, dtype == RSX_F16, d, nq, d, h->w_q32.as<float>(), ld, h->st);
     int64_t nq_pad = nq > 128 ? round_up(nq, 256) : 128;   // query tiles: 128 (k_flat_gemm) or 256 (k_flat_gemm2)
+    const bool certify = h->kind != KIND_IVFPQ && allow_fast && h->flat_cert != 0;
     if (h->kind != KIND_IVFPQ) {
         h->w_q16.ensure((size_t)nq_pad * ld * 2);
-        launch_convert_to_f16(dq, dtype == RSX_F16, nq, d, h->w_q16.as<__half>(), ld, nq_pad, nullptr, h->st);
+        h->w_flag.ensure(sizeof(int));
+        HIPCHECK(hipMemsetAsync(h->w_flag.p, 0, sizeof(int), h->st));
+        launch_convert_to_f16(dq, dtype == RSX_F16, nq, d, h->w_q16.as<__half>(), ld, nq_pad, h->w_flag.as<int>(), h->st);
     }
     h->w_state.ensure((size_t)nq * KP * 8);
     uint64_t* state = h->w_state.as<uint64_t>();
@@ -713,6 +797,22 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     fa.Q32 = h->w_q32.as<float>(); fa.ldq = ld; fa.d = d;
     fa.X = h->data.p; fa.x_f16 = h->storage_f16; fa.ld = ld;
     fa.D = dD; fa.I = dI;
+    if (certify) {
+        // |approx - exact| of the fp16-MFMA scan for ANY stored vector (Cauchy-Schwarz on the per-element errors):
+        //   fp32 accumulation of d exact products       (d + 2) 2^-24 |q| |x|
+        //   fp32 rows rounded to fp16 inside the scan   2^-11 |q| |x|        (fp16 storage is lossless)
+        //   fp32 queries rounded to fp16                2^-11 |q| |x|        (only when the batch held such a value: device flag)
+        //   L2: the ranking score adds -|x|^2/2 (fp32)  (d + 4) 2^-24 |x|^2  (folded into the absolute term)
+        const float u24 = 5.9604645e-8f, u11 = 4.8828125e-4f;
+        const float xmax = sqrtf(h->max_norm2) * 1.0000002f;
+        h->w_uncertain.ensure((size_t)nq * 4);
+        fa.uncertain = h->w_uncertain.as<int32_t>();
+        fa.cert_xmax = xmax;
+        fa.cert_rel = ((float)d + 2.0f) * u24 * 1.01f + (h->storage_f16 ? 0.0f : u11 * 1.002f);
+        fa.cert_rel_qlossy = u11 * 1.002f + u11 * u11;
+        fa.cert_qflag = h->w_flag.as<int>();
+        fa.cert_abs = sqrtf((float)d) * u24 + (h->metric == RSX_METRIC_L2 ? ((float)d + 4.0f) * u24 * xmax : 0.0f);
+    }
 
     if (h->kind == KIND_FLAT) {
         const float* bias = nullptr;
@@ -724,6 +824,19 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         const int64_t N = h->ntotal;
         if (N == 0) {
             launch_fill_u64(state, nq * KP, 0, h->st);
+        } else if (!allow_fast) {
+            // exact mode (queries the certificate could not clear): fp64 scores of every row, rounded once = the canonical
+            // scores themselves, then the ordinary selection
+            const int64_t tstride = round_up(N, 16);
+            h->w_temp.ensure((size_t)nq * tstride * 4);
+            ExactScoreArgs ea{};
+            ea.kind = KIND_FLAT; ea.metric = h->metric; ea.nq = nq; ea.Q32 = h->w_q32.as<float>(); ea.ldq = ld; ea.d = d;
+            ea.X = h->data.p; ea.x_f16 = h->storage_f16; ea.ld = ld; ea.flat_n = N;
+            ea.temp = h->w_temp.as<float>(); ea.tstride = tstride;
+            launch_exact_scores(ea, h->st);
+            tm.mark("scan");
+            select_rows(h, h->w_temp.as<float>(), tstride, nullptr, 0, N, 0, nq, KP, BUF, KP, state, false);
+            tm.mark("select");
         } else if (nq <= 32) {
             // small batch: stream the database once per group of 16 queries (list-scan kernel)
             int64_t tstride = round_up(N, 16);
@@ -795,12 +908,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         launch_finalize(fa, h->st);
         tm.mark("finalize");
         tm.finish();
+        if (certify && N > 0) rerun_uncertified(h, nq, dq, dtype, k, dD, dI, (size_t)round_up(N, 16) * 4);
         return;
     }
 
     // ---------------- IVF ----------------
     const int nlist = h->nlist;
     const int nprobe = std::min(h->nprobe, nlist);
+    if (nprobe > 4096) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: %d probed lists per query exceed this build's maximum of 4096", nprobe);
     // 1. coarse quantiser (exact fp32) + top-nprobe
     const int nlp = (int)round_up(nlist, 4);   // row stride of the coarse scores: 16-byte aligned rows for k_select
     h->w_coarse.ensure((size_t)nq * nlp * 4);
@@ -835,11 +950,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         tm.mark("count");
     }
     // host-side bound on a query's row of the score buffer: the nprobe longest (padded) lists
-    std::vector<int64_t> lens(h->h_len);
-    for (auto& v : lens) v = round_up(v, pad_to);
-    std::partial_sort(lens.begin(), lens.begin() + nprobe, lens.end(), std::greater<int64_t>());
-    int64_t tmax = 0, maxlen = lens[0];
-    for (int j = 0; j < nprobe; j++) tmax += lens[(size_t)j];
+    const auto padded = top_probe_sum(h, nprobe, pad_to, pad_to);    // the nprobe longest lists, padded: sum and maximum
+    int64_t tmax = padded.first, maxlen = padded.second;
     tmax = std::max<int64_t>(round_up(tmax, 256), 256);
     if (tmax >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "probed lists exceed 2^32 vectors per query");
     h->w_temp.ensure((size_t)nq * tmax * 4);
@@ -1017,6 +1129,16 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         }
         h->timing[allow_fast ? "scan_launches" : "fb_scan_launches"] += 1;
         tm.mark("scan");
+    } else if (!allow_fast) {
+        // exact mode (see the Flat branch): fp64 scores of every row of the probed lists into the score rows
+        ExactScoreArgs ea{};
+        ea.kind = KIND_IVFFLAT; ea.metric = h->metric; ea.nq = nq; ea.Q32 = h->w_q32.as<float>(); ea.ldq = ld; ea.d = d;
+        ea.X = h->data.p; ea.x_f16 = h->storage_f16; ea.ld = ld;
+        ea.probe_list = h->w_probelist.as<int32_t>(); ea.seg_start = h->w_segstart.as<int64_t>(); ea.nprobe = nprobe;
+        ea.list_base = h->d_base.as<int64_t>(); ea.list_len = h->d_len.as<int64_t>();
+        ea.temp = h->w_temp.as<float>(); ea.tstride = tmax;
+        launch_exact_scores(ea, h->st);
+        tm.mark("scan");
     } else {
         // group (query, probe) pairs by list, then list-major MFMA scan
         int64_t npairs = nq * nprobe;
@@ -1124,33 +1246,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     launch_finalize(fa, h->st);
     tm.mark("finalize");
     tm.finish();
-    if (fast) {
-        // queries whose certificate failed are re-run with the exact scan (rare; results are then exact too)
-        std::vector<int32_t> bad((size_t)nq);
-        HIPCHECK(hipMemcpyAsync(bad.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
-        size_t esz = dtype == RSX_F16 ? 2 : 4;
-        std::vector<int64_t> badq;
-        for (int64_t q = 0; q < nq; q++) if (bad[(size_t)q]) badq.push_back(q);
-        int64_t nbad = (int64_t)badq.size();
-        if (nbad > 0) {
-            // gather the uncertified queries into one contiguous batch, search it exactly, scatter the rows back
-            size_t qrow = (size_t)d * esz;
-            h->w_fbq.ensure((size_t)nbad * qrow);
-            h->w_fbD.ensure((size_t)nbad * k * 4);
-            h->w_fbI.ensure((size_t)nbad * k * 8);
-            for (int64_t i = 0; i < nbad; i++)
-                HIPCHECK(hipMemcpyAsync((char*)h->w_fbq.p + (size_t)i * qrow, (const char*)dq + (size_t)badq[(size_t)i] * qrow, qrow,
-                                        hipMemcpyDeviceToDevice, h->st));
-            search_batch(h, nbad, h->w_fbq.p, dtype, k, h->w_fbD.as<float>(), h->w_fbI.as<int64_t>(), false);
-            for (int64_t i = 0; i < nbad; i++) {
-                HIPCHECK(hipMemcpyAsync(dD + badq[(size_t)i] * k, h->w_fbD.as<float>() + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, h->st));
-                HIPCHECK(hipMemcpyAsync(dI + badq[(size_t)i] * k, h->w_fbI.as<int64_t>() + i * k, (size_t)k * 8, hipMemcpyDeviceToDevice, h->st));
-            }
-        }
-        h->timing["fallback_queries"] += (double)nbad;
-        h->timing["fast_queries"] += (double)nq;
-    }
+    if (fast || certify) rerun_uncertified(h, nq, dq, dtype, k, dD, dI, fast ? 0 : (size_t)tmax * 4);
 }
 
 // L2 ranking bias  -|x|^2/2  from the stored squared norms
@@ -1161,7 +1257,7 @@ __global__ void k_bias_from_norms(const float* norms, float* bias, int64_t n) {
 
 static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
     if (nq < 0 || k <= 0) RSX_THROW(RSX_ERR_INVALID, "search: nq=%lld k=%d", (long long)nq, k);
-    if (k > 2048) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: k = %d exceeds this build's maximum of 2048", k);
+    if (k > 4096) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: k = %d exceeds this build's maximum of 4096 (the reference backends' default k)", k);
     if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "search before train");
     if (nq == 0) return;
     if (!q || !D || !I) RSX_THROW(RSX_ERR_INVALID, "search: null pointer");
@@ -1187,11 +1283,7 @@ static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int 
     if (h->kind != KIND_FLAT) {
         const int nprobe = std::min(h->nprobe, h->nlist);
         const int pad_to = (h->kind == KIND_IVFPQ) ? 64 : 16;
-        std::vector<int64_t> lens(h->h_len);
-        for (auto& v : lens) v = round_up(v, pad_to);
-        std::partial_sort(lens.begin(), lens.begin() + nprobe, lens.end(), std::greater<int64_t>());
-        int64_t tmax = 0;
-        for (int j = 0; j < nprobe; j++) tmax += lens[(size_t)j];
+        int64_t tmax = top_probe_sum(h, nprobe, pad_to, pad_to).first;
         tmax = std::max<int64_t>(round_up(tmax, 256), 256);
         qb = std::max<int64_t>(1, std::min<int64_t>(qb, h->temp_budget / (tmax * 4)));
     } else if (nq <= 32) {
@@ -1294,6 +1386,7 @@ static void add_list_impl(rsx_index* h, int64_t l, int64_t n, const void* codes,
     } else {
         const void* dx = stage_rows(h, h->w_x, codes, n, h->d, dtype);
         decide_storage(h, dx, n, dtype);
+        track_max_norm(h, dx, n, dtype);
         ensure_capacity(h, need, true);
         for (int64_t i = 0; i < n; i++) dest[(size_t)i] = h->h_base[(size_t)l] + pos0 + i;
         h->w_dest.ensure((size_t)n * 8);
@@ -1795,7 +1888,7 @@ int rsx_set_nprobe(rsx_index_t* h, int nprobe) {
     return guarded([&] {
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         if (nprobe <= 0) RSX_THROW(RSX_ERR_INVALID, "nprobe must be positive (got %d)", nprobe);
-        if (nprobe > 2048) RSX_THROW(RSX_ERR_UNSUPPORTED, "nprobe = %d exceeds this build's maximum of 2048", nprobe);
+        // FAISS accepts any nprobe and probes min(nprobe, nlist) lists; the effective value is bounded at search time
         h->nprobe = nprobe;
         for (auto* s : h->shards) s->nprobe = nprobe;
     });
@@ -1891,7 +1984,7 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
         else if (s == "storage_dtype") *out = (h->kind == KIND_IVFPQ) ? -1 : (h->storage_f16 ? RSX_F16 : RSX_F32);
         else if (s == "code_size") *out = (h->kind == KIND_IVFPQ) ? h->M : (int64_t)h->d * (h->storage_f16 ? 2 : 4);
         else if (s == "device") *out = h->device;
-        else if (s == "max_k") *out = 2048;
+        else if (s == "max_k") *out = 4096;
         else if (s == "pq_layout") *out = (h->kind == KIND_IVFPQ && h->CB == 0) ? 1 : 0;
         else if (s == "hbm_bytes") *out = (int64_t)(h->data.bytes + h->ids.bytes + h->norms.bytes);
         else RSX_THROW(RSX_ERR_INVALID, "unknown property '%s'", key);
@@ -1928,6 +2021,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;
+        else if (s == "flat_cert") h->flat_cert = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;
         else RSX_THROW(RSX_ERR_INVALID, "unknown parameter '%s'", key);

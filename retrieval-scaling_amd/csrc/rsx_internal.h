@@ -108,6 +108,7 @@ void launch_synth_vectors(int d, int ncentres, uint32_t seed_c, uint32_t seed_x,
 void launch_synth_queries(int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t nbase,
                           uint32_t seed_q, float sigma_q, int64_t r0, int64_t n, __half* out, hipStream_t st);
 // scatter rows of a batch into list storage (IVF-Flat / Flat): dst row = dest_row[i]
+void launch_max_norm2(const void* x, int x_f16, int64_t n, int d, unsigned int* out_bits, hipStream_t st);
 void launch_scatter_rows(const void* x, int x_f16, int64_t n, int d, const int64_t* dest_row, void* storage,
                          int storage_f16, int ld, float* norms, const int64_t* ids_in, int64_t id0,
                          int64_t* ids_storage, hipStream_t st);
@@ -311,9 +312,25 @@ struct FinalizeArgs {
     const float* codebooks; int dsub;
     const float* probe_dis0; const void* qparam; int32_t* uncertain;
     const unsigned long long* cand_cnt; int cand_cap;   // filtered scan: per-query candidate counts / capacity
+    // Flat / IVF-Flat certificate (uncertain != null): the scan ordered candidates by an APPROXIMATE score (fp16 MFMA, fp32
+    // accumulation; queries or fp32 rows possibly rounded to fp16).  |approx - exact| <= cert_rel * |q| * cert_xmax + cert_abs
+    // for every stored vector; a query whose K'-th approximate candidate could still beat its exact k-th is flagged.
+    float cert_rel, cert_xmax, cert_abs;
+    const int* cert_qflag; float cert_rel_qlossy;   // *cert_qflag != 0: the batch held an fp32 query value fp16 cannot represent
     float* D; int64_t* I;
 };
 void launch_finalize(const FinalizeArgs& a, hipStream_t st);
+// Exact scores of the uncertified queries (fallback of the certificate above): fp64 dot product of the query with EVERY row
+// the query may see (Flat: all rows; IVF-Flat: the rows of its probed lists, laid out by seg_start), rounded once to fp32 —
+// the canonical score — into temp[q * tstride + column]; invalid columns get -inf.
+struct ExactScoreArgs {
+    int kind; int metric; int64_t nq;
+    const float* Q32; int ldq; int d;
+    const void* X; int x_f16; int ld; int64_t flat_n;
+    const int32_t* probe_list; const int64_t* seg_start; int nprobe; const int64_t* list_base; const int64_t* list_len;
+    float* temp; int64_t tstride;
+};
+void launch_exact_scores(const ExactScoreArgs& a, hipStream_t st);
 void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
                        float* Do, int64_t* Io, hipStream_t st);
 // single-index order (score desc, id asc) for the shards of ONE logical index (rsx_sharded_create); nshards * k <= 8192

@@ -269,7 +269,7 @@ def index_from_parsed(p, device=None):
             if len(i):
                 payload = c if kind == "IVFPQ" else np.ascontiguousarray(c).view(np.float32).reshape(len(i), d)
                 ix.add_list(l, payload, i)
-    ix.nprobe = max(1, min(int(p["nprobe"]), 2048))
+    ix.nprobe = max(1, int(p["nprobe"]))       # any value, as FAISS: the engine probes min(nprobe, nlist) lists
     return ix
 
 

@@ -91,6 +91,46 @@ def test_fp32_values_keep_fp32_storage(gpu, orc):
         assert np.allclose(D, Dr, rtol=0, atol=np.abs(Dr).max() * 2 ** -23)   # fp64 sum order: <= 1 ulp of fp32
 
 
+@pytest.mark.parametrize("kind", ["flat", "ivfflat"])
+@pytest.mark.parametrize("batch", [200, 7])
+def test_lossy_fp16_scan_is_certified_or_rerun(gpu, orc, kind, batch):
+    """fp32 rows and fp32 queries that fp16 cannot represent, on data where the fp16-MFMA scan CANNOT order the
+    candidates (20000 near-duplicates that differ in bits fp16 drops): the rounding error exceeds the rank-k to
+    rank-K' gap, so without the certificate the true top-k is silently lost.  With it every such query is
+    flagged by k_finalize and re-run through the exact fp64 path: ids equal exact brute force."""
+    rng = np.random.RandomState(11)
+    d, n, k = 64, 20000, 10
+    base = rng.randn(d).astype(np.float32)
+    x = (base[None, :] + 1e-5 * rng.randn(n, d)).astype(np.float32)      # identical once rounded to fp16
+    q = (base[None, :] + 0.01 * rng.randn(batch, d)).astype(np.float32)
+    if kind == "flat":
+        ix = gpu.IndexFlatIP(d)
+    else:
+        ix = gpu.IndexIVFFlat(None, d, 4, gpu.METRIC_INNER_PRODUCT)
+        cen = rng.randn(4, d).astype(np.float32); cen[0] = base
+        ix.set_centroids(cen / np.linalg.norm(cen, axis=1, keepdims=True))
+        ix.nprobe = 4
+    ix.add(x)
+    assert ix.storage_dtype == "float32"
+    Dr, Ir = orc.flat_search(q, x, k, 0)
+    ix.set_param("profile", 1)
+    D, I = ix.search(q, k)
+    assert np.array_equal(I, Ir), "certified / re-run result must be the exact ids"
+    assert np.allclose(D, Dr, rtol=0, atol=np.abs(Dr).max() * 2 ** -23)
+    assert ix.get_timing("fallback_queries") > 0, "this data cannot be certified from an fp16 scan"
+    ix.set_param("flat_cert", 0)                     # round-1 behaviour: the approximate top-K' is trusted
+    D0, I0 = ix.search(q, k)
+    assert not np.array_equal(I0, Ir), "the test data must actually defeat the uncertified scan"
+    ix.set_param("flat_cert", 1)
+    # well-separated data certifies without a single re-run (the fast path stays fast)
+    x2 = orc.synth_vectors(d, 5, 41, 42, 0.5, 0, 5000)
+    q2 = orc.synth_queries(d, 5, 41, 42, 0.5, 5000, 43, 0.1, 0, 50)
+    jx = gpu.IndexFlatIP(d); jx.add(x2); jx.set_param("profile", 1)
+    D2, I2 = jx.search(q2, k)
+    assert_same_results(D2, I2, *orc.flat_search(q2.astype(np.float32), x2.astype(np.float32), k, 0), "certified fp16 data")
+    assert jx.get_timing("fallback_queries") == 0
+
+
 def test_explicit_ids_and_large_k(gpu, orc):
     d, n = 64, 4000
     x = orc.synth_vectors(d, 5, 41, 42, 0.5, 0, n)
@@ -98,12 +138,13 @@ def test_explicit_ids_and_large_k(gpu, orc):
     ids = (np.arange(n, dtype=np.int64) * 7 + 1000003)[::-1].copy()
     ix = gpu.IndexFlatIP(d)
     ix.add_with_ids(x, ids)
-    for k in (1, 100, 2048):
+    for k in (1, 100, 2048, 3000, 4096):            # 4096 = the reference backends' default k (flat.py:138)
         D, I = ix.search(q, k)
         Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), k, 0, ids=ids)
         assert_same_results(D, I, Dr, Ir, f"k={k}")
-    with pytest.raises(RuntimeError, match="2048"):
-        ix.search(q, 4096)
+    assert ix._get("max_k") == 4096
+    with pytest.raises(RuntimeError, match="4096"):
+        ix.search(q, 4097)
 
 
 def test_device_pointers_match_host_pointers(gpu, orc):

@@ -202,7 +202,7 @@ def test_ivfpq_large_k_and_ties(gpu, orc):
     ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
     ix.set_centroids(cen); ix.set_codebooks(cb); ix.add(x)
     ix.nprobe = nlist
-    for k in (64, 1000, 2048):
+    for k in (64, 1000, 2048, 4096):
         D, I = ix.search(q, k)
         Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, nlist, k)
         assert np.array_equal(D, Dr), f"k={k} scores"

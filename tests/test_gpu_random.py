@@ -33,7 +33,7 @@ def test_random_ivfpq(gpu, orc, seed):
     ix.set_centroids(cen); ix.set_codebooks(cb)
     for c0 in range(0, n, 7001):                      # several add calls: list growth / re-layout
         ix.add(x[c0:c0 + 7001])
-    for nprobe, k in [(1, 1), (2, 10), (nlist, 10), (max(2, nlist // 2), 300), (nlist, 2048)]:
+    for nprobe, k in [(1, 1), (2, 10), (nlist, 10), (max(2, nlist // 2), 300), (nlist, 4096)]:
         ix.nprobe = nprobe
         D, I = ix.search(q, k)
         Dr, Ir = orc.ivfpq_search(cen, cb, lm, q.astype(np.float32), nprobe, k)

@@ -59,7 +59,8 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
            "queries_per_s": round(steps * nq / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
            "scan_ms": round(scan_ms, 3), "select_ms": round(ix.get_timing("select") / steps, 3),
            "finalize_ms": round(ix.get_timing("finalize") / steps, 3), "build_s": round(build_s, 1),
-           "storage_dtype": ix.storage_dtype}
+           "storage_dtype": ix.storage_dtype,
+           "certificate_fallback_queries_per_step": round(ix.get_timing("fallback_queries") / steps, 3)}
     if which == "flat":
         fl = 2.0 * nq * n * D
         res["roofline"] = {"bound": "mfma", "kernel": "k_flat_gemm2", "achieved": round(fl / (scan_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
