@@ -188,6 +188,35 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const void* x, int x_f16, 
         if (ids_storage) ids_storage[dst] = ids_in ? ids_in[i] : id0 + i;
     }
 }
+// Lloyd update, accumulation step (faiss::Clustering restated in oracle/rsx_oracle.c): sums[s][c][t] = x[i0][col_s + t] +
+// x[i1][col_s + t] + ... over the points assigned to centroid c of segment-set s IN POINT ORDER, one sequential fp32 chain
+// per (s, c, t) starting from 0 — bit-identical to the host loop it replaces (which summed point by point into the
+// centroid rows), with nsets * k * d independent chains in flight.  order[s][.] lists the points grouped by centroid
+// (stable), seg_off[s][c .. c+1] delimits centroid c's run.  Coarse quantiser: nsets = 1, col = 0, d = the full
+// dimension; PQ codebooks: nsets = M sub-spaces, col_s = s * dsub, d = dsub, k = 256.
+__global__ __launch_bounds__(256) void k_kmeans_accumulate(const float* x, int64_t ldx, int col_stride, int d, int k, int nsets, int64_t n,
+                                                           const int32_t* order, const int32_t* seg_off, float* sums) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (s, c, t), t fastest
+    const int64_t per_set = (int64_t)k * d;
+    const int s = (int)(gid / per_set);
+    if (s >= nsets) return;
+    const int64_t r = gid - (int64_t)s * per_set;
+    const int c = (int)(r / d), t = (int)(r - (int64_t)c * d);
+    const int32_t* ord = order + (int64_t)s * n;
+    const int32_t* so = seg_off + (int64_t)s * (k + 1);
+    const float* xs = x + (int64_t)s * col_stride + t;
+    float acc = 0.0f;
+    for (int32_t j = so[c]; j < so[c + 1]; j++) acc += xs[(int64_t)ord[j] * ldx];
+    sums[gid] = acc;
+}
+void launch_kmeans_accumulate(const float* x, int64_t ldx, int col_stride, int d, int k, int nsets, int64_t n, const int32_t* order,
+                              const int32_t* seg_off, float* sums, hipStream_t st) {
+    const int64_t total = (int64_t)nsets * k * d;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_kmeans_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, ldx, col_stride, d, k, nsets, n,
+                       order, seg_off, sums);
+}
+
 // max over the batch rows of |x|^2 (fp32 wave sums: an upper-bound ingredient of the Flat / IVF-Flat certificate, not a
 // score), folded into *out with an atomic max on the (non-negative) float's bit pattern.
 __global__ __launch_bounds__(256) void k_max_norm2(const void* x, int x_f16, int64_t n, int d, unsigned int* out) {

@@ -473,42 +473,63 @@ static void renorm_rows(int d, int k, float* c) {
     }
 }
 
-// one Lloyd update given assignments; x rows are [n, ldx] with the sub-vector at column offset `col`
-static void kmeans_update(int d, int k, int64_t n, const float* x, int ldx, int col, const int32_t* assign, int astride,
-                          float* cen) {
-    std::vector<int64_t> hassign((size_t)k, 0);
-    std::fill(cen, cen + (size_t)k * d, 0.0f);
-    for (int64_t i = 0; i < n; i++) {
-        int c = assign[(size_t)i * astride];
-        hassign[(size_t)c]++;
-        float* cc = cen + (size_t)c * d;
-        const float* xi = x + (size_t)i * ldx + col;
-        for (int t = 0; t < d; t++) cc[t] += xi[t];
+// One Lloyd update given assignments.  The accumulation (sum of the assigned points, point order, fp32) runs on the GPU
+// (k_kmeans_accumulate: one sequential chain per (centroid, dimension), all of them in flight); the host groups the points
+// by centroid (a stable counting sort of the assignment vector) and finishes the update on the k x d sums: division by the
+// counts, FAISS's empty-cluster split, both in the order the oracle uses.
+//   dx: training points on the device [n, ldx]; nsets sub-spaces at column offsets s * col_stride, each of width d, with its
+//   own assignment vector assign[s * astride_set + i * astride_pt]; cen: [nsets][k][d] on the host.
+struct KmeansWs { DevBuf order, off, sums; std::vector<int32_t> h_order, h_off; std::vector<float> h_sums; };
+
+static void kmeans_update_gpu(rsx_index* h, KmeansWs& ws, const float* dx, int64_t ldx, int col_stride, int d, int k, int nsets,
+                              int64_t n, const int32_t* assign, int64_t astride_set, int astride_pt, float* cen) {
+    ws.h_order.resize((size_t)nsets * n); ws.h_off.resize((size_t)nsets * (k + 1));
+    for (int s = 0; s < nsets; s++) {
+        int32_t* off = &ws.h_off[(size_t)s * (k + 1)];
+        std::fill(off, off + k + 1, 0);
+        const int32_t* as = assign + (size_t)s * astride_set;
+        for (int64_t i = 0; i < n; i++) off[as[(size_t)i * astride_pt] + 1]++;
+        for (int c = 0; c < k; c++) off[c + 1] += off[c];
+        std::vector<int32_t> cur(off, off + k);
+        int32_t* ord = &ws.h_order[(size_t)s * n];
+        for (int64_t i = 0; i < n; i++) ord[cur[(size_t)as[(size_t)i * astride_pt]]++] = (int32_t)i;   // stable: point order kept
     }
-    for (int j = 0; j < k; j++) {
-        if (hassign[(size_t)j] == 0) continue;
-        float norm = 1.0f / (float)hassign[(size_t)j];
-        float* cc = cen + (size_t)j * d;
-        for (int t = 0; t < d; t++) cc[t] *= norm;
-    }
-    uint64_t rs = 1234;
-    for (int ci = 0; ci < k; ci++) {
-        if (hassign[(size_t)ci] != 0) continue;
-        int cj = 0;
-        for (;;) {
-            double p = ((double)hassign[(size_t)cj] - 1.0) / (double)(n - k);
-            double r = (double)(splitmix(rs) >> 11) * (1.0 / 9007199254740992.0);
-            if (r < p) break;
-            cj = (cj + 1) % k;
+    ws.order.ensure(ws.h_order.size() * 4); ws.off.ensure(ws.h_off.size() * 4); ws.sums.ensure((size_t)nsets * k * d * 4);
+    HIPCHECK(hipMemcpyAsync(ws.order.p, ws.h_order.data(), ws.h_order.size() * 4, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(hipMemcpyAsync(ws.off.p, ws.h_off.data(), ws.h_off.size() * 4, hipMemcpyHostToDevice, h->st));
+    launch_kmeans_accumulate(dx, ldx, col_stride, d, k, nsets, n, ws.order.as<int32_t>(), ws.off.as<int32_t>(), ws.sums.as<float>(), h->st);
+    HIPCHECK(hipMemcpyAsync(cen, ws.sums.p, (size_t)nsets * k * d * 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+    for (int s = 0; s < nsets; s++) {
+        const int32_t* off = &ws.h_off[(size_t)s * (k + 1)];
+        float* cs = cen + (size_t)s * k * d;
+        std::vector<int64_t> hassign((size_t)k);
+        for (int j = 0; j < k; j++) hassign[(size_t)j] = off[j + 1] - off[j];
+        for (int j = 0; j < k; j++) {
+            if (hassign[(size_t)j] == 0) continue;
+            const float norm = 1.0f / (float)hassign[(size_t)j];
+            float* cc = cs + (size_t)j * d;
+            for (int t = 0; t < d; t++) cc[t] *= norm;
         }
-        float* a = cen + (size_t)ci * d; float* b = cen + (size_t)cj * d;
-        memcpy(a, b, sizeof(float) * (size_t)d);
-        for (int t = 0; t < d; t++) {
-            if (t % 2 == 0) { a[t] *= 1.0f + 1.0f / 1024.0f; b[t] *= 1.0f - 1.0f / 1024.0f; }
-            else { a[t] *= 1.0f - 1.0f / 1024.0f; b[t] *= 1.0f + 1.0f / 1024.0f; }
+        uint64_t rs = 1234;
+        for (int ci = 0; ci < k; ci++) {
+            if (hassign[(size_t)ci] != 0) continue;
+            int cj = 0;
+            for (;;) {
+                double p = ((double)hassign[(size_t)cj] - 1.0) / (double)(n - k);
+                double r = (double)(splitmix(rs) >> 11) * (1.0 / 9007199254740992.0);
+                if (r < p) break;
+                cj = (cj + 1) % k;
+            }
+            float* a_ = cs + (size_t)ci * d; float* b_ = cs + (size_t)cj * d;
+            memcpy(a_, b_, sizeof(float) * (size_t)d);
+            for (int t = 0; t < d; t++) {
+                if (t % 2 == 0) { a_[t] *= 1.0f + 1.0f / 1024.0f; b_[t] *= 1.0f - 1.0f / 1024.0f; }
+                else { a_[t] *= 1.0f - 1.0f / 1024.0f; b_[t] *= 1.0f + 1.0f / 1024.0f; }
+            }
+            hassign[(size_t)ci] = hassign[(size_t)cj] / 2;
+            hassign[(size_t)cj] -= hassign[(size_t)ci];
         }
-        hassign[(size_t)ci] = hassign[(size_t)cj] / 2;
-        hassign[(size_t)cj] -= hassign[(size_t)ci];
     }
 }
 
@@ -550,13 +571,14 @@ static void train_impl(rsx_index* h, int64_t n, const void* x, int dtype) {
         h->w_partial.ensure((size_t)nt * 2 * ct * 8);
         h->w_assign.ensure((size_t)nt * 4);
         std::vector<int32_t> assign((size_t)nt);
+        KmeansWs kws;
         for (int it = 0; it < 10; it++) {
             HIPCHECK(hipMemcpyAsync(dcen.p, cen.data(), (size_t)k * d * 4, hipMemcpyHostToDevice, h->st));
             launch_gemm_exact_argmax(dxt.p, 0, nt, d, dcen.as<float>(), k, d, h->w_partial.as<uint64_t>(),
                                      h->w_assign.as<int32_t>(), nullptr, h->st);
             HIPCHECK(hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)nt * 4, hipMemcpyDeviceToHost, h->st));
             HIPCHECK(hipStreamSynchronize(h->st));
-            kmeans_update(d, k, nt, xt, d, 0, assign.data(), 1, cen.data());
+            kmeans_update_gpu(h, kws, dxt.as<float>(), d, 0, d, k, 1, nt, assign.data(), 0, 1, cen.data());
             renorm_rows(d, k, cen.data());
         }
         set_centroids(h, cen.data());
@@ -597,17 +619,18 @@ static void train_impl(rsx_index* h, int64_t n, const void* x, int dtype) {
         DevBuf dcb, dcodes;
         dcb.ensure(cb.size() * 4); dcodes.ensure((size_t)nt * Mpad);
         std::vector<uint8_t> codes((size_t)nt * Mpad);
-        std::vector<int32_t> a32((size_t)nt);
+        std::vector<int32_t> a32((size_t)M * nt);
+        KmeansWs kws;
         for (int it = 0; it < 25; it++) {
             HIPCHECK(hipMemcpyAsync(dcb.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, h->st));
             launch_pq_encode(dres.p, 0, nt, d, d, M, Mpad, h->CB, nullptr, nullptr, dcb.as<float>(), nullptr, nullptr,
                              dcodes.as<uint8_t>(), h->st);
             HIPCHECK(hipMemcpyAsync(codes.data(), dcodes.p, codes.size(), hipMemcpyDeviceToHost, h->st));
             HIPCHECK(hipStreamSynchronize(h->st));
-            for (int m = 0; m < M; m++) {
-                for (int64_t i = 0; i < nt; i++) a32[(size_t)i] = codes[(size_t)i * Mpad + m];
-                kmeans_update(dsub, 256, nt, res.data(), d, m * dsub, a32.data(), 1, &cb[(size_t)m * 256 * dsub]);
-            }
+            for (int m = 0; m < M; m++)
+                for (int64_t i = 0; i < nt; i++) a32[(size_t)m * nt + i] = codes[(size_t)i * Mpad + m];
+            // all M sub-spaces in one accumulation launch (M x 256 x dsub chains over the residuals on the device)
+            kmeans_update_gpu(h, kws, dres.as<float>(), d, dsub, dsub, 256, M, nt, a32.data(), nt, 1, cb.data());
         }
         set_codebooks(h, cb.data());
     }

@@ -108,6 +108,8 @@ void launch_synth_vectors(int d, int ncentres, uint32_t seed_c, uint32_t seed_x,
 void launch_synth_queries(int d, int ncentres, uint32_t seed_c, uint32_t seed_x, float sigma, int64_t nbase,
                           uint32_t seed_q, float sigma_q, int64_t r0, int64_t n, __half* out, hipStream_t st);
 // scatter rows of a batch into list storage (IVF-Flat / Flat): dst row = dest_row[i]
+void launch_kmeans_accumulate(const float* x, int64_t ldx, int col_stride, int d, int k, int nsets, int64_t n, const int32_t* order,
+                              const int32_t* seg_off, float* sums, hipStream_t st);
 void launch_max_norm2(const void* x, int x_f16, int64_t n, int d, unsigned int* out_bits, hipStream_t st);
 void launch_scatter_rows(const void* x, int x_f16, int64_t n, int d, const int64_t* dest_row, void* storage,
                          int storage_f16, int ld, float* norms, const int64_t* ids_in, int64_t id0,
