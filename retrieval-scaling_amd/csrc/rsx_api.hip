@@ -1435,6 +1435,9 @@ struct FileHeader {
     int32_t version, kind, d, metric, nlist, M, nbits, trained, storage_f16, custom_ids, nprobe;
     int64_t ntotal;
 };
+// version >= 2 appends: what a LIST shard (rsx_set_param "add_list_mod") needs to keep assigning the logical index's
+// sequential ids after a reload — the vectors it saw but did not keep, and its (mod, rem)
+struct FileHeaderV2 { int64_t ndropped; int32_t add_list_mod, add_list_rem; };
 
 static void wr(FILE* f, const void* p, size_t n) {
     if (n && fwrite(p, 1, n, f) != n) RSX_THROW(RSX_ERR_IO, "short write");
@@ -1449,14 +1452,38 @@ static void save_impl(rsx_index* h, const char* path) {
     try {
         FileHeader hd{};
         memcpy(hd.magic, "RSX1", 4);
-        hd.version = 1; hd.kind = h->kind; hd.d = h->d; hd.metric = h->metric; hd.nlist = h->nlist; hd.M = h->M;
+        hd.version = 2; hd.kind = h->kind; hd.d = h->d; hd.metric = h->metric; hd.nlist = h->nlist; hd.M = h->M;
         hd.nbits = h->nbits; hd.trained = h->trained; hd.storage_f16 = h->storage_f16; hd.custom_ids = h->custom_ids;
         hd.nprobe = h->nprobe; hd.ntotal = h->ntotal;
         wr(f, &hd, sizeof(hd));
+        FileHeaderV2 h2{h->ndropped, h->add_list_mod, h->add_list_rem};
+        wr(f, &h2, sizeof(h2));
         int64_t nc = (int64_t)h->h_centroids.size(), ncb = (int64_t)h->h_codebooks.size();
         wr(f, &nc, 8); wr(f, h->h_centroids.data(), (size_t)nc * 4);
         wr(f, &ncb, 8); wr(f, h->h_codebooks.data(), (size_t)ncb * 4);
         std::vector<uint8_t> buf; std::vector<int64_t> ib;
+        if (h->kind == KIND_FLAT) {
+            // one list of ntotal rows, streamed in bounded chunks (a 10M x 768 index is 30 GB as fp32: no whole-index temporaries)
+            const int64_t n = h->h_len[0], CH = 262144;
+            wr(f, &n, 8);
+            DevBuf t; t.ensure((size_t)std::min(CH, std::max<int64_t>(n, 1)) * h->d * 4);
+            buf.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)) * h->d * 4);
+            const size_t esz = h->storage_f16 ? 2 : 4;
+            for (int64_t r0 = 0; r0 < n; r0 += CH) {
+                const int64_t nb = std::min(CH, n - r0);
+                launch_convert_to_f32(h->data.as<uint8_t>() + (size_t)r0 * h->ld * esz, h->storage_f16, h->ld, nb, h->d, t.as<float>(), h->d, h->st);
+                HIPCHECK(hipMemcpyAsync(buf.data(), t.p, (size_t)nb * h->d * 4, hipMemcpyDeviceToHost, h->st));
+                HIPCHECK(hipStreamSynchronize(h->st));
+                wr(f, buf.data(), (size_t)nb * h->d * 4);
+            }
+            ib.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)));
+            for (int64_t r0 = 0; r0 < n; r0 += CH) {
+                const int64_t nb = std::min(CH, n - r0);
+                if (h->custom_ids) HIPCHECK(hipMemcpy(ib.data(), h->ids.as<int64_t>() + r0, (size_t)nb * 8, hipMemcpyDeviceToHost));
+                else for (int64_t i = 0; i < nb; i++) ib[(size_t)i] = r0 + i;
+                wr(f, ib.data(), (size_t)nb * 8);
+            }
+        } else
         for (int l = 0; l < h->nlist; l++) {
             int64_t n = h->h_len[(size_t)l];
             wr(f, &n, 8);
@@ -1481,6 +1508,8 @@ static rsx_index* load_impl(const char* path, int device) {
         if (memcmp(hd.magic, "RSX1", 4) != 0) RSX_THROW(RSX_ERR_IO, "%s is not an RSX1 index file", path);
         h = create_common(hd.kind, hd.d, hd.nlist, hd.M, hd.nbits, hd.metric, device);
         h->nprobe = hd.nprobe;
+        FileHeaderV2 h2{0, 1, 0};
+        if (hd.version >= 2) rd(f, &h2, sizeof(h2));
         int64_t nc = 0, ncb = 0;
         rd(f, &nc, 8);
         std::vector<float> c((size_t)nc); rd(f, c.data(), (size_t)nc * 4);
@@ -1498,20 +1527,37 @@ static rsx_index* load_impl(const char* path, int device) {
             if (n && fseek(f, (long)(pb + (size_t)n * 8), SEEK_CUR) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
         }
         fseek(f, dir_pos, SEEK_SET);
-        if (h->kind != KIND_FLAT) {
-            if (!hd.storage_f16) { h->storage_f16 = 0; h->storage_decided = true; }
-            ensure_capacity(h, lens, true);
-        }
+        if (!hd.storage_f16 && h->kind != KIND_IVFPQ) { h->storage_f16 = 0; h->storage_decided = true; }
+        if (h->kind == KIND_FLAT && hd.custom_ids) h->custom_ids = true;
+        ensure_capacity(h, lens, true);      // exact reservation: the load never re-lays-out HBM
         std::vector<uint8_t> buf; std::vector<int64_t> ib;
+        if (h->kind == KIND_FLAT) {
+            // rows then ids, both streamed in bounded chunks (the ids sit behind the rows: two file cursors)
+            int64_t n = 0; rd(f, &n, 8);
+            const int64_t CH = 262144;
+            const long rows_pos = ftell(f);
+            const long ids_pos = rows_pos + (long)((size_t)n * h->d * 4);
+            buf.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)) * h->d * 4); ib.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)));
+            for (int64_t r0 = 0; r0 < n; r0 += CH) {
+                const int64_t nb = std::min(CH, n - r0);
+                if (fseek(f, rows_pos + (long)((size_t)r0 * h->d * 4), SEEK_SET) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
+                rd(f, buf.data(), (size_t)nb * h->d * 4);
+                if (hd.custom_ids) {
+                    if (fseek(f, ids_pos + (long)((size_t)r0 * 8), SEEK_SET) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
+                    rd(f, ib.data(), (size_t)nb * 8);
+                }
+                add_all(h, nb, buf.data(), RSX_F32, hd.custom_ids ? ib.data() : nullptr);
+            }
+        } else
         for (int l = 0; l < h->nlist; l++) {
             int64_t n = 0; rd(f, &n, 8);
             if (n == 0) continue;
             size_t pb = (h->kind == KIND_IVFPQ) ? (size_t)n * h->M : (size_t)n * h->d * 4;
             buf.resize(pb); ib.resize((size_t)n);
             rd(f, buf.data(), pb); rd(f, ib.data(), (size_t)n * 8);
-            if (h->kind == KIND_FLAT) add_all(h, n, buf.data(), RSX_F32, hd.custom_ids ? ib.data() : nullptr);
-            else add_list_impl(h, l, n, buf.data(), RSX_F32, ib.data());
+            add_list_impl(h, l, n, buf.data(), RSX_F32, ib.data());
         }
+        h->ndropped = h2.ndropped; h->add_list_mod = h2.add_list_mod; h->add_list_rem = h2.add_list_rem;
     } catch (...) {
         fclose(f);
         if (h) { if (h->st) (void)hipStreamDestroy(h->st); delete h; }

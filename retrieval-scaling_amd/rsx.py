@@ -415,7 +415,13 @@ def _wrap_handle(h):
 
 
 def write_index(index, path):
-    """faiss.write_index(index, path) — native RSX1 container (see rsx_faiss_io for .faiss files)."""
+    """faiss.write_index(index, path).  Default: the native RSX1 container (magic-tagged; rsx.read_index loads it whatever the
+    file is called — the reference's mirrors keep its `index_*.faiss` names).  RSX_INDEX_FORMAT=faiss writes a FAISS-format file
+    through rsx_faiss_io instead, for hand-over to a real faiss.read_index (written from upstream knowledge of the format,
+    unverified against a FAISS-produced file: DESIGN.md)."""
+    if os.environ.get("RSX_INDEX_FORMAT", "").lower() == "faiss" and index.nshards == 0:
+        from rsx_faiss_io import write_faiss_index
+        return write_faiss_index(index, os.fspath(path))
     _check(lib().rsx_save(index._h, os.fspath(path).encode()))
 
 

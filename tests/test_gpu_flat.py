@@ -171,3 +171,27 @@ def test_bad_arguments_raise(gpu):
     iv = gpu.IndexIVFFlat(None, 16, 4, 0)
     with pytest.raises(RuntimeError, match="train"):
         iv.add(np.zeros((4, 16), np.float32))       # add before train
+
+
+def test_flat_save_load_streams_in_chunks(gpu, tmp_path):
+    """RSX1 save / load of a Flat index moves rows in 256k-row chunks (no whole-index temporaries: a 10M x 768 index is
+    30 GB as fp32) — more than one chunk here, with and without explicit ids, storage dtype preserved."""
+    d, n = 32, 300_000
+    x = gpu.synth_vectors(d, 7, 3, 4, 0.5, 0, n)
+    q = gpu.synth_queries(d, 7, 3, 4, 0.5, n, 5, 0.1, 0, 33)
+    for with_ids in (False, True):
+        ix = gpu.IndexFlatIP(d)
+        ids = (np.arange(n, dtype=np.int64)[::-1] * 3 + 17).copy()
+        if with_ids:
+            ix.add_with_ids(x, ids)
+        else:
+            ix.add(x)
+        D, I = ix.search(q, 10)
+        path = str(tmp_path / f"flat_{int(with_ids)}.faiss")
+        gpu.write_index(ix, path)
+        jx = gpu.read_index(path)
+        assert jx.ntotal == n and jx.storage_dtype == ix.storage_dtype == "float16"
+        D2, I2 = jx.search(q, 10)
+        assert np.array_equal(D, D2) and np.array_equal(I, I2)
+        jx.add_with_ids(x[:5], ids[:5] + 10 ** 9) if with_ids else jx.add(x[:5])
+        assert jx.ntotal == n + 5

@@ -1,4 +1,6 @@
 """GPU: IVF-Flat and IVF-PQ through the C-ABI against the oracle and the golden fixtures."""
+import os
+
 import numpy as np
 import pytest
 
@@ -376,6 +378,21 @@ def test_list_sharded_index_equals_single_index(gpu, orc, kind):
     assert_same_results(Dm, Im, Df, If, f"list-sharded {kind}")
     with pytest.raises(RuntimeError):
         shards[0].set_param("add_list_mod", 2)          # only before the first add
+    # a list shard survives save / load: the vectors it dropped still count towards the sequential ids of later adds
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "shard1.faiss")
+        gpu.write_index(shards[1], path)
+        back = gpu.read_index(path)
+    back.nprobe = 5
+    extra = x[:600]
+    full.add(extra); back.add(extra)
+    for s in (shards[0], shards[2]):
+        s.add(extra)
+    Df2, If2 = full.search(q, k)
+    parts = [shards[0].search(q, k), back.search(q, k), shards[2].search(q, k)]
+    Dm2, Im2 = gpu.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    assert_same_results(Dm2, Im2, Df2, If2, f"list-sharded {kind} after reloading one shard")
 
 
 def test_sharded_searcher_over_rccl_single_rank(gpu, orc):
