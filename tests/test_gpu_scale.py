@@ -140,3 +140,67 @@ def test_indexer_facade_on_gpu(gpu, orc, tmp_path, index_type):
     ix2 = Indexer(cfg)              # reload from the files written above
     s2, p2, d2 = ix2.search(q, k=3)
     assert d2 == db_ids and s2 == scores and p2 == passages
+
+
+def _oracle_lists(orc, ix, need, nlist):
+    off = np.zeros(nlist + 1, np.int64); lens = np.zeros(nlist, np.int64); pay, ids = [], []
+    for l in need:
+        v, i = ix.get_list(int(l)); pay.append(v); ids.append(i); lens[l] = len(i)
+    np.cumsum(lens, out=off[1:])
+
+    class LM: pass
+    lm = LM(); lm.list_off = off; lm.payload = np.concatenate(pay); lm.ids = np.concatenate(ids)
+    return lm
+
+
+def test_flat_batch_1024(gpu, orc):
+    """BASELINE config 2's batch shape (1024 queries through the 256 x 256 MFMA tiles and the filtered second pass) at 1M
+    vectors: a sample of queries against the oracle, and the whole batch against itself in four sub-batches."""
+    import torch
+    d, n, nq, k = 768, 1_000_000, 1024, 10
+    x = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    gpu.synth_vectors(d, 4096, 1234, 10000, 0.5, 0, n, out=x)
+    q = torch.empty((nq, d), dtype=torch.float16, device="cuda")
+    gpu.synth_queries(d, 4096, 1234, 10000, 0.5, n, 999, 0.1, 0, nq, out=q)
+    ix = gpu.IndexFlatIP(d); ix.add(x)
+    ix.set_param("profile", 1)
+    D, I = ix.search(q, k)
+    assert ix.get_timing("fallback_queries") == 0          # fp16 data: the MFMA scan certifies every query
+    Dn, In = D.cpu().numpy(), I.cpu().numpy()
+    sample = [0, 255, 256, 511, 777, 1023]
+    Dr, Ir = orc.flat_search(q[sample].cpu().numpy().astype(np.float32), x.cpu().numpy().astype(np.float32), k, 0)
+    assert_same_results(Dn[sample], In[sample], Dr, Ir, "flat 1M batch 1024 vs oracle")
+    for s in range(0, nq, 256):
+        Ds, Is = ix.search(q[s:s + 256], k)
+        assert torch.equal(Ds, D[s:s + 256]) and torch.equal(Is, I[s:s + 256]), "batch decomposition must be invisible"
+
+
+@pytest.mark.parametrize("kind", ["ivfflat", "ivfpq"])
+def test_ivf_nlist4096_nprobe32_batch_1024(gpu, orc, kind):
+    """BASELINE configs 3 / 4's index parameters (nlist 4096, nprobe 32, batch 1024; IVF-PQ M = 96 on the rotated layout) at
+    1.5M vectors: a sample of queries against the oracle on the exported lists, batch-split invariance, and the probe
+    selection against the oracle's coarse quantiser."""
+    import torch
+    d, n, nlist, nprobe, nq, k = 768, 1_500_000, 4096, 32, 1024, 10
+    x = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    gpu.synth_vectors(d, 4096, 1234, 10000, 0.5, 0, n, out=x)
+    q = torch.empty((nq, d), dtype=torch.float16, device="cuda")
+    gpu.synth_queries(d, 4096, 1234, 10000, 0.5, n, 999, 0.1, 0, nq, out=q)
+    ix = gpu.IndexIVFFlat(None, d, nlist, 0) if kind == "ivfflat" else gpu.IndexIVFPQ(None, d, nlist, 96, 8, 0)
+    ix.train(x[:524288]); ix.add(x); ix.nprobe = nprobe
+    ls = ix.list_sizes()
+    assert ls.sum() == n and ls.max() > 2 * np.median(ls)          # k-means lists are NOT balanced
+    D, I = ix.search(q, k)
+    sample = [0, 256, 513, 1023]
+    qs = q[sample].cpu().numpy().astype(np.float32)
+    cen = ix.get_centroids()
+    pid, _ = orc.coarse_probe(cen, qs, nprobe)
+    lm = _oracle_lists(orc, ix, np.unique(pid), nlist)
+    if kind == "ivfflat":
+        Dr, Ir = orc.ivfflat_search(0, cen, lm, qs, nprobe, k)
+    else:
+        Dr, Ir = orc.ivfpq_search(cen, ix.get_codebooks(), lm, qs, nprobe, k)
+    assert_same_results(D[sample].cpu().numpy(), I[sample].cpu().numpy(), Dr, Ir, f"{kind} nlist 4096 nprobe 32 vs oracle")
+    for s in range(0, nq, 512):
+        Ds, Is = ix.search(q[s:s + 512], k)
+        assert torch.equal(Ds, D[s:s + 512]) and torch.equal(Is, I[s:s + 512]), "batch decomposition must be invisible"
