@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int 
         for (int j = 0; j < nprobe; j++) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
         // fp32 slack: < 300 roundings of relative size 2^-24 on magnitudes bounded by B
         float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
-        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 0.0f;
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 255.0f * (float)Mpad;   // no tighter bound computed on this path
         qp[q] = r;
     }
 }
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
         float d0 = 0.0f;
         for (int j = 0; j < nprobe; j++) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
         float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
-        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 0.0f;
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 255.0f * (float)Mpad;   // no tighter bound computed on this path
         qp[q] = r;
     }
 }
@@ -559,17 +559,26 @@ __global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, c
         e_quant += errb[q * Mpad + m];
         bias += mn;
     }
+    float mr = maxrange;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mr = fmaxf(mr, __shfl_xor(mr, off));
+    // largest integer sum any code vector can reach with this query's table: per sub-quantiser the entry of its maximum,
+    // quantised exactly as k_pq_lut_tiled<1> does (rint((mx - mn) / scale) clamped to 255) — the bound pair pruning uses
+    const float inv_s = 1.0f / (mr > 0.0f ? mr / 255.0f : 1.0f);
+    float smax = 0.0f;
+    for (int m = lane; m < Mpad; m += 64) smax += fminf(fmaxf(rintf((mm[2 * m + 1] - mm[2 * m]) * inv_s), 0.0f), 255.0f);
     for (int j = lane; j < nprobe; j += 64) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         absmax_sum += __shfl_xor(absmax_sum, off); e_quant += __shfl_xor(e_quant, off); bias += __shfl_xor(bias, off);
+        smax += __shfl_xor(smax, off);
         maxrange = fmaxf(maxrange, __shfl_xor(maxrange, off)); d0 = fmaxf(d0, __shfl_xor(d0, off));
     }
     if (lane == 0) {
         const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
         // fp32 slack: < 300 roundings of relative size 2^-24 on magnitudes bounded by B
         const float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
-        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 0.0f;
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = smax;
         qp[q] = r;
     }
 }
@@ -786,7 +795,7 @@ int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam
     A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
-    A.tau_key = nullptr; A.tau_stride = 0; A.cand = nullptr; A.cand_cnt = nullptr; A.cand_cap = 0;
+    A.tau_key = nullptr; A.tau_stride = 0; A.cand = nullptr; A.cand_cnt = nullptr; A.cand_cap = 0; A.prune = 0;
     if (a.Mpad == 96 && vpl == 8) {
         static int var = -1;
         if (var < 0) { const char* e = getenv("RSX_SCAN8_VARIANT"); var = e ? atoi(e) : 0; }
@@ -815,7 +824,7 @@ int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void*
     A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
-    A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap;
+    A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap; A.prune = 0;
     switch (a.Mpad / 16) {
         case 1: return launch_pq_scan8_v<1, true>(A, vpl, st);
         case 2: return launch_pq_scan8_v<2, true>(A, vpl, st);

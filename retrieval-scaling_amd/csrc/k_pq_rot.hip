@@ -95,9 +95,12 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
         if (k >= d.np) thr = INT_MAX;
         else if (FILTER && tau != 0ull) {
             const float ts = key_score(tau);
-            if (!(dis0 + __fmaf_rn(p.scale, (float)(255 * M), p.bias) >= ts)) thr = INT_MAX;
+            // p.pad = the largest sum this query's table can give any code vector (<= 255 M): nothing in this list can
+            // reach the threshold when even that falls short
+            int smax = (int)p.pad; if (smax <= 0 || smax > 255 * M) smax = 255 * M;
+            if (!(dis0 + __fmaf_rn(p.scale, (float)smax, p.bias) >= ts)) thr = INT_MAX;
             else {
-                int b0 = 0, b1 = 255 * M;
+                int b0 = 0, b1 = smax;
                 while (b0 < b1) {
                     const int mid = (b0 + b1) >> 1;
                     if (dis0 + __fmaf_rn(p.scale, (float)mid, p.bias) >= ts) b1 = mid; else b0 = mid + 1;
@@ -107,6 +110,10 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
         }
         d.cinit[k] = thr == INT_MAX ? -(1 << 30) : thr == INT_MIN ? (1 << 30) : -thr;
     }
+    // opt-in pair pruning (rsx_set_param "pq_prune"): no query of the group can produce a survivor here -> the scan skips
+    // the item (no table staging, no gathers).  Exact: the bound is on the very integer sums the scan would compute.
+    if (FILTER && A.prune && d.cinit[0] == -(1 << 30) && d.cinit[1] == -(1 << 30) && d.cinit[2] == -(1 << 30) && d.cinit[3] == -(1 << 30))
+        d.l = -2;
     items[item] = d;
 }
 
@@ -200,8 +207,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     for (;; buf ^= 1) {
         __syncthreads();    // #1: every wave has left the previous item's scan (table free), the item record is in LDS
         const PQRotItem* it = &islot[buf];
-        if (__builtin_amdgcn_readfirstlane(it->l) < 0) break;
+        const int item_l = __builtin_amdgcn_readfirstlane(it->l);
+        if (item_l == -1) break;
         item = __builtin_amdgcn_readfirstlane(it->pad0);
+        const bool skip_item = item_l < -1;         // pruned: no survivors possible, only the bookkeeping below runs
         const int np = __builtin_amdgcn_readfirstlane(it->np);
         const int64_t len = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->len >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->len);
         const int64_t base_row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->base_row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->base_row);
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         // ---- stage the group's table: work unit = (code, 4 consecutive m) -> 4 dwords (one per m: byte k = query k, as int8 = u8 - 128)
         {
             const int64_t q0 = it->q[0], q1 = it->q[1], q2 = it->q[2], q3 = it->q[3];
-            for (int e = tid; e < ((var & 4) ? 0 : 256 * (M / 4)); e += 1024) {
+            for (int e = tid; e < ((var & 4) || skip_item ? 0 : 256 * (M / 4)); e += 1024) {
                 const int c = e / (M / 4), m4 = e - c * (M / 4);
                 uint32_t in[4];
                 in[0] = *reinterpret_cast<const uint32_t*>(A.lut8 + (q0 * 256 + c) * M + m4 * 4);
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 
         // ---- scan: blocks tb0 + w + 16 j, j < bpw, ROT_D of them in flight
 #pragma unroll 1
-        for (int j0 = 0; j0 < ((var & 2) ? 0 : bpw); j0 += ROT_D) {
+        for (int j0 = 0; j0 < ((var & 2) || skip_item ? 0 : bpw); j0 += ROT_D) {
             if (tb0 + w + 16 * j0 >= nblk) break;
 #pragma unroll
             for (int dd = 0; dd < ROT_D; dd++) {
@@ -421,7 +430,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws, int seg_cap, hipStream_t st) {
+                       int cand_cap, void* item_ws, int seg_cap, int prune, hipStream_t st) {
     if (a.CB != 0 || !item_ws || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8t; A.qp = (const PQQParam*)qparam;
@@ -429,6 +438,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
     A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap;
+    A.prune = prune;
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
     switch (a.M) {

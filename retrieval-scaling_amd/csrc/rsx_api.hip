@@ -151,6 +151,7 @@ struct rsx_index {
     int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
     int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
     int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
+    int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
     int pq_pre_rows = 2048;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
@@ -1075,7 +1076,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 void* rws0 = rot ? rot_desc(mi, filtered ? pre_vpl : vpl, 0) : nullptr;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
-                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, h->st)
+                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, 0, h->st)
                             : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
             }
@@ -1104,7 +1105,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                                  total_groups, item_off, total_items, nlist,
                                                  max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rws1, rot_seg_cap, h->st)
+                                                 rws1, rot_seg_cap, h->pq_prune, h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
                                                      max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
@@ -2073,6 +2074,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_fast") h->pq_fast = (int)value;
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
         else if (s == "pq_filter") h->pq_filter = (int)value;
+        else if (s == "pq_prune") h->pq_prune = (int)value;
         else if (s == "add_list_mod" || s == "add_list_rem") {
             if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_UNSUPPORTED, "%s: IVF indexes only", key);
             if (h->ntotal + h->ndropped > 0) RSX_THROW(RSX_ERR_INVALID, "%s must be set before the first add", key);

@@ -204,7 +204,7 @@ int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void*
                            const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
                            int cand_cap, hipStream_t st);
 // shared by the list-major IVF-PQ scans (k_pq.hip, k_pq_rot.hip)
-struct PQQParam { float scale, bias, eps, pad; };
+struct PQQParam { float scale, bias, eps, pad; };   // pad: the largest integer table sum this query's u8 table can produce
 struct PQScan8Args {
     PQScanArgs b;
     const uint8_t* lut8; const PQQParam* qp;
@@ -213,6 +213,7 @@ struct PQScan8Args {
     int nlist; int max_items;
     // filtered output (FILTER = true): keys > tau_key[q] are appended to cand[q][0..cap)
     const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
+    int prune;   // k_pq_scan_rot: skip work items none of whose queries can beat its threshold in this list (exact bound)
 };
 
 // Work-item decode shared by the list-major scans.  Items are ordered (list, tile, group) so that the
@@ -242,7 +243,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, hipStream_t st);
+                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, int prune, hipStream_t st);
 // survivor segment capacity per (item, wave, query): 4x what a query's CLOSEST list is expected to yield (a wave scans
 // tile/16 vectors of it, of which the pre-pass threshold lets about KP / pre_rows through), never less than 128 and never
 // more than the wave's whole share of the tile (at which point no overflow is possible)

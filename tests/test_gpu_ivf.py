@@ -133,6 +133,10 @@ def test_golden_ivfpq(gpu, orc, name, layout):
     Da, Ia = ix.search(q, g["k"])
     assert_same_results(Da, Ia, g["D"], g["I"], name + " multi-launch pre-pass")
     ix.set_param("pq_prepass_fused", 1)
+    ix.set_param("pq_prune", 1)             # opt-in pair pruning: (list, group) items that cannot hold a survivor are skipped
+    Db, Ib = ix.search(q, g["k"])
+    assert_same_results(Db, Ib, g["D"], g["I"], name + " pair pruning")
+    ix.set_param("pq_prune", 0)
     ix.set_param("lut_tiled", 0)            # one workgroup per query builds its table (the tiled build is the dsub = 8 default)
     D9, I9 = ix.search(q, g["k"])
     assert_same_results(D9, I9, g["D"], g["I"], name + " per-query table build")

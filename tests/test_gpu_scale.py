@@ -204,3 +204,7 @@ def test_ivf_nlist4096_nprobe32_batch_1024(gpu, orc, kind):
     for s in range(0, nq, 512):
         Ds, Is = ix.search(q[s:s + 512], k)
         assert torch.equal(Ds, D[s:s + 512]) and torch.equal(Is, I[s:s + 512]), "batch decomposition must be invisible"
+    if kind == "ivfpq":
+        ix.set_param("pq_prune", 1)
+        Dp, Ip = ix.search(q, k)
+        assert torch.equal(Dp, D) and torch.equal(Ip, I), "pair pruning is exact"
