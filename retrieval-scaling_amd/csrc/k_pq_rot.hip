@@ -385,10 +385,20 @@ __global__ __launch_bounds__(64) void k_pq_rot_compact(const PQRotItem* __restri
         base = atomicAdd(&cand_cnt[q * CCS], (unsigned long long)total + (myover ? (unsigned long long)cand_cap + 1ull : 0ull));
     }
     base = __shfl(base, k) + (incl - c);
-    const uint64_t* src = seg_keys + ((size_t)item * 64 + lane) * seg_cap;
-    for (uint32_t e = 0; e < c; e++) {
-        const unsigned long long s2 = base + e;
-        if (s2 < (unsigned long long)cand_cap) cand[q * cand_cap + s2] = src[e];
+    // copy-out: the wave walks the (at most 64) non-empty segments, all lanes on one segment at a time (coalesced 8-byte moves)
+    uint64_t live = __builtin_amdgcn_ballot_w64(c != 0u);
+    while (live) {
+        const int sgm = __builtin_ctzll(live);
+        live &= live - 1;
+        const uint32_t cs = __builtin_amdgcn_readlane(c, sgm);
+        const unsigned long long bs = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), sgm) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)base, sgm);
+        const int64_t qs = items[item].q[sgm & 3];
+        const uint64_t* src = seg_keys + ((size_t)item * 64 + sgm) * seg_cap;
+        for (uint32_t e = lane; e < cs; e += 64) {
+            const unsigned long long s2 = bs + e;
+            if (s2 < (unsigned long long)cand_cap) cand[qs * cand_cap + s2] = src[e];
+        }
     }
 }
 
