@@ -219,6 +219,7 @@ struct FlatFilterArgs {
     const uint64_t* tau; int64_t tau_stride;     // tau[q * tau_stride]
     uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
     int nq; int qt; int64_t ntiles;              // real queries, query tiles, db tiles in [v0, v0 + nv)
+    int walk;                                    // k_flat_gemm2: persistent workgroups, fixed query tile, walking db tiles
 };
 
 template <bool XF16, bool FILTER>
@@ -368,49 +369,73 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
     uint64_t* s_tau = reinterpret_cast<uint64_t*>(fg2_smem + 2 * FG2_STAGE);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr0 = __builtin_amdgcn_readfirstlane(w >> 2), wc0 = __builtin_amdgcn_readfirstlane(w & 3);
-    // FILTER: the workgroup owns ONE db tile and passes every query tile over it (the db tile comes from HBM
-    // once, for the first pass; each CU streams a different tile, so the HBM requests in flight are all
-    // distinct).  !FILTER: one (query tile, db tile) pair per workgroup.
-    const int64_t vt0 = (FILTER ? (int64_t)blockIdx.x : (int64_t)blockIdx.y) * 256;
-    const int qi0 = FILTER ? 0 : (int)blockIdx.x;
-    const int npass = FILTER ? F.qt : 1;
+    // Work items of a workgroup = (query tile, db tile) pairs run through ONE software pipeline of K steps:
+    //  !FILTER       : one pair per workgroup (2-D grid).
+    //  FILTER, walk  : PERSISTENT workgroups (one per CU).  Workgroup b sits on XCD b % 8; slot s = b / 8 of that XCD keeps
+    //                  query tile s % qt and walks the db tiles  x + 8 (s / qt) + 8 (S / qt) n,  n = 0, 1, ...  The qt slots
+    //                  that share s / qt walk the SAME db tiles at the same pace, so a db tile comes from HBM once per XCD
+    //                  and its other qt - 1 readers hit that XCD's L2 (PMC FETCH_SIZE: 15.5 GB per 10M x 768 launch = the
+    //                  db itself, against 67.6 GB for the pass form below); the query tiles stay L2 resident.
+    //  FILTER, !walk : the workgroup owns ONE db tile and passes every query tile over it (small launches).
+    const bool walk = FILTER && F.walk != 0;
+    int qi0, nitems;
+    int64_t vt0, vt_step;
+    if (!FILTER) { vt0 = (int64_t)blockIdx.y * 256; vt_step = 0; qi0 = (int)blockIdx.x; nitems = 1; }
+    else if (!walk) { vt0 = (int64_t)blockIdx.x * 256; vt_step = 0; qi0 = 0; nitems = F.qt; }
+    else {
+        const int x = blockIdx.x & 7, s = blockIdx.x >> 3, ngq = (int)(gridDim.x >> 3) / F.qt;
+        qi0 = s % F.qt;
+        const int64_t t0 = x + 8 * (s / F.qt), tstep = 8 * (int64_t)ngq;
+        vt0 = t0 * 256; vt_step = tstep * 256;
+        nitems = t0 < F.ntiles ? (int)((F.ntiles - 1 - t0) / tstep) + 1 : 0;
+        if (nitems == 0) return;
+    }
     float* s_tf = reinterpret_cast<float*>(s_tau + 512);                        // tf[2][256]: the thresholds as floats
     if (FILTER && tid < 256) {
-        const uint64_t t = (tid < F.nq) ? F.tau[(int64_t)tid * F.tau_stride] : ~0ull;
-        s_tau[tid] = t;
-        s_tf[tid] = (tid < F.nq) ? key_score(t) : __builtin_inff();
+        const int64_t qn = (int64_t)qi0 * 256 + tid;
+        const uint64_t t = (qn < F.nq) ? F.tau[qn * F.tau_stride] : ~0ull;
+        s_tau[(qi0 & 1) * 256 + tid] = t;
+        s_tf[(qi0 & 1) * 256 + tid] = (qn < F.nq) ? key_score(t) : __builtin_inff();
     }
 
-    // DMA sources: wave w copies blocks [4w, 4w + 4) (8 rows each) of both operands, every stage
-    const char* srcA[4]; const char* srcB[4];
+    // DMA sources: wave w copies blocks [4w, 4w + 4) (8 rows each) of both operands, every stage.  The db rows are
+    // addressed from the walking tile base on the fly (one v_mad_u64_u32 per piece), clamped to the last row.
+    const char* srcA[4];
+    const char* xb[2];                           // X + v0 rows + the swizzled chunk of this lane (j even / odd)
+    const int r8 = lane >> 3;
     {
-        const int r8 = lane >> 3, p = lane & 7;
+        const int p = lane & 7;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int R = (4 * w + j) * 8 + r8;
             const int c = p ^ ((R >> 1) & 7);
-            int64_t xrow = vt0 + R; if (xrow > nv - 1) xrow = nv - 1;
             srcA[j] = reinterpret_cast<const char*>(Q16 + ((int64_t)qi0 * 256 + R) * ld) + c * 16;   // nq_pad % 256 == 0
-            srcB[j] = reinterpret_cast<const char*>(X + (v0 + xrow) * ld) + c * 16;
+            if (j < 2) xb[j] = reinterpret_cast<const char*>(X + v0 * ld) + c * 16;                    // c depends on j & 1 only
         }
     }
     const int KT = ld / 64;
-    const int G = npass * KT;                    // K steps of all passes, one software pipeline
-    const int64_t pass_bytes = (int64_t)256 * ld * 2;
-    int i_kt = 0; int64_t i_aoff = 0;            // position of the next stage to issue
+    const int G = nitems * KT;                   // K steps of all work items, one software pipeline
+    const int64_t a_step = walk ? 0 : (int64_t)256 * ld * 2;     // the next item's query tile ...
+    const int64_t i_vstep = vt_step;                              // ... or db tile
+    const uint32_t ld2 = (uint32_t)ld * 2u;
+    const int64_t vlast = nv - 1;
+    int i_kt = 0; int64_t i_aoff = 0, i_vt = vt0;    // position of the next stage to issue
     auto issue = [&](int buf, bool advance) {
         unsigned char* sa = fg2_smem + buf * FG2_STAGE + (4 * w) * 1024;
         unsigned char* sb = sa + 32768;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            int64_t xrow = i_vt + ((4 * w + j) * 8 + r8);
+            xrow = xrow > vlast ? vlast : xrow;
             fg2_dma16(srcA[j] + i_aoff + (int64_t)i_kt * 128, sa + j * 1024);
-            fg2_dma16(srcB[j] + (int64_t)i_kt * 128, sb + j * 1024);
+            fg2_dma16(xb[j & 1] + (uint64_t)(uint32_t)xrow * ld2 + (int64_t)i_kt * 128, sb + j * 1024);
         }
         // branch-free advance (a branch here would split the scheduling region the interleave below pins)
         i_kt += advance ? 1 : 0;
         const bool wrap = i_kt == KT;
         i_kt = wrap ? 0 : i_kt;
-        i_aoff += wrap ? pass_bytes : 0;
+        i_aoff += wrap ? a_step : 0;
+        i_vt += wrap ? i_vstep : 0;
     };
 
     floatx16 acc[4][2];
@@ -450,6 +475,7 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
     FG2_LOAD_FRAGS(0, 0, 0)
     const int lj0 = lane & 31, lh0 = lane >> 5;
     int kt = 0, qi = qi0;
+    int64_t vt = vt0;                            // db tile of the item being computed (the issue position runs ahead)
     for (int g = 0; g < G; g++) {
         // sub-step 0 carries the DMA of the NEXT stage (into the buffer every wave left at the last barrier);
         // the last step re-fetches its own stage into the idle buffer so the body stays branch-free.
@@ -493,7 +519,7 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
             continue;
         }
         kt = 0;
-        // ---- end of a pass: the 256 x 256 scores of query tile qi are complete
+        // ---- end of a work item: the 256 x 256 scores of (query tile qi, db tile vt) are complete
         const int64_t q0 = (int64_t)qi * 256;
         // launder the lane coordinates: everything derived from them below would otherwise be hoisted out of
         // the K loop as loop-invariant and held in ~70 VGPRs across the MFMA phase (-> spills)
@@ -502,7 +528,7 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
         if (!FILTER) {
 #pragma unroll
             for (int tj = 0; tj < 2; tj++) {
-                int64_t col = vt0 + wc * 64 + tj * 32 + lj;
+                int64_t col = vt + wc * 64 + tj * 32 + lj;
                 float bv = (bias && col < nv) ? bias[v0 + col] : 0.0f;
 #pragma unroll
                 for (int ti = 0; ti < 4; ti++)
@@ -518,7 +544,7 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
             float bv[2]; int64_t colv[2];
 #pragma unroll
             for (int tj = 0; tj < 2; tj++) {
-                colv[tj] = vt0 + wc * 64 + tj * 32 + lj;
+                colv[tj] = vt + wc * 64 + tj * 32 + lj;
                 bv[tj] = (bias && colv[tj] < nv) ? bias[v0 + colv[tj]] : 0.0f;
             }
             const bool in0 = colv[0] < nv, in1 = colv[1] < nv;
@@ -551,7 +577,7 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
                     }
                 }
             // thresholds of the next pass (read after at least one more barrier)
-            if (qi + 1 < npass && tid < 256) {
+            if (!walk && qi + 1 < nitems && tid < 256) {
                 const int64_t qn = (int64_t)(qi + 1) * 256 + tid;
                 const uint64_t t = (qn < F.nq) ? F.tau[qn * F.tau_stride] : ~0ull;
                 s_tau[((qi + 1) & 1) * 256 + tid] = t;
@@ -559,7 +585,8 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
             }
             if (KT == 1) __syncthreads();            // no K-loop barrier would order them before the next epilogue
         }
-        qi++;
+        qi += walk ? 0 : 1;
+        vt += vt_step;
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -610,8 +637,22 @@ void launch_flat_gemm_filter(const __half* Q16, int nq_pad, int nq, const void* 
     F.tau = tau; F.tau_stride = tau_stride; F.cand = cand; F.cand_cnt = cand_cnt; F.cand_cap = cand_cap;
     if (fg2_applies(nq_pad, x_f16, ld) && fg2_ready<true>()) {
         F.nq = nq; F.qt = nq_pad / 256; F.ntiles = (nv + 255) / 256;
-
-        hipLaunchKernelGGL((k_flat_gemm2<true>), dim3((unsigned)F.ntiles), dim3(512), FG2_SHM, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias,
+        // persistent walking workgroups (see the kernel) once every slot has a few db tiles to walk; RSX_FG2_WALK=0: off (A/B)
+        static int walk_on = -1;
+        if (walk_on < 0) { const char* e = getenv("RSX_FG2_WALK"); walk_on = e ? atoi(e) : 1; }
+        static int ncu_of[64] = {};
+        int& ncu = ncu_of[cur_device()];
+        if (ncu == 0) {
+            int dev = 0; hipDeviceProp_t pr;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                      ? pr.multiProcessorCount : 256;
+        }
+        const int slots = ((ncu / 8) / F.qt) * F.qt;           // per XCD, a multiple of the query tiles
+        unsigned grid = (unsigned)F.ntiles;
+        if (walk_on && slots > 0 && nv < ((int64_t)1 << 31) && F.ntiles >= (int64_t)4 * 8 * (slots / F.qt)) {
+            F.walk = 1; grid = 8u * (unsigned)slots;
+        }
+        hipLaunchKernelGGL((k_flat_gemm2<true>), dim3(grid), dim3(512), FG2_SHM, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias,
                            (float*)nullptr, (int64_t)0, F);
         return;
     }

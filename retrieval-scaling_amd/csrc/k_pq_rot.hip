@@ -395,10 +395,17 @@ __global__ __launch_bounds__(64) void k_pq_rot_compact(const PQRotItem* __restri
                                       (uint32_t)__builtin_amdgcn_readlane((int)base, sgm);
         const int64_t qs = items[item].q[sgm & 3];
         const uint64_t* src = seg_keys + ((size_t)item * 64 + sgm) * seg_cap;
-        for (uint32_t e = lane; e < cs; e += 64) {
-            const unsigned long long s2 = bs + e;
-            if (s2 < (unsigned long long)cand_cap) cand[qs * cand_cap + s2] = src[e];
+        // a row past its capacity is re-run exactly anyway (k_finalize flags it): nothing beyond cand_cap is moved
+        if (bs >= (unsigned long long)cand_cap) continue;
+        const uint32_t room = (uint32_t)((unsigned long long)cand_cap - bs);
+        const uint32_t ce = cs < room ? cs : room;
+        uint64_t* dst = cand + qs * cand_cap + bs;
+        uint32_t e = lane;
+        for (; e + 192 < ce; e += 256) {       // four independent loads in flight per lane
+            const uint64_t k0 = src[e], k1 = src[e + 64], k2 = src[e + 128], k3 = src[e + 192];
+            dst[e] = k0; dst[e + 64] = k1; dst[e + 128] = k2; dst[e + 192] = k3;
         }
+        for (; e < ce; e += 64) dst[e] = src[e];
     }
 }
 
