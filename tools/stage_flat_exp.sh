@@ -22,6 +22,8 @@ pmc() {  # name, env...
 rm -f gpurun_out/${TAG}_pmc_fetch_flat.md
 CHECK=64 run walk RSX_FG2_WALK=1
 CHECK=64 run stationary RSX_FG2_WALK=0
+if [ -n "${PMC:-}" ]; then
 pmc walk RSX_FG2_WALK=1
 pmc stationary RSX_FG2_WALK=0
-cat gpurun_out/${TAG}_pmc_fetch_flat.md gpurun_out/${TAG}_lds_fill_rate.txt; tail -3 gpurun_out/${TAG}_pytest_flat.log
+fi
+cat gpurun_out/${TAG}_pmc_fetch_flat.md gpurun_out/${TAG}_lds_fill_rate.txt 2>/dev/null; tail -3 gpurun_out/${TAG}_pytest_flat.log
