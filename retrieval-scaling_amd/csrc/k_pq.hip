@@ -28,6 +28,10 @@
 
 namespace rsx {
 
+// number of fp32 roundings separating the certificate's two scores (see k_pq_qparam), as a relative slack on B
+__device__ __forceinline__ float pq_round_slack(int M) { return (float)(3 * M + 12) * 5.9604645e-8f * 1.05f; }
+
+
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pq_lut(const float* Q32, int ldq, int d, int M, int dsub,
                                                 const float* codebooks, float* lut, int Mpad) {
@@ -347,9 +351,11 @@ __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int 
     if (c == 0) {
         float d0 = 0.0f;
         for (int j = 0; j < nprobe; j++) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
-        // fp32 slack: < 300 roundings of relative size 2^-24 on magnitudes bounded by B
+        // fp32 slack: every fp32 operation between the stored quantities and the two scores compared by the certificate rounds
+        // by at most 2^-24 of a magnitude bounded by B — M adds in the exact score's table sum (+1 for dis0), M adds in bias,
+        // M (mul, add, sub) in the per-entry error terms, and the fma + add of the approximate score: fewer than 3 M + 12
         float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
-        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 255.0f * (float)Mpad;   // no tighter bound computed on this path
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + pq_round_slack(M) * B; r.pad = 255.0f * (float)Mpad;   // no tighter bound computed on this path
         qp[q] = r;
     }
 }
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
         float d0 = 0.0f;
         for (int j = 0; j < nprobe; j++) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
         float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
-        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = 255.0f * (float)Mpad;   // no tighter bound computed on this path
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + pq_round_slack(M) * B; r.pad = 255.0f * (float)Mpad;   // no tighter bound computed on this path
         qp[q] = r;
     }
 }
@@ -576,9 +582,11 @@ __global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, c
     }
     if (lane == 0) {
         const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
-        // fp32 slack: < 300 roundings of relative size 2^-24 on magnitudes bounded by B
+        // fp32 slack: every fp32 operation between the stored quantities and the two scores compared by the certificate rounds
+        // by at most 2^-24 of a magnitude bounded by B — M adds in the exact score's table sum (+1 for dis0), M adds in bias,
+        // M (mul, add, sub) in the per-entry error terms, and the fma + add of the approximate score: fewer than 3 M + 12
         const float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;
-        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + 2.0e-5f * B; r.pad = smax;
+        PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + pq_round_slack(M) * B; r.pad = smax;
         qp[q] = r;
     }
 }
