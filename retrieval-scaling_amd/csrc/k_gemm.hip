@@ -158,9 +158,67 @@ __global__ void k_argmax_reduce(const uint64_t* partial, int64_t n, int npart, i
 
 static inline int aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// The same scores for a handful of rows (single-query / small-batch latency path): the 128 x 128 MFMA tile would run
+// nc / 128 workgroups with 127 idle rows each, and a thread walking its own centroid row has one cache line in flight.
+// Here a workgroup takes 16 centroids: all 256 threads pull the 16 rows into LDS with every load of the tile in flight at
+// once (coalesced 256-byte runs), then one thread per (row of X, centroid) runs the fp32 fmaf chain in k order — the same
+// bits as the MFMA kernel and the oracle.
+#define SS_ROWS 16
+#define SS_UNR 12
+template <int NQ>
+__global__ __launch_bounds__(256) void k_scores_small(const float* __restrict__ X, int n, int ldx, const float* __restrict__ C, int nc,
+                                                     int d, float* __restrict__ S, int64_t lds_) {
+    extern __shared__ __attribute__((aligned(16))) float ss_mem[];
+    const int rs = d + 4;                       // LDS row stride of the centroid tile (floats): 16-byte aligned rows
+    float* ss_c = ss_mem;                       // [SS_ROWS][rs]
+    float* ss_x = ss_mem + SS_ROWS * rs;        // [NQ][d]
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * SS_ROWS;
+    const int row = t >> 4, l16 = t & 15, d4 = d >> 2;
+    const int crow = c0 + row < nc ? c0 + row : nc - 1;
+    const float4* src = reinterpret_cast<const float4*>(C + (int64_t)crow * d);
+    for (int base = 0; base < d4; base += 16 * SS_UNR) {
+        float4 v[SS_UNR];
+#pragma unroll
+        for (int i = 0; i < SS_UNR; i++) { const int k4 = base + l16 + 16 * i; v[i] = k4 < d4 ? src[k4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int i = 0; i < SS_UNR; i++) { const int k4 = base + l16 + 16 * i; if (k4 < d4) *reinterpret_cast<float4*>(ss_c + row * rs + 4 * k4) = v[i]; }
+    }
+    for (int e = t; e < NQ * d; e += 256) { const int q = e / d, k = e - q * d; ss_x[e] = q < n ? X[(int64_t)q * ldx + k] : 0.0f; }
+    __syncthreads();
+    if (t < SS_ROWS * NQ) {
+        const int c = t & (SS_ROWS - 1), q = t >> 4;
+        const float* cr = ss_c + c * rs;
+        const float* xr = ss_x + q * d;
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int k4 = 0; k4 < d4; k4++) {
+            const float4 v = *reinterpret_cast<const float4*>(cr + 4 * k4), x = *reinterpret_cast<const float4*>(xr + 4 * k4);
+            acc = __fmaf_rn(x.x, v.x, acc); acc = __fmaf_rn(x.y, v.y, acc); acc = __fmaf_rn(x.z, v.z, acc); acc = __fmaf_rn(x.w, v.w, acc);
+        }
+        if (c0 + c < nc && q < n) S[(int64_t)q * lds_ + c0 + c] = acc;
+    }
+}
+
 void launch_gemm_exact_scores(const void* X, int x_f16, int64_t n, int ldx, const float* C, int nc, int d,
                               float* S, int64_t lds_, hipStream_t st) {
     if (n <= 0 || nc <= 0) return;
+    if (!x_f16 && n <= 8 && d % 4 == 0 && aligned16(C) && (size_t)(SS_ROWS * (d + 4) + 8 * d) * 4 <= 160 * 1024 - 1024) {
+        const unsigned g = (unsigned)((nc + SS_ROWS - 1) / SS_ROWS);
+        const float* Xf = (const float*)X;
+        const int NQ = n == 1 ? 1 : n == 2 ? 2 : n <= 4 ? 4 : 8;
+        const size_t shm = (size_t)(SS_ROWS * (d + 4) + NQ * d) * 4;
+        auto kern = NQ == 1 ? k_scores_small<1> : NQ == 2 ? k_scores_small<2> : NQ == 4 ? k_scores_small<4> : k_scores_small<8>;
+        static DevSize big;
+        if (shm > 48 * 1024 && big.need(shm)) {
+            (void)hipFuncSetAttribute((const void*)k_scores_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_scores_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_scores_small<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_scores_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        }
+        hipLaunchKernelGGL(kern, dim3(g), dim3(256), shm, st, Xf, (int)n, ldx, C, nc, d, S, lds_);
+        return;
+    }
     dim3 grid((nc + 127) / 128, (unsigned)((n + 127) / 128));
     int xv = aligned16(X) && (ldx % 8 == 0);
     int cv = aligned16(C) && (d % 4 == 0);

@@ -331,7 +331,8 @@ static bool select_radix_applies(const SelectArgs& a) {
     if (off < 0) { const char* e = getenv("RSX_SELECT_V1"); off = (e && atoi(e)) ? 1 : 0; }
     // measured: wins for the threshold pre-pass (2048 scores -> K' = 128) and the candidate merge, loses for the
     // probe selection (4096 scores -> 32 keys: k_select's buffer hardly ever needs a second sort there)
-    return !off && (a.keep_last || a.in_is_keys) && a.nseg == 1 && a.seg_base == 0 && !a.tau_ptr && a.n_uniform > 0 &&
+    // ... unless only a few rows are in flight (latency path): 256 threads per row instead of one wave
+    return !off && (a.keep_last || a.in_is_keys || a.nrows <= 16) && a.nseg == 1 && a.seg_base == 0 && !a.tau_ptr && a.n_uniform > 0 &&
            a.n_uniform <= 16384 && a.KP <= 4096;
 }
 
@@ -649,7 +650,7 @@ __device__ inline float pq_exact_sum_rot(const uint8_t* codes, int64_t row, int 
     return sum;
 }
 
-__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
+__global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t fin_buf[];
     const int KP = a.KP;
     int64_t* sid = (int64_t*)fin_buf;
@@ -681,7 +682,40 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
     }
     __syncthreads();
 
-    if (a.kind == KIND_IVFPQ && a.pq_rescore) {
+    if (a.kind == KIND_IVFPQ && a.pq_rescore && a.par_entries) {
+        // few queries in flight (latency path, launch_finalize): the K' x M table entries of the candidates' codes are
+        // independent — all threads compute them (code byte -> codeword -> 8 fmaf, the table builder's chain) into LDS, then
+        // one thread per candidate adds its row in m order: the same canonical sum, without M dependent loads per thread
+        float* ent = reinterpret_cast<float*>(fin_buf) + (((size_t)KP * 20 + 15) / 16) * 4;      // [KP][M + 1]
+        const int M = a.M, es = M + 1;
+        const float* qv = a.Q32 + q * a.ldq;
+        for (int e = tid; e < KP * M; e += nt) {
+            const int c = e / M, m = e - c * M;
+            const int64_t row = srow[c];
+            if (row < 0) continue;
+            const uint32_t code = a.codes[pq_code_addr(row, m, M, 0)];
+            const float* qs = qv + m * 8;
+            const float* cw = a.codebooks + ((int64_t)m * 256 + code) * 8;
+            const float4 x = ((const float4*)cw)[0], y = ((const float4*)cw)[1];
+            float t = 0.0f;
+            t = __fmaf_rn(qs[0], x.x, t); t = __fmaf_rn(qs[1], x.y, t); t = __fmaf_rn(qs[2], x.z, t); t = __fmaf_rn(qs[3], x.w, t);
+            t = __fmaf_rn(qs[4], y.x, t); t = __fmaf_rn(qs[5], y.y, t); t = __fmaf_rn(qs[6], y.z, t); t = __fmaf_rn(qs[7], y.w, t);
+            ent[c * es + m] = t;
+        }
+        __syncthreads();
+        for (int c = tid; c < KP; c += nt) {
+            if (srow[c] < 0) continue;
+            const uint32_t idx = key_idx(a.state[q * KP + c]);
+            const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+            int lo = 0, hi = a.nprobe;
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
+            const float dis0 = a.probe_dis0[q * a.nprobe + lo];
+            float sum = 0.0f;
+            for (int m = 0; m < M; m++) sum += ent[c * es + m];
+            sord[c] = f2ord((dis0 + sum) + 0.0f);
+        }
+        __syncthreads();
+    } else if (a.kind == KIND_IVFPQ && a.pq_rescore) {
         // one thread per candidate: canonical score = dis0 + (((0 + T[0][c0]) + T[1][c1]) + ...), fp32
         const float* T = a.lut32 ? a.lut32 + q * a.Mpad * 256 : nullptr;
         const float* qv = a.Q32 + q * a.ldq;
@@ -730,7 +764,27 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
         __syncthreads();
     }
 
-    // bitonic sort by (ord desc, id asc); invalid entries (ord 0, id INT64_MAX) sink to the end
+    // order by (ord desc, id asc); invalid entries (ord 0, id INT64_MAX) sink to the end.  Up to FIN_RANK_MAX candidates by
+    // counting: a candidate's position is the number of candidates that beat it (every thread walks the same LDS words —
+    // broadcasts — and there are two barriers instead of the 28 of a 128-key bitonic network); larger sets by the network.
+    if (a.rank_sort) {
+        uint32_t* sord2 = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(fin_buf) + (((size_t)KP * 20 + 15) / 16) * 16);
+        int64_t* sid2 = reinterpret_cast<int64_t*>(sord2 + KP + (KP & 1));
+        for (int c = tid; c < KP; c += nt) {
+            const uint32_t oi = sord[c];
+            const int64_t ii = sid[c];
+            int rank = 0;
+            for (int j = 0; j < KP; j++) {
+                const uint32_t oj = sord[j];
+                const int64_t ij = sid[j];
+                rank += ((oj > oi) || (oj == oi && (ij < ii || (ij == ii && j < c)))) ? 1 : 0;
+            }
+            sord2[rank] = oi; sid2[rank] = ii;
+        }
+        __syncthreads();
+        for (int c = tid; c < KP; c += nt) { sord[c] = sord2[c]; sid[c] = sid2[c]; }
+        __syncthreads();
+    } else
     for (int size = 2; size <= KP; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = tid; t < (KP >> 1); t += nt) {
@@ -841,11 +895,22 @@ void launch_exact_scores(const ExactScoreArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((a.tstride + 3) / 4), (unsigned)a.nq), dim3(256), 0, st, a);
 }
 
-void launch_finalize(const FinalizeArgs& a, hipStream_t st) {
-    if (a.nq <= 0) return;
+#define FIN_RANK_MAX 512
+void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
+    if (a0.nq <= 0) return;
+    FinalizeArgs a = a0;
     size_t shm = (size_t)a.KP * (8 + 8 + 4);
-    if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    const int waves = std::min(4, std::max(1, (a.KP + 63) / 64));
+    int waves = std::min(4, std::max(1, (a.KP + 63) / 64));
+    // a handful of queries leave the chip idle: 16 waves per query and the parallel table-entry form of the IVF-PQ re-score
+    const size_t base20 = (((size_t)a.KP * 20 + 15) / 16) * 16;
+    const size_t par_shm = base20 + (size_t)a.KP * (a.M + 1) * 4;
+    a.par_entries = (a.kind == KIND_IVFPQ && a.pq_rescore && a.CB == 0 && !a.lut32 && a.dsub == 8 && a.nq <= 64 && par_shm <= 64 * 1024) ? 1 : 0;
+    a.rank_sort = a.KP <= FIN_RANK_MAX ? 1 : 0;
+    if (a.rank_sort) shm = base20 + (size_t)a.KP * 12 + 16;       // the second copy shares the table-entry region (used earlier)
+    if (a.par_entries) { shm = std::max(shm, par_shm); waves = 16; }
+    else if (a.kind != KIND_IVFPQ && a.nq <= 64) waves = std::min(16, std::max(waves, a.KP / 4));   // one wave per candidate re-score
+    static DevSize big;
+    if (shm > 48 * 1024 && big.need(shm)) hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)a.nq), dim3(64 * waves), shm, st, a);
 }
 

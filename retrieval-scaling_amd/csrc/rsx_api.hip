@@ -88,6 +88,26 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
+// Page-locked host staging for the small transfers of the latency path (a single query in, k results and the
+// certificate flags out): copies to and from pageable memory go through the runtime's own staging and block the host.
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool ensure(size_t n) {          // false: no pinned memory to be had — the caller keeps the pageable path
+        if (n <= bytes) return true;
+        release();
+        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+        bytes = n;
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+    ~PinBuf() { release(); }
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+};
+
 static bool is_device_ptr(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t at;
@@ -129,6 +149,7 @@ struct rsx_index {
     bool trained = false;
     int64_t ntotal = 0;
     hipStream_t st = nullptr;
+    PinBuf pin_q, pin_out, pin_flags;     // latency path: pinned staging of queries / results / certificate flags
 
     // trained parameters
     std::vector<float> h_centroids, h_codebooks;
@@ -757,8 +778,16 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
 // temp_bytes_per_query > 0 bounds the exact path's score buffer (Flat / IVF-Flat): the re-run proceeds in chunks.
 static void rerun_uncertified(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI,
                               size_t temp_bytes_per_query) {
-    std::vector<int32_t> bad((size_t)nq);
-    HIPCHECK(hipMemcpyAsync(bad.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
+    std::vector<int32_t> bad_v;
+    const int32_t* bad;
+    if (nq <= 4096 && h->pin_flags.ensure(4096 * 4)) {
+        HIPCHECK(hipMemcpyAsync(h->pin_flags.p, h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
+        bad = h->pin_flags.as<int32_t>();
+    } else {
+        bad_v.resize((size_t)nq);
+        HIPCHECK(hipMemcpyAsync(bad_v.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
+        bad = bad_v.data();
+    }
     HIPCHECK(hipStreamSynchronize(h->st));
     const int d = h->d;
     const size_t esz = dtype == RSX_F16 ? 2 : 4;
@@ -1021,7 +1050,13 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             int vpl = 8;
             if (rot) { vpl = 32; while (vpl > 8 && 16 * (vpl / 2) >= avg_slabs) vpl /= 2; }
             if (h->scan_chunk > 0) vpl = std::max(1, std::min(rot ? 64 : 16, h->scan_chunk / 1024));
-            else while (vpl > 1 && (pairs / 4 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
+            else {
+                // enough items to balance the chip: a few thousand for a full batch; for a handful of queries every (query, list)
+                // pair is its own group and each item stages a whole table, so one item per CU is the better trade
+                const int64_t groups_est = pairs <= nlist / 4 ? pairs : pairs / 4 + 1;
+                const int64_t want_items = pairs <= nlist / 4 ? 256 : 2048;
+                while (vpl > 1 && groups_est * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < want_items) vpl /= 2;
+            }
             if (vpl != 64 && vpl != 32 && vpl != 16 && vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
             const int tile_rows = 64 * 16 * vpl;
             h->w_pairs.ensure((size_t)(pairs + 5 * (size_t)(nlist + 1) + 8) * 4);
@@ -1316,10 +1351,14 @@ static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int 
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         int64_t nb = std::min(qb, nq - q0);
         const void* dq;
+        const bool small = nb <= 64;      // latency path: stage through pinned memory (see PinBuf)
         if (q_dev) dq = (const char*)q + (size_t)q0 * h->d * esz;
         else {
-            h->w_qin.ensure((size_t)nb * h->d * esz);
-            HIPCHECK(hipMemcpyAsync(h->w_qin.p, (const char*)q + (size_t)q0 * h->d * esz, (size_t)nb * h->d * esz, hipMemcpyHostToDevice, h->st));
+            const size_t qbytes = (size_t)nb * h->d * esz;
+            const char* src = (const char*)q + (size_t)q0 * h->d * esz;
+            h->w_qin.ensure(qbytes);
+            if (small && h->pin_q.ensure(qbytes)) { memcpy(h->pin_q.p, src, qbytes); src = h->pin_q.as<char>(); }
+            HIPCHECK(hipMemcpyAsync(h->w_qin.p, src, qbytes, hipMemcpyHostToDevice, h->st));
             dq = h->w_qin.p;
         }
         float* dD; int64_t* dI;
@@ -1329,11 +1368,20 @@ static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int 
             dD = h->w_D.as<float>(); dI = h->w_I.as<int64_t>();
         }
         search_batch(h, nb, dq, dtype, k, dD, dI);
-        if (!o_dev) {
-            HIPCHECK(hipMemcpyAsync(D + q0 * k, dD, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->st));
-            HIPCHECK(hipMemcpyAsync(I + q0 * k, dI, (size_t)nb * k * 8, hipMemcpyDeviceToHost, h->st));
+        const size_t dbytes = (size_t)nb * k * 4, ibytes = (size_t)nb * k * 8;
+        const bool pin_out = !o_dev && small && h->pin_out.ensure(round_up(dbytes, 16) + ibytes);
+        if (pin_out) {
+            HIPCHECK(hipMemcpyAsync(h->pin_out.p, dD, dbytes, hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipMemcpyAsync(h->pin_out.as<char>() + round_up(dbytes, 16), dI, ibytes, hipMemcpyDeviceToHost, h->st));
+        } else if (!o_dev) {
+            HIPCHECK(hipMemcpyAsync(D + q0 * k, dD, dbytes, hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipMemcpyAsync(I + q0 * k, dI, ibytes, hipMemcpyDeviceToHost, h->st));
         }
         HIPCHECK(hipStreamSynchronize(h->st));
+        if (pin_out) {
+            memcpy(D + q0 * k, h->pin_out.p, dbytes);
+            memcpy(I + q0 * k, h->pin_out.as<char>() + round_up(dbytes, 16), ibytes);
+        }
     }
     HIPCHECK(hipGetLastError());
 }

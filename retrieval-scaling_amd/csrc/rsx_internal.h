@@ -321,6 +321,8 @@ struct FinalizeArgs {
     float cert_rel, cert_xmax, cert_abs;
     const int* cert_qflag; float cert_rel_qlossy;   // *cert_qflag != 0: the batch held an fp32 query value fp16 cannot represent
     float* D; int64_t* I;
+    int par_entries;               // set by launch_finalize: parallel table-entry form of the IVF-PQ re-score (small batches)
+    int rank_sort;                 // set by launch_finalize: order the candidates by counting (K' <= 1024) instead of a bitonic network
 };
 void launch_finalize(const FinalizeArgs& a, hipStream_t st);
 // Exact scores of the uncertified queries (fallback of the certificate above): fp64 dot product of the query with EVERY row

@@ -178,9 +178,13 @@ def latency(a):
     if a.param:
         run("_" + ",".join(a.param))
     ix.set_param("profile", 1)
+    stages = ("convert", "coarse", "select_probe", "lut8", "group", "scan0", "select0", "scan", "select", "finalize", "total")
     ix.search(q[:1], 10)
-    res["stage_ms_single_query"] = {s: round(ix.get_timing(s), 4) for s in
-                                    ("convert", "coarse", "select_probe", "lut8", "group", "scan0", "select0", "scan", "select", "finalize", "total")}
+    res["stage_ms_single_query"] = {s: round(ix.get_timing(s), 4) for s in stages}
+    ix.search(q[:1], 100)
+    res["stage_ms_single_query_k100"] = {s: round(ix.get_timing(s), 4) for s in stages}
+    ix.search(q[:16], 10)
+    res["stage_ms_batch16"] = {s: round(ix.get_timing(s), 4) for s in stages}
     print(json.dumps(res), flush=True)
 
 
