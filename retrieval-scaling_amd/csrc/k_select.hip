@@ -905,7 +905,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
     const size_t base20 = (((size_t)a.KP * 20 + 15) / 16) * 16;
     const size_t par_shm = base20 + (size_t)a.KP * (a.M + 1) * 4;
     a.par_entries = (a.kind == KIND_IVFPQ && a.pq_rescore && a.CB == 0 && !a.lut32 && a.dsub == 8 && a.nq <= 64 && par_shm <= 64 * 1024) ? 1 : 0;
-    a.rank_sort = a.KP <= FIN_RANK_MAX ? 1 : 0;
+    a.rank_sort = (a.KP <= FIN_RANK_MAX && a.nq <= 64) ? 1 : 0;     // fewer barriers, more instructions: a latency trade, not a throughput one
     if (a.rank_sort) shm = base20 + (size_t)a.KP * 12 + 16;       // the second copy shares the table-entry region (used earlier)
     if (a.par_entries) { shm = std::max(shm, par_shm); waves = 16; }
     else if (a.kind != KIND_IVFPQ && a.nq <= 64) waves = std::min(16, std::max(waves, a.KP / 4));   // one wave per candidate re-score
