@@ -210,12 +210,13 @@ void launch_gemm_exact_scores(const void* X, int x_f16, int64_t n, int ldx, cons
         const size_t shm = (size_t)(SS_ROWS * (d + 4) + NQ * d) * 4;
         auto kern = NQ == 1 ? k_scores_small<1> : NQ == 2 ? k_scores_small<2> : NQ == 4 ? k_scores_small<4> : k_scores_small<8>;
         static DevSize big;
-        if (shm > 48 * 1024 && big.need(shm)) {
-            (void)hipFuncSetAttribute((const void*)k_scores_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_scores_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_scores_small<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_scores_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        }
+        if (shm > 48 * 1024)
+            big.grow(shm, [&] {
+                (void)hipFuncSetAttribute((const void*)k_scores_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_scores_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_scores_small<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_scores_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+            });
         hipLaunchKernelGGL(kern, dim3(g), dim3(256), shm, st, Xf, (int)n, ldx, C, nc, d, S, lds_);
         return;
     }
@@ -661,9 +662,11 @@ static const size_t FG2_SHM = 2 * FG2_STAGE + 2 * 256 * 8 + 2 * 256 * 4;
 template <bool FILTER>
 static bool fg2_ready() {
     static DevOnce once;
-    if (once.first() && hipFuncSetAttribute((const void*)k_flat_gemm2<FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FG2_SHM) != hipSuccess)
-        return false;
-    return true;
+    static std::atomic<int> failed{0};
+    once.once([&] {
+        if (hipFuncSetAttribute((const void*)k_flat_gemm2<FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FG2_SHM) != hipSuccess) failed = 1;
+    });
+    return !failed;
 }
 // the 256 x 256 LDS-DMA kernel needs fp16 storage, K a multiple of 64 and enough queries to fill its tile
 static bool fg2_applies(int nq_pad, int x_f16, int ld) {
@@ -1003,10 +1006,10 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     if (a.chunk_rows == list_scan2_chunk_rows(a.x_f16, a.ld)) {
         size_t shm2 = (size_t)16 * (a.ld + 8) * 2 + 384 + 4 * LS2_D * 2048;
         static DevOnce once;
-        if (once.first()) {
+        once.once([&] {
             hipFuncSetAttribute((const void*)k_list_scan2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)k_list_scan2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+        });
         if (a.tau_key) hipLaunchKernelGGL(k_list_scan2<true>, grid, dim3(256), shm2, st, a);
         else hipLaunchKernelGGL(k_list_scan2<false>, grid, dim3(256), shm2, st, a);
         return;

@@ -610,7 +610,7 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
         dim3 grid((unsigned)((Mpad + LT_MB - 1) / LT_MB), (unsigned)((nq + LT_QC - 1) / LT_QC));
         const size_t osm = transposed ? (size_t)LT_QC * 256 * LT_MB : 0;
         static DevOnce once;
-        if (osm && once.first()) hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm);
+        if (osm) once.once([&] { hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm); });
         hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
         hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), osm, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
         hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)nq), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0, nprobe,
@@ -620,7 +620,7 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
     const size_t lds = pq_lut8_fused_lds(M, Mpad, dsub);
     auto kern = dsub == 8 ? k_pq_lut8f<8> : k_pq_lut8f<0>;
     static DevOnce once8, once0;
-    if ((dsub == 8 ? once8 : once0).first()) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (dsub == 8 ? once8 : once0).once([&] { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), lds, st, Q32, ldq, codebooks, dsub, M, Mpad, probe_dis0, nprobe,
                        lut8, (PQQParam*)qparam, transposed);
 }

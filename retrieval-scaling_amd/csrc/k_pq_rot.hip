@@ -33,6 +33,9 @@ namespace rsx {
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int ROT_D = 4;      // 16-vector code blocks in flight per wave (16 M bytes each)
+#ifndef ROT_CW
+#define ROT_CW 4              // items (waves) per workgroup of k_pq_rot_compact
+#endif
 
 __device__ __forceinline__ uint32_t lds_rd32(uint32_t addr) {
     // raw LDS address: the kernels below declare no static LDS, so the dynamic segment starts at 0
@@ -362,10 +365,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 
 // One wave per work item: append the item's (wave, query) survivor segments to the candidate rows of its queries — the only
 // atomics of the filtered scan live here, one reservation per (item, query), in a kernel with thousands of independent waves.
-__global__ __launch_bounds__(64) void k_pq_rot_compact(const PQRotItem* __restrict__ items, const int32_t* total_items,
+__global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem* __restrict__ items, const int32_t* total_items,
                                                        const uint64_t* __restrict__ seg_keys, const uint32_t* __restrict__ seg_cnt,
                                                        int seg_cap, uint64_t* cand, unsigned long long* cand_cnt, int cand_cap) {
-    const int item = blockIdx.x, lane = threadIdx.x;
+    const int item = blockIdx.x * ROT_CW + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (item >= *total_items) return;
     const int w = lane >> 2, k = lane & 3;
     const uint32_t c0 = seg_cnt[(size_t)item * 64 + lane];                 // lane = (wave, query) segment
@@ -416,13 +419,14 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     static DevOnce once;
     static int ncu_of[64] = {};
     int& ncu = ncu_of[cur_device()];
-    if (once.first()) {
-        if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
-            return -1;
+    static std::atomic<int> failed{0};
+    once.once([&] {
         int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) { failed = 1; return; }
         ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    }
+    });
+    if (failed) return -1;
     if (ncu <= 0) ncu = 256;
     PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
     uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(desc_ws) + (size_t)(A.max_items + 8) * 176);
@@ -437,7 +441,7 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, xcd_ctr,
                        seg_cap, bpw, var);
     if (FILTER)
-        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)A.max_items), dim3(64), 0, st, items, A.total_items, seg_keys, seg_cnt, seg_cap,
+        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, seg_keys, seg_cnt, seg_cap,
                            A.cand, A.cand_cnt, A.cand_cap);
     return 0;
 }
@@ -514,7 +518,9 @@ int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st) {
     if (a.CB != 0 || !pq_rot_applies(a.M)) return -1;
     const size_t shm = (size_t)a.Mpad * 1024;
     static DevSize attr;
-    if (attr.need(shm) && hipFuncSetAttribute((const void*)k_pq_scan_rot_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+    bool attr_ok = true;
+    attr.grow(shm, [&] { attr_ok = hipFuncSetAttribute((const void*)k_pq_scan_rot_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess; });
+    if (!attr_ok)
         return -1;
     hipLaunchKernelGGL(k_pq_scan_rot_exact, dim3((unsigned)pairs, (unsigned)a.max_chunks), dim3(1024), shm, st, a);
     return 0;

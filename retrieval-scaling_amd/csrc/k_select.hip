@@ -321,7 +321,7 @@ void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
     if (nq <= 0) return;
     size_t shm = (size_t)a.pre_rows * 8 + (size_t)a.KP * 8 + 264 * 4 + (size_t)a.Mpad * 256;
     static DevSize attr;
-    if (attr.need(shm)) hipFuncSetAttribute((const void*)k_pq_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr.grow(shm, [&] { hipFuncSetAttribute((const void*)k_pq_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
     hipLaunchKernelGGL(k_pq_prepass, dim3((unsigned)nq), dim3(1024), shm, st, a);
 }
 
@@ -650,6 +650,61 @@ __device__ inline float pq_exact_sum_rot(const uint8_t* codes, int64_t row, int 
     return sum;
 }
 
+// The same sum with the vector's code bytes fetched as the 16-byte (8-byte) pieces the rotated layout stores (rsx_internal.h):
+// for every run of 16 sub-quantisers the piece of lane group g, rotated left by i = row & 15 bytes, holds the codes in m
+// order.  One round trip for all M codes instead of M byte loads, and 16 independent codeword loads per run; table entries
+// by the table builder's fmaf chain, added in m order — the identical fp32 value.  dsub == 8, M in {32, 64, 96, 128}.
+__device__ inline void rot16_bytes(uint32_t (&w)[4], int i) {     // byte t of the result = byte (t - i) & 15 of the input
+    const int wi = i >> 2, bi = i & 3;
+    if (wi & 1) { const uint32_t t = w[3]; w[3] = w[2]; w[2] = w[1]; w[1] = w[0]; w[0] = t; }
+    if (wi & 2) { uint32_t t = w[0]; w[0] = w[2]; w[2] = t; t = w[1]; w[1] = w[3]; w[3] = t; }
+    if (bi) {
+        const int l = 8 * bi, r = 32 - l;
+        const uint32_t r0 = (w[0] << l) | (w[3] >> r), r1 = (w[1] << l) | (w[0] >> r), r2 = (w[2] << l) | (w[1] >> r), r3 = (w[3] << l) | (w[2] >> r);
+        w[0] = r0; w[1] = r1; w[2] = r2; w[3] = r3;
+    }
+}
+__device__ inline float pq_exact_sum_rot_wide(const uint8_t* codes, int64_t row, int M, const float* qv, const float* codebooks) {
+    const int i = (int)(row & 15);
+    const uint8_t* base = codes + (row >> 4) * (int64_t)(16 * M);
+    const int NF = M >> 6, nrun = M >> 4;
+    // run r < 4 NF: the 16-byte piece of lane group r & 3 in phase r >> 2; later runs: the two 8-byte pieces of lane groups
+    // h and h + 2 of the half phase (h = r & 1) — read as two 8-byte halves either way
+    auto piece = [&](int r, uint2& lo, uint2& hi) {
+        const uint8_t* p0; const uint8_t* p1;
+        if (r < 4 * NF) { p0 = base + (r >> 2) * 1024 + ((r & 3) * 16 + i) * 16; p1 = p0 + 8; }
+        else { const int h = r & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
+        lo = *reinterpret_cast<const uint2*>(p0); hi = *reinterpret_cast<const uint2*>(p1);
+    };
+    uint2 nlo, nhi;
+    piece(0, nlo, nhi);
+    float sum = 0.0f;
+    for (int run = 0; run < nrun; run++) {
+        uint32_t w[4] = {nlo.x, nlo.y, nhi.x, nhi.y};
+        if (run + 1 < nrun) piece(run + 1, nlo, nhi);        // the next run's codes travel while this run's codewords do
+        rot16_bytes(w, i);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int jj = half * 8 + j, m = run * 16 + jj;
+                const uint32_t code = (w[jj >> 2] >> (8 * (jj & 3))) & 255u;
+                const float* qs = qv + m * 8;
+                const float* cw = codebooks + ((int64_t)m * 256 + code) * 8;
+                const float4 x = ((const float4*)cw)[0], y = ((const float4*)cw)[1];
+                float e = 0.0f;
+                e = __fmaf_rn(qs[0], x.x, e); e = __fmaf_rn(qs[1], x.y, e); e = __fmaf_rn(qs[2], x.z, e); e = __fmaf_rn(qs[3], x.w, e);
+                e = __fmaf_rn(qs[4], y.x, e); e = __fmaf_rn(qs[5], y.y, e); e = __fmaf_rn(qs[6], y.z, e); e = __fmaf_rn(qs[7], y.w, e);
+                t[j] = e;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) sum += t[j];
+        }
+    }
+    return sum;
+}
+
 __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t fin_buf[];
     const int KP = a.KP;
@@ -729,7 +784,8 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             const float dis0 = a.probe_dis0[q * a.nprobe + lo];
             const int64_t slab = row >> 6; const int v = (int)(row & 63);
             const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-            const float sum = a.CB == 0 ? pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub)
+            const float sum = a.CB == 0 ? ((!T && a.dsub == 8) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
+                                                                  : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub))
                             : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                          : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
             sord[c] = f2ord((dis0 + sum) + 0.0f);
@@ -910,7 +966,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
     if (a.par_entries) { shm = std::max(shm, par_shm); waves = 16; }
     else if (a.kind != KIND_IVFPQ && a.nq <= 64) waves = std::min(16, std::max(waves, a.KP / 4));   // one wave per candidate re-score
     static DevSize big;
-    if (shm > 48 * 1024 && big.need(shm)) hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (shm > 48 * 1024) big.grow(shm, [&] { hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)a.nq), dim3(64 * waves), shm, st, a);
 }
 

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 namespace rsx {
 
@@ -37,13 +38,28 @@ enum { KIND_FLAT = 0, KIND_IVFFLAT = 1, KIND_IVFPQ = 2 };
 // process (rsx_sharded_create) every device needs its own call.  first() is true once per device; need(bytes) is true when
 // this device has not yet been granted that many bytes.
 inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+// Both are used from the host threads of a sharded handle concurrently: the check, the attribute call and the update happen
+// under one process-wide mutex, so no thread can launch a kernel between another thread's "first" and its attribute call.
+inline std::mutex& attr_mutex() { static std::mutex m; return m; }
 struct DevOnce {
-    std::atomic<uint64_t> m{0};
-    bool first() { const uint64_t b = 1ull << cur_device(); return !(m.fetch_or(b) & b); }
+    uint64_t m = 0;
+    template <typename F> void once(F&& f) {          // f(): the per-device set-up; runs once per device
+        std::lock_guard<std::mutex> g(attr_mutex());
+        const uint64_t b = 1ull << cur_device();
+        if (m & b) return;
+        f();
+        m |= b;
+    }
 };
 struct DevSize {
     size_t v[64] = {};
-    bool need(size_t bytes) { size_t& s = v[cur_device()]; if (bytes <= s) return false; s = bytes; return true; }
+    template <typename F> void grow(size_t bytes, F&& f) {   // f(): grant this device `bytes`; runs when it has fewer
+        std::lock_guard<std::mutex> g(attr_mutex());
+        size_t& s = v[cur_device()];
+        if (bytes <= s) return;
+        f();
+        s = bytes;
+    }
 };
 
 // Per-query candidate counters are atomically bumped from every CU: one counter per 128-byte line (8 B used), so that
