@@ -139,7 +139,9 @@ __device__ inline void bitonic_sort_desc_wg(uint64_t* buf, int n, int tid, int n
 
 // Top-KP (sorted descending into obuf, zero padded) of the N keys key_at(0..N-1) by a workgroup of NT threads.
 // hist: 256 ints, ctl: 8 ints of LDS.  Zero keys are "no element".
-template <int NT, class KeyAt>
+// ONLY_KTH: just a threshold is wanted — obuf[KP - 1] receives a lower bound of the KP-th largest key that no unselected key
+// reaches (the radix prefix; 0 when there are not more than KP keys), the other slots stay zero: no compaction, no sort.
+template <int NT, bool ONLY_KTH = false, class KeyAt>
 __device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf, int32_t* hist, int32_t* ctl) {
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 8) ctl[tid] = 0;          // [0] digit, [1] remaining, [2] valid count, [3] output cursor, [4] keys in the digit's bin
@@ -193,6 +195,11 @@ __device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf
             if (all_in) break;                          // (typically after 4 of the 8 rounds: the score bits are distinct)
         }
         kth = prefix;                                   // low bits zero after an early exit: a lower bound of those keys
+    }
+    if (ONLY_KTH) {
+        if (tid == 0) obuf[KP - 1] = V > KP ? kth : 0ull;
+        __syncthreads();
+        return;
     }
     for (int i = tid; i < N; i += NT) {
         const uint64_t key = key_at(i);
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
     }
     __syncthreads();
     auto key_at = [&](int i) -> uint64_t { return keys[i]; };
-    radix_topk_wg<1024>(key_at, nslab * 64, a.KP, obuf, hist, ctl);
+    radix_topk_wg<1024, true>(key_at, nslab * 64, a.KP, obuf, hist, ctl);      // the pre-pass only has to produce a threshold
     uint64_t* o = a.state + q * a.KP;
     for (int i = tid; i < a.KP; i += 1024) o[i] = (i == a.KP - 1) ? obuf[i] : 0ull;
     if (tid == 0) a.cand_cnt[q * CCS] = 0ull;
