@@ -450,13 +450,15 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
 // Tiled form of the same table build for dsub = 8 (what k_pq_lut8f computes, bit for bit).  k_pq_lut8f reads the whole
 // 786 KB codebook per query through one CU's L2 path (~47 GB/s): 4 rounds of ~30 us.  Here a workgroup takes the
 // codebook slice of LT_MB sub-quantisers (each wave two of them, 4 codewords per lane in registers) and streams
-// LT_QC queries past it, so the codebook is read 32x less often; the global maximum range a query's quantisation
+// LT_QC queries past it, so the codebook is read LT_QC x less often; the global maximum range a query's quantisation
 // scale needs is taken between two passes:
 //   pass 0: per (query, m) min / max of the entries        -> mnmx [nq][Mpad][2]
 //   pass 1: entries again, quantised with the query's scale -> lut8, per (query, m) max error -> err [nq][Mpad]
 //   k_pq_qparam: per query, the sums over m in m order      -> {scale, bias, eps}
 #define LT_MB 8
-#define LT_QC 32
+#ifndef LT_QC
+#define LT_QC 8      // queries per tile: 32 -> 8 quadruples the workgroups (1536 at batch 1024), measured 0.135 -> 0.100 ms for the build
+#endif
 template <int PASS>
 __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq, const float* codebooks, int M, int Mpad,
                                                       int64_t nq, float* mnmx, float* errb, uint8_t* lut8, int transposed) {
