@@ -120,18 +120,18 @@ def _resolve_devices(device, devices):
     if isinstance(devices, str):
         devices = list(range(get_num_gpus())) if devices.strip().lower() == "all" else [int(t) for t in devices.split(",") if t.strip()]
     devices = [int(t) for t in devices]
-    return devices if len(devices) > 1 else None
+    return devices or None
 
 
 def _create(kind, d, nlist, M, nbits, metric, device, devices):
     h = ctypes.c_void_p()
     devs = _resolve_devices(device, devices)
-    if devs is not None:
+    if devs is not None and len(devs) > 1:
         arr = (ctypes.c_int * len(devs))(*devs)
         _check(lib().rsx_sharded_create(kind, int(d), int(nlist), int(M), int(nbits), int(metric), len(devs), arr, ctypes.byref(h)))
         return h
-    if devices is not None and not isinstance(devices, str) and len(list(devices)) == 1:
-        device = list(devices)[0]
+    if devs is not None:           # a one-entry list ("2", [2]) names the device of an ordinary handle
+        device = devs[0]
     dev = default_device() if device is None else int(device)
     if kind == 0:
         _check(lib().rsx_flat_create(int(d), int(metric), dev, ctypes.byref(h)))
@@ -437,6 +437,9 @@ def read_index(path, device=None, devices=None):
         h = ctypes.c_void_p()
         _check(lib().rsx_load_sharded(path.encode(), len(devs), arr, ctypes.byref(h)))
         return _wrap_handle(h)
+    if device is None:                 # a plain (unsharded) file with devices=[d] or RSX_DEVICES set: its first entry
+        devs = _resolve_devices(None, devices)
+        device = devs[0] if devs else None
     if magic != b"RSX1":
         from rsx_faiss_io import read_faiss_index
         return read_faiss_index(path, device=device)

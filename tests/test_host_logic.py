@@ -339,3 +339,26 @@ def test_shard_range():
     spans = [shard_range(103, r, 8) for r in range(8)]
     assert spans[0][0] == 0 and spans[-1][1] == 103
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_device_list_resolution(monkeypatch):
+    """cfg.datastore.index.devices / RSX_DEVICES -> rsx._resolve_devices: explicit arguments win, then the facade's default,
+    then the environment; strings are comma lists; one entry names the device of an ordinary handle."""
+    import rsx
+    monkeypatch.delenv("RSX_DEVICES", raising=False)
+    rsx.set_default_devices(None)
+    try:
+        assert rsx._resolve_devices(None, None) is None
+        assert rsx._resolve_devices(3, None) is None                       # an explicit device: never sharded
+        assert rsx._resolve_devices(None, [0, 1, 2]) == [0, 1, 2]
+        assert rsx._resolve_devices(None, "1, 3") == [1, 3]
+        assert rsx._resolve_devices(None, [2]) == [2]
+        assert rsx._resolve_devices(None, []) is None
+        monkeypatch.setenv("RSX_DEVICES", "0,1")
+        assert rsx._resolve_devices(None, None) == [0, 1]
+        assert rsx._resolve_devices(5, None) is None                       # ... the environment does not override it either
+        rsx.set_default_devices([4, 5, 6])
+        assert rsx._resolve_devices(None, None) == [4, 5, 6]               # facade default before the environment
+        assert rsx._resolve_devices(None, [7, 8]) == [7, 8]
+    finally:
+        rsx.set_default_devices(None)
