@@ -28,13 +28,14 @@ class Indexer(object):
         # optional key (absent in the reference's configs -> one GPU, unchanged behaviour): cfg.datastore.index.devices =
         # [0, 1, ...] or "all" makes every engine object of this Indexer ONE handle over those GPUs (rsx_sharded_create):
         # the single index.search(all_queries, k) call of src/search.py:296 then spans the node
-        try:
-            devices = self.args.get("devices", None) if hasattr(self.args, "get") else getattr(self.args, "devices", None)
-        except (KeyError, AttributeError):     # attribute-style config objects without the key
-            devices = None
+        devices = self._opt("devices", None)
         if devices is not None:
             import rsx
             rsx.set_default_devices(devices if isinstance(devices, str) else list(devices))
+        # optional keys of SURVEY 8b, same rule (absent -> the defaults preserve behaviour): `backend` selects the engine
+        # module ("mi355x" | "faiss"), `storage_dtype` ("auto" | "float16") is checked once the index exists
+        from src.indicies import engine as _engine_sel
+        _engine_sel.set_backend(self._opt("backend", "mi355x"))
 
         passage_dir = self.cfg.datastore.embedding.passages_dir
         index_dir, embedding_paths = get_index_dir_and_embedding_paths(cfg)
@@ -63,6 +64,16 @@ class Indexer(object):
                                           **common)
         else:
             raise NotImplementedError
+        if self.index_type in ("Flat", "IVFFlat"):
+            _engine_sel.check_storage_dtype(self.datastore.index, self._opt("storage_dtype", "auto"))
+
+    def _opt(self, key, default):
+        """optional cfg.datastore.index key (OmegaConf node, dict-like or attribute container)"""
+        try:
+            v = self.args.get(key, default) if hasattr(self.args, "get") else getattr(self.args, key, default)
+        except (KeyError, AttributeError):
+            v = default
+        return default if v is None else v
 
     def search(self, query_embs, k=5):
         all_scores, all_passages, db_ids = self.datastore.search(query_embs, k)

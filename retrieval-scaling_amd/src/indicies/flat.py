@@ -1,13 +1,13 @@
 """FlatIndexer — exact inner-product index (mirror of reference src/indicies/flat.py).
 
 Same constructor kwargs, attributes (.index, .index_id_to_db_id, .psg_pos_id_map, .cuda) and
-search() return as the reference; the engine object is rsx.IndexFlatIP (HBM-resident, fp16 rows,
+search() return as the reference; the engine object is engine().IndexFlatIP (HBM-resident, fp16 rows,
 MFMA scan + exact re-rank) instead of faiss.IndexFlatIP.
 """
 import os
 import time
 
-import rsx
+from src.indicies.engine import engine
 from src.indicies.index_utils import BackendBase
 
 
@@ -24,10 +24,10 @@ class FlatIndexer(BackendBase):
 
         if os.path.exists(index_path) and os.path.exists(self.meta_file):
             print("Loading index...")
-            self.index = rsx.read_index(index_path)
+            self.index = engine().read_index(index_path)
             self.index_id_to_db_id = self.load_index_id_to_db_id()
         else:
-            self.index = rsx.IndexFlatIP(dimension)
+            self.index = engine().IndexFlatIP(dimension)
             self.index_id_to_db_id = []
             print("Building index...")
             self._build_index()
@@ -38,7 +38,7 @@ class FlatIndexer(BackendBase):
     def _build_index(self):
         start_time = time.time()
         self._add_shards(self.index)
-        rsx.write_index(self.index, self.index_path)
+        engine().write_index(self.index, self.index_path)
         self._save_meta()
         print(f"Adding took {time.time() - start_time} s")
         print(f"Total data indexed {len(self.index_id_to_db_id)}")

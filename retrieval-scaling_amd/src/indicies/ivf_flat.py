@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-import rsx
+from src.indicies.engine import engine
 from src.indicies.index_utils import BackendBase, load_embedding_shard
 
 
@@ -35,7 +35,7 @@ class IVFFlatIndexer(BackendBase):
 
         if os.path.exists(index_path) and os.path.exists(self.meta_file):
             print("Loading index...")
-            self.index = rsx.read_index(index_path)
+            self.index = engine().read_index(index_path)
             self.index_id_to_db_id = self.load_index_id_to_db_id()
             self.index.nprobe = self.probe
         else:
@@ -52,8 +52,8 @@ class IVFFlatIndexer(BackendBase):
 
     # ---- engine object (overridden by IVFPQIndexer)
     def _new_index(self):
-        quantizer = rsx.IndexFlatIP(self.dimension)
-        return rsx.IndexIVFFlat(quantizer, self.dimension, self.ncentroids, rsx.METRIC_INNER_PRODUCT)
+        quantizer = engine().IndexFlatIP(self.dimension)
+        return engine().IndexIVFFlat(quantizer, self.dimension, self.ncentroids, engine().METRIC_INNER_PRODUCT)
 
     # ---- training (reference ivf_flat.py:122-167)
     def _sample_and_train_index(self):
@@ -74,16 +74,16 @@ class IVFFlatIndexer(BackendBase):
         start_index.nprobe = self.probe
         np.random.seed(1)
         start_index.train(sampled_embs)
-        rsx.write_index(start_index, trained_index_path)
+        engine().write_index(start_index, trained_index_path)
 
     # ---- population (reference ivf_flat.py:169-189)
     def _add_keys(self, index_path, trained_index_path):
-        index = rsx.read_index(trained_index_path)
+        index = engine().read_index(trained_index_path)
         assert index.is_trained and index.ntotal == 0
         start_time = time.time()
         self._add_shards(index)
         index.nprobe = self.probe
-        rsx.write_index(index, index_path)
+        engine().write_index(index, index_path)
         self._save_meta()
         print(f"Adding took {time.time() - start_time} s")
         return index

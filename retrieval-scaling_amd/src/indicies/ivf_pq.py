@@ -6,7 +6,7 @@ cfg.datastore.index.n_bits here, base.py:68).
 """
 import numpy as np
 
-import rsx
+from src.indicies.engine import engine
 from src.indicies.ivf_flat import IVFFlatIndexer
 
 
@@ -24,6 +24,6 @@ class IVFPQIndexer(IVFFlatIndexer):
                          DSTORE_SIZE_BATCH=DSTORE_SIZE_BATCH)
 
     def _new_index(self):
-        quantizer = rsx.IndexFlatIP(self.dimension)
-        return rsx.IndexIVFPQ(quantizer, self.dimension, self.ncentroids, self.n_subquantizers, self.code_size,
-                              rsx.METRIC_INNER_PRODUCT)
+        quantizer = engine().IndexFlatIP(self.dimension)
+        return engine().IndexIVFPQ(quantizer, self.dimension, self.ncentroids, self.n_subquantizers, self.code_size,
+                              engine().METRIC_INNER_PRODUCT)

@@ -362,3 +362,59 @@ def test_device_list_resolution(monkeypatch):
         assert rsx._resolve_devices(None, [7, 8]) == [7, 8]
     finally:
         rsx.set_default_devices(None)
+
+
+def test_backend_and_storage_dtype_keys(tmp_path, orc, monkeypatch):
+    """SURVEY 8b optional config keys: `backend` selects the engine module the backends call — "faiss" resolves to the
+    `faiss` package (here the test double registered under that name; nothing is patched into rsx) and fails loudly when
+    the package is missing; `storage_dtype` is validated against what the index reports."""
+    import sys
+    import fake_engine
+    from src.indicies import engine as sel
+    from src.indicies.base import Indexer
+    tmp = str(tmp_path)
+    embs = write_datastore(tmp, orc)
+    q = np.concatenate([embs[0][5:6], embs[1][7:8]], 0)
+    try:
+        monkeypatch.setitem(sys.modules, "faiss", fake_engine)
+        cfg = make_cfg(tmp, "Flat", [0, 1])
+        cfg.datastore.index["backend"] = "faiss"
+        ix = Indexer(cfg)
+        assert sel.backend_name() == "faiss" and sel.engine() is fake_engine
+        assert isinstance(ix.datastore.index, fake_engine.IndexFlatIP)
+        D, I = orc.flat_search(q.astype(np.float32), np.concatenate(embs, 0).astype(np.float32), 3, 0)
+        scores, passages, db_ids = ix.search(q, k=3)
+        assert scores == D.tolist() and db_ids == [[[int(i) // 400, int(i) % 400] for i in row] for row in I]
+        # no faiss package -> a clear error, never a silent fallback to another engine
+        monkeypatch.delitem(sys.modules, "faiss")
+        monkeypatch.setattr("builtins.__import__", _no_faiss_import(__import__))
+        with pytest.raises(RuntimeError, match="faiss package is not importable"):
+            sel.set_backend("faiss")
+    finally:
+        monkeypatch.undo()
+        sel.set_backend("mi355x")
+    import rsx
+    assert sel.engine() is rsx and sel.backend_name() == "mi355x"
+    with pytest.raises(ValueError):
+        sel.set_backend("cuda")
+
+    class Ix:                       # what check_storage_dtype looks at
+        def __init__(self, sd):
+            self.storage_dtype = sd
+    assert sel.check_storage_dtype(Ix("float16"), "auto") == "float16"
+    assert sel.check_storage_dtype(Ix("float32"), None) == "float32"          # auto: data forced fp32 rows — fine
+    assert sel.check_storage_dtype(Ix("float16"), "float16") == "float16"
+    with pytest.raises(RuntimeError):
+        sel.check_storage_dtype(Ix("float32"), "float16")
+    with pytest.raises(NotImplementedError):
+        sel.check_storage_dtype(Ix("float16"), "float32")
+    with pytest.raises(ValueError):
+        sel.check_storage_dtype(Ix("float16"), "bf16")
+
+
+def _no_faiss_import(real):
+    def imp(name, *a, **k):
+        if name == "faiss":
+            raise ImportError("No module named 'faiss'")
+        return real(name, *a, **k)
+    return imp
