@@ -418,3 +418,36 @@ def _no_faiss_import(real):
             raise ImportError("No module named 'faiss'")
         return real(name, *a, **k)
     return imp
+
+
+def test_datastore_api_twin(tmp_path, orc, fake):
+    """api/api_index.py: shard selection, the {'scores','passages','IDs'} record, str / list queries, the reference's error
+    for other types, and the 30-call latency protocol — with an injected encoder (a lookup into the embeddings)."""
+    from api.api_index import DatastoreAPI, get_datastore, profile_time
+    tmp = str(tmp_path)
+    embs = write_datastore(tmp, orc)
+    table = {"q five": embs[0][5], "q seven": embs[1][7]}
+    calls = []
+
+    def enc(queries):
+        calls.append(list(queries))
+        return np.stack([table[s] for s in queries], 0)
+    ds = get_datastore(make_cfg(tmp, "Flat", [0, 1]), query_encoder_fn=enc)
+    r = ds.search("q five", 3)
+    assert set(r) == {"scores", "passages", "IDs"} and len(r["scores"]) == 1 and len(r["IDs"][0]) == 3
+    D, I = orc.flat_search(np.stack([table["q five"], table["q seven"]]).astype(np.float32),
+                           np.concatenate(embs, 0).astype(np.float32), 3, 0)
+    assert r["IDs"] == [[[int(i) // 400, int(i) % 400] for i in I[0]]] and r["scores"] == [D[0].tolist()]
+    r2 = ds.search(["q five", "q seven"], 3)
+    assert r2["scores"] == D.tolist() and r2["passages"][1][0] == f"shard {I[1, 0] // 400} chunk {I[1, 0] % 400} é"
+    with pytest.raises(AttributeError):
+        ds.search(5)
+    # one worker = one shard (api_index.py:23-27): ids are then relative to that shard only
+    one = DatastoreAPI(make_cfg(tmp, "Flat", [0, 1]), shard_id=1, query_encoder_fn=enc)
+    assert one.cfg.datastore.index.index_shard_ids == [1] and one.index.index.ntotal == 400
+    assert one.search("q seven", 1)["IDs"] == [[[1, 7]]]
+    n0 = len(calls)
+    per_query = profile_time(ds, "q five", 3)
+    assert len(calls) - n0 == 30 and per_query >= 0.0
+    with pytest.raises(RuntimeError):
+        DatastoreAPI(make_cfg(tmp, "Flat", [0, 1])).search("q five")
