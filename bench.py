@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=1024, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-recall", action="store_true", help="skip the exact ground truth (recall = null)")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2/3 and the second recall figure")
+    ap.add_argument("--no-faiss", action="store_true", help="skip the opportunistic FAISS leg (it only runs when `import faiss` works)")
     ap.add_argument("--diag", action="store_true", help="print a fast-vs-exact comparison of the first timed batch and exit")
     ap.add_argument("--shard", choices=["vectors", "lists"], default="vectors",
                     help="multi-GPU partition of the index: by contiguous id ranges (the reference's shards; default) or by "
@@ -70,6 +71,9 @@ def main():
                     help="engine parameter for an experiment (rsx_set_param), e.g. pq_filter=0; not for the reported line")
     ap.add_argument("--ab", action="store_true", help="also time the per-pair v1 scan kernel (same process, same index)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import rsx
@@ -364,6 +368,14 @@ def main():
         log(f"cpu baseline: {ns} queries x3 in {[round(t, 2) for t in times]} s on {orc.num_threads()} threads; parity with GPU ids+scores: {parity}")
         del lm
 
+    # ---------------- opportunistic FAISS leg: the real reference engine on the same index and queries, when the
+    # box has it (tools/faiss_leg.py; never required, {"available": false} otherwise)
+    faiss_res = None
+    if rank == 0 and world == 1 and not args.no_faiss:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from faiss_leg import faiss_leg
+        faiss_res = faiss_leg(index, Qgt.cpu().numpy(), k, args.nprobe, D1.cpu().numpy(), I1.cpu().numpy(), log=log)
+
     # ---------------- extras on their own indexes (N = 1): BASELINE configs 2 / 3, a second recall figure
     configs = None
     recall2 = None
@@ -433,11 +445,28 @@ def main():
             "configs": configs,
             "cpu_baseline": cpu,
             "cpu_parity_ids_and_scores_bit_exact": parity,
+            "faiss_baseline": faiss_res,
         }
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command line under torch.distributed.run with one rank
+    per GPU (the form the driver uses for N > 1), on a free loopback port; the ranks' stdout/stderr pass through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch:", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
 
 
 def kernel_source_hash():

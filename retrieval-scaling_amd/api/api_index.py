@@ -49,6 +49,7 @@ def get_datastore(cfg, shard_id=None, query_encoder_fn=None):
 def profile_time(ds, query="Sunny San Diego days", n_docs=3, calls=30, warmup=10):
     """The reference's latency protocol (api/api_index.py:88-95): `calls` single-query searches, the first `warmup` are not
     timed; returns seconds per query.  (tools/bench_configs.py latency applies it to the engine alone.)"""
+    assert calls > warmup >= 0, "profile_time: calls must exceed warmup (the reference protocol is 30 calls, 10 of them warm-up)"
     start = None
     for i in range(calls):
         if i == warmup:

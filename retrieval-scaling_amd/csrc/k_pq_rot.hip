@@ -32,11 +32,53 @@ namespace rsx {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int ROT_D = 4;      // 16-vector code blocks in flight per wave (16 M bytes each)
+#ifndef ROT_DEPTH
+#define ROT_DEPTH 4
+#endif
+constexpr int ROT_D = ROT_DEPTH;   // 16-vector code blocks in flight per wave (16 M bytes each); must divide the tile's blocks per wave
 #ifndef ROT_CW
 #define ROT_CW 4              // items (waves) per workgroup of k_pq_rot_compact
 #endif
 
+// pacing word: explicit LDS-space accesses (a generic volatile pointer compiles to flat_load, whose in-order vmcnt wait would
+// drain the wave's outstanding code loads at every loop iteration)
+__device__ __forceinline__ uint32_t lds_rd32_volatile(uint32_t addr) {
+    return *reinterpret_cast<const volatile __attribute__((address_space(3))) uint32_t*>((uintptr_t)addr);
+}
+__device__ __forceinline__ void lds_wr32(uint32_t addr, uint32_t v) {
+    *reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((uintptr_t)addr) = v;
+}
+// min over the 8 sibling-progress slots at `a` (every lane reads the same 32 bytes: a broadcast), values below `lo_ok` ignored
+__device__ __forceinline__ uint32_t sib_min8(uint32_t a, uint32_t lo_ok) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 x = *reinterpret_cast<const volatile __attribute__((address_space(3))) u4*>((uintptr_t)a);
+    const u4 y = *reinterpret_cast<const volatile __attribute__((address_space(3))) u4*>((uintptr_t)(a + 16));
+    uint32_t m = 0x7fffffffu;
+    const uint32_t v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const uint32_t t = v[i] < lo_ok ? 0x7fffffffu : v[i]; m = t < m ? t : m; }
+    return m;
+}
+// refresh the sibling-progress slots: an LDS-DMA load (lane i -> slot i).  Issued from inline assembly on purpose: the
+// compiler then knows neither a destination register nor an LDS write, so it inserts no vmcnt wait for it — with the builtin
+// (whose LDS write may alias the raw-address table gathers) or with a load into a register it drains vmcnt, i.e. the wave's
+// whole code prefetch, at every loop iteration (measured: the scan 1.5x slower).  sib_landed() is the explicit wait.
+__device__ __forceinline__ void sib_refresh(const uint32_t* gp, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc0" : : "v"(gp), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void sib_landed() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+// largest progress word among the 8 slots that belongs to a sibling on its FIRST pass (0 = not started, bit 30 = wrapped
+// around, 0x7fffffff = done / not a sibling); 0 when there is none
+__device__ __forceinline__ uint32_t sib_max8_first_pass(uint32_t a) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 x = *reinterpret_cast<const volatile __attribute__((address_space(3))) u4*>((uintptr_t)a);
+    const u4 y = *reinterpret_cast<const volatile __attribute__((address_space(3))) u4*>((uintptr_t)(a + 16));
+    const uint32_t v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const uint32_t t = v[i] < 0x40000000u ? v[i] : 0u; m = t > m ? t : m; }
+    return m;
+}
 __device__ __forceinline__ uint32_t lds_rd32(uint32_t addr) {
     // raw LDS address: the kernels below declare no static LDS, so the dynamic segment starts at 0
     return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)addr);
@@ -64,7 +106,7 @@ struct __attribute__((aligned(16))) PQRotItem {
 static_assert(sizeof(PQRotItem) == 176, "PQRotItem is copied as 11 x 16 bytes");
 
 template <int M, bool FILTER>
-__global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* items, uint32_t* xcd_ctr) {
+__global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* items, uint32_t* xcd_ctr, uint32_t* prog) {
     const PQScanArgs& a = A.b;
     const int item = blockIdx.x * 256 + threadIdx.x;
     if (item < 8) xcd_ctr[item * 32] = 0u;     // the scan's per-XCD work counters (one per 128-byte line)
@@ -79,6 +121,9 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
     const int pair0 = A.pair_off[lo] + 4 * gi;
     PQRotItem d;
     d.l = lo; d.tile = tile; d.np = (cnt - 4 * gi) > 4 ? 4 : (cnt - 4 * gi); d.pad0 = 0;
+    // the item's FAMILY = the ng query groups of one list tile, adjacent in the item order: [item - gi, item - gi + ng)
+    const int fam = ((gi < 0x3fff ? gi : 0x3fff) << 4) | ((ng < 0x3fff ? ng : 0x3fff) << 18);
+    prog[item] = 0u;
     d.len = a.list_len[lo]; d.base_row = a.list_base[lo];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -117,6 +162,7 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
     // the item (no table staging, no gathers).  Exact: the bound is on the very integer sums the scan would compute.
     if (FILTER && A.prune && d.cinit[0] == -(1 << 30) && d.cinit[1] == -(1 << 30) && d.cinit[2] == -(1 << 30) && d.cinit[3] == -(1 << 30))
         d.l = -2;
+    d.np |= fam;
     items[item] = d;
 }
 
@@ -127,9 +173,28 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
 // PREVIOUS item's survivor queues (their global reservations were issued before the staging and have landed by now),
 // [barrier] scan.  Nothing at an item boundary waits on a dependent global load except the table rows themselves.
 // ---------------------------------------------------------------------------------------
+#ifdef RSX_MEASURE
+// tools/ builds only: per-item trace of the scan (start / end wall clock in 10 ns ticks, workgroup, family) for the
+// sibling start-skew measurement (tools/exp_trace.py); the shipped library has neither the array nor the stores
+__device__ uint64_t g_rot_trace[4 * 65536];
+__device__ uint32_t g_rot_wave[16 * 16384];       // per (item < 16384, wave): scan-loop duration in 10 ns ticks
+extern "C" int rsx_debug_rot_trace(uint64_t* out, int n_items) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rot_trace), (size_t)n_items * 32) == hipSuccess ? 0 : -1;
+}
+extern "C" int rsx_debug_rot_wave(uint32_t* out, int n_items) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rot_wave), (size_t)n_items * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
 template <int NF, int NH, bool FILTER>
 __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ seg_keys,
-                                                      uint32_t* __restrict__ seg_cnt, uint32_t* xcd_ctr, int seg_cap, int bpw, int var) {
+                                                      uint32_t* __restrict__ seg_cnt, uint32_t* xcd_ctr, uint32_t* prog, int seg_cap, int bpw, int pace_arg, int var_arg) {
+    const int pace = pace_arg & 15;
+#ifdef RSX_MEASURE
+    const int var = var_arg;        // tools/ builds only: cost-split variants (skip staging / scan / survivor path)
+#else
+    constexpr int var = 0;          // the shipped library has no measurement branches
+#endif
     constexpr int M = 64 * NF + 32 * NH;
     constexpr int NPH = NF + NH;               // phases = table planes
     constexpr int TAB = NPH * 65536;           // plane p at p * 64 KiB; row = code * 256; a half phase uses 128 B of the row
@@ -157,7 +222,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     int xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
     if (xlo >= xhi) return;
     uint32_t* ctr = xcd_ctr + xcd * 32;
-    unsigned drawn = 0;          // wave 0, lane 0: the counter value of the last draw (consumed one item later)
+    unsigned drawn = 0;          // wave 0, lane 0: the counter value of the last draw
     // ---- per-lane constants, once per workgroup: rotation bytes, the one-hot B operand, the survivor-queue geometry
     uint32_t R0[NR0 > 0 ? NR0 : 1], R1[NR1 > 0 ? NR1 : 1];
 #pragma unroll
@@ -199,7 +264,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     if (w == 0) {
         if (lane == 0) { drawn = atomicAdd(ctr, 1u); }
         item = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
-        if (lane == 0) drawn = atomicAdd(ctr, 1u);
         uint4 r0 = make_uint4(0xffffffffu, 0, 0, 0);       // l = -1: end marker
         if (lane < 11 && item < xhi) r0 = reinterpret_cast<const uint4*>(&items[item])[lane];
         if (lane < 11) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
@@ -214,7 +278,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         if (item_l == -1) break;
         item = __builtin_amdgcn_readfirstlane(it->pad0);
         const bool skip_item = item_l < -1;         // pruned: no survivors possible, only the bookkeeping below runs
-        const int np = __builtin_amdgcn_readfirstlane(it->np);
+        const int np_raw = __builtin_amdgcn_readfirstlane(it->np);
+        const int np = np_raw & 15;
         const int64_t len = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->len >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->len);
         const int64_t base_row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->base_row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->base_row);
         const int nblk = (int)(((len + 63) >> 6) << 2);     // 16-vector blocks of the list, slab padding included
@@ -225,14 +290,31 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         // instead of needing a clamp (its sums are garbage that the pos < len test of the survivor path drops)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lp, 0, nblk * 16 * M, 0x00020000);
         v4u ca[ROT_D][NF > 0 ? NF : 1]; v2u cb[ROT_D];
-#pragma unroll
-        for (int dd = 0; dd < ROT_D; dd++) {     // the first ROT_D blocks of this wave: in flight during the table staging
-            const int so = (tb0 + w + 16 * dd) * (16 * M);
-#pragma unroll
-            for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
-            if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
+        // ---- circular scan (round 3): the sibling groups of a list tile (the item's family: adjacent items, different CUs of this
+        // XCD) read the same code lines, and a line lives ~5 us in the XCD's L2.  A workgroup that starts while a sibling is
+        // already under way therefore does not begin at the tile's first block: it JOINS the most advanced running sibling at
+        // its current position, scans to the end of the tile alongside it (one of the two fetches a line from HBM, the other
+        // finds it in the L2), then wraps around and scans the part it skipped.  No workgroup ever waits for another; block
+        // order never affects results (survivors are keys).  The start position needs the siblings' progress words, which
+        // wave 0 requests here (LDS-DMA, lane i -> slot i) and reads after its share of the table staging.
+        const int join_on = (pace_arg >> 7) & 1;
+        int f0 = item - ((np_raw >> 4) & 0x3fff), f1 = f0 + ((np_raw >> 18) & 0x3fff);
+        if (f0 < xlo) f0 = xlo;
+        if (f1 > xhi) f1 = xhi;
+        if (f1 - f0 > 8) {                    // the 8-item window around this item (one 32-byte LDS read)
+            int a0 = item - 3;
+            if (a0 < f0) a0 = f0;
+            if (a0 > f1 - 8) a0 = f1 - 8;
+            f0 = a0; f1 = a0 + 8;
         }
-
+        constexpr uint32_t allowed_a = (uint32_t)(TAB + 2 * 176);                  // LDS word: iterations the workgroup may START (brake)
+        constexpr uint32_t i0_a = (uint32_t)(TAB + 2 * 176 + 4);                   // LDS word: the item's first loop iteration (join)
+        constexpr uint32_t sib_a = (uint32_t)(TAB + 384);                          // LDS [8]: the siblings' progress as last seen
+        const bool family = (pace > 0 || join_on) && !skip_item && f1 - f0 > 1 && item >= f0 && item < f1;
+        if (w == 0) {
+            if (lane < 8) lds_wr32(sib_a + 4u * (uint32_t)lane, 0x7fffffffu);       // own slot and the lanes beyond the family never count
+            if (family && f0 + lane < f1 && f0 + lane != item) sib_refresh(&prog[f0 + lane], sib_a);
+        }
         // ---- stage the group's table: work unit = (code, 4 consecutive m) -> 4 dwords (one per m: byte k = query k, as int8 = u8 - 128)
         {
             const int64_t q0 = it->q[0], q1 = it->q[1], q2 = it->q[2], q3 = it->q[3];
@@ -257,13 +339,58 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             }
         }
         uint64_t* myseg = seg_keys + (((size_t)item * 16 + w) * 4 + nq4) * seg_cap;
-        // ---- next item's record: requested now by wave 0 (its index was drawn during the previous item: the counter's answer
-        // has had a barrier wait and a table staging to arrive), parked in LDS after the scan
+        // ---- next item: drawn JUST IN TIME (round 3).  The XCD's item order is (list, tile, group), so the workgroups that
+        // draw the sibling groups of a list tile are the ones that come free one after the other: they start within a few
+        // microseconds of each other and stream the same code lines, the followers out of the XCD's L2 (a line lives ~5 us
+        // there at this fill rate).  Round 2 drew one item AHEAD, which bound an item to a workgroup ~70 us before it started
+        // and scattered the siblings in time: L2 hit rate 21 %, 19.4 GB from the fabric for 9.6 GB of unique code bytes.
+        // Wave 0 issues the draw three loop iterations before the end of its share, the record load one iteration before the
+        // end: both latencies hide behind the last blocks of the scan.
         uint4 pre = make_uint4(0xffffffffu, 0, 0, 0);
-        int i1 = 0;
+        int i1 = 0x7fffffff;
+        int dstate = 0;                       // wave 0: 0 = not drawn, 1 = draw in flight, 2 = record requested
+        int nit0 = 0;                         // loop iterations of wave 0 for this item
+        {
+            int nb0 = skip_item ? 0 : (nblk - tb0 + 15) >> 4;
+            if (nb0 > bpw) nb0 = bpw;
+            if (nb0 < 0) nb0 = 0;
+            nit0 = (nb0 + ROT_D - 1) / ROT_D;
+        }
+        // ---- PACING (round 3): the sibling groups of a list tile (the item's family) run on different CUs of this XCD and read
+        // the same code lines; a line stays ~5 us in the XCD's L2, so the siblings must stay within a couple of loop iterations
+        // (16 waves x ROT_D blocks = 96 KiB of codes each) of each other for the followers to hit.  Wave 0 publishes the
+        // iteration it starts (prog[item], agent-scope store), sees the siblings' progress through LDS slots that an LDS-DMA
+        // load refreshes every iteration (no register destination -> no vmcnt wait in front of the wave's code prefetch; a
+        // slot may be an iteration or two stale, which only under-estimates a sibling: conservative), and lets the
+        // workgroup start iteration itx only while itx < min(close siblings' progress) + pace — a brake on whoever is ahead,
+        // never a barrier: at most 2 polls (~1 us each) per iteration and 12 per item, siblings more than pace + 2
+        // iterations behind are ignored (a late starter is lost to the L2 anyway).  Placement and timing never affect
+        // results, and a sibling that is not running cannot stall anyone for long.
+        const bool prio_rot = !((pace_arg >> 4) & 4);      // diagnostics: bit 2 of the flags switches the priority rotation off
+        const int pflags = (pace_arg >> 4) & 7;            // diagnostics (tools only): 1 = waves do not follow `allowed`, 2 = wave 0 does not brake
+        const bool paced = pace > 0 && family && nit0 > 1;
+        int pace_budget = 12;                 // wave 0: polls (~1 us each) left for this item
+#ifdef RSX_MEASURE
+        if (tid == 0 && item < 65536) {
+            g_rot_trace[4 * item + 0] = wall_clock64();
+            g_rot_trace[4 * item + 2] = ((uint64_t)blockIdx.x << 32) | (uint32_t)nit0;
+            g_rot_trace[4 * item + 3] = ((uint64_t)(uint32_t)f0 << 32) | (uint32_t)f1;
+        }
+#endif
         if (w == 0) {
-            i1 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
-            if (lane < 11 && i1 < xhi) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
+            if (lane == 0) lds_wr32(allowed_a, paced ? (uint32_t)pace : 0x7fffffffu);
+            uint32_t i0v = 0;
+            if (family) {
+                sib_landed();                 // the progress words requested before the staging (the wave's table loads are older: no extra wait)
+                if (join_on) {
+                    // most advanced sibling still on its first pass (bit 30 marks a wrapped one, 0 = not started, 0x7fffffff = done);
+                    // its word is a few microseconds old by the time this workgroup scans: start `ahead` iterations further on
+                    const uint32_t best = sib_max8_first_pass(sib_a);
+                    int ahead = (pace_arg >> 8) & 15; if (ahead == 0) ahead = 2;
+                    if (best != 0u && (int)best - 1 + ahead + 2 < nit0) i0v = best - 1u + (uint32_t)ahead;
+                }
+            }
+            if (lane == 0) lds_wr32(i0_a, i0v);
         }
         // ---- the lane's share of the item record: accumulator init, score parameters of the query it owns (n < 4)
         const int cinit = FILTER ? (n < 4 ? it->cinit[nq4] : -(1 << 30)) : 0;
@@ -273,11 +400,89 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         const uint64_t p_tau = it->tau[nq4];
         uint32_t qcnt = 0;                    // survivors of the lane's query so far (equal in the four lanes of a query)
         __syncthreads();    // #2: table staged
+#ifdef RSX_MEASURE
+        const uint64_t t_scan0 = wall_clock64();
+#endif
 
-        // ---- scan: blocks tb0 + w + 16 j, j < bpw, ROT_D of them in flight
+        // ---- scan: blocks tb0 + w + 16 j, j < nbw, ROT_D of them in flight, iterations in circular order from i0w
+        int nbw = ((var & 2) || skip_item) ? 0 : (nblk - tb0 - w + 15) >> 4;       // this wave's blocks of the tile
+        if (nbw > bpw) nbw = bpw;
+        if (nbw < 0) nbw = 0;
+        const int nitw = (nbw + ROT_D - 1) / ROT_D;
+        int i0w = join_on ? (int)__builtin_amdgcn_readfirstlane((int)lds_rd32_volatile(i0_a)) : 0;
+        if (i0w >= nitw) i0w = 0;
+        const int so_oob = nblk * (16 * M);                                        // past the descriptor's end: reads zeros
+#pragma unroll
+        for (int dd = 0; dd < ROT_D; dd++) {     // the first ROT_D blocks of this wave
+            const int so = nitw > 0 ? (tb0 + w + 16 * (i0w * ROT_D + dd)) * (16 * M) : so_oob;
+#pragma unroll
+            for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
+            if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
+        }
 #pragma unroll 1
-        for (int j0 = 0; j0 < ((var & 2) || skip_item ? 0 : bpw); j0 += ROT_D) {
-            if (tb0 + w + 16 * j0 >= nblk) break;
+        for (int k = 0; k < nitw; k++) {
+            int itx = i0w + k; if (itx >= nitw) itx -= nitw;
+            int nxt = itx + 1; if (nxt >= nitw) nxt = 0;
+            const bool wrapped = itx < i0w;
+            const int j0 = itx * ROT_D;
+            const int so_next = (k + 1 < nitw) ? (tb0 + w + 16 * (nxt * ROT_D)) * (16 * M) : so_oob;
+            if (prio_rot) {
+                // the four waves of a SIMD (w, w + 4, w + 8, w + 12) take turns at the top issue priority, one loop iteration each:
+                // with equal priorities the arbiter serves the OLDEST wave first, so wave w ran its share in 33 us and wave
+                // w + 12 needed 58 us (measured per wave) — the tail of every item ran one wave per SIMD deep.
+                switch ((k + (w >> 2)) & 3) {
+                    case 0: __builtin_amdgcn_s_setprio(3); break;
+                    case 1: __builtin_amdgcn_s_setprio(2); break;
+                    case 2: __builtin_amdgcn_s_setprio(1); break;
+                    default: __builtin_amdgcn_s_setprio(0); break;
+                }
+            }
+            if (family && w == 0 && !paced && lane == 0)      // join without brake: the progress word is still published
+                __hip_atomic_store(&prog[item], (uint32_t)(itx + 1) | (wrapped ? 0x40000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (paced && wrapped) {
+                if (w == 0 && lane == 0) {
+                    lds_wr32(allowed_a, 0x7fffffffu);             // second pass: nobody to keep pace with
+                    __hip_atomic_store(&prog[item], (uint32_t)(itx + 1) | 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else if (paced) {
+                if (w == 0) {
+                    // progress word: the siblings share this XCD's L2, so L2-level visibility is all that is needed — a plain store
+                    // (the vector L1 is write-through) and loads that bypass the L1 (sc0).  A device-scope store (sc1) writes
+                    // through to the fabric and its late acknowledgement holds the wave's in-order vmcnt queue, i.e. every code
+                    // load behind it (measured: the scan 1.45x slower with one such store per iteration).
+                    if (lane == 0) __hip_atomic_store(&prog[item], (uint32_t)(itx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // a sibling constrains only while it is within catch-up range (<= pace + 2 iterations behind, not-yet-started
+                    // ones included while this workgroup is that young): a late starter is lost to the L2 anyway
+                    const uint32_t lo_ok = (uint32_t)(itx + 1) > (uint32_t)(pace + 2) ? (uint32_t)(itx + 1) - (uint32_t)(pace + 2) : 0u;
+                    uint32_t mn = sib_min8(sib_a, lo_ok);     // one broadcast LDS read of the 8 slots, VALU min: no cross-lane traffic
+                    int polls = 0;
+                    while ((uint32_t)itx >= mn + (uint32_t)pace && polls < 2 && pace_budget > 0 && !(pflags & 2)) {   // ahead of a close sibling: brake
+                        __builtin_amdgcn_s_sleep(8);
+                        polls++; pace_budget--;
+                        if (f0 + lane < f1 && f0 + lane != item) sib_refresh(&prog[f0 + lane], sib_a);
+                        sib_landed();         // the brake path only: a fresh view costs the wave its prefetch depth once
+                        mn = sib_min8(sib_a, lo_ok);
+                    }
+                    // the other waves may run one iteration ahead of wave 0, never further than the pacing allows
+                    uint32_t al = mn + (uint32_t)pace;
+                    if (al < (uint32_t)itx + 2u) al = (uint32_t)itx + 2u;
+                    if (pace_budget <= 0) al = 0x7fffffffu;                                            // budget spent: the item runs free
+                    if (lane == 0) lds_wr32(allowed_a, al);
+                    // refresh the slots for the next iteration (never waited for: a stale slot only under-estimates a sibling)
+                    if (pace_budget > 0 && f0 + lane < f1 && f0 + lane != item) sib_refresh(&prog[f0 + lane], sib_a);
+                } else if (!(pflags & 1)) {
+                    int spins = 0;
+                    while ((uint32_t)itx >= lds_rd32_volatile(allowed_a) && spins < 4096) { __builtin_amdgcn_s_sleep(2); spins++; }
+                }
+            }
+            if (w == 0) {
+                if (dstate == 1 && k >= nit0 - 1) {
+                    i1 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+                    if (lane < 11 && i1 < xhi) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
+                    dstate = 2;
+                }
+                if (dstate == 0 && k >= nit0 - 3) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }
+            }
 #pragma unroll
             for (int dd = 0; dd < ROT_D; dd++) {
                 const int b = tb0 + w + 16 * (j0 + dd);
@@ -307,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 {   // the slot's code registers are dead: refill them in place
-                    const int so = (b + 16 * ROT_D) * (16 * M);
+                    const int so = so_next == so_oob ? so_oob : so_next + dd * 16 * (16 * M);
 #pragma unroll
                     for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
                     if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
@@ -355,10 +560,24 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         }
         // ---- item epilogue: the wave's four survivor counts leave with one store (lanes 0..3 own queries 0..3); wave 0 parks
         // the next record (or the end marker) and draws the index of the item after it
+        __builtin_amdgcn_s_setprio(0);
         if (FILTER && lane < 4) seg_cnt[((size_t)item * 16 + w) * 4 + lane] = qcnt;
+#ifdef RSX_MEASURE
+        if (lane == 0 && item < 16384) g_rot_wave[16 * item + w] = (uint32_t)(wall_clock64() - t_scan0);
+        if (tid == 0 && item < 65536) g_rot_trace[4 * item + 1] = wall_clock64() | ((uint64_t)(12 - pace_budget) << 56);
+#endif
+        if (w == 0 && lane == 0) {
+            lds_wr32(allowed_a, 0x7fffffffu);                                                // wave 0 is through: nobody waits on it
+            if (pace > 0) __hip_atomic_store(&prog[item], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         if (w == 0) {
+            if (dstate == 0) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }     // empty / pruned / one-iteration items
+            if (dstate == 1) {
+                i1 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+                if (lane < 11 && i1 < xhi) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
+            }
             if (lane < 11) reinterpret_cast<uint4*>(&islot[buf ^ 1])[lane] = pre;
-            if (lane == 0) { islot[buf ^ 1].pad0 = i1; drawn = atomicAdd(ctr, 1u); }
+            if (lane == 0) islot[buf ^ 1].pad0 = i1;
         }
     }
 }
@@ -415,7 +634,7 @@ __global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem*
 template <int NF, int NH, bool FILTER>
 static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, int seg_cap, hipStream_t st) {
     constexpr int M = 64 * NF + 32 * NH;
-    const size_t shm = (size_t)(NF + NH) * 65536 + 2 * 192;
+    const size_t shm = (size_t)(NF + NH) * 65536 + 384 + 256;   // tables | 2 item records (176 B each) + pacing word | sibling progress [64]
     static DevOnce once;
     static int ncu_of[64] = {};
     int& ncu = ncu_of[cur_device()];
@@ -432,14 +651,19 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(desc_ws) + (size_t)(A.max_items + 8) * 176);
     uint64_t* seg_keys = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(seg_cnt) + (size_t)(A.max_items + 8) * 256);
     uint32_t* xcd_ctr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(seg_keys) + (size_t)(A.max_items + 8) * 64 * seg_cap * 8);
-    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr);
+    uint32_t* prog = xcd_ctr + 256;
+    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog);
+#ifdef RSX_MEASURE
     static int var = -1;
     if (var < 0) { const char* e = getenv("RSX_ROT_VARIANT"); var = e ? atoi(e) : 0; }
+#else
+    const int var = 0;
+#endif
     // one persistent workgroup per CU (a multiple of 8: workgroup b serves XCD b % 8); never more than the work items
     int64_t grid = (ncu + 7) & ~7;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
-    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, xcd_ctr,
-                       seg_cap, bpw, var);
+    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, xcd_ctr, prog,
+                       seg_cap, bpw, A.pace, var);
     if (FILTER)
         hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, seg_keys, seg_cnt, seg_cap,
                            A.cand, A.cand_cnt, A.cand_cap);
@@ -451,7 +675,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws, int seg_cap, int prune, hipStream_t st) {
+                       int cand_cap, void* item_ws, int seg_cap, int prune, int pace, hipStream_t st) {
     if (a.CB != 0 || !item_ws || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8t; A.qp = (const PQQParam*)qparam;
@@ -459,7 +683,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
     A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap;
-    A.prune = prune;
+    A.prune = prune; A.pace = pace;
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
     switch (a.M) {

@@ -172,6 +172,9 @@ struct rsx_index {
     int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
     int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
     int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
+    int pq_pace = 128;    // rotated fast scan, L2 reuse between the query groups of a list tile: bit 7 = a late group JOINS its running
+                          // sibling's position and wraps around (default), bits 0-3 = additionally brake a group that runs this many
+                          // loop iterations ahead of a close sibling (0 = no brake), bits 8-11 = join offset (0 = 2 iterations)
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
@@ -208,6 +211,20 @@ struct rsx_index {
 };
 
 static void use_device(rsx_index* h) { HIPCHECK(hipSetDevice(h->device)); }
+
+// HBM held by the search / add workspaces of one (unsharded) handle — grows with the largest batch served so far, is never
+// part of the index payload (hbm_bytes) and is released with the handle.  The largest single item is the IVF-PQ fast scan's
+// per-item survivor segments (w_itemdesc: a few GB at the bench configuration, rsx_internal.h: pq_scan_rot_ws).
+static int64_t workspace_bytes(const rsx_index* h) {
+    const DevBuf* bufs[] = {&h->w_q32, &h->w_q16, &h->w_coarse, &h->w_keys1, &h->w_probekeys, &h->w_probelist, &h->w_dis0, &h->w_segstart,
+                            &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
+                            &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
+                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->sh_D, &h->sh_I, &h->sh_q,
+                            &h->sh_oD, &h->sh_oI};
+    int64_t t = 0;
+    for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
+    return t;
+}
 
 static void upload_dir(rsx_index* h) {
     h->dir_gen++;       // list lengths changed: the memoised host-side bounds below are stale
@@ -1041,6 +1058,11 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             int rot_seg_cap = 128;
             auto rot_desc = [&](int64_t items, int v, int pre_rows_) -> void* {   // work-item records + survivor segments of the rotated-layout scan
                 rot_seg_cap = pq_scan_rot_seg_cap(1024 * v, KP, pre_rows_);
+                // the segment pool is (items x 64 segments x seg_cap keys): bounded by a quarter of the temp budget (4 GiB by
+                // default) — a smaller segment only means that an unusually dense (item, wave, query) overflows, is counted, and
+                // sends its query to the exact re-run; reported by rsx_get "workspace_bytes"
+                const int64_t pool_budget = std::max<int64_t>(h->temp_budget / 4, (int64_t)1 << 30);
+                while (rot_seg_cap > 128 && (items + 8) * 64 * (int64_t)rot_seg_cap * 8 > pool_budget) rot_seg_cap /= 2;
                 h->w_itemdesc.ensure(pq_scan_rot_ws(items, rot_seg_cap));
                 return h->w_itemdesc.p;
             };
@@ -1111,7 +1133,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 void* rws0 = rot ? rot_desc(mi, filtered ? pre_vpl : vpl, 0) : nullptr;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
-                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, 0, h->st)
+                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, 0, 0, h->st)
                             : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
             }
@@ -1140,7 +1162,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                                  total_groups, item_off, total_items, nlist,
                                                  max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rws1, rot_seg_cap, h->pq_prune, h->st)
+                                                 rws1, rot_seg_cap, h->pq_prune, h->pq_pace, h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
                                                      max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
@@ -1700,8 +1722,11 @@ static void sharded_add(rsx_index* h, int64_t n, const void* x, int dtype, const
         const char* xp = (const char*)x + (size_t)lo * h->d * esz;
         DevBuf tmp;
         if (xdev >= 0 && xdev != c->device) {     // rows live on another GPU: one peer copy into this shard's staging buffer
+            // (on the child's own stream + a stream synchronise: a plain device-to-device hipMemcpy is not guaranteed to block
+            //  the host, and the child's kernels run on a non-blocking stream that is not ordered after the null stream)
             tmp.ensure((size_t)(hi - lo) * h->d * esz);
-            HIPCHECK(hipMemcpy(tmp.p, xp, (size_t)(hi - lo) * h->d * esz, hipMemcpyDefault));
+            HIPCHECK(hipMemcpyAsync(tmp.p, xp, (size_t)(hi - lo) * h->d * esz, hipMemcpyDefault, c->st));
+            HIPCHECK(hipStreamSynchronize(c->st));
             xp = (const char*)tmp.p;
         }
         add_all(c, hi - lo, xp, dtype, hid + lo);
@@ -1713,7 +1738,7 @@ static void sharded_add(rsx_index* h, int64_t n, const void* x, int dtype, const
 static void sharded_search(rsx_index* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
     const int N = (int)h->shards.size();
     if (nq < 0 || k <= 0) RSX_THROW(RSX_ERR_INVALID, "search: nq=%lld k=%d", (long long)nq, k);
-    if ((int64_t)N * k > 8192) RSX_THROW(RSX_ERR_UNSUPPORTED, "sharded search: nshards * k = %lld exceeds 8192", (long long)N * k);
+    if (k > 4096) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: k = %d exceeds this build's maximum of 4096 (the reference backends' default k)", k);
     if (nq == 0) return;
     if (!q || !D || !I) RSX_THROW(RSX_ERR_INVALID, "search: null pointer");
     const bool o_dev = is_device_ptr(D);
@@ -1725,16 +1750,19 @@ static void sharded_search(rsx_index* h, int64_t nq, const void* q, int dtype, i
     h->sh_D.ensure((size_t)N * blk * 4); h->sh_I.ensure((size_t)N * blk * 8);
     for_each_shard_parallel(h, [&](int r, rsx_index* c) {
         const void* qp = q;
-        if (qdev >= 0 && qdev != c->device) {     // the caller's queries sit on another GPU
+        if (qdev >= 0 && qdev != c->device) {     // the caller's queries sit on another GPU: peer copy on this shard's stream
             c->sh_q.ensure((size_t)nq * h->d * esz);
-            HIPCHECK(hipMemcpy(c->sh_q.p, q, (size_t)nq * h->d * esz, hipMemcpyDefault));
+            HIPCHECK(hipMemcpyAsync(c->sh_q.p, q, (size_t)nq * h->d * esz, hipMemcpyDefault, c->st));
+            HIPCHECK(hipStreamSynchronize(c->st));
             qp = c->sh_q.p;
         }
         c->sh_oD.ensure(blk * 4); c->sh_oI.ensure(blk * 8);
         search_impl(c, nq, qp, dtype, k, c->sh_oD.as<float>(), c->sh_oI.as<int64_t>());   // synchronises c->st
-        // fan-in: this shard's [nq, k] block -> the parent device's gather buffers
-        HIPCHECK(hipMemcpy(h->sh_D.as<float>() + (size_t)r * blk, c->sh_oD.p, blk * 4, hipMemcpyDefault));
-        HIPCHECK(hipMemcpy(h->sh_I.as<int64_t>() + (size_t)r * blk, c->sh_oI.p, blk * 8, hipMemcpyDefault));
+        // fan-in: this shard's [nq, k] block -> the parent device's gather buffers, asynchronously on the shard's stream (all
+        // shards copy concurrently); the stream is synchronised before the thread joins, so the merge below sees every block
+        HIPCHECK(hipMemcpyAsync(h->sh_D.as<float>() + (size_t)r * blk, c->sh_oD.p, blk * 4, hipMemcpyDefault, c->st));
+        HIPCHECK(hipMemcpyAsync(h->sh_I.as<int64_t>() + (size_t)r * blk, c->sh_oI.p, blk * 8, hipMemcpyDefault, c->st));
+        HIPCHECK(hipStreamSynchronize(c->st));
     });
     HIPCHECK(hipSetDevice(h->device));
     float* dD = D; int64_t* dI = I;
@@ -1742,13 +1770,56 @@ static void sharded_search(rsx_index* h, int64_t nq, const void* q, int dtype, i
         h->sh_oD.ensure(blk * 4); h->sh_oI.ensure(blk * 8);
         dD = h->sh_oD.as<float>(); dI = h->sh_oI.as<int64_t>();
     }
-    launch_merge_topk_byid(N, nq, k, h->metric, h->sh_D.as<float>(), h->sh_I.as<int64_t>(), dD, dI, h->st);
-    HIPCHECK(hipStreamSynchronize(h->st));
-    if (dD != D) {
-        HIPCHECK(hipMemcpy(D, dD, blk * 4, hipMemcpyDefault));
-        HIPCHECK(hipMemcpy(I, dI, blk * 8, hipMemcpyDefault));
+    // merge by (score, id) — associative, so any k works for any shard count: rounds of groups of G blocks with G * k <= 8192
+    // (one launch for the usual k; k = 4096 on 8 shards takes three rounds of pairs)
+    float* srcD = h->sh_D.as<float>(); int64_t* srcI = h->sh_I.as<int64_t>();
+    int cur = N;
+    const int G = std::max(2, 8192 / k);
+    DevBuf tD[2], tI[2];
+    int flip = 0;
+    while (cur > G) {
+        const int groups = (cur + G - 1) / G;
+        tD[flip].ensure((size_t)groups * blk * 4); tI[flip].ensure((size_t)groups * blk * 8);
+        for (int g = 0; g < groups; g++) {
+            const int n = std::min(G, cur - g * G);
+            launch_merge_topk_byid(n, nq, k, h->metric, srcD + (size_t)g * G * blk, srcI + (size_t)g * G * blk,
+                                   tD[flip].as<float>() + (size_t)g * blk, tI[flip].as<int64_t>() + (size_t)g * blk, h->st);
+        }
+        srcD = tD[flip].as<float>(); srcI = tI[flip].as<int64_t>();
+        cur = groups; flip ^= 1;
     }
+    launch_merge_topk_byid(cur, nq, k, h->metric, srcD, srcI, dD, dI, h->st);
+    if (dD != D) {
+        HIPCHECK(hipMemcpyAsync(D, dD, blk * 4, hipMemcpyDefault, h->st));
+        HIPCHECK(hipMemcpyAsync(I, dI, blk * 8, hipMemcpyDefault, h->st));
+    }
+    HIPCHECK(hipStreamSynchronize(h->st));     // also keeps the round buffers alive until the merges have run
     HIPCHECK(hipGetLastError());
+}
+
+// Bulk import of one inverted list into a sharded handle: the rows are cut into N contiguous pieces like every add call
+// (piece r -> shard r, ids kept), so a FAISS / RSX1 file written from ONE index can be spread over the node while loading.
+static void sharded_add_list(rsx_index* h, int64_t l, int64_t n, const void* codes, int dtype, const int64_t* ids) {
+    if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "add_list: use rsx_add for Flat");
+    if (!ids) RSX_THROW(RSX_ERR_INVALID, "add_list: ids required");
+    if (ptr_device(codes) >= 0 || ptr_device(ids) >= 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "add_list on a sharded handle takes host pointers");
+    if (n <= 0) return;
+    const int N = (int)h->shards.size();
+    const size_t rowb = h->kind == KIND_IVFPQ ? (size_t)h->M : (size_t)h->d * (dtype == RSX_F16 ? 2 : 4);
+    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
+        const int64_t lo = n * r / N, hi = n * (r + 1) / N;
+        if (hi > lo) add_list_impl(c, l, hi - lo, (const char*)codes + (size_t)lo * rowb, dtype, ids + lo);
+    });
+    h->ntotal += n;
+}
+static void sharded_reserve(rsx_index* h, const int64_t* counts) {      // exact when every list arrives in ONE add_list call
+    const int N = (int)h->shards.size();
+    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
+        std::vector<int64_t> need((size_t)c->nlist);
+        for (int l = 0; l < c->nlist; l++)
+            need[(size_t)l] = std::max(counts[l] * (r + 1) / N - counts[l] * r / N, c->h_len[(size_t)l]);
+        ensure_capacity(c, need, true);
+    });
 }
 
 static void sharded_save(rsx_index* h, const char* path) {
@@ -1764,12 +1835,101 @@ static void sharded_save(rsx_index* h, const char* path) {
     });
 }
 
+static void destroy_handle(rsx_index* h) {
+    if (!h) return;
+    for (auto* c : h->shards) { if (c->st) { (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->st); } delete c; }
+    if (h->st) { (void)hipSetDevice(h->device); (void)hipStreamDestroy(h->st); }
+    delete h;
+}
+
+// An RSX1 file written from ONE (unsharded) index, loaded onto several devices: the lists / rows are spread over the
+// shards as they stream in (nothing is staged on one GPU first), ids are kept, so the handle answers exactly like the
+// index the file was written from.
+static rsx_index* sharded_load_plain(const char* path, int ndev, const int* devices) {
+    FILE* f = fopen(path, "rb");
+    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s", path);
+    rsx_index* p = nullptr;
+    try {
+        FileHeader hd{};
+        rd(f, &hd, sizeof(hd));
+        if (memcmp(hd.magic, "RSX1", 4) != 0) RSX_THROW(RSX_ERR_IO, "%s is not an RSX1 index file", path);
+        FileHeaderV2 h2{0, 1, 0};
+        if (hd.version >= 2) rd(f, &h2, sizeof(h2));
+        if (h2.add_list_mod > 1) RSX_THROW(RSX_ERR_UNSUPPORTED, "%s is a list shard (add_list_mod = %d): it cannot be re-sharded", path, h2.add_list_mod);
+        p = sharded_create(hd.kind, hd.d, hd.nlist, hd.M, hd.nbits, hd.metric, ndev, devices);
+        p->nprobe = hd.nprobe;
+        for (auto* c : p->shards) c->nprobe = hd.nprobe;
+        int64_t nc = 0, ncb = 0;
+        rd(f, &nc, 8);
+        std::vector<float> cen((size_t)nc); rd(f, cen.data(), (size_t)nc * 4);
+        rd(f, &ncb, 8);
+        std::vector<float> cb((size_t)ncb); rd(f, cb.data(), (size_t)ncb * 4);
+        if (nc && nc != (int64_t)p->nlist * p->d) RSX_THROW(RSX_ERR_IO, "bad centroid block");
+        if (ncb && ncb != (int64_t)p->M * 256 * p->dsub) RSX_THROW(RSX_ERR_IO, "bad codebook block");
+        for (auto* c : p->shards) {
+            HIPCHECK(hipSetDevice(c->device));
+            if (nc) set_centroids(c, cen.data());
+            if (ncb) set_codebooks(c, cb.data());
+            update_trained(c);
+            if (!hd.storage_f16 && c->kind != KIND_IVFPQ) { c->storage_f16 = 0; c->storage_decided = true; }
+        }
+        p->trained = p->shards[0]->trained;
+        std::vector<uint8_t> buf; std::vector<int64_t> ib;
+        if (p->kind == KIND_FLAT) {
+            int64_t n = 0; rd(f, &n, 8);
+            const int64_t CH = 262144;
+            const long rows_pos = ftell(f);
+            const long ids_pos = rows_pos + (long)((size_t)n * p->d * 4);
+            buf.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)) * p->d * 4); ib.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)));
+            for (int64_t r0 = 0; r0 < n; r0 += CH) {
+                const int64_t nb = std::min(CH, n - r0);
+                if (fseek(f, rows_pos + (long)((size_t)r0 * p->d * 4), SEEK_SET) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
+                rd(f, buf.data(), (size_t)nb * p->d * 4);
+                if (hd.custom_ids) {
+                    if (fseek(f, ids_pos + (long)((size_t)r0 * 8), SEEK_SET) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
+                    rd(f, ib.data(), (size_t)nb * 8);
+                }
+                sharded_add(p, nb, buf.data(), RSX_F32, hd.custom_ids ? ib.data() : nullptr);
+            }
+        } else {
+            std::vector<int64_t> lens((size_t)p->nlist);
+            const long dir_pos = ftell(f);
+            for (int l = 0; l < p->nlist; l++) {
+                int64_t n = 0; rd(f, &n, 8); lens[(size_t)l] = n;
+                const size_t pb = (p->kind == KIND_IVFPQ) ? (size_t)n * p->M : (size_t)n * p->d * 4;
+                if (n && fseek(f, (long)(pb + (size_t)n * 8), SEEK_CUR) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
+            }
+            fseek(f, dir_pos, SEEK_SET);
+            sharded_reserve(p, lens.data());
+            for (int l = 0; l < p->nlist; l++) {
+                int64_t n = 0; rd(f, &n, 8);
+                if (n == 0) continue;
+                const size_t pb = (p->kind == KIND_IVFPQ) ? (size_t)n * p->M : (size_t)n * p->d * 4;
+                buf.resize(pb); ib.resize((size_t)n);
+                rd(f, buf.data(), pb); rd(f, ib.data(), (size_t)n * 8);
+                sharded_add_list(p, l, n, buf.data(), RSX_F32, ib.data());
+            }
+        }
+        p->sh_next_id = hd.ntotal + h2.ndropped;
+    } catch (...) {
+        fclose(f);
+        destroy_handle(p);
+        throw;
+    }
+    fclose(f);
+    return p;
+}
+
 static rsx_index* sharded_load(const char* path, int ndev, const int* devices) {
     FILE* f = fopen(path, "rb");
     if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s", path);
     int32_t hdr[4] = {0, 0, 0, 0}; int64_t next = 0;
     bool ok = fread(hdr, 1, sizeof(hdr), f) == sizeof(hdr) && fread(&next, 1, 8, f) == 8;
     fclose(f);
+    if (ok && memcmp(hdr, "RSX1", 4) == 0) {      // a plain single-index file: re-shard it over the devices while loading
+        if (ndev <= 0 || !devices) RSX_THROW(RSX_ERR_INVALID, "load_sharded: need at least one device");
+        return sharded_load_plain(path, ndev, devices);
+    }
     if (!ok || memcmp(hdr, "RSXS", 4) != 0) RSX_THROW(RSX_ERR_IO, "%s is not a sharded (RSXS) index manifest", path);
     const int ns = hdr[2];
     if (ns <= 0 || ns > 64) RSX_THROW(RSX_ERR_IO, "bad shard count in %s", path);
@@ -1967,7 +2127,7 @@ int rsx_reset(rsx_index_t* h) {
 int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts) {
     return guarded([&] {
         if (!h || !counts) RSX_THROW(RSX_ERR_INVALID, "null pointer");
-        if (is_sharded(h)) RSX_THROW(RSX_ERR_UNSUPPORTED, "reserve_lists: not available on a sharded handle");
+        if (is_sharded(h)) { sharded_reserve(h, counts); return; }
         use_device(h);
         std::vector<int64_t> need(counts, counts + h->nlist);
         for (int l = 0; l < h->nlist; l++) need[(size_t)l] = std::max(need[(size_t)l], h->h_len[(size_t)l]);
@@ -1977,7 +2137,12 @@ int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts) {
 int rsx_add_list(rsx_index_t* h, int64_t list_no, int64_t n, const void* codes, int dtype, const int64_t* ids) {
     return guarded([&] {
         if (!h || (!codes && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
-        if (is_sharded(h)) RSX_THROW(RSX_ERR_UNSUPPORTED, "add_list: not available on a sharded handle");
+        if (is_sharded(h)) {
+            if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "add_list before train");
+            if (list_no < 0 || list_no >= h->nlist) RSX_THROW(RSX_ERR_INVALID, "list %lld out of range", (long long)list_no);
+            sharded_add_list(h, list_no, n, codes, dtype, ids);
+            return;
+        }
         use_device(h);
         add_list_impl(h, list_no, n, codes, dtype, ids);
     });
@@ -2088,6 +2253,12 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
             if (s == "nprobe") { *out = h->nprobe; return; }
             if (s == "is_trained") { *out = h->trained; return; }
             if (s == "hbm_bytes") { *out = 0; for (auto* c : h->shards) *out += (int64_t)(c->data.bytes + c->ids.bytes + c->norms.bytes); return; }
+            if (s == "workspace_bytes") { *out = 0; for (auto* c : h->shards) *out += workspace_bytes(c); return; }
+            if (s == "storage_dtype" && h->kind != KIND_IVFPQ) {     // fp32 as soon as ANY shard had to widen its rows
+                *out = RSX_F16;
+                for (auto* c : h->shards) if (!c->storage_f16) *out = RSX_F32;
+                return;
+            }
             h = h->shards[0];
         }
         if (s == "ntotal") *out = h->ntotal;
@@ -2105,6 +2276,7 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
         else if (s == "max_k") *out = 4096;
         else if (s == "pq_layout") *out = (h->kind == KIND_IVFPQ && h->CB == 0) ? 1 : 0;
         else if (s == "hbm_bytes") *out = (int64_t)(h->data.bytes + h->ids.bytes + h->norms.bytes);
+        else if (s == "workspace_bytes") *out = workspace_bytes(h);
         else RSX_THROW(RSX_ERR_INVALID, "unknown property '%s'", key);
     });
 }
@@ -2123,6 +2295,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
         else if (s == "pq_filter") h->pq_filter = (int)value;
         else if (s == "pq_prune") h->pq_prune = (int)value;
+        else if (s == "pq_pace") h->pq_pace = std::max(0, (int)value);
         else if (s == "add_list_mod" || s == "add_list_rem") {
             if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_UNSUPPORTED, "%s: IVF indexes only", key);
             if (h->ntotal + h->ndropped > 0) RSX_THROW(RSX_ERR_INVALID, "%s must be set before the first add", key);

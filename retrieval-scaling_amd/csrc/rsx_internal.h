@@ -230,6 +230,7 @@ struct PQScan8Args {
     // filtered output (FILTER = true): keys > tau_key[q] are appended to cand[q][0..cap)
     const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
     int prune;   // k_pq_scan_rot: skip work items none of whose queries can beat its threshold in this list (exact bound)
+    int pace;    // k_pq_scan_rot: sibling query groups of a list tile stay within `pace` loop iterations of each other (0 = free-running)
 };
 
 // Work-item decode shared by the list-major scans.  Items are ordered (list, tile, group) so that the
@@ -259,7 +260,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, int prune, hipStream_t st);
+                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, int prune, int pace, hipStream_t st);
 // survivor segment capacity per (item, wave, query): 4x what a query's CLOSEST list is expected to yield (a wave scans
 // tile/16 vectors of it, of which the pre-pass threshold lets about KP / pre_rows through), never less than 128 and never
 // more than the wave's whole share of the tile (at which point no overflow is possible)
@@ -271,7 +272,7 @@ inline int pq_scan_rot_seg_cap(int tile_rows, int KP, int pre_rows) {
     return (int)c;
 }
 inline size_t pq_scan_rot_ws(int64_t max_items, int seg_cap) {   // item records + segment counts + segment keys + per-XCD counters
-    return (size_t)(max_items + 8) * (176 + 256 + (size_t)64 * seg_cap * 8) + 1024;
+    return (size_t)(max_items + 8) * (176 + 256 + (size_t)64 * seg_cap * 8 + 4) + 1024;   // ... + per-item progress words (pacing)
 }
 // exact per-(query, list) scan of the rotated layout (fp32 table, sequential sums = oracle bits): fallback / A-B path
 int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st);

@@ -109,6 +109,10 @@ def set_default_devices(devices):
     _default_devices = devices
 
 
+def get_default_devices():
+    return _default_devices
+
+
 def _resolve_devices(device, devices):
     """-> None (single-GPU handle on `device`) or a list of device ordinals (sharded handle)."""
     if devices is None and device is None:
@@ -427,22 +431,28 @@ def write_index(index, path):
 
 def read_index(path, device=None, devices=None):
     """faiss.read_index(path): loads an RSX1 container (RSXS: the manifest of a sharded index, one shard per device), or
-    a FAISS-format file via rsx_faiss_io."""
+    a FAISS-format file via rsx_faiss_io.
+
+    A multi-device request (devices=[...] / "all", cfg.datastore.index.devices, RSX_DEVICES) on a file written from ONE
+    index — RSX1 or FAISS — RE-SHARDS it while loading: every inverted list / row block is cut over the devices as it
+    streams in (ids kept), so an index built on one GPU or handed over from FAISS is served by the whole node and answers
+    exactly as before.  (write_index on the result saves the sharded form; the next load is then direct.)"""
     path = os.fspath(path)
     with open(path, "rb") as f:
         magic = f.read(4)
-    if magic == b"RSXS":
-        devs = _resolve_devices(device, devices) or [default_device() if device is None else int(device)]
+    devs = None if device is not None else _resolve_devices(None, devices)
+    multi = devs is not None and len(devs) > 1
+    if magic == b"RSXS" or (magic == b"RSX1" and multi):
+        devs = devs or [default_device() if device is None else int(device)]
         arr = (ctypes.c_int * len(devs))(*devs)
         h = ctypes.c_void_p()
         _check(lib().rsx_load_sharded(path.encode(), len(devs), arr, ctypes.byref(h)))
         return _wrap_handle(h)
-    if device is None:                 # a plain (unsharded) file with devices=[d] or RSX_DEVICES set: its first entry
-        devs = _resolve_devices(None, devices)
-        device = devs[0] if devs else None
+    if device is None and devs:        # a one-entry device list names the device of an ordinary handle
+        device = devs[0]
     if magic != b"RSX1":
         from rsx_faiss_io import read_faiss_index
-        return read_faiss_index(path, device=device)
+        return read_faiss_index(path, device=device, devices=devs if multi else None)
     h = ctypes.c_void_p()
     _check(lib().rsx_load(path.encode(), default_device() if device is None else int(device), ctypes.byref(h)))
     return _wrap_handle(h)

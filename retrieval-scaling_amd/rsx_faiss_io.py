@@ -234,18 +234,54 @@ def index_to_parsed(index):
 
 
 def write_faiss_index(index, path):
-    data = serialize_faiss(index_to_parsed(index))
-    with open(path, "wb") as f:
-        f.write(data)
+    """rsx index -> .faiss file, STREAMED: the header blocks first, then one inverted list at a time out of HBM (a 100M x 96-byte
+    IVF-PQ index is 10.4 GB; nothing here holds more than one list on the host).  Byte-identical to
+    serialize_faiss(index_to_parsed(index))."""
+    kind = {0: "Flat", 1: "IVFFlat", 2: "IVFPQ"}[index._get("kind")]
+    if kind == "Flat":
+        data = serialize_faiss(index_to_parsed(index))
+        with open(path, "wb") as f:
+            f.write(data)
+        return
+    d, nlist = index.d, index.nlist
+    sizes = np.asarray(index.list_sizes(), dtype=np.uint64)
+    with open(path, "wb") as out:
+        out.write(b"IwFl" if kind == "IVFFlat" else b"IwPQ")
+        _w_header(out, d, index.ntotal, index.is_trained, index.metric_type)
+        out.write(struct.pack("<QQ", nlist, index.nprobe))
+        _w_flat(out, d, METRIC_INNER_PRODUCT, index.get_centroids() if index.is_trained else np.zeros((0, d), np.float32))
+        out.write(struct.pack("<B", 0))
+        _w_vector(out, np.zeros(0, np.int64), np.int64)
+        if kind == "IVFPQ":
+            out.write(struct.pack("<BQ", 1, index.M))
+            out.write(struct.pack("<QQQ", d, index.M, 8))
+            _w_vector(out, index.get_codebooks() if index.is_trained else np.zeros((index.M, 256, d // index.M), np.float32), np.float32)
+        code_size = index.M if kind == "IVFPQ" else d * 4
+        out.write(b"ilar")
+        out.write(struct.pack("<QQ", nlist, code_size))
+        if int((sizes > 0).sum()) > nlist // 2:
+            out.write(b"full")
+            _w_vector(out, sizes, np.uint64)
+        else:
+            out.write(b"sprs")
+            nz = np.nonzero(sizes)[0]
+            _w_vector(out, np.stack([nz.astype(np.uint64), sizes[nz]], 1).reshape(-1), np.uint64)
+        for l in np.nonzero(sizes)[0]:
+            c, i = index.get_list(int(l))
+            c = np.ascontiguousarray(c, dtype=np.uint8 if kind == "IVFPQ" else np.float32)
+            out.write(c.view(np.uint8).tobytes())
+            out.write(np.ascontiguousarray(i, dtype=np.int64).tobytes())
 
 
-def index_from_parsed(p, device=None):
+def index_from_parsed(p, device=None, devices=None):
+    """devices = [d0, d1, ...]: build ONE handle over several GPUs (rsx_sharded_create) — the file's lists are cut over the
+    shards as they are imported (rsx_add_list on a sharded handle), ids kept."""
     import rsx
     kind, d, metric = p["kind"], p["d"], p["metric"]
     if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
         raise RuntimeError(f"unsupported metric {metric}")
     if kind == "Flat":
-        ix = rsx.IndexFlat(d, metric, device=device)
+        ix = rsx.IndexFlat(d, metric, device=device, devices=devices)
         if len(p["vectors"]):
             ix.add(p["vectors"])
         return ix
@@ -253,11 +289,11 @@ def index_from_parsed(p, device=None):
     if q["kind"] != "Flat" or q["metric"] != METRIC_INNER_PRODUCT:
         raise RuntimeError("only IndexFlatIP coarse quantisers are supported (the reference builds no other)")
     if kind == "IVFFlat":
-        ix = rsx.IndexIVFFlat(None, d, p["nlist"], metric, device=device)
+        ix = rsx.IndexIVFFlat(None, d, p["nlist"], metric, device=device, devices=devices)
     else:
         if p["nbits"] != 8 or not p["by_residual"]:
             raise RuntimeError("only nbits = 8, by_residual IVFPQ files are supported")
-        ix = rsx.IndexIVFPQ(None, d, p["nlist"], p["M"], 8, metric, device=device)
+        ix = rsx.IndexIVFPQ(None, d, p["nlist"], p["M"], 8, metric, device=device, devices=devices)
     if len(q["vectors"]):
         ix.set_centroids(q["vectors"])
         if kind == "IVFPQ":
@@ -273,5 +309,5 @@ def index_from_parsed(p, device=None):
     return ix
 
 
-def read_faiss_index(path, device=None):
-    return index_from_parsed(parse_faiss(path), device=device)
+def read_faiss_index(path, device=None, devices=None):
+    return index_from_parsed(parse_faiss(path), device=device, devices=devices)

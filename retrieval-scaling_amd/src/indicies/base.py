@@ -28,15 +28,24 @@ class Indexer(object):
         # optional key (absent in the reference's configs -> one GPU, unchanged behaviour): cfg.datastore.index.devices =
         # [0, 1, ...] or "all" makes every engine object of this Indexer ONE handle over those GPUs (rsx_sharded_create):
         # the single index.search(all_queries, k) call of src/search.py:296 then spans the node
+        # Both selections are scoped to THIS constructor (every engine object of an Indexer is created here: read_index /
+        # _new_index) and restored afterwards, so a later Indexer whose config omits the keys does not inherit them.
         devices = self._opt("devices", None)
-        if devices is not None:
-            import rsx
-            rsx.set_default_devices(devices if isinstance(devices, str) else list(devices))
+        import rsx
+        from src.indicies import engine as _engine_sel
+        prev_devices, prev_backend = rsx.get_default_devices(), _engine_sel.backend_name()
+        rsx.set_default_devices(None if devices is None else (devices if isinstance(devices, str) else list(devices)))
         # optional keys of SURVEY 8b, same rule (absent -> the defaults preserve behaviour): `backend` selects the engine
         # module ("mi355x" | "faiss"), `storage_dtype` ("auto" | "float16") is checked once the index exists
-        from src.indicies import engine as _engine_sel
         _engine_sel.set_backend(self._opt("backend", "mi355x"))
+        self.backend = _engine_sel.backend_name()
+        try:
+            self._construct(cfg, _engine_sel)
+        finally:
+            rsx.set_default_devices(prev_devices)
+            _engine_sel.set_backend(prev_backend)
 
+    def _construct(self, cfg, _engine_sel):
         passage_dir = self.cfg.datastore.embedding.passages_dir
         index_dir, embedding_paths = get_index_dir_and_embedding_paths(cfg)
         os.makedirs(index_dir, exist_ok=True)

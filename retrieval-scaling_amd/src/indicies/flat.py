@@ -34,6 +34,7 @@ class FlatIndexer(BackendBase):
 
         if self.pos_map_save_path is not None:
             self.psg_pos_id_map = self.load_psg_pos_id_map()
+            self.prepare_passage_table()
 
     def _build_index(self):
         start_time = time.time()

@@ -233,6 +233,12 @@ class BackendBase:
         self.__dict__["_psg_table"] = tab
         return tab
 
+    def prepare_passage_table(self):
+        """Build the id -> (file, offset, length) table NOW (the backends call this at the end of construction / load): for a
+        100M-entry id map it is minutes of work and GBs of temporaries that must not land inside the first served query."""
+        if self.psg_pos_id_map is not None and self.index_id_to_db_id is not None and len(self.index_id_to_db_id):
+            self._passage_table()
+
     def _passage_fd(self, file_no, files):
         cache = self.__dict__.setdefault("_psg_fds", collections.OrderedDict())
         fd = cache.get(file_no)
@@ -292,6 +298,9 @@ class BackendBase:
         files, file_no, offset, length, n = self._passage_table()
         rows = np.where(idx < 0, idx + n, idx)                 # Python's negative indexing, made explicit (see above)
         uniq, inv = np.unique(rows, return_inverse=True)
+        missing = uniq[file_no[uniq] < 0]
+        if len(missing):                                       # the reference's dict lookup raises KeyError here (flat.py:131)
+            raise KeyError(f"passage position map has no entry for db id {self.index_id_to_db_id[int(missing[0])]}")
         order = np.lexsort((offset[uniq], file_no[uniq]))      # file by file, front to back
         texts = [None] * len(uniq)
         for u in order:

@@ -49,6 +49,7 @@ class IVFFlatIndexer(BackendBase):
 
         if self.pos_map_save_path is not None:
             self.psg_pos_id_map = self.load_psg_pos_id_map()
+            self.prepare_passage_table()
 
     # ---- engine object (overridden by IVFPQIndexer)
     def _new_index(self):

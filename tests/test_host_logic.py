@@ -380,8 +380,11 @@ def test_backend_and_storage_dtype_keys(tmp_path, orc, monkeypatch):
         cfg = make_cfg(tmp, "Flat", [0, 1])
         cfg.datastore.index["backend"] = "faiss"
         ix = Indexer(cfg)
-        assert sel.backend_name() == "faiss" and sel.engine() is fake_engine
-        assert isinstance(ix.datastore.index, fake_engine.IndexFlatIP)
+        assert ix.backend == "faiss" and isinstance(ix.datastore.index, fake_engine.IndexFlatIP)
+        # the selection is scoped to that Indexer's construction: a later Indexer without the key gets the default engine
+        assert sel.backend_name() == "mi355x"
+        import rsx as _rsx
+        assert _rsx.get_default_devices() is None
         D, I = orc.flat_search(q.astype(np.float32), np.concatenate(embs, 0).astype(np.float32), 3, 0)
         scores, passages, db_ids = ix.search(q, k=3)
         assert scores == D.tolist() and db_ids == [[[int(i) // 400, int(i) % 400] for i in row] for row in I]
