@@ -48,21 +48,11 @@ __device__ __forceinline__ uint32_t lds_rd32_volatile(uint32_t addr) {
 __device__ __forceinline__ void lds_wr32(uint32_t addr, uint32_t v) {
     *reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((uintptr_t)addr) = v;
 }
-// min over the 8 sibling-progress slots at `a` (every lane reads the same 32 bytes: a broadcast), values below `lo_ok` ignored
-__device__ __forceinline__ uint32_t sib_min8(uint32_t a, uint32_t lo_ok) {
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const u4 x = *reinterpret_cast<const volatile __attribute__((address_space(3))) u4*>((uintptr_t)a);
-    const u4 y = *reinterpret_cast<const volatile __attribute__((address_space(3))) u4*>((uintptr_t)(a + 16));
-    uint32_t m = 0x7fffffffu;
-    const uint32_t v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-#pragma unroll
-    for (int i = 0; i < 8; i++) { const uint32_t t = v[i] < lo_ok ? 0x7fffffffu : v[i]; m = t < m ? t : m; }
-    return m;
-}
 // refresh the sibling-progress slots: an LDS-DMA load (lane i -> slot i).  Issued from inline assembly on purpose: the
 // compiler then knows neither a destination register nor an LDS write, so it inserts no vmcnt wait for it — with the builtin
 // (whose LDS write may alias the raw-address table gathers) or with a load into a register it drains vmcnt, i.e. the wave's
-// whole code prefetch, at every loop iteration (measured: the scan 1.5x slower).  sib_landed() is the explicit wait.
+// whole code prefetch, wherever the value is used.  sib_landed() is the explicit wait.  sc0: bypass this CU's L1 — the
+// siblings run on the same XCD, the words only have to be coherent at its L2.
 __device__ __forceinline__ void sib_refresh(const uint32_t* gp, uint32_t lds_base) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc0" : : "v"(gp), "s"(lds_base) : "memory");
 }
@@ -189,7 +179,6 @@ extern "C" int rsx_debug_rot_wave(uint32_t* out, int n_items) {
 template <int NF, int NH, bool FILTER>
 __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ seg_keys,
                                                       uint32_t* __restrict__ seg_cnt, uint32_t* xcd_ctr, uint32_t* prog, int seg_cap, int bpw, int pace_arg, int var_arg) {
-    const int pace = pace_arg & 15;
 #ifdef RSX_MEASURE
     const int var = var_arg;        // tools/ builds only: cost-split variants (skip staging / scan / survivor path)
 #else
@@ -218,11 +207,29 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     const int ti = *A.total_items;
     const int per_xcd = (ti + 7) >> 3;
     const int xcd = blockIdx.x & 7;
-    const int xlo = xcd * per_xcd;
+    int xlo = xcd * per_xcd;
     int xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
     if (xlo >= xhi) return;
     uint32_t* ctr = xcd_ctr + xcd * 32;
+    int cx = xcd, hops = 0;      // wave 0: the range being drawn from — its own XCD's, then (work stealing) the others' in turn
     unsigned drawn = 0;          // wave 0, lane 0: the counter value of the last draw
+    // wave 0: turn the last draw into an item index; when the range is exhausted move on to the next XCD's range and draw
+    // there (the ranges hold equal item COUNTS, not equal work: measured finish times of the 8 XCDs spread by 10 % of the
+    // kernel; a stolen item loses its L2 neighbourhood, which only matters for the last few)
+    auto resolve_draw = [&]() -> int {
+        for (;;) {
+            const int i = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+            if (i < xhi) return i;
+            if (hops >= 7) return 0x7fffffff;
+            hops++;
+            cx = (cx + 1) & 7;
+            xlo = cx * per_xcd;
+            xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
+            ctr = xcd_ctr + cx * 32;
+            if (xlo >= xhi) { drawn = 0u; xlo = 0; xhi = 0; continue; }
+            if (lane == 0) drawn = atomicAdd(ctr, 1u);
+        }
+    };
     // ---- per-lane constants, once per workgroup: rotation bytes, the one-hot B operand, the survivor-queue geometry
     uint32_t R0[NR0 > 0 ? NR0 : 1], R1[NR1 > 0 ? NR1 : 1];
 #pragma unroll
@@ -263,9 +270,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     int item = 0;
     if (w == 0) {
         if (lane == 0) { drawn = atomicAdd(ctr, 1u); }
-        item = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+        item = resolve_draw();
         uint4 r0 = make_uint4(0xffffffffu, 0, 0, 0);       // l = -1: end marker
-        if (lane < 11 && item < xhi) r0 = reinterpret_cast<const uint4*>(&items[item])[lane];
+        if (lane < 11 && item != 0x7fffffff) r0 = reinterpret_cast<const uint4*>(&items[item])[lane];
         if (lane < 11) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
         if (lane == 0) islot[0].pad0 = item;
     }
@@ -299,18 +306,22 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         // wave 0 requests here (LDS-DMA, lane i -> slot i) and reads after its share of the table staging.
         const int join_on = (pace_arg >> 7) & 1;
         int f0 = item - ((np_raw >> 4) & 0x3fff), f1 = f0 + ((np_raw >> 18) & 0x3fff);
-        if (f0 < xlo) f0 = xlo;
-        if (f1 > xhi) f1 = xhi;
+        {   // a family stays inside the item's own XCD range (its other part runs on another XCD: no shared L2)
+            const int rlo = (item / per_xcd) * per_xcd;
+            int rhi = rlo + per_xcd; if (rhi > ti) rhi = ti;
+            if (f0 < rlo) f0 = rlo;
+            if (f1 > rhi) f1 = rhi;
+        }
         if (f1 - f0 > 8) {                    // the 8-item window around this item (one 32-byte LDS read)
             int a0 = item - 3;
             if (a0 < f0) a0 = f0;
             if (a0 > f1 - 8) a0 = f1 - 8;
             f0 = a0; f1 = a0 + 8;
         }
-        constexpr uint32_t allowed_a = (uint32_t)(TAB + 2 * 176);                  // LDS word: iterations the workgroup may START (brake)
+        constexpr uint32_t chunk_a = (uint32_t)(TAB + 2 * 176);                    // LDS word: next unassigned chunk sequence number
         constexpr uint32_t i0_a = (uint32_t)(TAB + 2 * 176 + 4);                   // LDS word: the item's first loop iteration (join)
         constexpr uint32_t sib_a = (uint32_t)(TAB + 384);                          // LDS [8]: the siblings' progress as last seen
-        const bool family = (pace > 0 || join_on) && !skip_item && f1 - f0 > 1 && item >= f0 && item < f1;
+        const bool family = join_on && !skip_item && f1 - f0 > 1 && item >= f0 && item < f1;
         if (w == 0) {
             if (lane < 8) lds_wr32(sib_a + 4u * (uint32_t)lane, 0x7fffffffu);       // own slot and the lanes beyond the family never count
             if (family && f0 + lane < f1 && f0 + lane != item) sib_refresh(&prog[f0 + lane], sib_a);
@@ -356,20 +367,11 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             if (nb0 < 0) nb0 = 0;
             nit0 = (nb0 + ROT_D - 1) / ROT_D;
         }
-        // ---- PACING (round 3): the sibling groups of a list tile (the item's family) run on different CUs of this XCD and read
-        // the same code lines; a line stays ~5 us in the XCD's L2, so the siblings must stay within a couple of loop iterations
-        // (16 waves x ROT_D blocks = 96 KiB of codes each) of each other for the followers to hit.  Wave 0 publishes the
-        // iteration it starts (prog[item], agent-scope store), sees the siblings' progress through LDS slots that an LDS-DMA
-        // load refreshes every iteration (no register destination -> no vmcnt wait in front of the wave's code prefetch; a
-        // slot may be an iteration or two stale, which only under-estimates a sibling: conservative), and lets the
-        // workgroup start iteration itx only while itx < min(close siblings' progress) + pace — a brake on whoever is ahead,
-        // never a barrier: at most 2 polls (~1 us each) per iteration and 12 per item, siblings more than pace + 2
-        // iterations behind are ignored (a late starter is lost to the L2 anyway).  Placement and timing never affect
-        // results, and a sibling that is not running cannot stall anyone for long.
-        const bool prio_rot = !((pace_arg >> 4) & 4);      // diagnostics: bit 2 of the flags switches the priority rotation off
-        const int pflags = (pace_arg >> 4) & 7;            // diagnostics (tools only): 1 = waves do not follow `allowed`, 2 = wave 0 does not brake
-        const bool paced = pace > 0 && family && nit0 > 1;
-        int pace_budget = 12;                 // wave 0: polls (~1 us each) left for this item
+        const bool prio_rot = !((pace_arg >> 4) & 4);      // diagnostics: bit 6 of pq_pace switches the priority rotation off
+        // bit 4 of pq_pace: dynamic chunk distribution (an LDS counter instead of the static column = wave split).  Measured at
+        // the bench size: it equalises the waves' finish times (45 .. 57 us -> all 60 us) and leaves the item time unchanged —
+        // the CU's LDS + MFMA throughput is the bound, not the ragged tail — so the static split stays the default.
+        const bool dyn_on = ((pace_arg >> 4) & 1) != 0;
 #ifdef RSX_MEASURE
         if (tid == 0 && item < 65536) {
             g_rot_trace[4 * item + 0] = wall_clock64();
@@ -378,19 +380,18 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         }
 #endif
         if (w == 0) {
-            if (lane == 0) lds_wr32(allowed_a, paced ? (uint32_t)pace : 0x7fffffffu);
             uint32_t i0v = 0;
             if (family) {
                 sib_landed();                 // the progress words requested before the staging (the wave's table loads are older: no extra wait)
                 if (join_on) {
                     // most advanced sibling still on its first pass (bit 30 marks a wrapped one, 0 = not started, 0x7fffffff = done);
-                    // its word is a few microseconds old by the time this workgroup scans: start `ahead` iterations further on
+                    // its word is a few microseconds old by the time this workgroup scans: start `ahead` rows further on
                     const uint32_t best = sib_max8_first_pass(sib_a);
                     int ahead = (pace_arg >> 8) & 15; if (ahead == 0) ahead = 2;
-                    if (best != 0u && (int)best - 1 + ahead + 2 < nit0) i0v = best - 1u + (uint32_t)ahead;
+                    if (best != 0u && (int)best - 1 + ahead + 2 < nit0 - 1) i0v = best - 1u + (uint32_t)ahead;
                 }
             }
-            if (lane == 0) lds_wr32(i0_a, i0v);
+            if (lane == 0) { lds_wr32(i0_a, i0v); lds_wr32(chunk_a, 32u); }     // chunk sequence numbers 0..31 are pre-assigned
         }
         // ---- the lane's share of the item record: accumulator init, score parameters of the query it owns (n < 4)
         const int cinit = FILTER ? (n < 4 ? it->cinit[nq4] : -(1 << 30)) : 0;
@@ -404,32 +405,52 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         const uint64_t t_scan0 = wall_clock64();
 #endif
 
-        // ---- scan: blocks tb0 + w + 16 j, j < nbw, ROT_D of them in flight, iterations in circular order from i0w
-        int nbw = ((var & 2) || skip_item) ? 0 : (nblk - tb0 - w + 15) >> 4;       // this wave's blocks of the tile
-        if (nbw > bpw) nbw = bpw;
-        if (nbw < 0) nbw = 0;
-        const int nitw = (nbw + ROT_D - 1) / ROT_D;
-        int i0w = join_on ? (int)__builtin_amdgcn_readfirstlane((int)lds_rd32_volatile(i0_a)) : 0;
-        if (i0w >= nitw) i0w = 0;
+        // ---- scan.  The tile is a grid of CHUNKS: chunk (row r, column c) = the ROT_D blocks tb0 + c + 16 (r ROT_D + dd), i.e. the
+        // blocks column c of the 16 would scan in loop iteration r of a static round-robin.  Rows 0 .. R-1 are full, the last row
+        // has cl <= 16 non-empty chunks.  Chunks are taken in SEQUENCE order n = 0, 1, ...: the full rows circularly from row r0
+        // (the join position), the partial row last; column = n % 16.  Wave w takes the sequence numbers w, 16 + w, 32 + w, ...
+        // (static split), or — dyn_on — its first two statically and every further one from an LDS counter, one loop iteration
+        // ahead of its use.  Each wave keeps ROT_D blocks in flight: while chunk A is scanned its register slots are refilled
+        // with chunk B's blocks.
+        int nb0 = ((var & 2) || skip_item) ? 0 : (nblk - tb0 + 15) >> 4;           // blocks of column 0 (the longest column)
+        if (nb0 > bpw) nb0 = bpw;
+        if (nb0 < 0) nb0 = 0;
+        const int nrow = (nb0 + ROT_D - 1) / ROT_D;                                // = nit0
+        const int R = nrow > 0 ? nrow - 1 : 0;                                     // full rows
+        int cl = nrow > 0 ? nblk - tb0 - 16 * (R * ROT_D) : 0;                     // non-empty chunks of the last row
+        if (cl > 16) cl = 16;
+        if (cl < 0) cl = 0;
+        const int nch = 16 * R + cl;
+        int r0 = join_on ? (int)__builtin_amdgcn_readfirstlane((int)lds_rd32_volatile(i0_a)) : 0;
+        if (r0 >= R) r0 = 0;
         const int so_oob = nblk * (16 * M);                                        // past the descriptor's end: reads zeros
+        // sequence number -> byte offset of the chunk's first block (so_oob: no such chunk), its row, and whether it is on the second pass
+        auto chunk_of = [&](int nseq, int& row, bool& wrapped) -> int {
+            if (nseq >= nch) { row = 0; wrapped = true; return so_oob; }
+            int r = nseq >> 4;
+            if (r < R) { r += r0; wrapped = r >= R; if (wrapped) r -= R; } else { r = R; wrapped = r0 > 0; }
+            row = r;
+            return (tb0 + (nseq & 15) + 16 * (r * ROT_D)) * (16 * M);
+        };
+        int nA = w, nB = 16 + w, nC = 0x7fffffff;
+        int rowA = 0, rowB = 0; bool wrapA = false, wrapB = false;
+        int soA = chunk_of(nA, rowA, wrapA), soB = chunk_of(nB, rowB, wrapB);
 #pragma unroll
-        for (int dd = 0; dd < ROT_D; dd++) {     // the first ROT_D blocks of this wave
-            const int so = nitw > 0 ? (tb0 + w + 16 * (i0w * ROT_D + dd)) * (16 * M) : so_oob;
+        for (int dd = 0; dd < ROT_D; dd++) {     // chunk A's blocks
+            const int so = soA == so_oob ? so_oob : soA + dd * 16 * (16 * M);
 #pragma unroll
             for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
             if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
         }
 #pragma unroll 1
-        for (int k = 0; k < nitw; k++) {
-            int itx = i0w + k; if (itx >= nitw) itx -= nitw;
-            int nxt = itx + 1; if (nxt >= nitw) nxt = 0;
-            const bool wrapped = itx < i0w;
-            const int j0 = itx * ROT_D;
-            const int so_next = (k + 1 < nitw) ? (tb0 + w + 16 * (nxt * ROT_D)) * (16 * M) : so_oob;
+        for (int k = 0; nA < nch; k++) {
+            // the chunk after next: drawn now, needed at the end of this iteration
+            if (dyn_on) { if (lane == 0) nC = (int)__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + chunk_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            else nC = nB + 16;
+            const int b0 = soA / (16 * M);                                         // first block of chunk A
+            const int so_next = soB;
             if (prio_rot) {
-                // the four waves of a SIMD (w, w + 4, w + 8, w + 12) take turns at the top issue priority, one loop iteration each:
-                // with equal priorities the arbiter serves the OLDEST wave first, so wave w ran its share in 33 us and wave
-                // w + 12 needed 58 us (measured per wave) — the tail of every item ran one wave per SIMD deep.
+                // the four waves of a SIMD (w, w + 4, w + 8, w + 12) take turns at the top issue priority, one loop iteration each
                 switch ((k + (w >> 2)) & 3) {
                     case 0: __builtin_amdgcn_s_setprio(3); break;
                     case 1: __builtin_amdgcn_s_setprio(2); break;
@@ -437,55 +458,23 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                     default: __builtin_amdgcn_s_setprio(0); break;
                 }
             }
-            if (family && w == 0 && !paced && lane == 0)      // join without brake: the progress word is still published
-                __hip_atomic_store(&prog[item], (uint32_t)(itx + 1) | (wrapped ? 0x40000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (paced && wrapped) {
-                if (w == 0 && lane == 0) {
-                    lds_wr32(allowed_a, 0x7fffffffu);             // second pass: nobody to keep pace with
-                    __hip_atomic_store(&prog[item], (uint32_t)(itx + 1) | 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            } else if (paced) {
-                if (w == 0) {
-                    // progress word: the siblings share this XCD's L2, so L2-level visibility is all that is needed — a plain store
-                    // (the vector L1 is write-through) and loads that bypass the L1 (sc0).  A device-scope store (sc1) writes
-                    // through to the fabric and its late acknowledgement holds the wave's in-order vmcnt queue, i.e. every code
-                    // load behind it (measured: the scan 1.45x slower with one such store per iteration).
-                    if (lane == 0) __hip_atomic_store(&prog[item], (uint32_t)(itx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    // a sibling constrains only while it is within catch-up range (<= pace + 2 iterations behind, not-yet-started
-                    // ones included while this workgroup is that young): a late starter is lost to the L2 anyway
-                    const uint32_t lo_ok = (uint32_t)(itx + 1) > (uint32_t)(pace + 2) ? (uint32_t)(itx + 1) - (uint32_t)(pace + 2) : 0u;
-                    uint32_t mn = sib_min8(sib_a, lo_ok);     // one broadcast LDS read of the 8 slots, VALU min: no cross-lane traffic
-                    int polls = 0;
-                    while ((uint32_t)itx >= mn + (uint32_t)pace && polls < 2 && pace_budget > 0 && !(pflags & 2)) {   // ahead of a close sibling: brake
-                        __builtin_amdgcn_s_sleep(8);
-                        polls++; pace_budget--;
-                        if (f0 + lane < f1 && f0 + lane != item) sib_refresh(&prog[f0 + lane], sib_a);
-                        sib_landed();         // the brake path only: a fresh view costs the wave its prefetch depth once
-                        mn = sib_min8(sib_a, lo_ok);
-                    }
-                    // the other waves may run one iteration ahead of wave 0, never further than the pacing allows
-                    uint32_t al = mn + (uint32_t)pace;
-                    if (al < (uint32_t)itx + 2u) al = (uint32_t)itx + 2u;
-                    if (pace_budget <= 0) al = 0x7fffffffu;                                            // budget spent: the item runs free
-                    if (lane == 0) lds_wr32(allowed_a, al);
-                    // refresh the slots for the next iteration (never waited for: a stale slot only under-estimates a sibling)
-                    if (pace_budget > 0 && f0 + lane < f1 && f0 + lane != item) sib_refresh(&prog[f0 + lane], sib_a);
-                } else if (!(pflags & 1)) {
-                    int spins = 0;
-                    while ((uint32_t)itx >= lds_rd32_volatile(allowed_a) && spins < 4096) { __builtin_amdgcn_s_sleep(2); spins++; }
-                }
-            }
             if (w == 0) {
-                if (dstate == 1 && k >= nit0 - 1) {
-                    i1 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
-                    if (lane < 11 && i1 < xhi) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
+                // progress word for joining siblings: the row this workgroup is on.  The siblings share this XCD's L2, so L2-level
+                // visibility is all that is needed — a plain store (the vector L1 is write-through) and readers that bypass their
+                // L1 (sc0).  A device-scope store (sc1) writes through to the fabric and its late acknowledgement holds the wave's
+                // in-order vmcnt queue, i.e. every code load behind it (measured: the scan 1.45x slower with one per iteration).
+                if (family && lane == 0)
+                    __hip_atomic_store(&prog[item], (uint32_t)(rowA + 1) | (wrapA ? 0x40000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dstate == 1 && nA >= nch - 16) {
+                    i1 = resolve_draw();
+                    if (lane < 11 && i1 != 0x7fffffff) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
                     dstate = 2;
                 }
-                if (dstate == 0 && k >= nit0 - 3) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }
+                if (dstate == 0 && nA >= nch - 48) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }
             }
 #pragma unroll
             for (int dd = 0; dd < ROT_D; dd++) {
-                const int b = tb0 + w + 16 * (j0 + dd);
+                const int b = b0 + 16 * dd;
                 uint32_t gv[NG];
                 // addresses: (plane << 16) | (code << 8) | rotation byte — one v_perm each
                 if (NF >= 1) {
@@ -557,6 +546,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                     }
                 }
             }
+            nA = nB; soA = soB; rowA = rowB; wrapA = wrapB;
+            nB = __builtin_amdgcn_readfirstlane(nC);
+            soB = chunk_of(nB, rowB, wrapB);
         }
         // ---- item epilogue: the wave's four survivor counts leave with one store (lanes 0..3 own queries 0..3); wave 0 parks
         // the next record (or the end marker) and draws the index of the item after it
@@ -564,17 +556,15 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         if (FILTER && lane < 4) seg_cnt[((size_t)item * 16 + w) * 4 + lane] = qcnt;
 #ifdef RSX_MEASURE
         if (lane == 0 && item < 16384) g_rot_wave[16 * item + w] = (uint32_t)(wall_clock64() - t_scan0);
-        if (tid == 0 && item < 65536) g_rot_trace[4 * item + 1] = wall_clock64() | ((uint64_t)(12 - pace_budget) << 56);
+        if (tid == 0 && item < 65536) g_rot_trace[4 * item + 1] = wall_clock64();
 #endif
-        if (w == 0 && lane == 0) {
-            lds_wr32(allowed_a, 0x7fffffffu);                                                // wave 0 is through: nobody waits on it
-            if (pace > 0) __hip_atomic_store(&prog[item], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (w == 0 && lane == 0 && join_on)       // done: no sibling joins this item any more
+            __hip_atomic_store(&prog[item], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (w == 0) {
             if (dstate == 0) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }     // empty / pruned / one-iteration items
             if (dstate == 1) {
-                i1 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
-                if (lane < 11 && i1 < xhi) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
+                i1 = resolve_draw();
+                if (lane < 11 && i1 != 0x7fffffff) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
             }
             if (lane < 11) reinterpret_cast<uint4*>(&islot[buf ^ 1])[lane] = pre;
             if (lane == 0) islot[buf ^ 1].pad0 = i1;

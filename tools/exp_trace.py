@@ -90,6 +90,11 @@ def main():
                                "items_per_wg_mean": round(float(np.mean(nitems)), 1), "first_start_us_mean": round(float(np.mean(first)), 1),
                                "idle_tail_us_mean": round(float(np.mean(lastend)), 1), "idle_tail_us_max": round(float(np.max(lastend)), 1),
                                "gap_per_item_us": round(float(np.sum(gaps) / max(1, np.sum(nitems) - len(nitems))), 2)})
+    xc = blk[ks] & 7
+    out["per_xcd"] = {"items": [int((xc == x).sum()) for x in range(8)],
+                      "busy_ms": [round(float(((end[ks] - start[ks])[xc == x]).sum() * 1e-5), 2) for x in range(8)],
+                      "finish_us": [round(float((end[ks][xc == x].max() - lt0) * 0.01), 1) for x in range(8)],
+                      "first_wg_done_us": [round(float(min(end[ks[(blk[ks] == b)]].max() for b in np.unique(blk[ks][xc == x])) - lt0) * 0.01, 1) for x in range(8)]}
     wv = np.zeros((16384, 16), dtype=np.uint32)
     if hasattr(L, "rsx_debug_rot_wave") and L.rsx_debug_rot_wave(wv.ctypes.data_as(ctypes.c_void_p), 16384) == 0:
         sel = ks[(ks < 16384)]
