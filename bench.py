@@ -464,7 +464,7 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]   # "--": bench flags such as --n are not the launcher's
     log("self-launch:", " ".join(cmd))
     return subprocess.call(cmd, env=env)
 

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
         // cinit = -(that threshold - 128 M): the block's result is then >= 0 exactly for the survivors.
         int thr = INT_MIN;
         if (k >= d.np) thr = INT_MAX;
+        else if (FILTER && tile == 0 && A.excl && A.excl[q] == (uint16_t)(0x8000 | (pi - (int)q * a.nprobe))) thr = INT_MAX;   // emitted by the pre-pass
         else if (FILTER && tau != 0ull) {
             const float ts = key_score(tau);
             // p.pad = the largest sum this query's table can give any code vector (<= 255 M): nothing in this list can
@@ -665,7 +666,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws, int seg_cap, int prune, int pace, hipStream_t st) {
+                       int cand_cap, void* item_ws, int seg_cap, int prune, int pace, const uint16_t* excl, hipStream_t st) {
     if (a.CB != 0 || !item_ws || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8t; A.qp = (const PQQParam*)qparam;
@@ -673,7 +674,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
     A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap;
-    A.prune = prune; A.pace = pace;
+    A.prune = prune; A.pace = pace; A.excl = excl;
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
     switch (a.M) {

@@ -139,13 +139,13 @@ __device__ inline void bitonic_sort_desc_wg(uint64_t* buf, int n, int tid, int n
 
 // Top-KP (sorted descending into obuf, zero padded) of the N keys key_at(0..N-1) by a workgroup of NT threads.
 // hist: 256 ints, ctl: 8 ints of LDS.  Zero keys are "no element".
-// ONLY_KTH: just a threshold is wanted — obuf[KP - 1] receives a lower bound of the KP-th largest key that no unselected key
-// reaches (the radix prefix; 0 when there are not more than KP keys), the other slots stay zero: no compaction, no sort.
+// ONLY_KTH: just a threshold is wanted — obuf[0] (the only slot touched) receives a lower bound of the KP-th largest key that
+// no unselected key reaches (the radix prefix; 0 when there are not more than KP keys): no compaction, no sort.
 template <int NT, bool ONLY_KTH = false, class KeyAt>
 __device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf, int32_t* hist, int32_t* ctl) {
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 8) ctl[tid] = 0;          // [0] digit, [1] remaining, [2] valid count, [3] output cursor, [4] keys in the digit's bin
-    for (int i = tid; i < KP; i += NT) obuf[i] = 0;
+    if (!ONLY_KTH) for (int i = tid; i < KP; i += NT) obuf[i] = 0;
     __syncthreads();
     int myvalid = 0;
     for (int i = tid; i < N; i += NT) myvalid += key_at(i) != 0ull;
@@ -196,8 +196,8 @@ __device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf
         }
         kth = prefix;                                   // low bits zero after an early exit: a lower bound of those keys
     }
-    if (ONLY_KTH) {
-        if (tid == 0) obuf[KP - 1] = V > KP ? kth : 0ull;
+    if (ONLY_KTH) {     // obuf[0]: the threshold; 0 = the row holds no more than KP keys (no threshold), 1 = exactly KP valid keys
+        if (tid == 0) obuf[0] = V > KP ? kth : 0ull;
         __syncthreads();
         return;
     }
@@ -242,11 +242,11 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t pp_smem[];
-    uint64_t* keys = pp_smem;                                        // [pre_rows]
-    uint64_t* obuf = keys + a.pre_rows;                              // [KP]
-    int32_t* hist = reinterpret_cast<int32_t*>(obuf + a.KP);         // [256]
+    uint64_t* obuf = pp_smem;                                        // [2]
+    int32_t* hist = reinterpret_cast<int32_t*>(obuf + 2);            // [256]
     int32_t* ctl = hist + 256;                                       // [8]
     uint8_t* tab = reinterpret_cast<uint8_t*>(ctl + 8);              // [Mpad][256]
+    uint16_t* sums = reinterpret_cast<uint16_t*>(tab + (size_t)a.Mpad * 256);   // [pre_rows]: integer table sum + 1 (0 = no vector)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t q = blockIdx.x;
     // the closest probed list that holds vectors HERE (in a list-sharded index most probes hit other ranks' lists)
@@ -298,8 +298,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
             acc += __shfl_xor(acc, 32);
             if (g == 0) {
                 const int64_t pos = (int64_t)b * 16 + i;
-                const float sc = dis0 + __fmaf_rn(scale, (float)acc, bias);
-                keys[pos] = (pos < len) ? make_key(sc, (uint32_t)(col + pos)) : 0ull;
+                sums[pos] = (pos < len) ? (uint16_t)(acc + 1u) : (uint16_t)0;
             }
         }
     } else
@@ -314,19 +313,73 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
             for (int b = 0; b < 16; b++) acc += tg[b * 256 + ((wds[b >> 2] >> (8 * (b & 3))) & 255u)];
         }
         const int64_t pos = (int64_t)s * 64 + lane;
-        const float sc = dis0 + __fmaf_rn(scale, (float)acc, bias);
-        keys[pos] = (pos < len) ? make_key(sc, (uint32_t)(col + pos)) : 0ull;
+        sums[pos] = (pos < len) ? (uint16_t)(acc + 1u) : (uint16_t)0;
     }
     __syncthreads();
-    auto key_at = [&](int i) -> uint64_t { return keys[i]; };
-    radix_topk_wg<1024, true>(key_at, nslab * 64, a.KP, obuf, hist, ctl);      // the pre-pass only has to produce a threshold
+    // The approximate score dis0 + fma(scale, S, bias) is monotone in the integer sum S: the k-th best score of the sample
+    // is the score of the k-th largest S (a 16-bit radix walk).  Round 3 — threshold by CONSTRUCTION instead of by the K'-th
+    // sample key: the sample holds k vectors with approximate score >= a_k, hence exact score >= a_k - eps, so the query's
+    // exact k-th best score is >= a_k - eps; a vector with approximate score < tau = a_k - 2 eps has exact score
+    // < a_k - eps and cannot be among the top k.  Every vector the scan drops is therefore provably irrelevant, for any k,
+    // and the candidate count is what the data needs (measured: ~130 for k = 10, ~2300 for k = 1000) instead of a guess.
+    auto key_at = [&](int i) -> uint64_t { return (uint64_t)sums[i] << 48; };
+    radix_topk_wg<1024, true>(key_at, nslab * 64, a.k, obuf, hist, ctl);
     uint64_t* o = a.state + q * a.KP;
-    for (int i = tid; i < a.KP; i += 1024) o[i] = (i == a.KP - 1) ? obuf[i] : 0ull;
-    if (tid == 0) a.cand_cnt[q * CCS] = 0ull;
+    for (int i = tid; i < a.KP; i += 1024) o[i] = 0ull;              // the candidate merge starts from an empty state
+    if (tid == 0) {
+        uint64_t tau = 0ull;                                          // fewer than k sample vectors: no threshold
+        const uint64_t kth = obuf[0];
+        if (kth != 0ull) {
+            const float eps = a.qparam[q * 4 + 2];
+            const float a_k = dis0 + __fmaf_rn(scale, (float)((int)(kth >> 48) - 1), bias);   // kth: a lower bound of the k-th largest (S + 1)
+            float t = __fmaf_rn(-2.0002f, eps, a_k);
+            t -= fabsf(t) * 4.8e-7f + 1e-30f;                         // two ulps down: the subtraction's own rounding
+            tau = make_key(t, 0xFFFFFFFFu);                           // low word 0: every key with score >= t compares greater
+        }
+        a.tau[q] = tau;
+        // integer form of the threshold (the score is monotone in S): smallest S whose score reaches it
+        int sthr = 0;
+        if (tau != 0ull) {
+            const float ts = key_score(tau);
+            int b0 = 0, b1 = 255 * a.Mpad + 1;
+            while (b0 < b1) { const int mid = (b0 + b1) >> 1; if (dis0 + __fmaf_rn(scale, (float)mid, bias) >= ts) b1 = mid; else b0 = mid + 1; }
+            sthr = b0;
+        }
+        ctl[5] = sthr; ctl[6] = 0;
+    }
+    __syncthreads();
+    // Emission (round 3): when the sample covers the whole first scan tile of this list, the sample's own candidates leave
+    // from HERE — one workgroup per query, no contention — and the scan is told to drop this (query, list, tile 0): for
+    // large k almost every candidate of a query sits in its closest list, far more than a scan wave's survivor segment holds.
+    const int64_t tile0 = len < a.tile_rows ? len : a.tile_rows;
+    const bool emit = a.cand != nullptr && l >= 0 && tile0 <= (int64_t)n;
+    if (emit) {
+        const int sthr = ctl[5];
+        uint64_t* dst = a.cand + q * a.cand_cap;
+        const int ne = (int)tile0;              // exactly the rows of tile 0: the scan still covers the list's other tiles
+        for (int i0 = 0; i0 < ne; i0 += 1024) {
+            const int i = i0 + tid;
+            const int sv = i < ne ? (int)sums[i] : 0;
+            const bool pass = sv != 0 && sv - 1 >= sthr;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&ctl[6], __builtin_popcountll(m));
+            base = __shfl(base, 0);
+            if (pass) {
+                const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pos < a.cand_cap) dst[pos] = make_key(dis0 + __fmaf_rn(scale, (float)(sv - 1), bias), (uint32_t)(col + i));
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.cand_cnt[q * CCS] = emit ? (unsigned long long)ctl[6] : 0ull;
+        if (a.excl) a.excl[q] = (uint16_t)(emit ? (0x8000 | j0) : 0);
+    }
 }
 void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
     if (nq <= 0) return;
-    size_t shm = (size_t)a.pre_rows * 8 + (size_t)a.KP * 8 + 264 * 4 + (size_t)a.Mpad * 256;
+    size_t shm = 16 + 264 * 4 + (size_t)a.Mpad * 256 + (size_t)a.pre_rows * 2 + 64;
     static DevSize attr;
     attr.grow(shm, [&] { hipFuncSetAttribute((const void*)k_pq_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
     hipLaunchKernelGGL(k_pq_prepass, dim3((unsigned)nq), dim3(1024), shm, st, a);
@@ -340,7 +393,7 @@ static bool select_radix_applies(const SelectArgs& a) {
     // probe selection (4096 scores -> 32 keys: k_select's buffer hardly ever needs a second sort there)
     // ... unless only a few rows are in flight (latency path): 256 threads per row instead of one wave
     return !off && (a.keep_last || a.in_is_keys || a.nrows <= 16) && a.nseg == 1 && a.seg_base == 0 && !a.tau_ptr && a.n_uniform > 0 &&
-           a.n_uniform <= 16384 && a.KP <= 4096;
+           (a.n_uniform <= 16384 || (a.in_is_keys && a.row_n && a.n_uniform <= 65536)) && a.KP <= 4096;
 }
 
 void launch_select(const SelectArgs& a, hipStream_t st) {
@@ -877,7 +930,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             float s_k = have_k ? ord2f(sord[a.k - 1]) : -__builtin_inff();
             if (!(a_last + eps < s_k)) bad = 1;
         }
-        if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad = 1;   // candidates were dropped
+        if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad |= 2;  // candidates were dropped (reason bit 1: overflow)
         a.uncertain[q] = bad;
     }
     if (a.kind != KIND_IVFPQ && a.uncertain) {

@@ -188,7 +188,7 @@ struct rsx_index {
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl;
     std::map<std::string, double> timing;
 
     // Flat / IVF-Flat: largest |x|^2 ever added (certificate of the MFMA scan); device copy is the running atomic max
@@ -219,7 +219,7 @@ static int64_t workspace_bytes(const rsx_index* h) {
     const DevBuf* bufs[] = {&h->w_q32, &h->w_q16, &h->w_coarse, &h->w_keys1, &h->w_probekeys, &h->w_probelist, &h->w_dis0, &h->w_segstart,
                             &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
                             &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
-                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->sh_D, &h->sh_I, &h->sh_q,
+                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->sh_D, &h->sh_I, &h->sh_q,
                             &h->sh_oD, &h->sh_oI};
     int64_t t = 0;
     for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
@@ -705,7 +705,12 @@ struct StageTimer {
 
 static void kp_for(const rsx_index* h, int k, bool fast, int& KP, int& BUF) {
     int want;
-    if (h->kind == KIND_IVFPQ && fast) want = h->pq_fast_kp > 0 ? std::max(k, h->pq_fast_kp) : k + std::max(118, k / 2);
+    // fast IVF-PQ scan: K' = the candidates re-scored exactly per query.  With the round-3 threshold (k_pq_prepass: the sample's
+    // k-th best approximate score minus 2 eps) the scan admits what the data needs — measured on the bench mixture ~130 keys
+    // for k = 10, ~500 for k = 100, ~2300 for k = 1000, ~3400 for k = 2000 — and K' only has to hold them: 3k, at least
+    // k + 118, at most 4096 (k_finalize sorts K' candidates in LDS).  A query with more candidates keeps its best K' by
+    // approximate score and is still certified against the K'-th one (k_finalize) or re-run exactly.
+    if (h->kind == KIND_IVFPQ && fast) want = h->pq_fast_kp > 0 ? std::max(k, h->pq_fast_kp) : std::min(4096, std::max(k + 118, 3 * k));
     else if (h->kind == KIND_IVFPQ) want = (k >= 512) ? k : k + 4;
     else want = k + std::max(8, k / 16);
     KP = std::max(16, pow2ceil(want));
@@ -809,7 +814,9 @@ static void rerun_uncertified(rsx_index* h, int64_t nq, const void* dq, int dtyp
     const int d = h->d;
     const size_t esz = dtype == RSX_F16 ? 2 : 4;
     std::vector<int64_t> badq;
-    for (int64_t q = 0; q < nq; q++) if (bad[(size_t)q]) badq.push_back(q);
+    int64_t n_over = 0;
+    for (int64_t q = 0; q < nq; q++) if (bad[(size_t)q]) { badq.push_back(q); n_over += (bad[(size_t)q] & 2) != 0; }
+    h->timing["fallback_overflow_queries"] += (double)n_over;     // of the fallbacks: candidate buffer / survivor segment overflows
     const int64_t nbad = (int64_t)badq.size();
     h->timing["fallback_queries"] += (double)nbad;
     h->timing["fast_queries"] += (double)nq;
@@ -1106,13 +1113,23 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 while (pre_vpl > 1 && 64 * 16 * pre_vpl < KP * 4) pre_vpl *= 2;   // ... but well above K' candidates
                 if (pre_vpl > vpl) pre_vpl = vpl;
             }
-            const int pre_rows = filtered ? 64 * 16 * pre_vpl : tile_rows;
-            // one-launch pre-pass (k_pq_prepass: score the prefix with byte gathers on the query's own 24 KiB table,
-            // select the K'-th key in LDS) when its LDS footprint allows; else grouping + k_pq_scan8 + selection
-            const bool fused_pre = filtered && h->pq_prepass_fused != 0 &&
-                                   (size_t)pre_rows * 8 + (size_t)KP * 8 + (size_t)h->Mpad * 256 + 2048 <= 150 * 1024;
+            int pre_rows = filtered ? 64 * 16 * pre_vpl : tile_rows;
+            // one-launch pre-pass (k_pq_prepass: score a prefix of the closest list with byte gathers on the query's own table,
+            // 16-bit integer sums in LDS, k-th largest by a radix walk -> threshold a_k - 2 eps) when its LDS footprint allows;
+            // else grouping + scan of the prefix + selection (K'-th key of the prefix as the threshold)
+            bool fused_pre = filtered && h->pq_prepass_fused != 0;
             if (fused_pre) {
-                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
+                // the sample's k-th best score is the threshold: the sample must be a large part of the closest list once k is large
+                // (measured at 24k-vector lists: a 2048-vector prefix gives ~1000 candidates per query for k = 10 but ~20000 for
+                // k = 100) — 160 k vectors, at least pq_pre_rows, at most 32768 (64 KiB of 16-bit sums in LDS)
+                int64_t want_rows = std::max<int64_t>(h->pq_pre_rows > 0 ? h->pq_pre_rows : 2048, std::min<int64_t>(32768, (int64_t)160 * k));
+                want_rows = std::min<int64_t>(round_up(want_rows, 64), round_up(std::max<int64_t>(maxlen, 64), 64));
+                pre_rows = (int)want_rows;
+                fused_pre = (size_t)pre_rows * 2 + (size_t)h->Mpad * 256 + 2048 <= 150 * 1024;
+                if (!fused_pre) pre_rows = 64 * 16 * pre_vpl;
+            }
+            if (fused_pre) {
+                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 64 ? 65536 : 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 PQPrepassArgs pa{};
@@ -1121,7 +1138,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 pa.seg_start = h->w_segstart.as<int64_t>();
                 pa.lut8 = h->w_lut8.as<uint8_t>(); pa.qparam = h->w_qparam.as<float>();
                 pa.nprobe = nprobe; pa.Mpad = h->Mpad; pa.pre_rows = pre_rows; pa.KP = KP; pa.CB = h->CB;
+                pa.k = k;
                 pa.state = state; pa.cand_cnt = h->w_candcnt.as<unsigned long long>();
+                h->w_tau.ensure((size_t)nq * 8);
+                pa.tau = h->w_tau.as<uint64_t>();
+                if (rot) {       // the sample's own candidates leave from the pre-pass; the scan drops that (query, list, tile 0)
+                    h->w_excl.ensure((size_t)nq * 2);
+                    pa.cand = h->w_cand.as<uint64_t>(); pa.cand_cap = cand_cap; pa.tile_rows = tile_rows; pa.excl = h->w_excl.as<uint16_t>();
+                }
                 launch_pq_prepass(pa, nq, h->st);
                 done = true;
             } else {
@@ -1133,13 +1157,13 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 void* rws0 = rot ? rot_desc(mi, filtered ? pre_vpl : vpl, 0) : nullptr;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
-                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, 0, 0, h->st)
+                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, 0, 0, nullptr, h->st)
                             : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
             }
             if (done && filtered) {
                 tm.mark("scan0");
-                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
+                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 64 ? 65536 : 16384);
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 // multi-launch form: top-K' of the scored prefix of the closest list, row prefix
@@ -1158,14 +1182,17 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    h->st);
                 tm.mark("group");
                 void* rws1 = rot ? rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, pre_rows) : nullptr;
+                // threshold keys: one per query from the one-launch pre-pass, else the K'-th key the selection left in the state rows
+                const uint64_t* tau_ptr = fused_pre ? h->w_tau.as<uint64_t>() : state + (KP - 1);
+                const int64_t tau_stride = fused_pre ? 1 : KP;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist,
-                                                 max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
+                                                 max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rws1, rot_seg_cap, h->pq_prune, h->pq_pace, h->st)
+                                                 rws1, rot_seg_cap, h->pq_prune, h->pq_pace, (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr, h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
-                                                     max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, state + (KP - 1), KP,
+                                                     max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,
                                                      h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
                                                      h->st)) == 0;
             }

@@ -230,6 +230,7 @@ struct PQScan8Args {
     // filtered output (FILTER = true): keys > tau_key[q] are appended to cand[q][0..cap)
     const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
     int prune;   // k_pq_scan_rot: skip work items none of whose queries can beat its threshold in this list (exact bound)
+    const uint16_t* excl;   // k_pq_scan_rot: per query, 0x8000 | probe rank whose tile 0 the pre-pass already emitted (null: none)
     int pace;    // k_pq_scan_rot: sibling query groups of a list tile stay within `pace` loop iterations of each other (0 = free-running)
 };
 
@@ -260,7 +261,8 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, int prune, int pace, hipStream_t st);
+                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, int prune, int pace,
+                       const uint16_t* excl, hipStream_t st);
 // survivor segment capacity per (item, wave, query): 4x what a query's CLOSEST list is expected to yield (a wave scans
 // tile/16 vectors of it, of which the pre-pass threshold lets about KP / pre_rows through), never less than 128 and never
 // more than the wave's whole share of the tile (at which point no overflow is possible)
@@ -306,7 +308,12 @@ struct PQPrepassArgs {
     const int32_t* probe_list; const float* probe_dis0; const int64_t* seg_start;
     const uint8_t* lut8; const float* qparam;   // [nq][Mpad][256] u8 tables; [nq] {scale, bias, eps, pad}
     int nprobe; int Mpad; int pre_rows; int KP; int CB;   // CB = 0: rotated layout, lut8 transposed
+    int k;                                                 // the search's k: the threshold is derived from the sample's k-th best score
     uint64_t* state; unsigned long long* cand_cnt;
+    uint64_t* tau;                                         // [nq] out: threshold key (score a_k - 2 eps, low word 0), 0 = none
+    // emission (null cand = off): the sample's keys above the threshold go straight to cand[q][..] when the sample covers the
+    // first scan tile (tile_rows) of the list; excl[q] = 0x8000 | probe rank tells the scan to drop that (query, list, tile 0)
+    uint64_t* cand; int cand_cap; int tile_rows; uint16_t* excl;
 };
 void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
 void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,

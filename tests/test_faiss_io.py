@@ -2,6 +2,7 @@
 
 No FAISS-produced file exists offline, so these pin the layout field by field against the published
 index_write.cpp structure restated in rsx_faiss_io.py, plus round trips."""
+import os
 import struct
 
 import numpy as np
@@ -105,3 +106,47 @@ def test_engine_roundtrip_through_faiss_files(gpu, orc, tmp_path):
     fio.write_faiss_index(iv, p3)
     D, I = gpu.read_index(p3).search(qi, gi["k"])
     assert_same_results(D, I, gi["D"], gi["I"], "IwFl file")
+
+
+@pytest.mark.gpu
+def test_streamed_writer_matches_serializer_and_faiss_leg(gpu, orc, tmp_path, monkeypatch):
+    """write_faiss_index streams list by list; its bytes must equal serialize_faiss(index_to_parsed(index)).  The bench's
+    opportunistic FAISS leg (tools/faiss_leg.py) is then driven end to end with a stand-in `faiss` module whose read_index
+    parses the file and searches with the CPU oracle: the hand-over file, the comparison and the verdict keys all run."""
+    import sys
+    import types
+    from util import load_golden, regen_gpu
+    g = load_golden("ivfpq_d64_m16")
+    x, q = regen_gpu(gpu, g)
+    ix = gpu.IndexIVFPQ(None, g["d"], g["nlist"], g["M"], 8, 0)
+    ix.set_centroids(g["centroids"]); ix.set_codebooks(g["codebooks"]); ix.add(x)
+    ix.nprobe = g["nprobe"]
+    path = str(tmp_path / "streamed.faiss")
+    fio.write_faiss_index(ix, path)
+    assert open(path, "rb").read() == fio.serialize_faiss(fio.index_to_parsed(ix))
+
+    class _Fx:
+        def __init__(self, p):
+            self.p, self.nprobe, self.ntotal = p, 1, p["ntotal"]
+
+        def search(self, xq, k):
+            il = self.p["invlists"]
+            a = np.concatenate([np.full(len(i), l, np.int64) for l, i in enumerate(il["ids"])])
+            lm = orc.ListMajor(a, np.concatenate(il["ids"]), np.concatenate(il["codes"]), self.p["nlist"])
+            return orc.ivfpq_search(self.p["quantizer"]["vectors"], self.p["codebooks"], lm, np.asarray(xq, np.float32), self.nprobe, k)
+
+    fake = types.ModuleType("faiss")
+    fake.__version__ = "stand-in"
+    fake.read_index = lambda p: _Fx(fio.parse_faiss(p))
+    fake.omp_get_max_threads = lambda: 1
+    monkeypatch.setitem(sys.modules, "faiss", fake)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from faiss_leg import faiss_leg, compare
+    D, I = ix.search(q, g["k"])
+    r = faiss_leg(ix, q, g["k"], g["nprobe"], D, I, log=lambda *a: None, repeats=1)
+    assert r["available"] and r["parity"] == "green" and r["ids_identical"] and r["scores_bit_identical"] and r["faiss_ntotal"] == g["n"]
+    # compare(): a swap inside a run of equal scores is a tie-order difference, a different id is not
+    Df = np.array([[3.0, 2.0, 2.0, 1.0]], np.float32); If = np.array([[5, 7, 9, 1]])
+    c = compare(Df, If, Df.copy(), np.array([[5, 9, 7, 1]]))
+    assert c["parity"] == "green" and c["ids_differ_only_in_tie_order_queries"] == 1 and not c["ids_identical"]
+    assert compare(Df, If, Df.copy(), np.array([[5, 7, 8, 1]]))["parity"] == "differs"
