@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
     int32_t* ctl = hist + 256;
     const int tid = threadIdx.x;
     const int64_t row = blockIdx.x;
+    if (a.row_filter && a.row_filter[row] != 1) return;
     int64_t n = a.row_n ? a.row_n[row * a.row_n_stride] : a.n_uniform;
     if (a.row_n && a.n_uniform > 0 && n > a.n_uniform) n = a.n_uniform;
     const int nin = (int)n;
@@ -774,6 +775,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     const int tid = threadIdx.x, nt = blockDim.x;   // 1..4 waves
     const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
     const int64_t q = blockIdx.x;
+    if (a.row_filter && a.row_filter[q] != 1) return;
 
     for (int c = tid; c < KP; c += nt) {
         uint64_t key = a.state[q * KP + c];
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         const float eps = reinterpret_cast<const float*>(a.qparam)[q * 4 + 2];
         uint64_t last = a.state[q * KP + (KP - 1)];
         int bad = 0;
-        if (last != 0) {  // the candidate buffer is full: vectors were excluded
+        if (last != 0 && !a.no_cert) {  // the candidate buffer is full: vectors were excluded
             float a_last = key_score(last);
             bool have_k = sord[a.k - 1] != 0 && sid[a.k - 1] != INT64_MAX;
             float s_k = have_k ? ord2f(sord[a.k - 1]) : -__builtin_inff();
@@ -1012,6 +1014,41 @@ void launch_exact_scores(const ExactScoreArgs& a, hipStream_t st) {
 }
 
 #define FIN_RANK_MAX 512
+// Exact re-score of EVERY candidate of the flagged queries, in place: cand[q][c] = (approximate score, index) becomes
+// (canonical fp32 score, index).  With the round-3 threshold the candidate row of a query holds every vector that can reach
+// its top k (unless the row overflowed), so a query whose K' best approximate candidates could not be certified is settled
+// from its own row — |C| x M table look-ups — instead of an exact scan of all its probed lists.
+__global__ __launch_bounds__(256) void k_pq_rescore_all(FinalizeArgs a, uint64_t* cand, int cand_cap) {
+    const int64_t q = blockIdx.x;
+    if (a.row_filter[q] != 1) return;
+    unsigned long long n = a.cand_cnt[q * CCS];
+    if (n > (unsigned long long)cand_cap) n = (unsigned long long)cand_cap;
+    const float* T = a.lut32 ? a.lut32 + q * a.Mpad * 256 : nullptr;
+    const float* qv = a.Q32 + q * a.ldq;
+    const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+    for (unsigned long long c = (unsigned long long)blockIdx.y * 256 + threadIdx.x; c < n; c += (unsigned long long)gridDim.y * 256) {
+        const uint64_t key = cand[q * cand_cap + c];
+        if (!key) continue;
+        const uint32_t idx = key_idx(key);
+        int lo = 0, hi = a.nprobe;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
+        const int32_t l = a.probe_list[q * a.nprobe + lo];
+        const int64_t row = a.list_base[l] + ((int64_t)idx - ss[lo]);
+        const float dis0 = a.probe_dis0[q * a.nprobe + lo];
+        const int64_t slab = row >> 6; const int v = (int)(row & 63);
+        const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
+        const float sum = a.CB == 0 ? ((!T && a.dsub == 8) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
+                                                              : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub))
+                        : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
+                                     : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
+        cand[q * cand_cap + c] = make_key(dis0 + sum, idx);
+    }
+}
+void launch_pq_rescore_all(const FinalizeArgs& a, uint64_t* cand, int cand_cap, hipStream_t st) {
+    if (a.nq <= 0) return;
+    hipLaunchKernelGGL(k_pq_rescore_all, dim3((unsigned)a.nq, 16), dim3(256), 0, st, a, cand, cand_cap);
+}
+
 void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
     if (a0.nq <= 0) return;
     FinalizeArgs a = a0;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -188,7 +189,7 @@ struct rsx_index {
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2;
     std::map<std::string, double> timing;
 
     // Flat / IVF-Flat: largest |x|^2 ever added (certificate of the MFMA scan); device copy is the running atomic max
@@ -219,7 +220,7 @@ static int64_t workspace_bytes(const rsx_index* h) {
     const DevBuf* bufs[] = {&h->w_q32, &h->w_q16, &h->w_coarse, &h->w_keys1, &h->w_probekeys, &h->w_probelist, &h->w_dis0, &h->w_segstart,
                             &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
                             &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
-                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->sh_D, &h->sh_I, &h->sh_q,
+                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->sh_D, &h->sh_I, &h->sh_q,
                             &h->sh_oD, &h->sh_oI};
     int64_t t = 0;
     for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
@@ -799,18 +800,32 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
 // kind and their result rows replaced — rare, and what makes the fast paths EXACT rather than "almost always right".
 // temp_bytes_per_query > 0 bounds the exact path's score buffer (Flat / IVF-Flat): the re-run proceeds in chunks.
 static void rerun_uncertified(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI,
-                              size_t temp_bytes_per_query) {
+                              size_t temp_bytes_per_query, const std::function<void()>& second_chance = nullptr) {
     std::vector<int32_t> bad_v;
     const int32_t* bad;
-    if (nq <= 4096 && h->pin_flags.ensure(4096 * 4)) {
-        HIPCHECK(hipMemcpyAsync(h->pin_flags.p, h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
-        bad = h->pin_flags.as<int32_t>();
-    } else {
-        bad_v.resize((size_t)nq);
-        HIPCHECK(hipMemcpyAsync(bad_v.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
-        bad = bad_v.data();
+    auto read_flags = [&]() {
+        if (nq <= 4096 && h->pin_flags.ensure(4096 * 4)) {
+            HIPCHECK(hipMemcpyAsync(h->pin_flags.p, h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
+            bad = h->pin_flags.as<int32_t>();
+        } else {
+            bad_v.resize((size_t)nq);
+            HIPCHECK(hipMemcpyAsync(bad_v.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
+            bad = bad_v.data();
+        }
+        HIPCHECK(hipStreamSynchronize(h->st));
+    };
+    read_flags();
+    if (second_chance) {
+        // flag 1 = the certificate could not clear the query although none of its candidates was dropped: every vector that
+        // can matter is still in its candidate row — re-rank from a larger K' there before paying for an exact scan
+        int64_t n1 = 0;
+        for (int64_t q = 0; q < nq; q++) n1 += bad[(size_t)q] == 1;
+        if (n1 > 0) {
+            h->timing["second_chance_queries"] += (double)n1;
+            second_chance();
+            read_flags();
+        }
     }
-    HIPCHECK(hipStreamSynchronize(h->st));
     const int d = h->d;
     const size_t esz = dtype == RSX_F16 ? 2 : 4;
     std::vector<int64_t> badq;
@@ -1033,6 +1048,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     if (tmax >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "probed lists exceed 2^32 vectors per query");
     h->w_temp.ensure((size_t)nq * tmax * 4);
     bool filtered = false;   // fast path with in-kernel candidate filtering (no full score buffer)
+    bool fused_pre_used = false;   // ... whose threshold came from the one-launch pre-pass (complete candidate rows: second chance)
     int cand_cap = 0;
     // the exact kernels gather fp32 table entries; the fast path builds the table in LDS (when it fits)
     const bool fused_lut = h->kind == KIND_IVFPQ && fast && pq_lut8_fused_lds(h->M, h->Mpad, h->dsub) <= 160 * 1024 - 64;
@@ -1147,6 +1163,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     pa.cand = h->w_cand.as<uint64_t>(); pa.cand_cap = cand_cap; pa.tile_rows = tile_rows; pa.excl = h->w_excl.as<uint16_t>();
                 }
                 launch_pq_prepass(pa, nq, h->st);
+                fused_pre_used = true;
                 done = true;
             } else {
                 launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
@@ -1354,7 +1371,32 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     launch_finalize(fa, h->st);
     tm.mark("finalize");
     tm.finish();
-    if (fast || certify) rerun_uncertified(h, nq, dq, dtype, k, dD, dI, fast ? 0 : (size_t)tmax * 4);
+    std::function<void()> second;
+    if (fast && filtered && fused_pre_used) {
+        second = [&]() {
+            // the flagged queries' candidate rows are complete (threshold by construction) and did not overflow: score every
+            // candidate exactly in place, then the best K2 >= k + 64 of them by (exact score, index) go through k_finalize for
+            // the (score, id) order — no certificate needed, no exact scan
+            h->timing["rescore_all_launches"] += 1;
+            FinalizeArgs fr = fa;
+            fr.row_filter = h->w_uncertain.as<int32_t>();
+            launch_pq_rescore_all(fr, h->w_cand.as<uint64_t>(), cand_cap, h->st);
+            const int KP2 = std::min(4096, std::max(128, pow2ceil(k + 64)));
+            h->w_state2.ensure((size_t)nq * KP2 * 8);
+            SelectArgs b{};
+            b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cand_cap;
+            b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cand_cap;
+            b.seg_len = round_up(cand_cap, 256); b.nseg = 1; b.idx_base = 0;
+            b.init = nullptr; b.out = h->w_state2.as<uint64_t>(); b.out_row_stride = KP2;
+            b.nrows = nq; b.KP = KP2; b.BUF = 2 * KP2; b.k = KP2;
+            b.row_filter = h->w_uncertain.as<int32_t>();
+            launch_select(b, h->st);
+            FinalizeArgs f2 = fa;
+            f2.state = h->w_state2.as<uint64_t>(); f2.KP = KP2; f2.row_filter = h->w_uncertain.as<int32_t>(); f2.no_cert = 1;
+            launch_finalize(f2, h->st);
+        };
+    }
+    if (fast || certify) rerun_uncertified(h, nq, dq, dtype, k, dD, dI, fast ? 0 : (size_t)tmax * 4, second);
 }
 
 // L2 ranking bias  -|x|^2/2  from the stored squared norms

@@ -300,6 +300,7 @@ struct SelectArgs {
     // threshold pre-pass form (nseg == 1): write only the row's KP-th key (the other KP-1 slots zero) and reset
     // the row's candidate counter, so no extra launches sit between the pre-pass and the filtered scan
     int keep_last; unsigned long long* zero_cnt;
+    const int32_t* row_filter;              // optional (radix form): only rows with row_filter[row] == 1 are processed
 };
 void launch_select(const SelectArgs& a, hipStream_t st);
 // IVF-PQ threshold pre-pass in one launch (k_pq_prepass): needs the 16-byte-granule code layout
@@ -345,10 +346,14 @@ struct FinalizeArgs {
     float cert_rel, cert_xmax, cert_abs;
     const int* cert_qflag; float cert_rel_qlossy;   // *cert_qflag != 0: the batch held an fp32 query value fp16 cannot represent
     float* D; int64_t* I;
+    const int32_t* row_filter;     // optional: only queries with row_filter[q] == 1 are processed (second-chance pass)
+    int no_cert;                   // the state keys are the best of a COMPLETE, exactly scored candidate row: nothing to certify
     int par_entries;               // set by launch_finalize: parallel table-entry form of the IVF-PQ re-score (small batches)
     int rank_sort;                 // set by launch_finalize: order the candidates by counting (K' <= 1024) instead of a bitonic network
 };
 void launch_finalize(const FinalizeArgs& a, hipStream_t st);
+// exact scores for every candidate key of the queries with a.row_filter[q] == 1, in place (a.cand_cnt gives the row lengths)
+void launch_pq_rescore_all(const FinalizeArgs& a, uint64_t* cand, int cand_cap, hipStream_t st);
 // Exact scores of the uncertified queries (fallback of the certificate above): fp64 dot product of the query with EVERY row
 // the query may see (Flat: all rows; IVF-Flat: the rows of its probed lists, laid out by seg_start), rounded once to fp32 —
 // the canonical score — into temp[q * tstride + column]; invalid columns get -inf.

@@ -123,7 +123,9 @@ def test_golden_ivfpq(gpu, orc, name, layout):
     ix.set_param("profile", 1)
     D7, I7 = ix.search(q, g["k"])
     assert_same_results(D7, I7, g["D"], g["I"], name + " starved fast scan")
-    assert ix.get_timing("fallback_queries") > auto_fallbacks, "K' = k cannot be certifiable for every query"
+    # (round 3: an uncertified query is first re-ranked from its complete candidate row — second_chance_queries — and only
+    #  re-run through the exact scan if that row overflowed)
+    assert ix.get_timing("fallback_queries") + ix.get_timing("second_chance_queries") > auto_fallbacks, "K' = k cannot be certifiable for every query"
     ix.set_param("pq_fast_kp", 0)
     ix.set_param("pq_filter", 0)            # fast scan through the full score buffer instead of in-kernel filtering
     D8, I8 = ix.search(q, g["k"])
