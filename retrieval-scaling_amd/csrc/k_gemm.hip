@@ -670,8 +670,7 @@ static bool fg2_ready() {
 }
 // the 256 x 256 LDS-DMA kernel needs fp16 storage, K a multiple of 64 and enough queries to fill its tile
 static bool fg2_applies(int nq_pad, int x_f16, int ld) {
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("RSX_FLAT_GEMM_V1"); off = (e && atoi(e)) ? 1 : 0; }
+    static const int off = measure_env("RSX_FLAT_GEMM_V1", 0);
     return !off && x_f16 && nq_pad % 256 == 0 && ld % 64 == 0;
 }
 
@@ -699,8 +698,7 @@ void launch_flat_gemm_filter(const __half* Q16, int nq_pad, int nq, const void* 
     if (fg2_applies(nq_pad, x_f16, ld) && fg2_ready<true>()) {
         F.nq = nq; F.qt = nq_pad / 256; F.ntiles = (nv + 255) / 256;
         // persistent walking workgroups (see the kernel) once every slot has a few db tiles to walk; RSX_FG2_WALK=0: off (A/B)
-        static int walk_on = -1;
-        if (walk_on < 0) { const char* e = getenv("RSX_FG2_WALK"); walk_on = e ? atoi(e) : 1; }
+        static const int walk_on = measure_env("RSX_FG2_WALK", 1);
         static int ncu_of[64] = {};
         int& ncu = ncu_of[cur_device()];
         if (ncu == 0) {
@@ -995,8 +993,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
 
 // rows per work item k_list_scan2 is built for (0: it does not apply to this storage)
 int list_scan2_chunk_rows(int x_f16, int ld) {
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("RSX_LIST_SCAN_V1"); off = (e && atoi(e)) ? 1 : 0; }
+    static const int off = measure_env("RSX_LIST_SCAN_V1", 0);
     return (!off && x_f16 && ld % 64 == 0) ? 64 * LS2_NB : 0;
 }
 

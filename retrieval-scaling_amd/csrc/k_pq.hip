@@ -806,12 +806,13 @@ int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
     A.tau_key = nullptr; A.tau_stride = 0; A.cand = nullptr; A.cand_cnt = nullptr; A.cand_cap = 0; A.prune = 0;
+#ifdef RSX_MEASURE     // cost-split variants (wrong results on purpose): tools/ builds only, not even instantiated in librsx.so
     if (a.Mpad == 96 && vpl == 8) {
-        static int var = -1;
-        if (var < 0) { const char* e = getenv("RSX_SCAN8_VARIANT"); var = e ? atoi(e) : 0; }
+        static const int var = measure_env("RSX_SCAN8_VARIANT", 0);
         if (var == 1) return launch_pq_scan8_t<6, 8, 1>(A, st);
         if (var == 2) return launch_pq_scan8_t<6, 8, 2>(A, st);
     }
+#endif
     switch (a.Mpad / 16) {
         case 1: return launch_pq_scan8_v<1>(A, vpl, st);
         case 2: return launch_pq_scan8_v<2>(A, vpl, st);

@@ -644,12 +644,7 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint32_t* xcd_ctr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(seg_keys) + (size_t)(A.max_items + 8) * 64 * seg_cap * 8);
     uint32_t* prog = xcd_ctr + 256;
     hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog);
-#ifdef RSX_MEASURE
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("RSX_ROT_VARIANT"); var = e ? atoi(e) : 0; }
-#else
-    const int var = 0;
-#endif
+    static const int var = measure_env("RSX_ROT_VARIANT", 0);
     // one persistent workgroup per CU (a multiple of 8: workgroup b serves XCD b % 8); never more than the work items
     int64_t grid = (ncu + 7) & ~7;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;

@@ -388,8 +388,7 @@ void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
 
 // rows short enough for the radix form (single segment; the counting passes re-read the row 9 times from L1/L2)
 static bool select_radix_applies(const SelectArgs& a) {
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("RSX_SELECT_V1"); off = (e && atoi(e)) ? 1 : 0; }
+    static const int off = measure_env("RSX_SELECT_V1", 0);
     // measured: wins for the threshold pre-pass (2048 scores -> K' = 128) and the candidate merge, loses for the
     // probe selection (4096 scores -> 32 keys: k_select's buffer hardly ever needs a second sort there)
     // ... unless only a few rows are in flight (latency path): 256 threads per row instead of one wave

@@ -34,6 +34,16 @@ __host__ __device__ inline float key_score(uint64_t k) { return ord2f((uint32_t)
 
 enum { KIND_FLAT = 0, KIND_IVFFLAT = 1, KIND_IVFPQ = 2 };
 
+// Environment switches between kernel generations / cost-split variants exist ONLY in the -DRSX_MEASURE build that tools/ load
+// through RSX_LIB (csrc/Makefile: librsx_measure.so).  In the shipped librsx.so this is the constant `dflt`: no environment
+// variable can change which kernel serves a search, let alone make one skip part of its work.
+#ifdef RSX_MEASURE
+#include <cstdlib>
+inline int measure_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+constexpr int measure_env(const char*, int dflt) { return dflt; }
+#endif
+
 // hipFuncSetAttribute (dynamic LDS above 64 KiB) is a per-DEVICE property of a kernel: with several GPUs driven from one
 // process (rsx_sharded_create) every device needs its own call.  first() is true once per device; need(bytes) is true when
 // this device has not yet been granted that many bytes.

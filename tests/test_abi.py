@@ -50,3 +50,17 @@ def test_product_does_not_import_oracle():
             if re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M) or "liborc" in txt or "orc_" in txt.replace("orc_synth", ""):
                 bad.append(os.path.join(root, f))
     assert not bad, bad
+
+
+def test_shipped_library_has_no_measurement_switches(rsxlib):
+    """RSX_ROT_VARIANT / RSX_SCAN8_VARIANT / RSX_*_V1 used to sit in the production kernels' launchers — an environment
+    variable could make rsx_search skip part of its work.  They now exist only in the -DRSX_MEASURE build (librsx_measure.so,
+    loaded by tools/ through RSX_LIB): the shipped librsx.so must not even contain the variable names.  RSX_PQ_LAYOUT (which
+    of two result-identical code layouts a NEW index uses) is the one documented environment knob."""
+    import subprocess
+    lib = os.path.join(PKG, "csrc", "librsx.so")
+    names = set(re.findall(rb"RSX_[A-Z0-9_]+", open(lib, "rb").read()))
+    assert names <= {b"RSX_PQ_LAYOUT", b"RSX_OK"} | {n for n in names if n.startswith(b"RSX_ERR_") or n.startswith(b"RSX_METRIC") or n in (b"RSX_F16", b"RSX_F32")}, names
+    # the measurement build is a separate target, never loaded by the product
+    assert "librsx_measure.so" in open(os.path.join(PKG, "csrc", "Makefile")).read()
+    assert "measure" not in open(os.path.join(PKG, "rsx.py")).read().lower()
