@@ -135,6 +135,11 @@ def main():
     Q = torch.empty((nsteps * nq, D), dtype=torch.float16, device=dev)
     rsx.synth_queries(D, NCENTRES, SEED_C, SEED_X, SIGMA, n_total, SEED_Q, SIGMA_Q, 0, nsteps * nq, out=Q)
     Qgt = Q[args.warmup * nq:(args.warmup + 1) * nq]  # recall is measured on the first timed batch
+    # ... and on a second batch that asks an answerable question of THIS index: queries = a base vector + 0.02 noise (the 0.1
+    # noise of the prescribed batch leaves ranks 2..10 to chance at PQ resolution: DESIGN.md 5)
+    Qlow = torch.empty((nq, D), dtype=torch.float16, device=dev)
+    rsx.synth_queries(D, NCENTRES, SEED_C, SEED_X, SIGMA, n_total, SEED_Q + 1, 0.02, 0, nq, out=Qlow)
+    Qgt2 = torch.cat([Qgt, Qlow], 0)
 
     # ---------------- add (+ streaming exact ground truth with the Flat engine)
     t0 = time.time()
@@ -155,7 +160,7 @@ def main():
         if flat is not None:
             flat.reset()
             flat.add(buf[:nb])
-            Dc, Ic = flat.search(Qgt, k)
+            Dc, Ic = flat.search(Qgt2, k)
             Ic = Ic + c0
             if gtD is None:
                 gtD, gtI = Dc, Ic
@@ -178,6 +183,9 @@ def main():
         if searcher is not None:
             return searcher.search(q, k)
         return index.search(q, k)
+
+    def step_q(q):
+        return searcher.search(q, k) if searcher is not None else index.search(q, k)
 
     def barrier():
         if world > 1:
@@ -298,14 +306,22 @@ def main():
     # recall@k of the first timed batch against the exact streaming ground truth (all shards merged)
     D1, I1 = step(args.warmup)
     recall = None
+    recall_low = None
     if gtD is not None:
         if world > 1:
             gD = torch.empty((world,) + tuple(gtD.shape), dtype=gtD.dtype, device=dev)
             gI = torch.empty((world,) + tuple(gtI.shape), dtype=gtI.dtype, device=dev)
             dist.all_gather_into_tensor(gD, gtD.contiguous()); dist.all_gather_into_tensor(gI, gtI.contiguous())
             gtD, gtI = rsx.merge_topk(gD, gI)
-        a, b = I1.cpu().numpy(), gtI.cpu().numpy()
+        gt = gtI.cpu().numpy()
+        a, b = I1.cpu().numpy(), gt[:nq]
         recall = float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a, b)]))
+        _, I2 = step_q(Qlow)
+        a2, b2 = I2.cpu().numpy(), gt[nq:]
+        recall_low = {"recall_at_10": round(float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a2, b2)])), 4),
+                      "recall_at_1": round(float(np.mean(a2[:, 0] == b2[:, 0])), 4),
+                      "recall_at_1_prescribed_queries": round(float(np.mean(a[:, 0] == b[:, 0])), 4),
+                      "queries": "base vector + 0.02 noise (seed 1000), same 100M index, same nprobe; ground truth = exact streaming Flat search"}
 
     ls = index.list_sizes()
     hist = {"lists": int(len(ls)), "empty": int((ls == 0).sum()), "min": int(ls.min()), "p5": int(np.percentile(ls, 5)),
@@ -316,6 +332,7 @@ def main():
     # queries of the first timed batch and the same index (probed lists copied to the host), three repeats.
     cpu = None
     parity = None
+    lm = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         from oracle import oracle as orc
         ns = min(args.cpu_queries, nq)
@@ -366,7 +383,34 @@ def main():
                 log(f" q={qi}\n  cpu I {Ik[qi].tolist()}\n  gpu I {Ig[qi].tolist()}\n  cpu D {Dk[qi].tolist()}\n  gpu D {Dg[qi].tolist()}")
         cpu["heap_variant_vs_canonical"] = {"queries_with_a_tie_in_different_order": heap_tie_queries, "scores_identical": heap_scores_equal}
         log(f"cpu baseline: {ns} queries x3 in {[round(t, 2) for t in times]} s on {orc.num_threads()} threads; parity with GPU ids+scores: {parity}")
-        del lm
+
+    # ---------------- the reference's own n_docs on the headline index (ric/conf/default.yaml:84, ivf_pq.yaml:78: n_docs 1000;
+    # scripts/post_procress.sh:2: 2000): ms per batch, fallbacks, and an oracle spot check
+    ops = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        ops = {}
+        for kk in (100, 1000, 2000):
+            nrep = min(5, args.steps)
+            for i in range(2):                      # untimed: workspaces of this k, and of its (rare) exact re-runs, get allocated here
+                index.search(Q[i * nq:(i + 1) * nq], kk)
+            index.set_param("profile", 1)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + nrep):
+                Dk_, Ik_ = index.search(Q[i * nq:(i + 1) * nq], kk)
+            torch.cuda.synchronize(); el_k = (time.perf_counter() - t1) / nrep
+            r = {"ms_per_step": round(el_k * 1e3, 3), "queries_per_s": round(nq / el_k, 1),
+                 "exact_fallback_queries_per_step": round(index.get_timing("fallback_queries") / nrep, 2),
+                 "reranked_from_candidate_row_per_step": round(index.get_timing("second_chance_queries") / nrep, 2),
+                 "stage_ms": {s_: round(index.get_timing(s_) / nrep, 4) for s_ in ("scan0", "scan", "select", "finalize", "total")}}
+            index.set_param("profile", 0)
+            if cpu is not None:       # the probed lists of the first timed batch are still on the host: 8 queries against the oracle
+                Dg_, Ig_ = index.search(Qgt[:8], kk)
+                Do_, Io_ = orc.ivfpq_search(cen, cb, lm, qs[:8], args.nprobe, kk)
+                r["oracle_parity_ids_and_scores"] = bool(np.array_equal(Io_, Ig_.cpu().numpy()) and np.array_equal(Do_, Dg_.cpu().numpy()))
+                r["oracle_checked_queries"] = 8
+            ops[f"k{kk}"] = r
+            log(f"headline index at k={kk}: {r}")
+    lm = None
 
     # ---------------- opportunistic FAISS leg: the real reference engine on the same index and queries, when the
     # box has it (tools/faiss_leg.py; never required, {"available": false} otherwise)
@@ -388,10 +432,20 @@ def main():
         import bench_configs
         configs = {}
         for name, kw in (("flat_10M_batch1024", dict(which="flat", n=10_000_000, steps=5, check=4, small_batches=False)),
-                         ("ivfflat_100M_nlist4096_nprobe32", dict(which="ivfflat", n=100_000_000, steps=5, check=2))):
+                         # BASELINE config 2 as written ("exact L2"): the same 10M through the L2 metric
+                         ("flat_10M_batch1024_L2", dict(which="flat", n=10_000_000, steps=5, check=4, small_batches=False, metric="l2")),
+                         ("ivfflat_100M_nlist4096_nprobe32", dict(which="ivfflat", n=100_000_000, steps=5, check=2)),
+                         # the reference's own shipped operating points: ric/conf/example_config.yaml:70-76 (IVFFlat, ncentroids
+                         # 2048, probe 128; 20M vectors here to bound the run) and ric/conf/ivf_pq.yaml:64-78 (IVFPQ, M 16,
+                         # ncentroids 8192, probe 512, n_docs 1000)
+                         ("ivfflat_20M_nlist2048_nprobe128", dict(which="ivfflat", n=20_000_000, nlist=2048, nprobe=128, steps=3, check=2)),
+                         ("ivfpq_100M_M16_nlist8192_nprobe512", dict(which="ivfpq_ref"))):
             t0 = time.time()
             try:
-                configs[name] = bench_configs.measure(**kw)
+                if kw["which"] == "ivfpq_ref":
+                    configs[name] = bench_configs.measure_ivfpq(100_000_000, 16, 8192, 512, ks=(10, 1000), steps=3, check=2)
+                else:
+                    configs[name] = bench_configs.measure(**kw)
             except Exception as e:   # a config that cannot run (e.g. a smaller GPU) must not lose the headline line
                 configs[name] = {"error": repr(e)}
             log(f"config {name}: {time.time() - t0:.1f}s -> {json.dumps(configs[name])[:300]}")
@@ -411,6 +465,7 @@ def main():
             "dtype": "u8 codes; i8-table integer scan (MFMA-i8 adder tree), exact f32-table re-rank (certified)",
             "data": "synthetic",
             "recall_at_10": recall,
+            "recall_low_noise_queries": recall_low,
             "recall_informative": recall2,
             "config": {"workload": f"{n_total}x{D} IVF-PQ M={args.m} nbits=8 nlist={args.nlist} nprobe={args.nprobe} "
                                    f"batch={nq} k={k}, inner product, by_residual",
@@ -442,6 +497,7 @@ def main():
             "certificate_fallback_fraction": fallbacks,
             "filter_survivors_per_query": {"mean": round(cand_keys / max(1, nq), 1), "max": cand_keys_max},
             "ab_exact_kernels_same_process": ab,
+            "reference_n_docs_on_this_index": ops,
             "configs": configs,
             "cpu_baseline": cpu,
             "cpu_parity_ids_and_scores_bit_exact": parity,

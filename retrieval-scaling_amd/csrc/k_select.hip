@@ -393,7 +393,7 @@ static bool select_radix_applies(const SelectArgs& a) {
     // probe selection (4096 scores -> 32 keys: k_select's buffer hardly ever needs a second sort there)
     // ... unless only a few rows are in flight (latency path): 256 threads per row instead of one wave
     return !off && (a.keep_last || a.in_is_keys || a.nrows <= 16) && a.nseg == 1 && a.seg_base == 0 && !a.tau_ptr && a.n_uniform > 0 &&
-           (a.n_uniform <= 16384 || (a.in_is_keys && a.row_n && a.n_uniform <= 65536)) && a.KP <= 4096;
+           (a.n_uniform <= 16384 || (a.in_is_keys && a.row_n && a.n_uniform <= 131072)) && a.KP <= 4096;
 }
 
 void launch_select(const SelectArgs& a, hipStream_t st) {
@@ -951,7 +951,18 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
                     const float a_last = key_score(last);
                     const bool have_k = sord[a.k - 1] != 0 && sid[a.k - 1] != INT64_MAX;
                     const float s_k = have_k ? ord2f(sord[a.k - 1]) : -__builtin_inff();
-                    if (!(a_last + eps < s_k)) bad = 1;
+                    if (a.metric == 0) {
+                        if (!(a_last + eps < s_k)) bad = 1;
+                    } else {
+                        // L2: the scan ranks by r = <q,x> - |x|^2/2 (larger = closer), the exact re-score is s = -|q - x|^2 =
+                        // 2 r - |q|^2.  Round 3 fix: the two used to be compared as they stood (different quantities: every L2
+                        // query with more than K' rows failed the certificate and took the exact path).  Bring the excluded
+                        // vectors' bound into the re-score's units: s <= 2 (r~_last + eps) - |q|^2, plus the roundings of the
+                        // conversion and of the fp32 result.
+                        const double a_conv = 2.0 * (double)a_last - q2;
+                        const double e_conv = 2.0 * (double)eps + 3.0e-7 * (fabs(a_conv) + q2 + fabs((double)s_k));
+                        if (!(a_conv + e_conv < (double)s_k)) bad = 1;
+                    }
                 }
                 if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad = 1;
                 a.uncertain[q] = bad;

@@ -1145,7 +1145,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 if (!fused_pre) pre_rows = 64 * 16 * pre_vpl;
             }
             if (fused_pre) {
-                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 64 ? 65536 : 16384);
+                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 512 ? 131072 : (k > 64 ? 65536 : 16384));
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 PQPrepassArgs pa{};
@@ -1180,7 +1180,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             }
             if (done && filtered) {
                 tm.mark("scan0");
-                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 64 ? 65536 : 16384);
+                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 512 ? 131072 : (k > 64 ? 65536 : 16384));
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 // multi-launch form: top-K' of the scored prefix of the closest list, row prefix

@@ -153,23 +153,25 @@ def _oracle_lists(orc, ix, need, nlist):
     return lm
 
 
-def test_flat_batch_1024(gpu, orc):
+@pytest.mark.parametrize("metric", [0, 1])
+def test_flat_batch_1024(gpu, orc, metric):
     """BASELINE config 2's batch shape (1024 queries through the 256 x 256 MFMA tiles and the filtered second pass) at 1M
-    vectors: a sample of queries against the oracle, and the whole batch against itself in four sub-batches."""
+    vectors, inner product and — config 2 as written, "exact L2" — the L2 metric: a sample of queries against the oracle,
+    and the whole batch against itself in four sub-batches."""
     import torch
     d, n, nq, k = 768, 1_000_000, 1024, 10
     x = torch.empty((n, d), dtype=torch.float16, device="cuda")
     gpu.synth_vectors(d, 4096, 1234, 10000, 0.5, 0, n, out=x)
     q = torch.empty((nq, d), dtype=torch.float16, device="cuda")
     gpu.synth_queries(d, 4096, 1234, 10000, 0.5, n, 999, 0.1, 0, nq, out=q)
-    ix = gpu.IndexFlatIP(d); ix.add(x)
+    ix = gpu.IndexFlat(d, metric); ix.add(x)
     ix.set_param("profile", 1)
     D, I = ix.search(q, k)
-    assert ix.get_timing("fallback_queries") == 0          # fp16 data: the MFMA scan certifies every query
+    assert ix.get_timing("fallback_queries") == 0          # fp16 data: the MFMA scan certifies every query (both metrics)
     Dn, In = D.cpu().numpy(), I.cpu().numpy()
     sample = [0, 255, 256, 511, 777, 1023]
-    Dr, Ir = orc.flat_search(q[sample].cpu().numpy().astype(np.float32), x.cpu().numpy().astype(np.float32), k, 0)
-    assert_same_results(Dn[sample], In[sample], Dr, Ir, "flat 1M batch 1024 vs oracle")
+    Dr, Ir = orc.flat_search(q[sample].cpu().numpy().astype(np.float32), x.cpu().numpy().astype(np.float32), k, metric)
+    assert_same_results(Dn[sample], In[sample], Dr, Ir, f"flat 1M batch 1024 metric {metric} vs oracle")
     for s in range(0, nq, 256):
         Ds, Is = ix.search(q[s:s + 256], k)
         assert torch.equal(Ds, D[s:s + 256]) and torch.equal(Is, I[s:s + 256]), "batch decomposition must be invisible"

@@ -14,19 +14,20 @@ D, NC = 768, 4096
 SC, SX, SQ = 1234, 10000, 999
 
 
-def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, small_batches=True):
+def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, small_batches=True, metric="ip", k=10):
     """One non-headline config on cuda:0 -> result dict (the same object bench.py embeds under "configs")."""
     import torch, rsx
     from oracle import oracle as orc
     dev = torch.device("cuda", 0)
     n = n or (10_000_000 if which == "flat" else 20_000_000)
-    nq, k = batch, 10
+    nq = batch
+    mcode = 1 if metric == "l2" else 0
     Q = torch.empty((nq * (steps + 1), D), dtype=torch.float16, device=dev)
     rsx.synth_queries(D, NC, SC, SX, 0.5, n, SQ, 0.1, 0, Q.shape[0], out=Q)
     buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
     t0 = time.time()
     if which == "flat":
-        ix = rsx.IndexFlatIP(D)
+        ix = rsx.IndexFlat(D, rsx.METRIC_L2 if mcode else rsx.METRIC_INNER_PRODUCT)
     else:
         ix = rsx.IndexIVFFlat(None, D, nlist, rsx.METRIC_INNER_PRODUCT)
         nt = min(n, 256 * nlist)
@@ -55,7 +56,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
         Dq, Iq = ix.search(Q[s * nq:(s + 1) * nq], k)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     scan_ms = ix.get_timing("scan") / steps
-    res = {"config": f"{which} {n}x{D} batch={nq} k={k}" + (f" nlist={nlist} nprobe={nprobe}" if which == "ivfflat" else ""),
+    res = {"config": f"{which} {n}x{D} batch={nq} k={k}" + (f" nlist={nlist} nprobe={nprobe}" if which == "ivfflat" else f" metric={'L2' if mcode else 'IP'}"),
            "queries_per_s": round(steps * nq / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
            "scan_ms": round(scan_ms, 3), "select_ms": round(ix.get_timing("select") / steps, 3),
            "finalize_ms": round(ix.get_timing("finalize") / steps, 3), "build_s": round(build_s, 1),
@@ -98,9 +99,9 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
             for c0 in range(0, n, buf.shape[0]):
                 nb = min(buf.shape[0], n - c0)
                 rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb])
-                Dc, Ic = orc.flat_search(qs, buf[:nb].cpu().numpy().astype(np.float32), k, 0)
+                Dc, Ic = orc.flat_search(qs, buf[:nb].cpu().numpy().astype(np.float32), k, mcode)
                 Ic = Ic + c0
-                best = (Dc, Ic) if best is None else orc.merge_topk(np.stack([best[0], Dc]), np.stack([best[1], Ic]))
+                best = (Dc, Ic) if best is None else orc.merge_topk(np.stack([best[0], Dc]), np.stack([best[1], Ic]), mcode)
             ok = bool(np.array_equal(best[1], Iq[:check].cpu().numpy()) and np.array_equal(best[0], Dq[:check].cpu().numpy()))
         else:
             cen = ix.get_centroids()
@@ -122,9 +123,74 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
     return res
 
 
+def measure_ivfpq(n=100_000_000, M=16, nlist=8192, nprobe=512, ks=(10, 1000), steps=3, batch=1024, check=4):
+    """The reference's shipped IVF-PQ operating point (ric/conf/ivf_pq.yaml:64-78: n_subquantizers 16, ncentroids 8192,
+    probe 512, n_docs 1000) on n synthetic vectors: ms per batch for each k, fallbacks, oracle spot check."""
+    import torch, rsx
+    from oracle import oracle as orc
+    dev = torch.device("cuda", 0)
+    nq = batch
+    t0 = time.time()
+    ix = rsx.IndexIVFPQ(None, D, nlist, M, 8, rsx.METRIC_INNER_PRODUCT)
+    nt = min(n, 256 * nlist)
+    xt = torch.empty((nt, D), dtype=torch.float16, device=dev)
+    stride = max(1, n // nt)
+    for b in range(0, nt, 4096):
+        nb = min(4096, nt - b)
+        rsx.synth_vectors(D, NC, SC, SX, 0.5, (b * stride) % max(1, n - nb), nb, out=xt[b:b + nb])
+    ix.train(xt); del xt
+    ix.nprobe = nprobe
+    buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
+    for c0 in range(0, n, buf.shape[0]):
+        nb = min(buf.shape[0], n - c0)
+        rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb]); ix.add(buf[:nb])
+    del buf
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    Q = torch.empty((nq * (steps + 1), D), dtype=torch.float16, device=dev)
+    rsx.synth_queries(D, NC, SC, SX, 0.5, n, SQ, 0.1, 0, Q.shape[0], out=Q)
+    res = {"config": f"ivfpq {n}x{D} M={M} nlist={nlist} nprobe={nprobe} batch={nq}", "build_s": round(build_s, 1),
+           "code_layout": "rotated" if ix._get("pq_layout") == 1 else "granule", "by_k": {}}
+    lm = None
+    for k in ks:
+        ix.search(Q[:nq], k)
+        ix.set_param("profile", 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for s in range(1, steps + 1):
+            Dq, Iq = ix.search(Q[s * nq:(s + 1) * nq], k)
+        torch.cuda.synchronize(); el = (time.perf_counter() - t0) / steps
+        r = {"ms_per_step": round(el * 1e3, 3), "queries_per_s": round(nq / el, 1),
+             "stage_ms": {x: round(ix.get_timing(x) / steps, 4) for x in ("coarse", "select_probe", "lut8", "group", "scan0", "scan", "select", "finalize", "total")},
+             "exact_fallback_queries_per_step": round(ix.get_timing("fallback_queries") / steps, 2),
+             "reranked_from_candidate_row_per_step": round(ix.get_timing("second_chance_queries") / steps, 2)}
+        ix.set_param("profile", 0)
+        if check:
+            qs = Q[steps * nq:steps * nq + check].cpu().numpy().astype(np.float32)
+            cen, cb = ix.get_centroids(), ix.get_codebooks()
+            if lm is None:
+                pid, _ = orc.coarse_probe(cen, qs, min(nprobe, nlist))
+                need = np.unique(pid[pid >= 0])
+                ls = ix.list_sizes()
+                lens = np.zeros(nlist, np.int64); lens[need] = ls[need]
+                off = np.zeros(nlist + 1, np.int64); np.cumsum(lens, out=off[1:])
+
+                class LM: pass
+                lm = LM(); lm.list_off = off
+                lm.payload = np.empty((int(off[-1]), M), np.uint8); lm.ids = np.empty(int(off[-1]), np.int64)
+                for l in need:
+                    c, i = ix.get_list(int(l)); lm.payload[off[l]:off[l + 1]] = c; lm.ids[off[l]:off[l + 1]] = i
+            Dr, Ir = orc.ivfpq_search(cen, cb, lm, qs, nprobe, k)
+            r["oracle_parity_ids_and_scores"] = bool(np.array_equal(Ir, Iq[:check].cpu().numpy()) and np.array_equal(Dr, Dq[:check].cpu().numpy()))
+            r["oracle_checked_queries"] = int(check)
+        res["by_k"][f"k{k}"] = r
+    del ix, Q
+    torch.cuda.synchronize()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", choices=["flat", "ivfflat", "latency"])
+    ap.add_argument("which", choices=["flat", "ivfflat", "latency", "ivfpq_ref"])
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024)
@@ -135,6 +201,9 @@ def main():
     a = ap.parse_args()
     if a.which == "latency":
         return latency(a)
+    if a.which == "ivfpq_ref":
+        print(json.dumps(measure_ivfpq(a.n or 100_000_000, steps=a.steps, check=a.check)), flush=True)
+        return
     print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check)), flush=True)
 
 

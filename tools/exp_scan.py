@@ -63,6 +63,8 @@ def main():
                 Dd, Ii = ix.search(Q[i * nq:(i + 1) * nq], k)
             torch.cuda.synchronize(); el = time.perf_counter() - t0
             st = {x: round(ix.get_timing(x) / args.steps, 4) for x in ("coarse", "select_probe", "lut8", "group", "scan0", "scan", "select", "finalize", "total")}
+            fbst = {x: round(ix.get_timing("fb_" + x), 3) for x in ("convert", "coarse", "select_probe", "lut", "scan", "select", "finalize", "total")}
+            fbl = ix.get_timing("fb_scan_launches")
             fb = ix.get_timing("fallback_queries")
             fbo = ix.get_timing("fallback_overflow_queries")
             ix.set_param("profile", 2); ix.search(Q[:nq], k)
@@ -78,7 +80,7 @@ def main():
             for name in kv:      # back to defaults for the next setting
                 ix.set_param(name, 0.0 if name in ("pq_pace", "scan_chunk", "pq_prune", "pq_fast_kp") else 1.0)
             r = {"set": s, "round": rnd, "qps": round(args.steps * nq / el, 1), "ms_per_step": round(el / args.steps * 1e3, 4), "stages": st,
-                 "fallback_queries": fb, "fallback_overflow": fbo, "cand_mean": round(ck, 1), "cand_max": ckm, "same_as_first": same}
+                 "fallback_queries": fb, "fb_stage_ms_total": fbst, "fb_launches": fbl, "fallback_overflow": fbo, "cand_mean": round(ck, 1), "cand_max": ckm, "same_as_first": same}
             print(json.dumps(r), flush=True); out.append(r)
 
 
