@@ -65,8 +65,8 @@ def main():
     ap.add_argument("--diag", action="store_true", help="print a fast-vs-exact comparison of the first timed batch and exit")
     ap.add_argument("--shard", choices=["vectors", "lists"], default="vectors",
                     help="multi-GPU partition of the index: by contiguous id ranges (the reference's shards; default) or by "
-                         "inverted lists (rank r owns lists l %% N == r) — experimental: measured slower until the ranks "
-                         "exchange their pre-pass thresholds, see DESIGN.md section 6")
+                         "inverted lists (rank r owns lists l %% N == r; the ranks all-reduce(MAX) their pre-pass thresholds between the "
+                         "two calls of the search, see DESIGN.md section 6)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
                     help="engine parameter for an experiment (rsx_set_param), e.g. pq_filter=0; not for the reported line")
     ap.add_argument("--ab", action="store_true", help="also time the per-pair v1 scan kernel (same process, same index)")
@@ -176,7 +176,7 @@ def main():
         n_local = index.ntotal      # experiment: one list shard of an N-way index measured on a single GPU
     assert index.ntotal == n_local
 
-    searcher = ShardedSearcher(index, id_offset=0 if list_shards else lo) if world > 1 else None
+    searcher = ShardedSearcher(index, id_offset=0 if list_shards else lo, exchange_thresholds=list_shards) if world > 1 else None
 
     def step(i):
         q = Q[i * nq:(i + 1) * nq]

@@ -152,6 +152,20 @@ int rsx_set_nprobe(rsx_index_t* h, int nprobe);
  * Result order: score descending (IP) / distance ascending (L2); equal scores by id ascending. */
 int rsx_search(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I);
 
+/* The same search in TWO calls, for callers that improve the per-query thresholds between the threshold pre-pass and the scan —
+ * the LIST-sharded multi-GPU form (rsx_set_param "add_list_mod"): a rank that does not own a query's closest lists derives
+ * a weak threshold from its own lists; after an all-reduce(MAX) of the threshold keys every rank filters as hard as the single
+ * index would (the reference has no counterpart: its shards are independent indexes, src/search.py:282-303).
+ *   rsx_search_prepass: starts rsx_search(h, nq, q, dtype, k, D, I) and returns once the thresholds are final on the device:
+ *       *tau_dev = device pointer to nq uint64 keys (high word = order-preserving score bits: compare as unsigned; 0 = no
+ *       threshold), valid until rsx_search_scan; *tau_dev = NULL, *ntau = 0 when this search has no pre-pass (Flat, exact
+ *       modes, nprobe 1).  Any key may be RAISED to another valid lower bound of the query's k-th best score; nq must not
+ *       exceed "query_batch".
+ *   rsx_search_scan: runs the rest; D / I (given to the first call) are complete when it returns its status. */
+int rsx_search_prepass(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I, uint64_t** tau_dev,
+                       int64_t* ntau);
+int rsx_search_scan(rsx_index_t* h);
+
 /* Multi-shard merge of per-shard top-k       — src/search.py:362-367 (post_hoc_merge_topk),
  *                                               api/serve_main_node.py:150-163 (rerank_elements)
  * D,I: [nshards, nq, k].  Output [nq, k]: best first; ties keep the earlier shard first, then the

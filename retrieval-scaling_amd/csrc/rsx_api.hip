@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <memory>
@@ -201,6 +202,19 @@ struct rsx_index {
     // directory generation instead of a partial_sort over nlist two to four times per search batch
     uint64_t dir_gen = 0;
     std::map<std::tuple<int, int, int>, std::pair<uint64_t, std::pair<int64_t, int64_t>>> bound_cache;
+
+    // two-call search (rsx_search_prepass / rsx_search_scan: the caller exchanges the per-query thresholds between the calls,
+    // e.g. an all-reduce(MAX) across the ranks of a LIST-sharded index).  The search runs on a worker thread that parks right
+    // after the threshold pre-pass; all of this is guarded by tc_mu.
+    struct TwoCall {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool active = false, parked = false, go = false, done = false;
+        uint64_t* tau = nullptr; int64_t ntau = 0;
+        int status = 0; std::string err;
+    };
+    std::unique_ptr<TwoCall> tc;
 
     // single-process multi-GPU handle (rsx_sharded_create): this object owns one child index per device and nothing else
     std::vector<rsx_index*> shards;
@@ -1165,6 +1179,16 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 launch_pq_prepass(pa, nq, h->st);
                 fused_pre_used = true;
                 done = true;
+                if (h->tc && h->tc->active && allow_fast) {
+                    // two-call search: the thresholds are final on the device; hand them to the caller and wait for rsx_search_scan
+                    HIPCHECK(hipStreamSynchronize(h->st));
+                    rsx_index::TwoCall& t = *h->tc;
+                    std::unique_lock<std::mutex> lk(t.mu);
+                    t.tau = h->w_tau.as<uint64_t>(); t.ntau = nq; t.parked = true;
+                    t.cv.notify_all();
+                    t.cv.wait(lk, [&] { return t.go; });
+                    t.parked = false; t.tau = nullptr; t.ntau = 0;
+                }
             } else {
                 launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
                                    pairs_sorted, h->d_len.as<int64_t>(), pre_rows, item_off, total_items, nprobe, 0,
@@ -2064,6 +2088,11 @@ int rsx_load_sharded(const char* path, int ndev, const int* devices, rsx_index_t
 int rsx_destroy(rsx_index_t* h) {
     return guarded([&] {
         if (!h) return;
+        if (h->tc && h->tc->active) {       // an unfinished two-call search: let it run to the end before the handle goes away
+            { std::lock_guard<std::mutex> lk(h->tc->mu); h->tc->go = true; }
+            h->tc->cv.notify_all();
+            if (h->tc->th.joinable()) h->tc->th.join();
+        }
         for (auto* c : h->shards) {
             (void)hipSetDevice(c->device);
             if (c->st) { (void)hipStreamSynchronize(c->st); (void)hipStreamDestroy(c->st); }
@@ -2257,6 +2286,45 @@ int rsx_search(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, floa
         }
         use_device(h);
         search_impl(h, nq, q, dtype, k, D, I);
+    });
+}
+
+int rsx_search_prepass(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I, uint64_t** tau_dev,
+                       int64_t* ntau) {
+    return guarded([&] {
+        if (!h || !tau_dev || !ntau) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
+        if (is_sharded(h)) RSX_THROW(RSX_ERR_UNSUPPORTED, "search_prepass: not available on a sharded handle (its shards share one process)");
+        if (nq > h->query_batch) RSX_THROW(RSX_ERR_UNSUPPORTED, "search_prepass: nq = %lld exceeds query_batch = %d (one internal batch per two-call search)", (long long)nq, h->query_batch);
+        if (!h->tc) h->tc.reset(new rsx_index::TwoCall());
+        rsx_index::TwoCall& t = *h->tc;
+        if (t.active) RSX_THROW(RSX_ERR_INVALID, "search_prepass: the previous two-call search has not been finished with rsx_search_scan");
+        t.active = true; t.parked = false; t.go = false; t.done = false; t.status = 0; t.err.clear(); t.tau = nullptr; t.ntau = 0;
+        t.th = std::thread([h, nq, q, dtype, k, D, I] {
+            rsx_index::TwoCall& tt = *h->tc;
+            int st_ = RSX_OK; std::string msg;
+            try { HIPCHECK(hipSetDevice(h->device)); search_impl(h, nq, q, dtype, k, D, I); }
+            catch (const RsxError& e) { st_ = e.code; msg = e.what(); }
+            catch (const std::exception& e) { st_ = RSX_ERR_INVALID; msg = e.what(); }
+            std::lock_guard<std::mutex> lk(tt.mu);
+            tt.status = st_; tt.err = msg; tt.done = true;
+            tt.cv.notify_all();
+        });
+        std::unique_lock<std::mutex> lk(t.mu);
+        t.cv.wait(lk, [&] { return t.parked || t.done; });
+        *tau_dev = t.parked ? t.tau : nullptr;       // null: this search has no threshold pre-pass (Flat, exact paths, one probe, ...)
+        *ntau = t.parked ? t.ntau : 0;
+    });
+}
+int rsx_search_scan(rsx_index_t* h) {
+    return guarded([&] {
+        if (!h || !h->tc || !h->tc->active) RSX_THROW(RSX_ERR_INVALID, "search_scan without rsx_search_prepass");
+        rsx_index::TwoCall& t = *h->tc;
+        { std::lock_guard<std::mutex> lk(t.mu); t.go = true; }
+        t.cv.notify_all();
+        t.th.join();
+        t.active = false;
+        if (t.status != RSX_OK) throw RsxError(t.status, t.err);
     });
 }
 

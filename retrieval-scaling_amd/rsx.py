@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "rsx_last_error", "rsx_version", "rsx_device_count", "rsx_flat_create", "rsx_ivfflat_create",
     "rsx_ivfpq_create", "rsx_sharded_create", "rsx_load_sharded", "rsx_destroy", "rsx_train", "rsx_set_centroids", "rsx_set_codebooks",
     "rsx_get_centroids", "rsx_get_codebooks", "rsx_add", "rsx_assign", "rsx_reset", "rsx_reserve_lists", "rsx_add_list",
-    "rsx_get_list", "rsx_get_list_sizes", "rsx_set_nprobe", "rsx_search", "rsx_merge_topk", "rsx_pack_topk", "rsx_merge_packed", "rsx_get",
+    "rsx_get_list", "rsx_get_list_sizes", "rsx_set_nprobe", "rsx_search", "rsx_search_prepass", "rsx_search_scan", "rsx_merge_topk", "rsx_pack_topk", "rsx_merge_packed", "rsx_get",
     "rsx_set_param",
     "rsx_get_timing", "rsx_save", "rsx_load", "rsx_synth_vectors", "rsx_synth_queries",
 ]
@@ -268,6 +268,35 @@ class Index:
         I = np.empty((n, k), dtype=np.int64)
         _check(lib().rsx_search(self._h, ctypes.c_int64(n), p, dt, k, D.ctypes.data_as(ctypes.c_void_p),
                                 I.ctypes.data_as(ctypes.c_void_p)))
+        return D, I
+
+    def search_prepass(self, x, k):
+        """First half of a two-call search (rsx_search_prepass): CUDA-tensor queries in -> a CUDA int64 tensor VIEW of the nq
+        threshold keys (or None when this search has none).  The keys are unsigned 64-bit integers: flip the sign bit
+        (`t ^= -2**63`) before comparing / reducing them as int64 and flip it back afterwards.  Finish with search_scan()."""
+        import torch
+        keep, p, n, dt, on_dev = _as_matrix(x, self.d, "search")
+        assert on_dev, "search_prepass takes CUDA-tensor queries (the thresholds live in HBM)"
+        k = int(k)
+        D = torch.empty((n, k), dtype=torch.float32, device=keep.device)
+        I = torch.empty((n, k), dtype=torch.int64, device=keep.device)
+        _sync_producer(keep, on_dev)
+        tau, ntau = ctypes.c_void_p(), ctypes.c_int64(0)
+        _check(lib().rsx_search_prepass(self._h, ctypes.c_int64(n), p, dt, k, ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                        ctypes.byref(tau), ctypes.byref(ntau)))
+        self._two_call = (keep, D, I)
+        if not tau.value or ntau.value == 0:
+            return None
+
+        class _View:      # zero-copy view of library memory through the CUDA array interface
+            __cuda_array_interface__ = {"shape": (ntau.value,), "typestr": "<i8", "data": (tau.value, False), "version": 2}
+        return torch.as_tensor(_View(), device=keep.device)
+
+    def search_scan(self):
+        """Second half: runs the scan with the (possibly raised) thresholds -> (D, I) CUDA tensors."""
+        keep, D, I = self._two_call
+        self._two_call = None
+        _check(lib().rsx_search_scan(self._h))
         return D, I
 
     # -- inspection (parity tests, writer)

@@ -39,25 +39,68 @@ def merge_topk_host(D, I, metric=0):
     return Do, Io
 
 
+_SIGN = -(2 ** 63)
+
+
+def raise_thresholds(taus):
+    """Elementwise maximum of several threshold-key vectors (CUDA int64 views of UNSIGNED keys), written back to all of them:
+    what the all-reduce(MAX) does across ranks, for several local handles (single-process tests / tools)."""
+    import torch
+    live = [t for t in taus if t is not None]
+    if len(live) < 2:
+        return
+    m = live[0] ^ _SIGN
+    for t in live[1:]:
+        m = torch.maximum(m, t ^ _SIGN)
+    m ^= _SIGN
+    for t in live:
+        t.copy_(m)
+
+
 class ShardedSearcher:
     """Wraps a rank-local index whose vectors are ids [id_offset, id_offset + ntotal)."""
 
-    def __init__(self, local_index, id_offset=0, group=None, metric=0, force_collective=False):
+    def __init__(self, local_index, id_offset=0, group=None, metric=0, force_collective=False, exchange_thresholds=False):
         import torch.distributed as dist
         self.index = local_index
         self.id_offset = int(id_offset)
         self.group = group
         self.metric = metric
         self.force_collective = force_collective   # run the all-gather + merge even with one rank (tests)
+        # LIST shards (rsx_set_param "add_list_mod"): a rank that does not own a query's closest lists derives a weak filter
+        # threshold from its own lists; with exchange_thresholds the search runs in two calls and the ranks all-reduce(MAX)
+        # the per-query threshold keys in between (one extra collective of nq x 8 bytes), so every rank filters as hard as
+        # the single index would.  Vector shards see the same lists on every rank and do not need it.
+        self.exchange_thresholds = exchange_thresholds
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def _search_two_call(self, q, k):
+        import torch
+        import torch.distributed as dist
+        tau = self.index.search_prepass(q, k)
+        # every rank takes part in the collective, also one whose search has no pre-pass (it contributes "no threshold")
+        t = (tau ^ _SIGN) if tau is not None else torch.full((q.shape[0],), _SIGN, dtype=torch.int64, device=q.device)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        else:                                   # gloo (CPU tests on a GPU box): through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            t = h.to(q.device)
+        if tau is not None:
+            tau.copy_(t ^ _SIGN)
+            torch.cuda.current_stream(q.device).synchronize()     # the library's stream reads the keys next
+        return self.index.search_scan()
 
     def search(self, q, k):
         """q: [nq, d] — the SAME batch on every rank (numpy / CPU tensor / CUDA tensor).
         Returns merged (D, I) [nq, k] on every rank, in the container type of the local result."""
         import torch
         import torch.distributed as dist
-        D, I = self.index.search(q, k)
+        if self.exchange_thresholds and torch.is_tensor(q) and q.is_cuda and self.world_size > 1:
+            D, I = self._search_two_call(q, k)
+        else:
+            D, I = self.index.search(q, k)
         as_numpy = not torch.is_tensor(D)
         if as_numpy:
             D, I = torch.from_numpy(np.ascontiguousarray(D)), torch.from_numpy(np.ascontiguousarray(I))

@@ -382,6 +382,31 @@ def test_list_sharded_index_equals_single_index(gpu, orc, kind):
     Dm, Im = gpu.merge_topk(np.stack(Ds), np.stack(Is))
     # exact cross-shard score ties may come back in shard order instead of id order; none in this data
     assert_same_results(Dm, Im, Df, If, f"list-sharded {kind}")
+    if kind == "ivfpq":
+        # two-call search (rsx_search_prepass / rsx_search_scan): the shards' thresholds are raised to their maximum between the
+        # pre-pass and the scan — what the all-reduce(MAX) of sharded.ShardedSearcher(exchange_thresholds=True) does across
+        # ranks.  Same merged bits, no exact re-runs, and no shard keeps more candidates than before.
+        import torch
+        from sharded import raise_thresholds
+        qd = torch.from_numpy(q).cuda()
+        for s in shards:
+            s.set_param("profile", 2)
+        plain = [s.search(qd, k) for s in shards]
+        cand_plain = [s.get_timing("cand_keys") for s in shards]
+        for s in shards:
+            s.set_param("profile", 2)
+        taus = [s.search_prepass(qd, k) for s in shards]
+        assert any(t is not None for t in taus)
+        raise_thresholds(taus)
+        torch.cuda.synchronize()
+        two = [s.search_scan() for s in shards]
+        cand_two = [s.get_timing("cand_keys") for s in shards]
+        assert sum(s.get_timing("fallback_queries") for s in shards) == 0
+        assert all(b <= a for a, b in zip(cand_plain, cand_two)) and sum(cand_two) < sum(cand_plain)
+        Dm3, Im3 = gpu.merge_topk(torch.stack([d_ for d_, _ in two]), torch.stack([i_ for _, i_ in two]))
+        assert_same_results(Dm3.cpu().numpy(), Im3.cpu().numpy(), Df, If, "list-sharded ivfpq, thresholds exchanged")
+        for s in shards:
+            s.set_param("profile", 1)
     with pytest.raises(RuntimeError):
         shards[0].set_param("add_list_mod", 2)          # only before the first add
     # a list shard survives save / load: the vectors it dropped still count towards the sequential ids of later adds
