@@ -62,6 +62,20 @@ def _worker(rank, world, port, ret):
             Dr, Ir = full.search(q, kk)
             ok[f"{kind}_k{kk}"] = bool(np.array_equal(I, Ir) and np.array_equal(D, Dr))
         ok[f"{kind}_tie"] = bool(list(searcher.search(q[:1], 5)[1][0]) == list(full.search(q[:1], 5)[1][0]))
+        if kind == "ivfpq":
+            # LIST shards + the threshold exchange: rank r keeps the lists l % 2 == r of the same add stream; the search runs in
+            # two calls (rsx_search_prepass / rsx_search_scan) with ONE all-reduce(MAX) of the threshold keys in between
+            ls = rsx.IndexIVFPQ(None, d, nlist, M, 8, rsx.METRIC_INNER_PRODUCT)
+            ls.set_centroids(full.get_centroids()); ls.set_codebooks(full.get_codebooks())
+            ls.set_param("add_list_mod", world); ls.set_param("add_list_rem", rank)
+            ls.nprobe = 4
+            ls.add(x)
+            ls.set_param("profile", 1)
+            qd = torch.from_numpy(q).cuda()
+            Dl, Il = ShardedSearcher(ls, id_offset=0, exchange_thresholds=True).search(qd, k)
+            Dr, Ir = full.search(q, k)
+            ok["ivfpq_list_shards_exchanged"] = bool(np.array_equal(Il.cpu().numpy(), Ir) and np.array_equal(Dl.cpu().numpy(), Dr))
+            ok["ivfpq_list_shards_no_exact_rerun"] = bool(ls.get_timing("fallback_queries") == 0)
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
