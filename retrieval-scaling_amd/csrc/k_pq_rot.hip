@@ -186,6 +186,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     constexpr int var = 0;          // the shipped library has no measurement branches
 #endif
     constexpr int M = 64 * NF + 32 * NH;
+    constexpr int RD = NF >= 2 ? 2 : ROT_D;    // code blocks in flight per wave (M = 128: two 2 KiB blocks — four would not fit 128 VGPRs)
     constexpr int NPH = NF + NH;               // phases = table planes
     constexpr int TAB = NPH * 65536;           // plane p at p * 64 KiB; row = code * 256; a half phase uses 128 B of the row
     constexpr int NG = M / 4;                  // gathers per lane per block
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         // offset in an SGPR, lane * 16 in one constant VGPR): no address VALU, and a block past the list's end reads zeros
         // instead of needing a clamp (its sums are garbage that the pos < len test of the survivor path drops)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lp, 0, nblk * 16 * M, 0x00020000);
-        v4u ca[ROT_D][NF > 0 ? NF : 1]; v2u cb[ROT_D];
+        v4u ca[RD][NF > 0 ? NF : 1]; v2u cb[RD];
         // ---- circular scan (round 3): the sibling groups of a list tile (the item's family: adjacent items, different CUs of this
         // XCD) read the same code lines, and a line lives ~5 us in the XCD's L2.  A workgroup that starts while a sibling is
         // already under way therefore does not begin at the tile's first block: it JOINS the most advanced running sibling at
@@ -327,18 +328,34 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             if (lane < 8) lds_wr32(sib_a + 4u * (uint32_t)lane, 0x7fffffffu);       // own slot and the lanes beyond the family never count
             if (family && f0 + lane < f1 && f0 + lane != item) sib_refresh(&prog[f0 + lane], sib_a);
         }
-        // ---- stage the group's table: work unit = (code, 4 consecutive m) -> 4 dwords (one per m: byte k = query k, as int8 = u8 - 128)
+        // ---- stage the group's table: work unit = (code, 4 consecutive m) -> 4 dwords (one per m: byte k = query k, as int8 = u8 - 128).
+        // All the loads of a thread's 256 * (M / 4) / 1024 units are issued before the first one is used (round 3: the loop
+        // used to pay one L2 round trip per unit, 6 in a row for M = 96).
         {
             const int64_t q0 = it->q[0], q1 = it->q[1], q2 = it->q[2], q3 = it->q[3];
-            for (int e = tid; e < ((var & 4) || skip_item ? 0 : 256 * (M / 4)); e += 1024) {
+            constexpr int NU = (256 * (M / 4) + 1023) / 1024;
+            const int nunits = ((var & 4) || skip_item) ? 0 : 256 * (M / 4);
+            constexpr int GB = NU <= 6 ? NU : (NU + 1) / 2;          // loads in flight per thread: at most 6 x 4 registers
+            uint32_t in[GB][4];
+#pragma unroll
+            for (int g0 = 0; g0 < NU; g0 += GB) {
+#pragma unroll
+            for (int u = 0; u < GB; u++) {
+                const int e = tid + (g0 + u) * 1024;
+                const int ee = e < nunits ? e : 0;
+                const int c = ee / (M / 4), m4 = ee - c * (M / 4);
+                in[u][0] = *reinterpret_cast<const uint32_t*>(A.lut8 + (q0 * 256 + c) * M + m4 * 4);
+                in[u][1] = np > 1 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q1 * 256 + c) * M + m4 * 4) : 0u;
+                in[u][2] = np > 2 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q2 * 256 + c) * M + m4 * 4) : 0u;
+                in[u][3] = np > 3 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q3 * 256 + c) * M + m4 * 4) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < GB; u++) {
+                const int e = tid + (g0 + u) * 1024;
+                if (e >= nunits) continue;
                 const int c = e / (M / 4), m4 = e - c * (M / 4);
-                uint32_t in[4];
-                in[0] = *reinterpret_cast<const uint32_t*>(A.lut8 + (q0 * 256 + c) * M + m4 * 4);
-                in[1] = np > 1 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q1 * 256 + c) * M + m4 * 4) : 0u;
-                in[2] = np > 2 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q2 * 256 + c) * M + m4 * 4) : 0u;
-                in[3] = np > 3 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q3 * 256 + c) * M + m4 * 4) : 0u;
-                const uint32_t t0 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);
-                const uint32_t u0 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u), u1 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
+                const uint32_t t0 = __builtin_amdgcn_perm(in[u][1], in[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[u][1], in[u][0], 0x07030602u);
+                const uint32_t u0 = __builtin_amdgcn_perm(in[u][3], in[u][2], 0x05010400u), u1 = __builtin_amdgcn_perm(in[u][3], in[u][2], 0x07030602u);
                 uint4 o;
                 o.x = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
                 o.y = __builtin_amdgcn_perm(u0, t0, 0x07060302u) ^ 0x80808080u;
@@ -348,6 +365,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 const int p = m < 64 * NF ? (m >> 6) : NF;
                 const int slot = m < 64 * NF ? (m & 63) : (m - 64 * NF);
                 *reinterpret_cast<uint4*>(sb + p * 65536 + c * 256 + slot * 4) = o;
+            }
             }
         }
         uint64_t* myseg = seg_keys + (((size_t)item * 16 + w) * 4 + nq4) * seg_cap;
@@ -366,7 +384,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             int nb0 = skip_item ? 0 : (nblk - tb0 + 15) >> 4;
             if (nb0 > bpw) nb0 = bpw;
             if (nb0 < 0) nb0 = 0;
-            nit0 = (nb0 + ROT_D - 1) / ROT_D;
+            nit0 = (nb0 + RD - 1) / RD;
         }
         const bool prio_rot = !((pace_arg >> 4) & 4);      // diagnostics: bit 6 of pq_pace switches the priority rotation off
         // bit 4 of pq_pace: dynamic chunk distribution (an LDS counter instead of the static column = wave split).  Measured at
@@ -406,19 +424,19 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         const uint64_t t_scan0 = wall_clock64();
 #endif
 
-        // ---- scan.  The tile is a grid of CHUNKS: chunk (row r, column c) = the ROT_D blocks tb0 + c + 16 (r ROT_D + dd), i.e. the
+        // ---- scan.  The tile is a grid of CHUNKS: chunk (row r, column c) = the RD blocks tb0 + c + 16 (r RD + dd), i.e. the
         // blocks column c of the 16 would scan in loop iteration r of a static round-robin.  Rows 0 .. R-1 are full, the last row
         // has cl <= 16 non-empty chunks.  Chunks are taken in SEQUENCE order n = 0, 1, ...: the full rows circularly from row r0
         // (the join position), the partial row last; column = n % 16.  Wave w takes the sequence numbers w, 16 + w, 32 + w, ...
         // (static split), or — dyn_on — its first two statically and every further one from an LDS counter, one loop iteration
-        // ahead of its use.  Each wave keeps ROT_D blocks in flight: while chunk A is scanned its register slots are refilled
+        // ahead of its use.  Each wave keeps RD blocks in flight: while chunk A is scanned its register slots are refilled
         // with chunk B's blocks.
         int nb0 = ((var & 2) || skip_item) ? 0 : (nblk - tb0 + 15) >> 4;           // blocks of column 0 (the longest column)
         if (nb0 > bpw) nb0 = bpw;
         if (nb0 < 0) nb0 = 0;
-        const int nrow = (nb0 + ROT_D - 1) / ROT_D;                                // = nit0
+        const int nrow = (nb0 + RD - 1) / RD;                                // = nit0
         const int R = nrow > 0 ? nrow - 1 : 0;                                     // full rows
-        int cl = nrow > 0 ? nblk - tb0 - 16 * (R * ROT_D) : 0;                     // non-empty chunks of the last row
+        int cl = nrow > 0 ? nblk - tb0 - 16 * (R * RD) : 0;                     // non-empty chunks of the last row
         if (cl > 16) cl = 16;
         if (cl < 0) cl = 0;
         const int nch = 16 * R + cl;
@@ -426,18 +444,20 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         if (r0 >= R) r0 = 0;
         const int so_oob = nblk * (16 * M);                                        // past the descriptor's end: reads zeros
         // sequence number -> byte offset of the chunk's first block (so_oob: no such chunk), its row, and whether it is on the second pass
-        auto chunk_of = [&](int nseq, int& row, bool& wrapped) -> int {
-            if (nseq >= nch) { row = 0; wrapped = true; return so_oob; }
+        auto row_of = [&](int nseq, bool& wrapped) -> int {          // row of a valid sequence number, and whether it is on the second pass
             int r = nseq >> 4;
             if (r < R) { r += r0; wrapped = r >= R; if (wrapped) r -= R; } else { r = R; wrapped = r0 > 0; }
-            row = r;
-            return (tb0 + (nseq & 15) + 16 * (r * ROT_D)) * (16 * M);
+            return r;
+        };
+        auto chunk_of = [&](int nseq) -> int {
+            if (nseq >= nch) return so_oob;
+            bool wr_;
+            return (tb0 + (nseq & 15) + 16 * (row_of(nseq, wr_) * RD)) * (16 * M);
         };
         int nA = w, nB = 16 + w, nC = 0x7fffffff;
-        int rowA = 0, rowB = 0; bool wrapA = false, wrapB = false;
-        int soA = chunk_of(nA, rowA, wrapA), soB = chunk_of(nB, rowB, wrapB);
+        int soA = chunk_of(nA), soB = chunk_of(nB);
 #pragma unroll
-        for (int dd = 0; dd < ROT_D; dd++) {     // chunk A's blocks
+        for (int dd = 0; dd < RD; dd++) {     // chunk A's blocks
             const int so = soA == so_oob ? so_oob : soA + dd * 16 * (16 * M);
 #pragma unroll
             for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
@@ -464,8 +484,11 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 // visibility is all that is needed — a plain store (the vector L1 is write-through) and readers that bypass their
                 // L1 (sc0).  A device-scope store (sc1) writes through to the fabric and its late acknowledgement holds the wave's
                 // in-order vmcnt queue, i.e. every code load behind it (measured: the scan 1.45x slower with one per iteration).
-                if (family && lane == 0)
-                    __hip_atomic_store(&prog[item], (uint32_t)(rowA + 1) | (wrapA ? 0x40000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (family) {
+                    bool wrapA; const int rowA = row_of(nA, wrapA);
+                    if (lane == 0)
+                        __hip_atomic_store(&prog[item], (uint32_t)(rowA + 1) | (wrapA ? 0x40000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 if (dstate == 1 && nA >= nch - 16) {
                     i1 = resolve_draw();
                     if (lane < 11 && i1 != 0x7fffffff) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
@@ -474,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 if (dstate == 0 && nA >= nch - 48) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }
             }
 #pragma unroll
-            for (int dd = 0; dd < ROT_D; dd++) {
+            for (int dd = 0; dd < RD; dd++) {
                 const int b = b0 + 16 * dd;
                 uint32_t gv[NG];
                 // addresses: (plane << 16) | (code << 8) | rotation byte — one v_perm each
@@ -547,9 +570,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                     }
                 }
             }
-            nA = nB; soA = soB; rowA = rowB; wrapA = wrapB;
+            nA = nB; soA = soB;
             nB = __builtin_amdgcn_readfirstlane(nC);
-            soB = chunk_of(nB, rowB, wrapB);
+            soB = chunk_of(nB);
         }
         // ---- item epilogue: the wave's four survivor counts leave with one store (lanes 0..3 own queries 0..3); wave 0 parks
         // the next record (or the end marker) and draws the index of the item after it
