@@ -386,11 +386,17 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             if (nb0 < 0) nb0 = 0;
             nit0 = (nb0 + RD - 1) / RD;
         }
-        const bool prio_rot = !((pace_arg >> 4) & 4);      // diagnostics: bit 6 of pq_pace switches the priority rotation off
-        // bit 4 of pq_pace: dynamic chunk distribution (an LDS counter instead of the static column = wave split).  Measured at
-        // the bench size: it equalises the waves' finish times (45 .. 57 us -> all 60 us) and leaves the item time unchanged —
-        // the CU's LDS + MFMA throughput is the bound, not the ragged tail — so the static split stays the default.
+        // static columns up to sequence number dyn_from, the tail from the LDS counter (which starts there): the waves of a SIMD do
+        // not run at one speed — the arbiter favours the oldest — and with a fully static split the slowest wave finished its share
+        // 9 us after the fastest (49 vs 58 us per item, measured); drawing EVERY chunk dynamically cost more in LDS atomics than the
+        // balance returned, so only the last dyn_rows rows of a tile are drawn
+        // (bit 4 of pq_pace: every chunk dynamic — measured: all waves then finish together at 60 us, later than the slowest did)
         const bool dyn_on = ((pace_arg >> 4) & 1) != 0;
+        const int dyn_rows = dyn_on ? 0x7fff : (int)((pace_arg >> 12) & 15);      // bits 12-15 of pq_pace (0 = static throughout)
+        int dyn_from = 16 * (nit0 - dyn_rows);                                      // nit0 rows in all, the last one possibly partial
+        if (dyn_from < 32) dyn_from = 32;
+        if (dyn_rows == 0) dyn_from = 0x7fffffff;
+        const bool prio_rot = !((pace_arg >> 4) & 4);      // diagnostics: bit 6 of pq_pace switches the priority rotation off
 #ifdef RSX_MEASURE
         if (tid == 0 && item < 65536) {
             g_rot_trace[4 * item + 0] = wall_clock64();
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                     if (best != 0u && (int)best - 1 + ahead + 2 < nit0 - 1) i0v = best - 1u + (uint32_t)ahead;
                 }
             }
-            if (lane == 0) { lds_wr32(i0_a, i0v); lds_wr32(chunk_a, 32u); }     // chunk sequence numbers 0..31 are pre-assigned
+            if (lane == 0) { lds_wr32(i0_a, i0v); lds_wr32(chunk_a, (uint32_t)dyn_from); }
         }
         // ---- the lane's share of the item record: accumulator init, score parameters of the query it owns (n < 4)
         const int cinit = FILTER ? (n < 4 ? it->cinit[nq4] : -(1 << 30)) : 0;
@@ -466,8 +472,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 #pragma unroll 1
         for (int k = 0; nA < nch; k++) {
             // the chunk after next: drawn now, needed at the end of this iteration
-            if (dyn_on) { if (lane == 0) nC = (int)__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + chunk_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-            else nC = nB + 16;
+            if (nB + 16 < dyn_from) nC = nB + 16;
+            else if (lane == 0) nC = (int)__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + chunk_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int b0 = soA / (16 * M);                                         // first block of chunk A
             const int so_next = soB;
             if (prio_rot) {

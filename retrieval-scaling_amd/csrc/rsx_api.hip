@@ -174,9 +174,11 @@ struct rsx_index {
     int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
     int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
     int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
-    int pq_pace = 128;    // rotated fast scan, L2 reuse between the query groups of a list tile: bit 7 = a late group JOINS its running
-                          // sibling's position and wraps around (default), bits 0-3 = additionally brake a group that runs this many
-                          // loop iterations ahead of a close sibling (0 = no brake), bits 8-11 = join offset (0 = 2 iterations)
+    int pq_pace = 128 | (4 << 12);   // rotated fast scan schedule (never changes a result): bit 7 = a query group that starts while a
+                          // sibling group of its list tile is under way JOINS it at its position and wraps around (L2 reuse of the code
+                          // lines), bits 8-11 = join offset in tile rows (0 = 2), bits 12-15 = the last n rows of a tile are handed to
+                          // the waves dynamically (default 4; 0 = static columns), bit 4 = every chunk dynamic, bit 6 = no issue-
+                          // priority rotation
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
