@@ -161,3 +161,61 @@ def test_config5_eight_ranks_sharded_searcher(gpu, tmp_path):
     assert set(got) == set(range(NSHARDS))
     for r in range(NSHARDS):                      # every rank holds the merged result, and it is the single index's
         assert_same_results(got[r][0], got[r][1], Ds, Is, f"config 5: rank {r} of 8, merged result vs single index")
+
+
+def test_headline_size_100M_parity_and_invariants(gpu, orc):
+    """BASELINE config 4 at its FULL size — 100M x 768, IVF-PQ M = 96, nlist 4096, nprobe 32, batch 1024, k = 10 — as a test
+    (full-size parity used to rest on the bench line alone).  The lists are ~24k vectors long here (366 at the
+    1.5M test sizes): whole-list tiles, multi-tile lists, sibling-group joins and the work stealing all run at their real
+    shapes.  Checks: a sample of queries bit-equal to the CPU oracle on the exported probed lists, batch-split invariance of
+    the whole batch, k = 100 (the 16k-vector pre-pass sample and the emission path) against the oracle, and no exact re-runs."""
+    import torch
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * (1 << 30):
+        pytest.skip("needs ~25 GB of free HBM")
+    n, nq, k = 100_000_000, 1024, 10
+    ix = gpu.IndexIVFPQ(None, D, NLIST, M, 8, gpu.METRIC_INNER_PRODUCT, device=0)
+    nt = 256 * NLIST
+    xt = torch.empty((nt, D), dtype=torch.float16, device=dev)
+    stride = n // nt
+    for b in range(0, nt, 4096):
+        gpu.synth_vectors(D, NCENT, SEED_C, SEED_X, 0.5, (b * stride) % (n - 4096), 4096, out=xt[b:b + 4096])
+    ix.train(xt); del xt
+    ix.nprobe = NPROBE
+    buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
+    for c0 in range(0, n, 1_000_000):
+        gpu.synth_vectors(D, NCENT, SEED_C, SEED_X, 0.5, c0, 1_000_000, out=buf); ix.add(buf)
+    del buf
+    assert ix.ntotal == n
+    q = torch.empty((nq, D), dtype=torch.float16, device=dev)
+    gpu.synth_queries(D, NCENT, SEED_C, SEED_X, 0.5, n, SEED_Q, 0.1, 0, nq, out=q)
+    ix.set_param("profile", 1)
+    Dg, Ig = ix.search(q, k)
+    assert ix.get_timing("fallback_queries") <= 2                       # the fast scan certifies (nearly) every query at this size
+    for s in range(0, nq, 256):                                         # batch decomposition must be invisible
+        Ds, Is = ix.search(q[s:s + 256], k)
+        assert torch.equal(Ds, Dg[s:s + 256]) and torch.equal(Is, Ig[s:s + 256])
+    sample = [0, 1, 255, 256, 511, 640, 777, 1023]
+    qs = q[sample].cpu().numpy().astype(np.float32)
+    cen, cb = ix.get_centroids(), ix.get_codebooks()
+    ls = ix.list_sizes()
+    pid, _ = orc.coarse_probe(cen, qs, NPROBE)
+    need = np.unique(pid[pid >= 0])
+    lens = np.zeros(NLIST, dtype=np.int64); lens[need] = ls[need]
+    off = np.zeros(NLIST + 1, dtype=np.int64); np.cumsum(lens, out=off[1:])
+
+    class LM:
+        pass
+    lm = LM()
+    lm.list_off = off
+    lm.payload = np.empty((int(off[-1]), M), np.uint8)
+    lm.ids = np.empty(int(off[-1]), np.int64)
+    for l in need:
+        c, i = ix.get_list(int(l))
+        lm.payload[off[l]:off[l + 1]] = c; lm.ids[off[l]:off[l + 1]] = i
+    Do, Io = orc.ivfpq_search(cen, cb, lm, qs, NPROBE, k)
+    assert_same_results(Dg.cpu().numpy()[sample], Ig.cpu().numpy()[sample], Do, Io, "100M IVF-PQ vs CPU oracle (sample of 8 queries)")
+    D1, I1 = ix.search(q[sample], 100)
+    Do1, Io1 = orc.ivfpq_search(cen, cb, lm, qs, NPROBE, 100)
+    assert_same_results(D1.cpu().numpy(), I1.cpu().numpy(), Do1, Io1, "100M IVF-PQ k = 100 vs CPU oracle")
