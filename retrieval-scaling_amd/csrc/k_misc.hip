@@ -370,3 +370,85 @@ void launch_residuals(const float* x, int64_t n, int d, const float* centroids, 
 }
 
 }  // namespace rsx
+
+
+// ---------------------------------------------------------------------------------------
+// Destination rows of an add batch, computed on the device (round 3; reference: InvertedLists::add_entries appends in
+// arrival order — src/indicies/ivf_flat.py:180, ivf_pq.py:185).  dest[i] = first free row of list a[i] + the number of earlier
+// rows of the batch assigned to the same list: a STABLE rank, so the in-list order is the insertion order whatever the
+// launch geometry.  Three small kernels around one 4-byte-per-list read-back (the host must see the per-list totals to grow
+// the lists) instead of the assignments going to the host and a row table coming back (12 bytes per vector):
+//   k_add_count : segment g (one wave) -> cnt[g][l] = rows of the segment assigned to list l (kept lists only)
+//   k_add_scan  : per list, exclusive scan over the segments (in place) and the batch total
+//   k_add_place : segment g walks its rows 64 at a time; LDS holds the running first-free row of every list
+// Lists that are not this shard's (l % mod != rem) get dest = -1.
+// ---------------------------------------------------------------------------------------
+namespace rsx {
+constexpr int ADD_SEG = 1024;      // rows per segment
+
+__global__ __launch_bounds__(64) void k_add_count(const int32_t* assign, int64_t n, int nlist, int lmod, int lrem, int32_t* cnt) {
+    extern __shared__ int32_t ac_lds[];
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    for (int l = lane; l < nlist; l += 64) ac_lds[l] = 0;
+    __syncthreads();
+    const int64_t r0 = g * ADD_SEG;
+    for (int64_t i = r0 + lane; i < r0 + ADD_SEG && i < n; i += 64) {
+        const int32_t l = assign[i];
+        if (lmod <= 1 || l % lmod == lrem) atomicAdd(&ac_lds[l], 1);
+    }
+    __syncthreads();
+    for (int l = lane; l < nlist; l += 64) cnt[g * nlist + l] = ac_lds[l];
+}
+__global__ void k_add_scan(int32_t* cnt, int64_t nseg, int nlist, int32_t* total) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlist) return;
+    int32_t run = 0;
+    for (int64_t g = 0; g < nseg; g++) { const int32_t c = cnt[g * nlist + l]; cnt[g * nlist + l] = run; run += c; }
+    total[l] = run;
+}
+__global__ __launch_bounds__(64) void k_add_place(const int32_t* assign, int64_t n, int nlist, int lmod, int lrem, const int32_t* off,
+                                                  const int64_t* start, int64_t* dest) {
+    extern __shared__ int32_t ap_lds[];      // running offset (rows of this batch already placed) per list
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    for (int l = lane; l < nlist; l += 64) ap_lds[l] = off[g * nlist + l];
+    __syncthreads();
+    const int64_t r0 = g * ADD_SEG;
+    for (int64_t c0 = r0; c0 < r0 + ADD_SEG && c0 < n; c0 += 64) {
+        const int64_t i = c0 + lane;
+        const bool in = i < n;
+        const int32_t l = in ? assign[i] : -1;
+        const bool keep = in && (lmod <= 1 || l % lmod == lrem);
+        // stable rank among the lanes of this chunk with the same list: walk the distinct lists, lowest lane first
+        int rank = 0, base = 0;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(keep);
+        while (todo) {
+            const int lead = __builtin_ctzll(todo);
+            const int32_t lk = __builtin_amdgcn_readlane(l, lead);
+            const uint64_t same = __builtin_amdgcn_ballot_w64(keep && l == lk);
+            if (keep && l == lk) {
+                rank = __builtin_popcountll(same & ((1ull << lane) - 1ull));
+                base = ap_lds[lk];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == lead) ap_lds[lk] = base + __builtin_popcountll(same);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~same;
+        }
+        if (in) dest[i] = keep ? start[l] + base + rank : -1;
+    }
+}
+void launch_add_destinations(const int32_t* assign, int64_t n, int nlist, int lmod, int lrem, int32_t* seg_cnt /* [nseg][nlist] */,
+                             int32_t* total /* [nlist] */, hipStream_t st) {
+    const int64_t nseg = (n + ADD_SEG - 1) / ADD_SEG;
+    hipLaunchKernelGGL(k_add_count, dim3((unsigned)nseg), dim3(64), (size_t)nlist * 4, st, assign, n, nlist, lmod, lrem, seg_cnt);
+    hipLaunchKernelGGL(k_add_scan, dim3((unsigned)((nlist + 255) / 256)), dim3(256), 0, st, seg_cnt, nseg, nlist, total);
+}
+void launch_add_place(const int32_t* assign, int64_t n, int nlist, int lmod, int lrem, const int32_t* seg_off, const int64_t* start,
+                      int64_t* dest, hipStream_t st) {
+    const int64_t nseg = (n + ADD_SEG - 1) / ADD_SEG;
+    hipLaunchKernelGGL(k_add_place, dim3((unsigned)nseg), dim3(64), (size_t)nlist * 4, st, assign, n, nlist, lmod, lrem, seg_off, start, dest);
+}
+int64_t add_dest_segments(int64_t n) { return (n + ADD_SEG - 1) / ADD_SEG; }
+}  // namespace rsx

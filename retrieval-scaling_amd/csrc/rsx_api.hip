@@ -192,7 +192,7 @@ struct rsx_index {
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart;
     std::map<std::string, double> timing;
 
     // Flat / IVF-Flat: largest |x|^2 ever added (certificate of the MFMA scan); device copy is the running atomic max
@@ -236,7 +236,7 @@ static int64_t workspace_bytes(const rsx_index* h) {
     const DevBuf* bufs[] = {&h->w_q32, &h->w_q16, &h->w_coarse, &h->w_keys1, &h->w_probekeys, &h->w_probelist, &h->w_dis0, &h->w_segstart,
                             &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
                             &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
-                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->sh_D, &h->sh_I, &h->sh_q,
+                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->sh_D, &h->sh_I, &h->sh_q,
                             &h->sh_oD, &h->sh_oI};
     int64_t t = 0;
     for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
@@ -466,26 +466,47 @@ static void add_batch(rsx_index* h, int64_t n, const void* x, int dtype, const i
     h->w_assign.ensure((size_t)n * 4);
     launch_gemm_exact_argmax(dx, dtype == RSX_F16, n, h->d, h->d_centroids.as<float>(), h->nlist, h->d,
                              h->w_partial.as<uint64_t>(), h->w_assign.as<int32_t>(), nullptr, h->st);
-    std::vector<int32_t> assign((size_t)n);
-    HIPCHECK(hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHECK(hipStreamSynchronize(h->st));
-
-    std::vector<int64_t> need(h->h_len);
-    std::vector<int64_t> pos((size_t)n);
-    // list-sharded multi-GPU index: this handle keeps only the lists l with l % add_list_mod == add_list_rem; the other
-    // vectors of the stream are assigned (they advance the sequential ids) and dropped
+    // placement on the device (round 3): only the per-list totals of the batch visit the host (4 bytes per list — it has to
+    // grow the lists), not the assignments (4 bytes per vector out, 8 back): stable ranks = insertion order inside a list.
+    // List-sharded multi-GPU index: this handle keeps only the lists l with l % add_list_mod == add_list_rem; the other
+    // vectors of the stream are assigned (they advance the sequential ids) and dropped.
     const int lmod = std::max(1, h->add_list_mod), lrem = h->add_list_rem;
+    const int64_t nseg = add_dest_segments(n);
+    std::vector<int64_t> need(h->h_len);
     int64_t nkept = 0;
-    for (int64_t i = 0; i < n; i++) {
-        const int32_t l = assign[(size_t)i];
-        if (lmod > 1 && l % lmod != lrem) { pos[(size_t)i] = -1; continue; }
-        pos[(size_t)i] = need[(size_t)l]++;  // insertion order inside a list
-        nkept++;
-    }
-    ensure_capacity(h, need, false);
-    for (int64_t i = 0; i < n; i++) if (pos[(size_t)i] >= 0) pos[(size_t)i] += h->h_base[(size_t)assign[(size_t)i]];
     h->w_dest.ensure((size_t)n * 8);
-    HIPCHECK(hipMemcpyAsync(h->w_dest.p, pos.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+    if ((size_t)h->nlist * 4 > 60 * 1024) {
+        // more lists than the placement kernels' LDS table holds (15360): the round-2 host placement
+        std::vector<int32_t> assign((size_t)n);
+        HIPCHECK(hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));
+        std::vector<int64_t> pos((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const int32_t l = assign[(size_t)i];
+            if (lmod > 1 && l % lmod != lrem) { pos[(size_t)i] = -1; continue; }
+            pos[(size_t)i] = need[(size_t)l]++;
+            nkept++;
+        }
+        ensure_capacity(h, need, false);
+        for (int64_t i = 0; i < n; i++) if (pos[(size_t)i] >= 0) pos[(size_t)i] += h->h_base[(size_t)assign[(size_t)i]];
+        HIPCHECK(hipMemcpyAsync(h->w_dest.p, pos.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));   // pos is a local
+    } else {
+    h->w_addcnt.ensure((size_t)(nseg + 1) * h->nlist * 4);
+    int32_t* seg_cnt = h->w_addcnt.as<int32_t>();
+    int32_t* d_total = seg_cnt + (size_t)nseg * h->nlist;
+    launch_add_destinations(h->w_assign.as<int32_t>(), n, h->nlist, lmod, lrem, seg_cnt, d_total, h->st);
+    std::vector<int32_t> total((size_t)h->nlist);
+    HIPCHECK(hipMemcpyAsync(total.data(), d_total, (size_t)h->nlist * 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(hipStreamSynchronize(h->st));
+    for (int l = 0; l < h->nlist; l++) { need[(size_t)l] += total[(size_t)l]; nkept += total[(size_t)l]; }
+    ensure_capacity(h, need, false);
+    std::vector<int64_t> start((size_t)h->nlist);
+    for (int l = 0; l < h->nlist; l++) start[(size_t)l] = h->h_base[(size_t)l] + h->h_len[(size_t)l];
+    h->w_addstart.ensure((size_t)h->nlist * 8);
+    HIPCHECK(hipMemcpyAsync(h->w_addstart.p, start.data(), (size_t)h->nlist * 8, hipMemcpyHostToDevice, h->st));
+    launch_add_place(h->w_assign.as<int32_t>(), n, h->nlist, lmod, lrem, seg_cnt, h->w_addstart.as<int64_t>(), h->w_dest.as<int64_t>(), h->st);
+    }
 
     if (h->kind == KIND_IVFPQ) {
         launch_pq_encode(dx, dtype == RSX_F16, n, h->d, h->d, h->M, h->Mpad, h->CB, h->d_centroids.as<float>(),

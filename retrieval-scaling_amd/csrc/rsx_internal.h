@@ -140,6 +140,11 @@ void launch_max_norm2(const void* x, int x_f16, int64_t n, int d, unsigned int* 
 void launch_scatter_rows(const void* x, int x_f16, int64_t n, int d, const int64_t* dest_row, void* storage,
                          int storage_f16, int ld, float* norms, const int64_t* ids_in, int64_t id0,
                          int64_t* ids_storage, hipStream_t st);
+// destination rows of an add batch on the device (k_misc.hip): per-list totals first (the host grows the lists), then the rows
+int64_t add_dest_segments(int64_t n);
+void launch_add_destinations(const int32_t* assign, int64_t n, int nlist, int lmod, int lrem, int32_t* seg_cnt, int32_t* total, hipStream_t st);
+void launch_add_place(const int32_t* assign, int64_t n, int nlist, int lmod, int lrem, const int32_t* seg_off, const int64_t* start,
+                      int64_t* dest, hipStream_t st);
 // copy lists between two layouts (re-layout on growth). row_bytes = bytes per row group unit.
 void launch_copy_lists(int nlist, const int64_t* old_base, const int64_t* new_base, const int64_t* len,
                        const uint8_t* old_data, uint8_t* new_data, int64_t unit_rows, int64_t unit_bytes,
