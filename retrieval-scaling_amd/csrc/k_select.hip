@@ -609,8 +609,12 @@ void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, in
                            tile_cap);
         return;
     }
-    hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
-    hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
+    if (cursor == cnt + (nlist + 1)) {      // the callers lay the two arrays end to end: one launch
+        hipLaunchKernelGGL(k_zero_i32, dim3((2 * nlist + 1 + 255) / 256), dim3(256), 0, st, cnt, 2 * nlist + 1);
+    } else {
+        hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
+        hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
+    }
     hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, nprobe, jmin, jmax, cnt);
     hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, group_size, pair_off, group_off, total_groups,
                        list_len, tile_rows, tile_cap, item_off, total_items);

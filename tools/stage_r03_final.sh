@@ -19,6 +19,16 @@ python tools/pmc_summary.py gpurun_out/pmc_sq/${TAG}_results.db gpurun_out/${TAG
 python tools/pmc_summary.py gpurun_out/pmc_sq2/${TAG}_results.db gpurun_out/${TAG}_pmc_sq_counters.md '%k_pq_scan%'
 rm -rf gpurun_out/pmc_sq gpurun_out/pmc_sq2
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_ivfpq100M.json 2> gpurun_out/${TAG}_bench.log; echo "exit $?" >> gpurun_out/${TAG}_bench.log
+: > gpurun_out/${TAG}_per_rank_workloads.txt
+for cfg in "50000000 1024" "25000000 1024" "12500000 1024"; do
+  set -- $cfg
+  timeout 600 python bench.py --n $1 --batch $2 --steps 20 --warmup 5 --cpu-queries 0 --no-recall --no-configs > gpurun_out/${TAG}_n$1_b$2.json 2> gpurun_out/${TAG}_n$1_b$2.log
+  python - gpurun_out/${TAG}_n$1_b$2.json $1 $2 >> gpurun_out/${TAG}_per_rank_workloads.txt <<'P'
+import json,sys
+j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); s=j["stage_ms_per_step"]
+print(f"n={sys.argv[2]} batch={sys.argv[3]}: {j['ms_per_step']:.3f} ms/step, scan {s['scan']:.3f}, fixed {j['ms_per_step']-s['scan']:.3f}, {j['value']:.0f} q/s of this one rank")
+P
+done
 timeout 600 python bench.py --n 125000000 --steps 10 --warmup 3 --cpu-queries 0 --no-recall --no-configs > gpurun_out/${TAG}_bench_125M_one_rank_of_config5.json 2> gpurun_out/${TAG}_bench_125M.log; echo "exit $?" >> gpurun_out/${TAG}_bench_125M.log
 timeout 500 python tools/bench_configs.py latency > gpurun_out/${TAG}_latency_ivfpq100M.json 2> gpurun_out/${TAG}_latency.log; echo "exit $?" >> gpurun_out/${TAG}_latency.log
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_flat" -o $TAG -- python "$OLDPWD/tools/bench_configs.py" flat --check 64 --steps 3 > "$OLDPWD/gpurun_out/${TAG}_flat10M.json" 2> "$OLDPWD/gpurun_out/${TAG}_flat10M.log" ); echo "exit $?" >> gpurun_out/${TAG}_flat10M.log
