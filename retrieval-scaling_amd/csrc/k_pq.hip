@@ -715,16 +715,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
         prm_t[i] = FILTER ? A.tau_key[qq[i] * A.tau_stride] : 0ull;
     }
     __syncthreads();
-    // rolled on purpose: one slab body is ~1000 instructions; unrolling VPL of them overflows the 64 KB
-    // instruction cache
-#pragma unroll 1
-    for (int u = 0; u < VPL; u++) {
-        const int64_t s = s0 + w + 16 * u;
-        if (s >= nslab) break;
-        const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
-        uint4 c[NCH];
-#pragma unroll
-        for (int gg = 0; gg < NCH; gg++) c[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
+    // one slab: 64 vectors x NCH x 16 look-ups for the group's <= 4 queries, then the score / candidate output
+    auto slab = [&](const uint4 (&c)[NCH], const int64_t s) {
         uint32_t acc02 = 0, acc13 = 0;   // 16-bit fields: queries (0,2) and (1,3); 96*255 < 65536
 #pragma unroll
         for (int gg = 0; gg < NCH; gg++) {
@@ -769,6 +761,57 @@ __global__ __launch_bounds__(1024) void k_pq_scan8(PQScan8Args A) {
                     base = __shfl(base, leader);
                     const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
                     if (pass && slot < (unsigned long long)A.cand_cap) A.cand[q * A.cand_cap + slot] = key;
+                }
+            }
+        }
+    };
+    // Slabs in flight per wave (round 3).  The loop used to load a slab and use it at once: every iteration paid a full HBM
+    // round trip (~2 us against ~0.3 us of gathers), which made the small-M scans latency-bound (M = 16, nprobe 512: 8.9 ms
+    // where the LDS gathers need ~5).  Now PD slabs travel while one is summed.  Two register rings alternate (a slot's
+    // refill lands in the OTHER ring: the words being summed stay live through the body, so an in-place refill would be a
+    // copy behind a vmcnt(0)); the loop is unrolled 2 PD times so the slots are plain registers, and every wait is
+    // `vmcnt((PD - 1) NCH)` on the entry and on the back edge alike (the prologue issues in slot order).
+    // M >= 64 (NCH >= 4) keeps the plain form: those sizes run on the rotated layout, and 2 PD NCH x 4 registers would spill.
+    constexpr int PD = NCH == 1 ? 4 : (NCH <= 3 ? 2 : 0);
+    const int wu = __builtin_amdgcn_readfirstlane(w);      // scalar slab numbers: the loop's branches stay uniform
+    if constexpr (PD == 0) {
+        // rolled on purpose: one slab body is ~1000 instructions; unrolling VPL of them overflows the 64 KB instruction cache
+#pragma unroll 1
+        for (int u = 0; u < VPL; u++) {
+            const int64_t s = s0 + wu + 16 * u;
+            if (s >= nslab) break;
+            const uint8_t* sp = a.codes + (slab_base + s) * slab_bytes;
+            uint4 c[NCH];
+#pragma unroll
+            for (int gg = 0; gg < NCH; gg++) c[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
+            slab(c, s);
+        }
+    } else {
+        uint4 ring[2][PD][NCH];
+        auto fetch = [&](uint4 (&dst)[NCH], const int64_t sl) {
+            const uint8_t* sp = a.codes + (slab_base + sl) * slab_bytes;
+#pragma unroll
+            for (int gg = 0; gg < NCH; gg++) dst[gg] = *reinterpret_cast<const uint4*>(sp + gg * 1024 + lane * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int p = 0; p < PD; p++) {
+            const int64_t sl = s0 + wu + 16 * p;
+            fetch(ring[0][p], (p < VPL && sl < nslab) ? sl : s0);     // s0 < nslab: a valid slab either way
+        }
+        bool done = false;
+#pragma unroll 1
+        for (int u0 = 0; u0 < VPL && !done; u0 += 2 * PD) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int p = 0; p < PD; p++) {
+                    const int u = u0 + h * PD + p;
+                    const int64_t s = s0 + wu + 16 * u;
+                    if (done || u >= VPL || s >= nslab) { done = true; continue; }
+                    const int64_t sn = s + 16 * PD;         // the slot's next slab goes to the other ring
+                    if (u + PD < VPL && sn < nslab) fetch(ring[h ^ 1][p], sn);
+                    slab(ring[h][p], s);
                 }
             }
         }

@@ -468,6 +468,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 #pragma unroll
             for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
             if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
+            // keep the issue order dd = 0 .. RD-1: the loop waits for slot dd with `vmcnt(loads of the RD-1 younger slots)`, and one
+            // s_waitcnt serves both the loop entry and the back edge — with the scheduler's order (slot 0 LAST) the entry needs
+            // vmcnt(0), so every iteration drained all RD refills it had just issued (prefetch distance one block instead of RD)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll 1
         for (int k = 0; nA < nch; k++) {
@@ -627,8 +631,22 @@ __global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem*
         base = atomicAdd(&cand_cnt[q * CCS], (unsigned long long)total + (myover ? (unsigned long long)cand_cap + 1ull : 0ull));
     }
     base = __shfl(base, k) + (incl - c);
-    // copy-out: the wave walks the (at most 64) non-empty segments, all lanes on one segment at a time (coalesced 8-byte moves)
-    uint64_t live = __builtin_amdgcn_ballot_w64(c != 0u);
+    // copy-out.  Short segments — the usual case since the thresholds are tight: ~130 survivors per query, one or two per (wave,
+    // query) of an item — are moved by their own lane, all 64 segments in ONE round trip (round 3: the wave used to walk the
+    // non-empty segments one after the other, a dependent load + store per segment, ~50 us per batch).
+    if (c != 0u && c <= 4u && base < (unsigned long long)cand_cap) {
+        const unsigned long long room = (unsigned long long)cand_cap - base;
+        const uint32_t ce = (unsigned long long)c < room ? c : (uint32_t)room;
+        const uint64_t* src = seg_keys + ((size_t)item * 64 + lane) * seg_cap;
+        uint64_t kk[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) kk[e] = (uint32_t)e < ce ? src[e] : 0ull;
+        uint64_t* dst = cand + q * cand_cap + base;
+#pragma unroll
+        for (int e = 0; e < 4; e++) if ((uint32_t)e < ce) dst[e] = kk[e];
+    }
+    // longer segments: the wave walks them, all lanes on one segment at a time (coalesced 8-byte moves)
+    uint64_t live = __builtin_amdgcn_ballot_w64(c > 4u);
     while (live) {
         const int sgm = __builtin_ctzll(live);
         live &= live - 1;

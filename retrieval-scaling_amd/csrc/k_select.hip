@@ -64,26 +64,80 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         tau = buf[k - 1] > tau ? buf[k - 1] : tau;
         __syncthreads();
     }
-    // software pipeline: the next 256-element tile's loads are in flight while this one is filtered
-    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 0 && start + lane * 4 + 3 < end) nxt = *reinterpret_cast<const float4*>(sf + start + lane * 4);
-    for (int64_t base = start; base < end; base += 256) {
+    // Round 3 — a strong STARTING threshold for score rows (the probe selection: 4096 coarse scores -> 32 keys).  One cheap
+    // pass takes every lane's largest key; the k-th largest of those 64 lane maxima is a lower bound of the row's k-th best
+    // key (k distinct keys reach it), so the filter below admits ~1.4 k keys instead of filling and re-sorting its buffer
+    // from an empty threshold (two 256-key sorts on one wave were most of the 50 us this selection took per 1024 rows).
+    if (MODE == 0 && k <= 64 && end - start >= 1024) {
+        uint64_t mx = 0ull;
+        for (int64_t base = start; base < end; base += 2048) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {       // eight 1 KiB tiles in flight
+                const int64_t e0 = base + u * 256 + lane * 4;
+                v[u] = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+                if (e0 + 3 < end) v[u] = *reinterpret_cast<const float4*>(sf + e0);
+                else {
+                    if (e0 < end) v[u].x = sf[e0];
+                    if (e0 + 1 < end) v[u].y = sf[e0 + 1];
+                    if (e0 + 2 < end) v[u].z = sf[e0 + 2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i0 = a.idx_base + (uint32_t)(base + u * 256 + lane * 4);
+                const uint64_t k0 = make_key(v[u].x, i0), k1 = make_key(v[u].y, i0 + 1), k2 = make_key(v[u].z, i0 + 2), k3 = make_key(v[u].w, i0 + 3);
+                const uint64_t m01 = k0 > k1 ? k0 : k1, m23 = k2 > k3 ? k2 : k3, m = m01 > m23 ? m01 : m23;
+                mx = m > mx ? m : mx;
+            }
+        }
+        // bitonic sort of the 64 lane maxima across the wave (descending: lane i ends with the i-th largest)
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const uint32_t olo = __shfl_xor((uint32_t)mx, stride), ohi = __shfl_xor((uint32_t)(mx >> 32), stride);
+                const uint64_t o = ((uint64_t)ohi << 32) | olo;
+                const bool keep_max = ((lane & stride) == 0) == ((lane & size) == 0);
+                mx = keep_max ? (mx > o ? mx : o) : (mx < o ? mx : o);
+            }
+        }
+        const uint32_t klo = __shfl((uint32_t)mx, k - 1), khi = __shfl((uint32_t)(mx >> 32), k - 1);
+        const uint64_t kth = ((uint64_t)khi << 32) | klo;
+        if (kth > 1ull && kth - 1ull > tau) tau = kth - 1ull;       // keys >= kth pass `key > tau`
+    }
+    // four 256-element tiles per round, their loads all in flight before the first one is filtered
+    for (int64_t base4 = start; base4 < end; base4 += 1024) {
+        float4 fv[4]; uint64_t kv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t e0 = base4 + u * 256 + lane * 4;
+            if (MODE == 0) {
+                fv[u] = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+                if (e0 + 3 < end) fv[u] = *reinterpret_cast<const float4*>(sf + e0);
+                else {
+                    if (e0 < end) fv[u].x = sf[e0];
+                    if (e0 + 1 < end) fv[u].y = sf[e0 + 1];
+                    if (e0 + 2 < end) fv[u].z = sf[e0 + 2];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) kv[u][e] = (e0 + e < end) ? sk[e0 + e] : 0ull;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+        const int64_t base = base4 + u * 256;
+        if (base >= end) break;
         int64_t e0 = base + lane * 4;
         uint64_t key[4];
         if (MODE == 0) {
-            float v[4];
-            if (e0 + 3 < end) {
-                v[0] = nxt.x; v[1] = nxt.y; v[2] = nxt.z; v[3] = nxt.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = (e0 + e < end) ? sf[e0 + e] : -__builtin_inff();
-            }
-            if (e0 + 256 + 3 < end) nxt = *reinterpret_cast<const float4*>(sf + e0 + 256);
+            const float v[4] = {fv[u].x, fv[u].y, fv[u].z, fv[u].w};
 #pragma unroll
             for (int e = 0; e < 4; e++) key[e] = make_key(v[e], a.idx_base + (uint32_t)(e0 + e));
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) key[e] = (e0 + e < end) ? sk[e0 + e] : 0ull;
+            for (int e = 0; e < 4; e++) key[e] = kv[u][e];
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -105,10 +159,15 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
             if (pass) buf[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = key[e];
             cnt += np;
         }
+        }
     }
-    for (int i = cnt + lane; i < BUF; i += 64) buf[i] = 0;
+    // final sort: the smallest power of two that holds the keys and the KP output slots (BUF is a power of two >= 2 KP)
+    int nsort = KP;
+    while (nsort < cnt) nsort <<= 1;
+    if (nsort > BUF || (nsort & (nsort - 1))) nsort = BUF;
+    for (int i = cnt + lane; i < nsort; i += 64) buf[i] = 0;
     __syncthreads();
-    bitonic_sort_desc(buf, BUF, lane);
+    bitonic_sort_desc(buf, nsort, lane);
     uint64_t* o = a.out + row * a.out_row_stride + (int64_t)seg * KP;
     for (int i = lane; i < KP; i += 64) o[i] = (a.keep_last && i != KP - 1) ? 0ull : buf[i];
     if (a.zero_cnt && lane == 0 && seg == 0) a.zero_cnt[row * CCS] = 0ull;
@@ -241,7 +300,7 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
 // writes it as the query's threshold (state[q][KP-1], the other slots zero) and resets the candidate counter.
 // Replaces pair grouping + k_pq_scan8<unfiltered> + selection (5 launches) for that step.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pq_prepass(PQPrepassArgs a) {   // <= 64 VGPRs: two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) uint64_t pp_smem[];
     uint64_t* obuf = pp_smem;                                        // [2]
     int32_t* hist = reinterpret_cast<int32_t*>(obuf + 2);            // [256]
@@ -274,12 +333,27 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
         const int M = a.Mpad, NF = M >> 6, NH = (M >> 5) & 1;
         const int g = lane >> 4, i = lane & 15;
         const int nblk = nslab * 4;
-        for (int b = w; b < nblk; b += 16) {
-            const uint8_t* bp = a.codes + ((a.list_base[l] >> 4) + b) * (int64_t)(16 * M);
+        const uint8_t* lbase = a.codes + ((l >= 0 ? a.list_base[l] : 0) >> 4) * (int64_t)(16 * M);
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        // one block ahead: the next block's code loads are issued before this block's gathers (the loop used to pay one HBM
+        // round trip per block, 8 in a row for the 2048-row sample).  Deeper batches were measured and rejected: two or four
+        // blocks in flight need 96 / 116 VGPRs, which halves the workgroups per CU (86 -> 107 us).
+        auto fetch = [&](int b, uint4 (&cf)[2], uint2& ch) {
+            const uint8_t* bp = lbase + (int64_t)b * (16 * M);
+#pragma unroll
+            for (int p = 0; p < 2; p++) cf[p] = p < NF ? *reinterpret_cast<const uint4*>(bp + p * 1024 + lane * 16) : make_uint4(0u, 0u, 0u, 0u);
+            ch = NH ? *reinterpret_cast<const uint2*>(bp + NF * 1024 + lane * 8) : make_uint2(0u, 0u);
+        };
+        uint4 cf[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)}, nf[2]; uint2 ch = make_uint2(0u, 0u), nh;
+        if (wu < nblk) fetch(wu, cf, ch);
+#pragma unroll 1
+        for (int b = wu; b < nblk; b += 16) {
+            fetch(b + 16 < nblk ? b + 16 : b, nf, nh);
             uint32_t acc = 0;
-            for (int p = 0; p < NF; p++) {
-                const uint4 c = *reinterpret_cast<const uint4*>(bp + p * 1024 + lane * 16);
-                const uint32_t wds[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll 1
+            for (int p = 0; p < NF; p++) {      // rolled (one copy of the 16 gathers): unrolled, the kernel needs 90 VGPRs = one workgroup per CU
+                const uint4 c4 = p == 0 ? cf[0] : cf[1];
+                const uint32_t wds[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
                 for (int s2 = 0; s2 < 16; s2++) {
                     const int m = 64 * p + 16 * g + ((i + s2) & 15);
@@ -287,8 +361,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
                 }
             }
             if (NH) {
-                const uint2 c = *reinterpret_cast<const uint2*>(bp + NF * 1024 + lane * 8);
-                const uint32_t wds[2] = {c.x, c.y};
+                const uint32_t wds[2] = {ch.x, ch.y};
 #pragma unroll
                 for (int s2 = 0; s2 < 8; s2++) {
                     const int m = 64 * NF + 16 * (g & 1) + ((i + s2 + 8 * (g >> 1)) & 15);
@@ -301,6 +374,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass(PQPrepassArgs a) {
                 const int64_t pos = (int64_t)b * 16 + i;
                 sums[pos] = (pos < len) ? (uint16_t)(acc + 1u) : (uint16_t)0;
             }
+            cf[0] = nf[0]; cf[1] = nf[1]; ch = nh;
         }
     } else
     for (int s = w; s < nslab; s += 16) {
@@ -392,7 +466,8 @@ static bool select_radix_applies(const SelectArgs& a) {
     // measured: wins for the threshold pre-pass (2048 scores -> K' = 128) and the candidate merge, loses for the
     // probe selection (4096 scores -> 32 keys: k_select's buffer hardly ever needs a second sort there)
     // ... unless only a few rows are in flight (latency path): 256 threads per row instead of one wave
-    return !off && (a.keep_last || a.in_is_keys || a.nrows <= 16) && a.nseg == 1 && a.seg_base == 0 && !a.tau_ptr && a.n_uniform > 0 &&
+    // ... or many keys are kept (nprobe 512 of 8192 lists: one wave re-sorted its 1024-key buffer for 1.07 ms per 1024 rows)
+    return !off && (a.keep_last || a.in_is_keys || a.nrows <= 16 || a.KP >= 256) && a.nseg == 1 && a.seg_base == 0 && !a.tau_ptr && a.n_uniform > 0 &&
            (a.n_uniform <= 16384 || (a.in_is_keys && a.row_n && a.n_uniform <= 131072)) && a.KP <= 4096;
 }
 

@@ -182,7 +182,7 @@ struct rsx_index {
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
-    int pq_pre_rows = 2048;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
+    int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
     int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
     int flat_filter = 1;  // Flat: one filtered GEMM launch after the first chunk (0 = score buffer per chunk)
@@ -1175,7 +1175,12 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // the sample's k-th best score is the threshold: the sample must be a large part of the closest list once k is large
                 // (measured at 24k-vector lists: a 2048-vector prefix gives ~1000 candidates per query for k = 10 but ~20000 for
                 // k = 100) — 160 k vectors, at least pq_pre_rows, at most 32768 (64 KiB of 16-bit sums in LDS)
-                int64_t want_rows = std::max<int64_t>(h->pq_pre_rows > 0 ? h->pq_pre_rows : 2048, std::min<int64_t>(32768, (int64_t)160 * k));
+                // (round 3, measured on the bench index at k = 10: 2048 / 4096 / 8192 / 16384 sample rows leave 1046 / 633 / 372 / 217
+                // candidates per query; the pre-pass costs 85 / 131 / 239 / 446 us and the scan 2.50 / 2.41 / 2.43 / 2.42 ms: 4096 is
+                // the best total for a full batch, a few queries keep the cheaper 2048)
+                int64_t base_rows = h->pq_pre_rows > 0 ? h->pq_pre_rows : 2048;
+                if (nq <= 64) base_rows = std::min<int64_t>(base_rows, 2048);
+                int64_t want_rows = std::max<int64_t>(base_rows, std::min<int64_t>(32768, (int64_t)160 * k));
                 want_rows = std::min<int64_t>(round_up(want_rows, 64), round_up(std::max<int64_t>(maxlen, 64), 64));
                 pre_rows = (int)want_rows;
                 fused_pre = (size_t)pre_rows * 2 + (size_t)h->Mpad * 256 + 2048 <= 150 * 1024;
