@@ -467,8 +467,15 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
     __shared__ float s_mn[LT_QC * LT_MB];
     extern __shared__ __attribute__((aligned(16))) uint8_t lt_obuf[];   // transposed output: [LT_QC][256][LT_MB] bytes (64 KiB)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int m0 = blockIdx.x * LT_MB;
-    const int64_t q0 = (int64_t)blockIdx.y * LT_QC;
+    // 1-D grid, XCD-aware (round 3): workgroup b runs on XCD b % 8; the sub-quantiser blocks of ONE query tile get ids that differ by
+    // multiples of 8, so they run on one XCD one after the other and their 8-byte pieces of the tile's 96-byte table rows merge in
+    // that XCD's L2 into whole lines (with the 2-D grid they came from all 8 XCDs: 12 masked partial write-backs per row)
+    const int nmb = (Mpad + LT_MB - 1) / LT_MB, nqt = (int)((nq + LT_QC - 1) / LT_QC);
+    const int rest = (int)(blockIdx.x >> 3);
+    const int qt = (rest / nmb) * 8 + (int)(blockIdx.x & 7);
+    if (qt >= nqt) return;
+    const int m0 = (rest % nmb) * LT_MB;
+    const int64_t q0 = (int64_t)qt * LT_QC;
     const int nqc = (int)((nq - q0) < LT_QC ? (nq - q0) : LT_QC);
     for (int i = tid; i < LT_QC * LT_MB * 8; i += 256) {
         const int qi = i / (LT_MB * 8), t = i % (LT_MB * 8);
@@ -609,7 +616,8 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
     if (ws && dsub == 8) {   // tiled: codebook slices shared by 32 queries
         float* mnmx = reinterpret_cast<float*>(ws);
         float* errb = mnmx + (size_t)nq * Mpad * 2;
-        dim3 grid((unsigned)((Mpad + LT_MB - 1) / LT_MB), (unsigned)((nq + LT_QC - 1) / LT_QC));
+        const int64_t nmb = (Mpad + LT_MB - 1) / LT_MB, nqt8 = (((nq + LT_QC - 1) / LT_QC) + 7) / 8;
+        dim3 grid((unsigned)(nmb * nqt8 * 8));
         const size_t osm = transposed ? (size_t)LT_QC * 256 * LT_MB : 0;
         static DevOnce once;
         if (osm) once.once([&] { hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm); });
@@ -848,7 +856,7 @@ int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam
     A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
-    A.tau_key = nullptr; A.tau_stride = 0; A.cand = nullptr; A.cand_cnt = nullptr; A.cand_cap = 0; A.prune = 0;
+    A.tau_key = nullptr; A.tau_stride = 0; A.cand = nullptr; A.cand_cnt = nullptr; A.cand_cap = 0; A.prune = 0; A.excl = nullptr; A.pace = 0; A.qitems = nullptr; A.qitems_tmax = 0;
 #ifdef RSX_MEASURE     // cost-split variants (wrong results on purpose): tools/ builds only, not even instantiated in librsx.so
     if (a.Mpad == 96 && vpl == 8) {
         static const int var = measure_env("RSX_SCAN8_VARIANT", 0);
@@ -878,7 +886,7 @@ int launch_pq_scan8_filter(const PQScanArgs& a, const uint8_t* lut8, const void*
     A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
-    A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap; A.prune = 0;
+    A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap; A.prune = 0; A.excl = nullptr; A.pace = 0; A.qitems = nullptr; A.qitems_tmax = 0;
     switch (a.Mpad / 16) {
         case 1: return launch_pq_scan8_v<1, true>(A, vpl, st);
         case 2: return launch_pq_scan8_v<2, true>(A, vpl, st);

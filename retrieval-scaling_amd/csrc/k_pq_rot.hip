@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
         const int64_t col = a.seg_start[q * (a.nprobe + 1) + (pi - (int)q * a.nprobe)];
         const float dis0 = a.probe_dis0[pi];
         d.q[k] = (int32_t)q; d.dis0[k] = dis0; d.scale[k] = p.scale; d.bias[k] = p.bias;
+        if (FILTER && A.qitems && k < d.np && tile < A.qitems_tmax) A.qitems[(int64_t)pi * A.qitems_tmax + tile] = item * 4 + k;
         d.off[k] = FILTER ? col : q * a.tstride + col;
         const uint64_t tau = FILTER ? A.tau_key[q * A.tau_stride] : 0ull;
         d.tau[k] = tau;
@@ -686,8 +687,8 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     if (failed) return -1;
     if (ncu <= 0) ncu = 256;
     PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
-    uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(desc_ws) + (size_t)(A.max_items + 8) * 176);
-    uint64_t* seg_keys = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(seg_cnt) + (size_t)(A.max_items + 8) * 256);
+    uint32_t* seg_cnt = pq_scan_rot_ws_cnt(desc_ws, A.max_items);
+    uint64_t* seg_keys = pq_scan_rot_ws_keys(desc_ws, A.max_items);
     uint32_t* xcd_ctr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(seg_keys) + (size_t)(A.max_items + 8) * 64 * seg_cap * 8);
     uint32_t* prog = xcd_ctr + 256;
     hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog);
@@ -697,7 +698,7 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
     hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, xcd_ctr, prog,
                        seg_cap, bpw, A.pace, var);
-    if (FILTER)
+    if (FILTER && !A.qitems)     // with qitems the segments are consumed in place by k_pq_gather_select
         hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, seg_keys, seg_cnt, seg_cap,
                            A.cand, A.cand_cnt, A.cand_cap);
     return 0;
@@ -708,7 +709,8 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws, int seg_cap, int prune, int pace, const uint16_t* excl, hipStream_t st) {
+                       int cand_cap, void* item_ws, int seg_cap, int prune, int pace, const uint16_t* excl, int32_t* qitems,
+                       int qitems_tmax, hipStream_t st) {
     if (a.CB != 0 || !item_ws || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8t; A.qp = (const PQQParam*)qparam;
@@ -716,7 +718,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     A.item_off = item_off; A.total_items = total_items;
     A.nlist = nlist; A.max_items = (int)max_items;
     A.tau_key = tau_key; A.tau_stride = tau_stride; A.cand = cand; A.cand_cnt = cand_cnt; A.cand_cap = cand_cap;
-    A.prune = prune; A.pace = pace; A.excl = excl;
+    A.prune = prune; A.pace = pace; A.excl = excl; A.qitems = qitems; A.qitems_tmax = qitems_tmax;
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
     switch (a.M) {

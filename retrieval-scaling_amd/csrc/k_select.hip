@@ -294,6 +294,133 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Candidate gather + selection for the rotated fast scan (PQGatherArgs, rsx_internal.h).  k_pq_scan_rot leaves a query's survivors
+// in (item, wave, slot) segments; k_pq_rot_compact appended them to the query's candidate row with one returning atomic per
+// (item, query) — ~40 dependent device-scope atomics on ONE counter per query, 40-50 us per batch whatever else the kernel did —
+// and k_select_radix then read the row back.  Here the query's workgroup finds its own segments (qitems: the inverse of the item
+// order, written by k_pq_rot_items), sums their counts, copies the keys behind what the pre-pass emitted and selects the K'
+// largest from LDS.  Key order inside the row is free (keys are distinct; every consumer sorts or re-scores).
+// ---------------------------------------------------------------------------------------
+constexpr int GS_LCAP = 2048;      // row lengths up to this are selected from LDS; longer rows are read back from the candidate row
+__global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t gs_smem[];
+    const int KP = a.KP, NP = a.nprobe * a.tmax, NS = NP * 16;
+    uint64_t* obuf = gs_smem;                                      // [KP]
+    uint64_t* lkeys = obuf + KP;                                   // [GS_LCAP]
+    int32_t* hist = reinterpret_cast<int32_t*>(lkeys + GS_LCAP);   // [256]
+    int32_t* ctl = hist + 256;                                     // [8]
+    int32_t* misc = ctl + 8;                                       // [8]: 0 overflow flag, 1..4 wave totals
+    int32_t* slots = misc + 8;                                     // [NP]: item * 4 + slot, -1 = no such tile
+    uint16_t* cnts = reinterpret_cast<uint16_t*>(slots + NP);      // [NS]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t q = blockIdx.x;
+    if (tid < 8) misc[tid] = 0;
+    __syncthreads();
+    // 1. the query's segments and their counts: three short phases, every load of a phase independent of the others
+    //    (a) tiles per probed list, (b) the work item + slot of every (probe rank, tile), (c) the 16 wave counters of each
+    int32_t* ntl = hist;                                           // [nprobe] (hist is free until the selection)
+    for (int j = tid; j < a.nprobe; j += 256) {
+        const int32_t l = a.probe_list[q * a.nprobe + j];
+        ntl[j] = l >= 0 ? (int)((a.list_len[l] + a.tile_rows - 1) / a.tile_rows) : 0;
+    }
+    __syncthreads();
+    for (int p = tid; p < NP; p += 256) {
+        const int j = p / a.tmax, t = p - j * a.tmax;
+        slots[p] = t < ntl[j] ? a.qitems[(q * a.nprobe + j) * a.tmax + t] : -1;
+    }
+    __syncthreads();
+    {
+        bool over = false;
+        for (int s0 = tid; s0 < NS; s0 += 256 * 8) {
+            uint32_t c[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int s2 = s0 + u * 256;
+                const int32_t slot = s2 < NS ? slots[s2 >> 4] : -1;
+                c[u] = slot >= 0 ? a.seg_cnt[(size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int s2 = s0 + u * 256;
+                if (s2 >= NS) break;
+                if (c[u] > (uint32_t)a.seg_cap) { over = true; c[u] = (uint32_t)a.seg_cap; }
+                cnts[s2] = (uint16_t)c[u];
+            }
+        }
+        if (over) misc[0] = 1;
+    }
+    const unsigned long long e0 = a.cand_cnt[q * CCS];             // keys the pre-pass emitted (row prefix)
+    __syncthreads();
+    // 2. thread t owns the segments s = t, t + 256, ... (the closest list's segments, where most survivors sit, spread over the
+    //    threads); exclusive scan of the threads' totals
+    int mine = 0;
+    for (int s2 = tid; s2 < NS; s2 += 256) mine += cnts[s2];
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+    if (lane == 63) misc[1 + w] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++) { const int v = misc[1 + ww]; if (ww < w) wbase += v; total += v; }
+    const bool over = misc[0] != 0;
+    const unsigned long long e0c = e0 < (unsigned long long)a.cand_cap ? e0 : (unsigned long long)a.cand_cap;
+    // the row's count: past the capacity when a segment dropped keys (k_finalize then flags the query), exactly like the compaction's
+    if (tid == 0) a.cand_cnt[q * CCS] = e0 + (unsigned long long)total + (over ? (unsigned long long)a.cand_cap + 1ull : 0ull);
+    const unsigned long long nrow_ = e0c + (unsigned long long)total;
+    const int nrow = (int)(nrow_ < (unsigned long long)a.cand_cap ? nrow_ : (unsigned long long)a.cand_cap);   // keys that fit the row
+    const bool in_lds = nrow_ <= (unsigned long long)GS_LCAP;
+    // 3. copy: segment keys -> candidate row (and LDS when the whole row fits)
+    uint64_t* row = a.cand + q * a.cand_cap;
+    if (in_lds) for (int i2 = tid; i2 < (int)e0c; i2 += 256) lkeys[i2] = row[i2];
+    int pos = (int)e0c + wbase + incl - mine;
+    for (int s2 = tid; s2 < NS; s2 += 256) {
+        const int c = cnts[s2];
+        if (c == 0) continue;
+        const int32_t slot = slots[s2 >> 4];
+        const uint64_t* src = a.seg_keys + ((size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)) * a.seg_cap;
+        for (int e = 0; e < c; e += 4) {
+            uint64_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) kk[u] = e + u < c ? src[e + u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (e + u >= c) break;
+                const int pp = pos + e + u;
+                if (pp < a.cand_cap) row[pp] = kk[u];
+                if (in_lds) lkeys[pp] = kk[u];
+            }
+        }
+        pos += c;
+    }
+    __syncthreads();        // workgroup-scope release / acquire: the row (and lkeys) written above are visible to every thread
+    // 4. the K' largest keys, sorted, to the state row
+    if (in_lds) {
+        auto key_at = [&](int i2) -> uint64_t { return lkeys[i2]; };
+        radix_topk_wg<256>(key_at, nrow, KP, obuf, hist, ctl);
+    } else {
+        auto key_at = [&](int i2) -> uint64_t { return row[i2]; };
+        radix_topk_wg<256>(key_at, nrow, KP, obuf, hist, ctl);
+    }
+    uint64_t* o = a.state + q * KP;
+    for (int i2 = tid; i2 < KP; i2 += 256) o[i2] = obuf[i2];
+}
+
+static size_t gather_select_lds(int nprobe, int tmax, int KP) {
+    return (size_t)KP * 8 + (size_t)GS_LCAP * 8 + (256 + 8 + 8) * 4 + (size_t)nprobe * tmax * 4 + (size_t)nprobe * tmax * 16 * 2 + 64;
+}
+bool pq_gather_select_applies(int nprobe, int tmax, int KP) {
+    return tmax >= 1 && tmax <= 16 && nprobe <= 256 && (int64_t)nprobe * tmax * 16 <= 16384 && KP <= 4096 && gather_select_lds(nprobe, tmax, KP) <= 96 * 1024;
+}
+void launch_pq_gather_select(const PQGatherArgs& a, int64_t nq, hipStream_t st) {
+    if (nq <= 0) return;
+    const size_t shm = gather_select_lds(a.nprobe, a.tmax, a.KP);
+    static DevSize attr;
+    attr.grow(shm, [&] { (void)hipFuncSetAttribute((const void*)k_pq_gather_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
+    hipLaunchKernelGGL(k_pq_gather_select, dim3((unsigned)nq), dim3(256), shm, st, a);
+}
+
+// ---------------------------------------------------------------------------------------
 // IVF-PQ threshold pre-pass in ONE launch: a workgroup per query scores the first pre_rows vectors of the
 // query's closest NON-EMPTY probed list with the query's 8-bit table (24 KiB in LDS, byte gathers; the SAME integer sums and
 // the same fp32 expression as k_pq_scan8, hence the same keys), selects their K'-th largest key in LDS and

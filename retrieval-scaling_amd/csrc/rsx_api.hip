@@ -182,6 +182,7 @@ struct rsx_index {
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
+    int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
     int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
     int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
@@ -192,7 +193,7 @@ struct rsx_index {
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart, w_qitems;
     std::map<std::string, double> timing;
 
     // Flat / IVF-Flat: largest |x|^2 ever added (certificate of the MFMA scan); device copy is the running atomic max
@@ -236,7 +237,7 @@ static int64_t workspace_bytes(const rsx_index* h) {
     const DevBuf* bufs[] = {&h->w_q32, &h->w_q16, &h->w_coarse, &h->w_keys1, &h->w_probekeys, &h->w_probelist, &h->w_dis0, &h->w_segstart,
                             &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
                             &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
-                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->sh_D, &h->sh_I, &h->sh_q,
+                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->w_qitems, &h->sh_D, &h->sh_I, &h->sh_q,
                             &h->sh_oD, &h->sh_oI};
     int64_t t = 0;
     for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
@@ -1085,6 +1086,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     if (tmax >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "probed lists exceed 2^32 vectors per query");
     h->w_temp.ensure((size_t)nq * tmax * 4);
     bool filtered = false;   // fast path with in-kernel candidate filtering (no full score buffer)
+    bool use_gather = false; int gs_tmax = 0; PQGatherArgs gs{};   // ... whose candidates are gathered and selected in one launch
     bool fused_pre_used = false;   // ... whose threshold came from the one-launch pre-pass (complete candidate rows: second chance)
     int cand_cap = 0;
     // the exact kernels gather fp32 table entries; the fast path builds the table in LDS (when it fits)
@@ -1226,7 +1228,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 void* rws0 = rot ? rot_desc(mi, filtered ? pre_vpl : vpl, 0) : nullptr;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
-                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, 0, 0, nullptr, h->st)
+                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, 0, 0, nullptr, nullptr, 0, h->st)
                             : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
             }
@@ -1254,11 +1256,24 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // threshold keys: one per query from the one-launch pre-pass, else the K'-th key the selection left in the state rows
                 const uint64_t* tau_ptr = fused_pre ? h->w_tau.as<uint64_t>() : state + (KP - 1);
                 const int64_t tau_stride = fused_pre ? 1 : KP;
+                // candidate gather + selection in one launch when the (probe rank, tile) table of a query is small (rsx_internal.h)
+                gs_tmax = (int)((maxlen + tile_rows - 1) / tile_rows);
+                use_gather = rot && h->pq_gather != 0 && pq_gather_select_applies(nprobe, gs_tmax, KP);
+                if (use_gather) {
+                    h->w_qitems.ensure((size_t)nq * nprobe * gs_tmax * 4);
+                    gs.probe_list = h->w_probelist.as<int32_t>(); gs.list_len = h->d_len.as<int64_t>(); gs.nprobe = nprobe;
+                    gs.tile_rows = tile_rows; gs.tmax = gs_tmax; gs.qitems = h->w_qitems.as<int32_t>();
+                    const int64_t mi = max_scan_items(h, nq, nprobe, 4, tile_rows);
+                    gs.seg_cnt = pq_scan_rot_ws_cnt(rws1, mi); gs.seg_keys = pq_scan_rot_ws_keys(rws1, mi); gs.seg_cap = rot_seg_cap;
+                    gs.cand = h->w_cand.as<uint64_t>(); gs.cand_cnt = h->w_candcnt.as<unsigned long long>(); gs.cand_cap = cand_cap;
+                    gs.state = state; gs.KP = KP;
+                }
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist,
                                                  max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rws1, rot_seg_cap, h->pq_prune, h->pq_pace, (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr, h->st)
+                                                 rws1, rot_seg_cap, h->pq_prune, h->pq_pace, (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
+                                                 use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
                                                      max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,
@@ -1387,16 +1402,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             tm.mark("scan");
         }
     }
-    if (filtered && h->profile >= 2) {   // diagnostics: keys that passed the in-kernel filter
-        std::vector<unsigned long long> cnts((size_t)nq * CCS);
-        HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
-        double tot = 0, mx = 0;
-        for (int64_t qi = 0; qi < nq; qi++) { const double c = (double)cnts[(size_t)qi * CCS]; tot += c; mx = std::max(mx, c); }
-        h->timing["cand_keys"] += tot; h->timing["cand_keys_max"] = std::max(h->timing["cand_keys_max"], mx);
-    }
     // 3. per-query k-selection over the score rows
-    if (filtered) {
+    if (filtered && use_gather) {
+        launch_pq_gather_select(gs, nq, h->st);
+    } else if (filtered) {
         // merge the filtered candidates (keys) into state0: one wave per query, the whole buffer in one segment
         SelectArgs b{};
         b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cand_cap;
@@ -1412,6 +1421,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     (fast || h->kind == KIND_IVFFLAT) ? KP : k, state, false);
     }
     tm.mark("select");
+    if (filtered && h->profile >= 2) {   // diagnostics: keys that passed the in-kernel filter
+        std::vector<unsigned long long> cnts((size_t)nq * CCS);
+        HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(hipStreamSynchronize(h->st));
+        double tot = 0, mx = 0;
+        for (int64_t qi = 0; qi < nq; qi++) { const double c = (double)cnts[(size_t)qi * CCS]; tot += c; mx = std::max(mx, c); }
+        h->timing["cand_keys"] += tot; h->timing["cand_keys_max"] = std::max(h->timing["cand_keys_max"], mx);
+    }
     fa.probe_list = h->w_probelist.as<int32_t>(); fa.seg_start = h->w_segstart.as<int64_t>(); fa.nprobe = nprobe;
     if (fast) {
         fa.pq_rescore = 1; fa.codes = h->data.as<uint8_t>(); fa.M = h->M; fa.Mpad = h->Mpad; fa.CB = h->CB;
@@ -2475,6 +2492,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
+        else if (s == "pq_gather") h->pq_gather = (int)value;
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;

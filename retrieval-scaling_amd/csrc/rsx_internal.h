@@ -247,6 +247,9 @@ struct PQScan8Args {
     int prune;   // k_pq_scan_rot: skip work items none of whose queries can beat its threshold in this list (exact bound)
     const uint16_t* excl;   // k_pq_scan_rot: per query, 0x8000 | probe rank whose tile 0 the pre-pass already emitted (null: none)
     int pace;    // k_pq_scan_rot: sibling query groups of a list tile stay within `pace` loop iterations of each other (0 = free-running)
+    // k_pq_rot_items (optional): qitems[(q * nprobe + probe rank) * qitems_tmax + tile] = item * 4 + slot of that (query, list tile) —
+    // the inverse of the item order, which lets k_pq_gather_select find a query's survivor segments without atomics
+    int32_t* qitems; int qitems_tmax;
 };
 
 // Work-item decode shared by the list-major scans.  Items are ordered (list, tile, group) so that the
@@ -277,7 +280,8 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
                        int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, int prune, int pace,
-                       const uint16_t* excl, hipStream_t st);
+                       const uint16_t* excl, int32_t* qitems /* non-null: fill it and leave the segments for k_pq_gather_select */,
+                       int qitems_tmax, hipStream_t st);
 // survivor segment capacity per (item, wave, query): 4x what a query's CLOSEST list is expected to yield (a wave scans
 // tile/16 vectors of it, of which the pre-pass threshold lets about KP / pre_rows through), never less than 128 and never
 // more than the wave's whole share of the tile (at which point no overflow is possible)
@@ -291,6 +295,22 @@ inline int pq_scan_rot_seg_cap(int tile_rows, int KP, int pre_rows) {
 inline size_t pq_scan_rot_ws(int64_t max_items, int seg_cap) {   // item records + segment counts + segment keys + per-XCD counters
     return (size_t)(max_items + 8) * (176 + 256 + (size_t)64 * seg_cap * 8 + 4) + 1024;   // ... + per-item progress words (pacing)
 }
+// the parts of that workspace: segment (item, wave w, slot k) has its count at seg_cnt[(item * 16 + w) * 4 + k] and its keys at
+// seg_keys[((item * 16 + w) * 4 + k) * seg_cap ...]
+inline uint32_t* pq_scan_rot_ws_cnt(void* ws, int64_t max_items) { return reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ws) + (size_t)(max_items + 8) * 176); }
+inline uint64_t* pq_scan_rot_ws_keys(void* ws, int64_t max_items) { return reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(ws) + (size_t)(max_items + 8) * (176 + 256)); }
+// Candidate gather + selection in one launch (round 3; replaces k_pq_rot_compact + the candidate merge when nprobe x tiles is small):
+// one workgroup per query walks the query's own survivor segments (through qitems), lays their keys end to end in the query's
+// candidate row behind what the pre-pass emitted, sets the row count (past the capacity when a segment overflowed, as the
+// compaction did) and writes the K' largest keys to the state row — no atomics, no second pass over the row.
+struct PQGatherArgs {
+    const int32_t* probe_list; const int64_t* list_len; int nprobe; int tile_rows; int tmax;
+    const int32_t* qitems; const uint32_t* seg_cnt; const uint64_t* seg_keys; int seg_cap;
+    uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
+    uint64_t* state; int KP;
+};
+bool pq_gather_select_applies(int nprobe, int tmax, int KP);
+void launch_pq_gather_select(const PQGatherArgs& a, int64_t nq, hipStream_t st);
 // exact per-(query, list) scan of the rotated layout (fp32 table, sequential sums = oracle bits): fallback / A-B path
 int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st);
 // codes for rows of a batch: residual vs centroid[assign] (centroids may be null -> no residual).
