@@ -731,6 +731,273 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
 }
 
 // ---------------------------------------------------------------------------------------
+// Threshold pre-pass on the scan's own machinery (round 3): FOUR queries per workgroup share one table image in the scan's
+// format (one dword = the four queries' bytes), each query's sample — the first pre_rows vectors of ITS closest list — is
+// scanned by a group of four waves with the scan's conflict-free gathers and the MFMA adder, the 16-bit integer sums go to LDS,
+// and the k-th largest of each sample gives the query's threshold exactly as k_pq_prepass (k_select.hip) derives it:
+// tau = a_k - 2 eps.  k_pq_prepass scores the same rows with byte gathers on a per-query byte table (~3.5-way bank
+// conflicts, one query per gather): 137 us per 1024 queries x 4096 rows against ~50 here.  No emission (small k only: the
+// caller keeps k_pq_prepass when the sample has to cover the first scan tile).
+// ---------------------------------------------------------------------------------------
+template <int NF, int NH>
+__global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t nq) {
+    constexpr int M = 64 * NF + 32 * NH;
+    constexpr int NPH = NF + NH;
+    constexpr int TAB = NPH * 65536;
+    constexpr int NG = M / 4;
+    constexpr int NR1 = NPH > 1 ? rot_nreg(1, NF >= 2 ? 16 : 8) : 0;
+    constexpr int NR0 = NF >= 1 ? 4 : rot_nreg(0, 8);
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) uint32_t pp4_s[];
+    uint8_t* sb = reinterpret_cast<uint8_t*>(pp4_s);
+    uint16_t* sums = reinterpret_cast<uint16_t*>(sb + TAB);                               // [4][pre_rows]: integer sum + 1, 0 = no vector
+    int32_t* hist = reinterpret_cast<int32_t*>(sb + TAB + (size_t)4 * a.pre_rows * 2);    // [4][256]
+    int32_t* ctl = hist + 1024;                                                           // [4][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15, n = lane & 15;
+    const int grp = w >> 2, wq = w & 3;                  // query slot of this wave, wave within the slot
+    const int64_t q0 = (int64_t)blockIdx.x * 4;
+    const int np = (int)((nq - q0) < 4 ? (nq - q0) : 4);
+    const int64_t q = q0 + (grp < np ? grp : 0);
+    // ---- rotation bytes and the one-hot B operand, as in k_pq_scan_rot
+    uint32_t R0[NR0 > 0 ? NR0 : 1], R1[NR1 > 0 ? NR1 : 1];
+#pragma unroll
+    for (int r = 0; r < NR0; r++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+            const int s = r * 4 + bb;
+            const uint32_t rot = NF >= 1 ? (uint32_t)(64 * g + 4 * ((i + s) & 15))
+                                         : (uint32_t)(64 * (g & 1) + 4 * ((i + s + 8 * (g >> 1)) & 15));
+            v |= rot << (8 * bb);
+        }
+        R0[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < NR1; r++) {
+        uint32_t v = 0x01000000u;
+#pragma unroll
+        for (int bb = 0; bb < 3; bb++) {
+            const int s = r * 3 + bb;
+            const uint32_t rot = NF >= 2 ? (uint32_t)(64 * g + 4 * ((i + s) & 15))
+                                         : (uint32_t)(64 * (g & 1) + 4 * ((i + s + 8 * (g >> 1)) & 15));
+            v |= (rot & 255u) << (8 * bb);
+        }
+        R1[r] = v;
+    }
+    const int bsel = n < 4 ? (1 << (8 * n)) : 0;
+    const v4i Bm = {bsel, bsel, bsel, bsel};
+    // ---- the four tables, staged exactly like a scan item's (unit = (code, 4 consecutive m) -> 4 dwords, byte k = query k as int8)
+    {
+        const int64_t qa = q0, qb = q0 + (np > 1 ? 1 : 0), qc = q0 + (np > 2 ? 2 : 0), qd = q0 + (np > 3 ? 3 : 0);
+        constexpr int NU = (256 * (M / 4) + 1023) / 1024;
+        constexpr int nunits = 256 * (M / 4);
+        uint32_t in[NU][4];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int e = tid + u * 1024;
+            const int ee = e < nunits ? e : 0;
+            const int c = ee / (M / 4), m4 = ee - c * (M / 4);
+            in[u][0] = *reinterpret_cast<const uint32_t*>(a.lut8 + (qa * 256 + c) * M + m4 * 4);
+            in[u][1] = np > 1 ? *reinterpret_cast<const uint32_t*>(a.lut8 + (qb * 256 + c) * M + m4 * 4) : 0u;
+            in[u][2] = np > 2 ? *reinterpret_cast<const uint32_t*>(a.lut8 + (qc * 256 + c) * M + m4 * 4) : 0u;
+            in[u][3] = np > 3 ? *reinterpret_cast<const uint32_t*>(a.lut8 + (qd * 256 + c) * M + m4 * 4) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int e = tid + u * 1024;
+            if (e >= nunits) continue;
+            const int c = e / (M / 4), m4 = e - c * (M / 4);
+            const uint32_t t0 = __builtin_amdgcn_perm(in[u][1], in[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[u][1], in[u][0], 0x07030602u);
+            const uint32_t u0 = __builtin_amdgcn_perm(in[u][3], in[u][2], 0x05010400u), u1 = __builtin_amdgcn_perm(in[u][3], in[u][2], 0x07030602u);
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
+            o.y = __builtin_amdgcn_perm(u0, t0, 0x07060302u) ^ 0x80808080u;
+            o.z = __builtin_amdgcn_perm(u1, t1, 0x05040100u) ^ 0x80808080u;
+            o.w = __builtin_amdgcn_perm(u1, t1, 0x07060302u) ^ 0x80808080u;
+            const int m = m4 * 4;
+            const int p = m < 64 * NF ? (m >> 6) : NF;
+            const int slot = m < 64 * NF ? (m & 63) : (m - 64 * NF);
+            *reinterpret_cast<uint4*>(sb + p * 65536 + c * 256 + slot * 4) = o;
+        }
+    }
+    for (int t = tid; t < 1024 + 32; t += 1024) hist[t] = 0;
+    // ---- my query's closest probed list that holds vectors here (wave-uniform)
+    int32_t l = -1; int64_t len = 0; int j0 = 0;
+    if (grp < np) {
+        for (int j = 0; j < a.nprobe; j++) {
+            const int32_t lj = a.probe_list[q * a.nprobe + j];
+            if (lj >= 0 && a.list_len[lj] > 0) { l = lj; len = a.list_len[lj]; j0 = j; break; }
+        }
+    }
+    l = __builtin_amdgcn_readfirstlane(l); j0 = __builtin_amdgcn_readfirstlane(j0);
+    const int nrows = (int)(len < a.pre_rows ? len : a.pre_rows);
+    const int nblk = __builtin_amdgcn_readfirstlane((nrows + 15) >> 4);
+    const uint8_t* lp = a.codes + ((l >= 0 ? a.list_base[l] : 0) >> 4) * (int64_t)(16 * M);
+    uint16_t* mysum = sums + (size_t)grp * a.pre_rows;
+    __syncthreads();        // tables staged, histograms zero
+    // ---- scan: wave wq of the slot takes blocks wq, wq + 4, ...; PD blocks in flight per wave (register slots refilled in place
+    // right after their codes have become gather addresses, as in k_pq_scan_rot; the prologue issues in slot order so that one
+    // s_waitcnt serves the loop entry and the back edge)
+    {
+        constexpr int PD = 4;
+        constexpr int NFx = NF > 0 ? NF : 1;
+        v4u ca[PD][NFx]; v2u cb[PD];
+        auto fetch = [&](int b, v4u (&xa)[NFx], v2u& xb) {
+            const uint8_t* bp = lp + (int64_t)b * (16 * M);
+#pragma unroll
+            for (int p = 0; p < NF; p++) xa[p] = *reinterpret_cast<const v4u*>(bp + p * 1024 + lane * 16);
+            if (NH) xb = *reinterpret_cast<const v2u*>(bp + NF * 1024 + lane * 8);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const int blast = nblk > 0 ? nblk - 1 : 0;
+#pragma unroll
+        for (int d = 0; d < PD; d++) cb[d] = v2u{0u, 0u};
+        if (nblk > 0) {       // ONE conditional region: four separately guarded fetches would each count as "maybe not issued" in the waits
+#pragma unroll
+            for (int d = 0; d < PD; d++) fetch(wq + 4 * d < nblk ? wq + 4 * d : blast, ca[d], cb[d]);
+        }
+#pragma unroll 1
+        for (int b0 = wq; b0 < nblk; b0 += 4 * PD) {
+#pragma unroll
+            for (int d = 0; d < PD; d++) {
+                const int b = b0 + 4 * d;        // past the sample's end the slot holds the last block again: summed, not stored (a
+                uint32_t gv[NG];                 // `break` here would make every slot's wait a vmcnt(0): the exit path has no younger loads)
+                if (NF >= 1) {
+                    const uint32_t cw[4] = {ca[d][0].x, ca[d][0].y, ca[d][0].z, ca[d][0].w};
+#pragma unroll
+                    for (int s = 0; s < 16; s++)
+                        gv[s] = __builtin_amdgcn_perm(cw[s >> 2], R0[s >> 2], 0x0c0c0000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s & 3));
+                }
+                if (NF >= 2) {
+                    const uint32_t cw[4] = {ca[d][NFx - 1].x, ca[d][NFx - 1].y, ca[d][NFx - 1].z, ca[d][NFx - 1].w};
+#pragma unroll
+                    for (int s = 0; s < 16; s++)
+                        gv[16 + s] = __builtin_amdgcn_perm(cw[s >> 2], R1[s / 3], 0x0c030000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s % 3));
+                }
+                if (NH) {
+                    const uint32_t cw[2] = {cb[d].x, cb[d].y};
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        if (NF == 0)
+                            gv[s] = __builtin_amdgcn_perm(cw[s >> 2], R0[s >> 2], 0x0c0c0000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s & 3));
+                        else
+                            gv[16 * NF + s] = __builtin_amdgcn_perm(cw[s >> 2], R1[s / 3], 0x0c030000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s % 3));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(b + 4 * PD < nblk ? b + 4 * PD : blast, ca[d], cb[d]);      // the slot's codes are dead: refill in place
+#pragma unroll
+                for (int s = 0; s < NG; s++) gv[s] = lds_rd32(gv[s]);
+                v4i C = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < NG / 4; t++) {
+                    const v4i Av = {(int)gv[4 * t], (int)gv[4 * t + 1], (int)gv[4 * t + 2], (int)gv[4 * t + 3]};
+                    C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
+                }
+                // lanes (g, n): C[r] = sum over m of (u8 - 128) for vector 4 g + r of the block and query n; my slot's query is n == grp
+                if (n == grp && b < nblk) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int pos = b * 16 + 4 * g + r;
+                        mysum[pos] = pos < len ? (uint16_t)(C[r] + 128 * M + 1) : (uint16_t)0;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- k-th largest (sum + 1) of each slot's sample: two 8-bit radix rounds over the 16-bit values, the four slots side by side
+    // with the same barriers.  ctl[slot]: [0] high byte, [1] remaining rank, [2] low byte / -1 = fewer than k vectors
+    const int tg = (wq << 6) | lane;                     // thread within the slot
+    int32_t* hs = hist + grp * 256;
+    int32_t* cs = ctl + grp * 8;
+    const int N = nblk * 16;
+    auto find_bin = [&](int want) -> int {              // wave 0 of the slot: the bin holding the want-th largest; leaves the rank inside it in cs[1]
+        const int h0 = hs[4 * lane], h1 = hs[4 * lane + 1], h2 = hs[4 * lane + 2], h3 = hs[4 * lane + 3];
+        const int sum4 = h0 + h1 + h2 + h3;
+        int suf = sum4;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_down(suf, off); if (lane + off < 64) suf += y; }
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(suf >= want);
+        int res = -1;
+        if (mk != 0ull) {
+            const int L = 63 - __builtin_clzll((unsigned long long)mk);
+            const int runL = __shfl(suf - sum4, L);
+            const int a0 = __shfl(h0, L), a1 = __shfl(h1, L), a2 = __shfl(h2, L), a3 = __shfl(h3, L);
+            const int hb[4] = {a0, a1, a2, a3};
+            int run = runL;
+            for (int bb = 3; bb >= 0; bb--) {
+                if (run + hb[bb] >= want) { res = 4 * L + bb; if (lane == 0) cs[1] = want - run; break; }
+                run += hb[bb];
+            }
+        }
+        return res;
+    };
+    for (int t = tg; t < N; t += 256) { const int v = mysum[t]; if (v) atomicAdd(&hs[v >> 8], 1); }
+    __syncthreads();
+    if (wq == 0) { const int d = find_bin(a.k); if (lane == 0) cs[0] = d; }
+    __syncthreads();
+    const int dhi = cs[0], want2 = cs[1];
+    __syncthreads();
+    for (int t = tg; t < 256; t += 256) hs[t] = 0;
+    __syncthreads();
+    if (dhi >= 0) for (int t = tg; t < N; t += 256) { const int v = mysum[t]; if (v && (v >> 8) == dhi) atomicAdd(&hs[v & 255], 1); }
+    __syncthreads();
+    if (wq == 0) { const int e = dhi >= 0 ? find_bin(want2) : -1; if (lane == 0) cs[2] = e; }
+    __syncthreads();
+    // ---- the threshold (k_pq_prepass's arithmetic), the empty merge state, the candidate counter
+    if (grp < np) {
+        uint64_t* o = a.state + q * a.KP;
+        for (int t = tg; t < a.KP; t += 256) o[t] = 0ull;
+        if (tg == 0) {
+            uint64_t tau = 0ull;
+            const int dlo = cs[2];
+            if (dhi >= 0 && dlo >= 0 && l >= 0) {
+                const float scale = a.qparam[q * 4 + 0], bias = a.qparam[q * 4 + 1], eps = a.qparam[q * 4 + 2];
+                const float dis0 = a.probe_dis0[q * a.nprobe + j0];
+                const int kth = (dhi << 8) | dlo;                                         // = (k-th largest integer sum) + 1
+                const float a_k = dis0 + __fmaf_rn(scale, (float)(kth - 1), bias);
+                float t = __fmaf_rn(-2.0002f, eps, a_k);
+                t -= fabsf(t) * 4.8e-7f + 1e-30f;
+                tau = make_key(t, 0xFFFFFFFFu);
+            }
+            a.tau[q] = tau;
+            a.cand_cnt[q * CCS] = 0ull;
+            if (a.excl) a.excl[q] = (uint16_t)0;
+        }
+    }
+}
+
+template <int NF, int NH>
+static void launch_pq_prepass4_t(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
+    const size_t shm = (size_t)(NF + NH) * 65536 + (size_t)4 * a.pre_rows * 2 + (1024 + 32) * 4 + 64;
+    static DevSize attr;
+    attr.grow(shm, [&] { (void)hipFuncSetAttribute((const void*)k_pq_prepass4<NF, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
+    hipLaunchKernelGGL((k_pq_prepass4<NF, NH>), dim3((unsigned)((nq + 3) / 4)), dim3(1024), shm, st, a, nq);
+}
+// sample rows the 4-query form can hold beside its tables (0: this M has no such kernel)
+int pq_prepass4_max_rows(int M) {
+    if (!pq_rot_applies(M)) return 0;
+    const int nph = (M >> 6) + ((M >> 5) & 1);
+    const int64_t room = (int64_t)160 * 1024 - (int64_t)nph * 65536 - (1024 + 32) * 4 - 64 - 256;
+    return room < 8 * 64 ? 0 : (int)(room / 8 / 64 * 64);
+}
+int launch_pq_prepass4(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
+    if (nq <= 0) return 0;
+    if (a.CB != 0 || a.pre_rows <= 0 || a.pre_rows % 64 || a.pre_rows > pq_prepass4_max_rows(a.Mpad)) return -1;
+    switch (a.Mpad) {
+        case 32: launch_pq_prepass4_t<0, 1>(a, nq, st); return 0;
+        case 64: launch_pq_prepass4_t<1, 0>(a, nq, st); return 0;
+        case 96: launch_pq_prepass4_t<1, 1>(a, nq, st); return 0;
+        case 128: launch_pq_prepass4_t<2, 0>(a, nq, st); return 0;
+        default: return -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Exact scan of the rotated layout: workgroup = (query, probed list, chunk of slabs), the query's fp32 table in LDS
 // (M KiB), one thread per vector, code bytes through pq_code_addr, sums in m order (= k_pq_scan = the oracle).
 // ---------------------------------------------------------------------------------------

@@ -182,6 +182,7 @@ struct rsx_index {
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
+    int pq_prepass4 = 1;     // rotated fast scan, small k, full batches: threshold pre-pass with four queries per workgroup on the scan's table format
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
     int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
@@ -1173,6 +1174,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // 16-bit integer sums in LDS, k-th largest by a radix walk -> threshold a_k - 2 eps) when its LDS footprint allows;
             // else grouping + scan of the prefix + selection (K'-th key of the prefix as the threshold)
             bool fused_pre = filtered && h->pq_prepass_fused != 0;
+            bool pre4 = false;
             if (fused_pre) {
                 // the sample's k-th best score is the threshold: the sample must be a large part of the closest list once k is large
                 // (measured at 24k-vector lists: a 2048-vector prefix gives ~1000 candidates per query for k = 10 but ~20000 for
@@ -1184,6 +1186,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 if (nq <= 64) base_rows = std::min<int64_t>(base_rows, 2048);
                 int64_t want_rows = std::max<int64_t>(base_rows, std::min<int64_t>(32768, (int64_t)160 * k));
                 want_rows = std::min<int64_t>(round_up(want_rows, 64), round_up(std::max<int64_t>(maxlen, 64), 64));
+                // small k, full batch, rotated layout: the 4-queries-per-workgroup form (k_pq_prepass4) — its sample is what fits the LDS
+                // beside the four-query table image (3520 rows at M = 96)
+                pre4 = rot && h->pq_prepass4 != 0 && nq >= 64 && (int64_t)160 * k <= base_rows && pq_prepass4_max_rows(h->Mpad) >= 1024;
+                if (pre4) want_rows = std::min<int64_t>(want_rows, pq_prepass4_max_rows(h->Mpad));
                 pre_rows = (int)want_rows;
                 fused_pre = (size_t)pre_rows * 2 + (size_t)h->Mpad * 256 + 2048 <= 150 * 1024;
                 if (!fused_pre) pre_rows = 64 * 16 * pre_vpl;
@@ -1206,7 +1212,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     h->w_excl.ensure((size_t)nq * 2);
                     pa.cand = h->w_cand.as<uint64_t>(); pa.cand_cap = cand_cap; pa.tile_rows = tile_rows; pa.excl = h->w_excl.as<uint16_t>();
                 }
-                launch_pq_prepass(pa, nq, h->st);
+                if (!(pre4 && launch_pq_prepass4(pa, nq, h->st) == 0)) launch_pq_prepass(pa, nq, h->st);
                 fused_pre_used = true;
                 done = true;
                 if (h->tc && h->tc->active && allow_fast) {
@@ -2493,6 +2499,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_gather") h->pq_gather = (int)value;
+        else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;

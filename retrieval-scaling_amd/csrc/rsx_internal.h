@@ -352,6 +352,10 @@ struct PQPrepassArgs {
     uint64_t* cand; int cand_cap; int tile_rows; uint16_t* excl;
 };
 void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
+// the same threshold from four queries per workgroup on the scan's table format (k_pq_rot.hip: k_pq_prepass4; no emission);
+// returns -1 when it does not apply (layout, M, or a sample larger than pq_prepass4_max_rows(M))
+int pq_prepass4_max_rows(int M);
+int launch_pq_prepass4(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
 void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
                         int pad_to, int32_t* probe_list, float* probe_dis0, int64_t* seg_start, hipStream_t st);
 // tile_rows > 0: also build the (list, tile, group) work-item table: item_off[nlist+1], total_items
