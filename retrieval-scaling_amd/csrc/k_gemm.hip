@@ -824,17 +824,21 @@ __global__ __launch_bounds__(256) void k_list_scan(ListScanArgs a) {
 #define LS2_D 6
 #define LS2_NB 8            // 16-row blocks per wave per chunk -> chunk_rows = 4 waves x 16 x 8 = 512
 
-template <bool FILTER>
+// QT = 16-query tiles per group (round 3): with many probing queries per list (nlist 2048 / nprobe 128: 64 on average) groups of 16
+// pass over every list four times — the rows are re-read from L2 / HBM for each pass (0.20 of HBM on unique bytes).  A group of
+// 16 QT queries reads the row stream ONCE and issues QT x 2 MFMAs per K step against the same two row fragments.
+template <bool FILTER, int QT>
 __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
+    constexpr int NQG = 16 * QT;
     extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
     const int qstride = (a.ld + 8) * 2;
     unsigned char* Qs = ls_smem;
-    int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + 16 * qstride);   // [16] score-buffer offset | (FILTER) row column
-    int64_t* sq = segoff + 16;                                              // [16] query            (FILTER)
-    uint64_t* stau = reinterpret_cast<uint64_t*>(sq + 16);                  // [16] threshold key    (FILTER)
+    int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + NQG * qstride);  // [NQG] score-buffer offset | (FILTER) row column
+    int64_t* sq = segoff + NQG;                                             // [NQG] query            (FILTER)
+    uint64_t* stau = reinterpret_cast<uint64_t*>(sq + NQG);                 // [NQG] threshold key    (FILTER)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* ring = ls_smem + 16 * qstride + 384 + w * (LS2_D * 2048);
+    unsigned char* ring = ls_smem + NQG * qstride + 24 * NQG + w * (LS2_D * 2048);
     const int g = blockIdx.x;
     const int chunk = blockIdx.y;
 
@@ -843,7 +847,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
     int pair0 = 0;
     if (a.flat_mode) {
         base = 0; len = a.flat_n;
-        np = a.nq - 16 * g; if (np > 16) np = 16;
+        np = a.nq - NQG * g; if (np > NQG) np = NQG;
         if (np <= 0) return;
     } else {
         if (g >= *a.total_groups) return;
@@ -852,8 +856,8 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
         const int l = lo;
         int gi = g - a.group_off[l];
         int cnt = a.pair_off[l + 1] - a.pair_off[l];
-        np = cnt - 16 * gi; if (np > 16) np = 16;
-        pair0 = a.pair_off[l] + 16 * gi;
+        np = cnt - NQG * gi; if (np > NQG) np = NQG;
+        pair0 = a.pair_off[l] + NQG * gi;
         base = a.list_base[l]; len = a.list_len[l];
     }
     const int64_t len_pad = (len + 15) & ~15ll;
@@ -861,23 +865,43 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
     if (c0 >= len_pad) return;
     int64_t c1 = c0 + 64 * LS2_NB; if (c1 > len_pad) c1 = len_pad;
 
-    // stage the group's queries (16 rows of ld halfs) and their score-buffer offsets
-    for (int i = 0; i < 16; i++) {
+    // stage the group's queries (NQG rows of ld halfs) and their score-buffer offsets.  Round 3: the query numbers first (one per
+    // thread), then every thread's share of the NQG x ld / 8 sixteen-byte pieces with eight loads in flight — the loop used to
+    // take the queries one after the other, an index load and a row load each: 2 round trips per query, 32 us per work item for 16
+    // queries against the ~40 us its 512 rows take to stream.
+    int32_t* sqn = reinterpret_cast<int32_t*>(ls_smem + NQG * qstride + 24 * NQG + 4 * LS2_D * 2048);     // [NQG] query numbers
+    if (tid < NQG) {
         int64_t q = -1;
-        if (i < np) {
-            if (a.flat_mode) q = 16 * (int64_t)g + i;
-            else q = a.pairs_sorted[pair0 + i] / a.nprobe;
-        }
-        for (int t = tid * 8; t < a.ld; t += 256 * 8) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q >= 0) v = *reinterpret_cast<const uint4*>(a.Q16 + q * a.ld + t);
-            *reinterpret_cast<uint4*>(Qs + i * qstride + t * 2) = v;
+        if (tid < np) q = a.flat_mode ? NQG * (int64_t)g + tid : a.pairs_sorted[pair0 + tid] / a.nprobe;
+        sqn[tid] = (int32_t)q;
+    }
+    __syncthreads();
+    {
+        const int ppr = a.ld >> 3;                        // 16-byte pieces per query row
+        const int npc = NQG * ppr;
+        for (int p0 = tid; p0 < npc; p0 += 256 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int pc = p0 + u * 256;
+                const int i = pc < npc ? pc / ppr : 0, t = pc < npc ? pc - i * ppr : 0;
+                const int q = sqn[i];
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (pc < npc && q >= 0) v[u] = *reinterpret_cast<const uint4*>(a.Q16 + (int64_t)q * a.ld + t * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int pc = p0 + u * 256;
+                if (pc >= npc) break;
+                const int i = pc / ppr, t = pc - i * ppr;
+                *reinterpret_cast<uint4*>(Qs + i * qstride + t * 16) = v[u];
+            }
         }
     }
-    if (tid < 16) {
+    if (tid < NQG) {
         int64_t off = 0;
         if (tid < np) {
-            if (a.flat_mode) off = (16 * (int64_t)g + tid) * a.tstride;
+            if (a.flat_mode) off = (NQG * (int64_t)g + tid) * a.tstride;
             else {
                 int pidx = a.pairs_sorted[pair0 + tid];
                 int64_t q = pidx / a.nprobe; int j = pidx % a.nprobe;
@@ -888,7 +912,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
         if (FILTER) {
             int64_t q = 0; uint64_t t = ~0ull;      // padding slot: nothing passes
             if (tid < np) {
-                q = a.flat_mode ? 16 * (int64_t)g + tid : a.pairs_sorted[pair0 + tid] / a.nprobe;
+                q = a.flat_mode ? NQG * (int64_t)g + tid : a.pairs_sorted[pair0 + tid] / a.nprobe;
                 t = a.tau_key[q * a.tau_stride];
                 segoff[tid] = off - q * a.tstride;  // the column inside the query's row = the candidate's index
             }
@@ -935,9 +959,11 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
     const int swz = (lr >> 1) & 7;
     const int boff0 = lr * 128 + (((0 + kg) ^ swz) << 4), boff1 = lr * 128 + (((4 + kg) ^ swz) << 4);
     const unsigned char* qa_base = Qs + lr * qstride + (8 * kg) * 2;
-    floatx4 acc[LS2_NB];
+    floatx4 acc[QT][LS2_NB];
 #pragma unroll
-    for (int i = 0; i < LS2_NB; i++) acc[i] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < QT; t++)
+#pragma unroll
+        for (int i = 0; i < LS2_NB; i++) acc[t][i] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
     int slot = 0;
 #pragma unroll
     for (int i = 0; i < LS2_NB; i++) {
@@ -950,10 +976,13 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
                 const unsigned char* bs = ring + slot * 2048;
                 half8 x0 = *reinterpret_cast<const half8*>(bs + boff0);
                 half8 x1 = *reinterpret_cast<const half8*>(bs + boff1);
-                half8 q0 = *reinterpret_cast<const half8*>(qa_base + (kt * 64) * 2);
-                half8 q1 = *reinterpret_cast<const half8*>(qa_base + (kt * 64 + 32) * 2);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0, x0, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q1, x1, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < QT; t++) {
+                    half8 q0 = *reinterpret_cast<const half8*>(qa_base + t * 16 * qstride + (kt * 64) * 2);
+                    half8 q1 = *reinterpret_cast<const half8*>(qa_base + t * 16 * qstride + (kt * 64 + 32) * 2);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0, x0, acc[t][i], 0, 0, 0);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q1, x1, acc[t][i], 0, 0, 0);
+                }
                 slot = (slot + 1 == LS2_D) ? 0 : slot + 1;
             }
         }
@@ -966,13 +995,15 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
             const int64_t rloc = r0 + 64 * i + lr;
             const float bv = (a.bias && rloc < len) ? a.bias[base + rloc] : 0.0f;
 #pragma unroll
+            for (int t = 0; t < QT; t++)
+#pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int qi = kg * 4 + r;
+                const int qi = t * 16 + kg * 4 + r;
                 if (!FILTER) {
-                    if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[i][r] + bv : -__builtin_inff();
+                    if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[t][i][r] + bv : -__builtin_inff();
                 } else {
                     // lanes 16 kg .. 16 kg + 15 hold query qi's scores of the block's 16 rows
-                    const uint64_t key = (rloc < len && qi < np) ? make_key(acc[i][r] + bv, (uint32_t)(segoff[qi] + rloc)) : 0ull;
+                    const uint64_t key = (rloc < len && qi < np) ? make_key(acc[t][i][r] + bv, (uint32_t)(segoff[qi] + rloc)) : 0ull;
                     const bool pass = key > stau[qi];
                     const uint64_t mask = __ballot(pass);
                     const uint64_t mine = (mask >> (16 * kg)) & 0xffffull;
@@ -997,18 +1028,38 @@ int list_scan2_chunk_rows(int x_f16, int ld) {
     return (!off && x_f16 && ld % 64 == 0) ? 64 * LS2_NB : 0;
 }
 
+// 16-query tiles per group the LDS holds beside the four DMA rings (queries 16 qt x (ld + 8) halfs)
+int list_scan2_max_qtiles(int ld) {
+    for (int qt = 4; qt > 1; qt >>= 1)
+        if ((size_t)16 * qt * (ld + 8) * 2 + 28 * 16 * qt + 4 * LS2_D * 2048 <= 158 * 1024) return qt;
+    return 1;
+}
+
 void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     if (a.max_groups <= 0 || a.max_chunks <= 0) return;
     dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
     if (a.chunk_rows == list_scan2_chunk_rows(a.x_f16, a.ld)) {
-        size_t shm2 = (size_t)16 * (a.ld + 8) * 2 + 384 + 4 * LS2_D * 2048;
+        const int qt = (a.qtiles == 2 || a.qtiles == 4) && !a.flat_mode && list_scan2_max_qtiles(a.ld) >= a.qtiles ? a.qtiles : 1;
+        size_t shm2 = (size_t)16 * qt * (a.ld + 8) * 2 + 24 * 16 * qt + 4 * LS2_D * 2048 + 4 * 16 * qt;
         static DevOnce once;
         once.once([&] {
-            hipFuncSetAttribute((const void*)k_list_scan2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)k_list_scan2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-        if (a.tau_key) hipLaunchKernelGGL(k_list_scan2<true>, grid, dim3(256), shm2, st, a);
-        else hipLaunchKernelGGL(k_list_scan2<false>, grid, dim3(256), shm2, st, a);
+        if (qt == 4) {
+            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 4>), grid, dim3(256), shm2, st, a);
+            else hipLaunchKernelGGL((k_list_scan2<false, 4>), grid, dim3(256), shm2, st, a);
+        } else if (qt == 2) {
+            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 2>), grid, dim3(256), shm2, st, a);
+            else hipLaunchKernelGGL((k_list_scan2<false, 2>), grid, dim3(256), shm2, st, a);
+        } else {
+            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 1>), grid, dim3(256), shm2, st, a);
+            else hipLaunchKernelGGL((k_list_scan2<false, 1>), grid, dim3(256), shm2, st, a);
+        }
         return;
     }
     size_t shm = (size_t)16 * (a.ld + 8) * 2 + 16 * sizeof(int64_t);

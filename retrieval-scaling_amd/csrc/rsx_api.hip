@@ -182,6 +182,7 @@ struct rsx_index {
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
+    int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scan: 1 = choose 16 / 32 / 64 queries per group from the queries per list, 2 / 4 = force, 0 = always 16
     int pq_prepass4 = 1;     // rotated fast scan, small k, full batches: threshold pre-pass with four queries per workgroup on the scan's table format
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
     int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
@@ -1347,7 +1348,16 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int32_t* pair_off = cursor + (nlist + 1);
         int32_t* group_off = pair_off + (nlist + 1);
         int32_t* total_groups = group_off + (nlist + 1);
-        launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
+        // query tiles per group of the LDS-DMA list scan: with ~64 probing queries per list (nlist 2048 / nprobe 128) groups of 16 read
+        // every list four times; 32 / 64 queries per group read it twice / once (k_list_scan2<_, QT>)
+        int ls_qt = 1;
+        if (h->scan_chunk <= 0 && h->ivf_qtiles != 0 && list_scan2_chunk_rows(h->storage_f16, ld) > 0) {
+            const int64_t qpl = npairs / std::max(1, nlist);
+            ls_qt = h->ivf_qtiles > 1 ? h->ivf_qtiles : (qpl >= 40 ? 4 : qpl >= 20 ? 2 : 1);
+            ls_qt = std::min(ls_qt == 3 ? 2 : ls_qt, list_scan2_max_qtiles(ld));
+            if (ls_qt != 2 && ls_qt != 4) ls_qt = 1;
+        }
+        launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,
                            pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, 0, h->st);
         tm.mark("group");
         const float* bias = nullptr;
@@ -1365,6 +1375,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         while (chunk_rows > 256 && (int64_t)a.max_groups * ((maxlen + chunk_rows - 1) / chunk_rows) < want) chunk_rows /= 2;
         if (h->scan_chunk <= 0 && list_scan2_chunk_rows(h->storage_f16, ld) > 0) chunk_rows = list_scan2_chunk_rows(h->storage_f16, ld);
         a.chunk_rows = (int)chunk_rows;
+        a.qtiles = ls_qt;
         a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
         // Same two-stage shape as the IVF-PQ fast path when the LDS-DMA kernel applies: score a prefix of every
         // query's closest list, take its K'-th key as the query's threshold, then scan everything with the keys
@@ -1376,6 +1387,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                            (int64_t)KP * 4 <= chunk_rows && (h->ivf_filter > 1 || nq * tmax >= (int64_t)500000000);
         if (want_filter) {
             a.max_chunks = 1;                                      // the first chunk of ...
+            a.qtiles = 1;                                          // (groups of 16 there: most lists are the closest of at most a few queries)
             launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
                                pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, 1, 0, h->st);   // ... the closest list only
             launch_list_scan(a, h->st);
@@ -1388,9 +1400,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                         std::min<int64_t>(maxlen, chunk_rows), 0, nq, KP, BUF, KP, state, false,
                         h->w_candcnt.as<unsigned long long>());
             tm.mark("select0");
-            launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
+            launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,
                                pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, 0, h->st);
             tm.mark("group");
+            a.qtiles = ls_qt;
             a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
             a.tau_key = state + (KP - 1); a.tau_stride = KP;
             a.cand = h->w_cand.as<uint64_t>(); a.cand_cnt = h->w_candcnt.as<unsigned long long>(); a.cand_cap = cand_cap;
@@ -2500,6 +2513,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_gather") h->pq_gather = (int)value;
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
+        else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;

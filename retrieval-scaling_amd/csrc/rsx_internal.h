@@ -189,12 +189,14 @@ struct ListScanArgs {
     int flat_mode; int64_t flat_n; int nq;  // flat_mode: single list, groups = blocks of 16 queries
     float* temp; int64_t tstride;
     int chunk_rows;                         // rows per work item (multiple of 64)
+    int qtiles;                             // k_list_scan2: 16-query tiles per group (1, 2, 4): the grouping must have used 16 x qtiles
     int max_groups; int max_chunks;
     // filtered output (k_list_scan2 only; tau_key != null): keys > tau_key[q * tau_stride] are appended to
     // cand[q][0..cand_cap) (count in cand_cnt[q]) instead of storing every score
     const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
 };
 int list_scan2_chunk_rows(int x_f16, int ld);   // work-item rows of the LDS-DMA list scan, 0 if it does not apply
+int list_scan2_max_qtiles(int ld);              // ... and the 16-query tiles per group its LDS holds
 void launch_list_scan(const ListScanArgs& a, hipStream_t st);
 
 // k_pq.hip
