@@ -827,9 +827,13 @@ __global__ __launch_bounds__(256) void k_list_scan(ListScanArgs a) {
 // QT = 16-query tiles per group (round 3): with many probing queries per list (nlist 2048 / nprobe 128: 64 on average) groups of 16
 // pass over every list four times — the rows are re-read from L2 / HBM for each pass (0.20 of HBM on unique bytes).  A group of
 // 16 QT queries reads the row stream ONCE and issues QT x 2 MFMAs per K step against the same two row fragments.
-template <bool FILTER, int QT>
-__global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
+// NW waves per workgroup, each with a ring of D stages.  64-query groups take 8 waves x 3 stages: their 97 KiB of queries leave room
+// for one workgroup per CU only, and with four waves (one per SIMD) nothing overlapped a wave's DMA issue, LDS latency and MFMAs.
+template <bool FILTER, int QT, int NW, int D>
+__global__ __launch_bounds__(64 * NW) void k_list_scan2(ListScanArgs a) {
     constexpr int NQG = 16 * QT;
+    constexpr int NT = 64 * NW;                  // threads
+    constexpr int BR = 16 * NW;                  // rows between a wave's consecutive blocks
     extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
     const int qstride = (a.ld + 8) * 2;
     unsigned char* Qs = ls_smem;
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
     uint64_t* stau = reinterpret_cast<uint64_t*>(sq + NQG);                 // [NQG] threshold key    (FILTER)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* ring = ls_smem + NQG * qstride + 24 * NQG + w * (LS2_D * 2048);
+    unsigned char* ring = ls_smem + NQG * qstride + 24 * NQG + w * (D * 2048);
     const int g = blockIdx.x;
     const int chunk = blockIdx.y;
 
@@ -861,15 +865,15 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
         base = a.list_base[l]; len = a.list_len[l];
     }
     const int64_t len_pad = (len + 15) & ~15ll;
-    const int64_t c0 = (int64_t)chunk * (64 * LS2_NB);
+    const int64_t c0 = (int64_t)chunk * (BR * LS2_NB);
     if (c0 >= len_pad) return;
-    int64_t c1 = c0 + 64 * LS2_NB; if (c1 > len_pad) c1 = len_pad;
+    int64_t c1 = c0 + BR * LS2_NB; if (c1 > len_pad) c1 = len_pad;
 
     // stage the group's queries (NQG rows of ld halfs) and their score-buffer offsets.  Round 3: the query numbers first (one per
     // thread), then every thread's share of the NQG x ld / 8 sixteen-byte pieces with eight loads in flight — the loop used to
     // take the queries one after the other, an index load and a row load each: 2 round trips per query, 32 us per work item for 16
     // queries against the ~40 us its 512 rows take to stream.
-    int32_t* sqn = reinterpret_cast<int32_t*>(ls_smem + NQG * qstride + 24 * NQG + 4 * LS2_D * 2048);     // [NQG] query numbers
+    int32_t* sqn = reinterpret_cast<int32_t*>(ls_smem + NQG * qstride + 24 * NQG + NW * D * 2048);     // [NQG] query numbers
     if (tid < NQG) {
         int64_t q = -1;
         if (tid < np) q = a.flat_mode ? NQG * (int64_t)g + tid : a.pairs_sorted[pair0 + tid] / a.nprobe;
@@ -879,11 +883,11 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
     {
         const int ppr = a.ld >> 3;                        // 16-byte pieces per query row
         const int npc = NQG * ppr;
-        for (int p0 = tid; p0 < npc; p0 += 256 * 8) {
+        for (int p0 = tid; p0 < npc; p0 += NT * 8) {
             uint4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int pc = p0 + u * 256;
+                const int pc = p0 + u * NT;
                 const int i = pc < npc ? pc / ppr : 0, t = pc < npc ? pc - i * ppr : 0;
                 const int q = sqn[i];
                 v[u] = make_uint4(0, 0, 0, 0);
@@ -891,7 +895,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int pc = p0 + u * 256;
+                const int pc = p0 + u * NT;
                 if (pc >= npc) break;
                 const int i = pc / ppr, t = pc - i * ppr;
                 *reinterpret_cast<uint4*>(Qs + i * qstride + t * 16) = v[u];
@@ -921,9 +925,9 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
     }
     __syncthreads();
 
-    // this wave's blocks: rows c0 + 16 w + 64 i, i < nb
+    // this wave's blocks: rows c0 + 16 w + BR i, i < nb
     const int64_t r0 = c0 + 16 * w;
-    const int nb = r0 < c1 ? (int)((c1 - r0 + 63) >> 6) : 0;
+    const int nb = r0 < c1 ? (int)((c1 - r0 + BR - 1) / BR) : 0;
     if (nb == 0) return;
     const int KT = a.ld >> 6;
     const int T = nb * KT;
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
         off0 = (uint32_t)R0 * (uint32_t)(a.ld * 2) + ((p ^ ((R0 >> 1) & 7)) << 4);
         off1 = (uint32_t)R1 * (uint32_t)(a.ld * 2) + ((p ^ ((R1 >> 1) & 7)) << 4);
     }
-    const int64_t blk_bytes = (int64_t)64 * a.ld * 2;       // the wave's next block is 64 rows further
+    const int64_t blk_bytes = (int64_t)BR * a.ld * 2;       // the wave's next block is BR rows further
     int i_kt = 0, i_slot = 0; int64_t i_boff = 0; int i_left = T;   // issue position
     auto issue = [&]() {
         const char* gsrc = xb + i_boff + (int64_t)i_kt * 128;
@@ -950,10 +954,10 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
         const bool wrap = i_kt == KT;
         i_kt = wrap ? 0 : i_kt;
         i_boff += wrap ? blk_bytes : 0;
-        i_slot = (i_slot + 1 == LS2_D) ? 0 : i_slot + 1;
+        i_slot = (i_slot + 1 == D) ? 0 : i_slot + 1;
     };
 #pragma unroll
-    for (int d = 0; d < LS2_D - 1; d++) issue();
+    for (int d = 0; d < D - 1; d++) issue();
 
     const int lr = lane & 15, kg = lane >> 4;
     const int swz = (lr >> 1) & 7;
@@ -971,8 +975,9 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
             for (int kt = 0; kt < KT; kt++) {
                 issue();
                 // all but the newest LS2_D - 1 stages (2 pieces each) have landed -> this stage is in LDS
-                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                static_assert(2 * (LS2_D - 1) == 10, "the vmcnt literal above");
+                static_assert(D == 6 || D == 3, "the vmcnt literals below are 2 (D - 1)");
+                if (D == 6) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 const unsigned char* bs = ring + slot * 2048;
                 half8 x0 = *reinterpret_cast<const half8*>(bs + boff0);
                 half8 x1 = *reinterpret_cast<const half8*>(bs + boff1);
@@ -983,7 +988,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
                     acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0, x0, acc[t][i], 0, 0, 0);
                     acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q1, x1, acc[t][i], 0, 0, 0);
                 }
-                slot = (slot + 1 == LS2_D) ? 0 : slot + 1;
+                slot = (slot + 1 == D) ? 0 : slot + 1;
             }
         }
     }
@@ -992,7 +997,7 @@ __global__ __launch_bounds__(256) void k_list_scan2(ListScanArgs a) {
 #pragma unroll
     for (int i = 0; i < LS2_NB; i++) {
         if (i < nb) {
-            const int64_t rloc = r0 + 64 * i + lr;
+            const int64_t rloc = r0 + BR * i + lr;
             const float bv = (a.bias && rloc < len) ? a.bias[base + rloc] : 0.0f;
 #pragma unroll
             for (int t = 0; t < QT; t++)
@@ -1031,34 +1036,43 @@ int list_scan2_chunk_rows(int x_f16, int ld) {
 // 16-query tiles per group the LDS holds beside the four DMA rings (queries 16 qt x (ld + 8) halfs)
 int list_scan2_max_qtiles(int ld) {
     for (int qt = 4; qt > 1; qt >>= 1)
-        if ((size_t)16 * qt * (ld + 8) * 2 + 28 * 16 * qt + 4 * LS2_D * 2048 <= 158 * 1024) return qt;
+        if ((size_t)16 * qt * (ld + 8) * 2 + 28 * 16 * qt + (size_t)(4 * LS2_D) * 2048 <= 158 * 1024) return qt;      // (8 x 3 stages = the same 48 KiB)
     return 1;
 }
 
 void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     if (a.max_groups <= 0 || a.max_chunks <= 0) return;
     dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
-    if (a.chunk_rows == list_scan2_chunk_rows(a.x_f16, a.ld)) {
-        const int qt = (a.qtiles == 2 || a.qtiles == 4) && !a.flat_mode && list_scan2_max_qtiles(a.ld) >= a.qtiles ? a.qtiles : 1;
-        size_t shm2 = (size_t)16 * qt * (a.ld + 8) * 2 + 24 * 16 * qt + 4 * LS2_D * 2048 + 4 * 16 * qt;
+    const int base_rows = list_scan2_chunk_rows(a.x_f16, a.ld);
+    if (base_rows > 0 && (a.chunk_rows == base_rows || (a.qtiles == 4 && a.chunk_rows == 2 * base_rows))) {
+        // the grouping was made for 16 x qtiles queries per group: qtiles is binding (a smaller kernel would misread the groups)
+        const int qt = (a.qtiles == 2 || a.qtiles == 4) && !a.flat_mode ? a.qtiles : 1;
+        const bool wide = qt == 4 && a.chunk_rows == 2 * base_rows;        // 8 waves x 3 stages, 1024 rows per work item
+        const int nw = wide ? 8 : 4, dd = wide ? 3 : LS2_D;
+        size_t shm2 = (size_t)16 * qt * (a.ld + 8) * 2 + 28 * 16 * qt + (size_t)nw * dd * 2048;
         static DevOnce once;
         once.once([&] {
-            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 1, 4, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 1, 4, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 2, 4, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 2, 4, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 4, 4, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 4, 4, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-        if (qt == 4) {
-            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 4>), grid, dim3(256), shm2, st, a);
-            else hipLaunchKernelGGL((k_list_scan2<false, 4>), grid, dim3(256), shm2, st, a);
+        if (wide) {
+            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 4, 8, 3>), grid, dim3(512), shm2, st, a);
+            else hipLaunchKernelGGL((k_list_scan2<false, 4, 8, 3>), grid, dim3(512), shm2, st, a);
+        } else if (qt == 4) {
+            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 4, 4, LS2_D>), grid, dim3(256), shm2, st, a);
+            else hipLaunchKernelGGL((k_list_scan2<false, 4, 4, LS2_D>), grid, dim3(256), shm2, st, a);
         } else if (qt == 2) {
-            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 2>), grid, dim3(256), shm2, st, a);
-            else hipLaunchKernelGGL((k_list_scan2<false, 2>), grid, dim3(256), shm2, st, a);
+            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 2, 4, LS2_D>), grid, dim3(256), shm2, st, a);
+            else hipLaunchKernelGGL((k_list_scan2<false, 2, 4, LS2_D>), grid, dim3(256), shm2, st, a);
         } else {
-            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 1>), grid, dim3(256), shm2, st, a);
-            else hipLaunchKernelGGL((k_list_scan2<false, 1>), grid, dim3(256), shm2, st, a);
+            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 1, 4, LS2_D>), grid, dim3(256), shm2, st, a);
+            else hipLaunchKernelGGL((k_list_scan2<false, 1, 4, LS2_D>), grid, dim3(256), shm2, st, a);
         }
         return;
     }

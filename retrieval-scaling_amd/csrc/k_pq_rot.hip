@@ -739,6 +739,13 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
 // conflicts, one query per gather): 137 us per 1024 queries x 4096 rows against ~50 here.  No emission (small k only: the
 // caller keeps k_pq_prepass when the sample has to cover the first scan tile).
 // ---------------------------------------------------------------------------------------
+#ifdef RSX_MEASURE
+__device__ uint64_t g_pp4_trace[64 * 16 * 8];          // [workgroup < 64][wave][mark]
+extern "C" int rsx_debug_pp4_trace(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp4_trace), sizeof(uint64_t) * 64 * 16 * 8) == hipSuccess ? 0 : -1; }
+#define PP4_MARK(i) do { if (blockIdx.x < 64 && lane == 0) g_pp4_trace[(blockIdx.x * 16 + w) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP4_MARK(i)
+#endif
 template <int NF, int NH>
 __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t nq) {
     constexpr int M = 64 * NF + 32 * NH;
@@ -758,6 +765,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15, n = lane & 15;
     const int grp = w >> 2, wq = w & 3;                  // query slot of this wave, wave within the slot
+    PP4_MARK(0);
     const int64_t q0 = (int64_t)blockIdx.x * 4;
     const int np = (int)((nq - q0) < 4 ? (nq - q0) : 4);
     const int64_t q = q0 + (grp < np ? grp : 0);
@@ -837,7 +845,9 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
     const int nblk = __builtin_amdgcn_readfirstlane((nrows + 15) >> 4);
     const uint8_t* lp = a.codes + ((l >= 0 ? a.list_base[l] : 0) >> 4) * (int64_t)(16 * M);
     uint16_t* mysum = sums + (size_t)grp * a.pre_rows;
+    PP4_MARK(1);
     __syncthreads();        // tables staged, histograms zero
+    PP4_MARK(2);
     // ---- scan: wave wq of the slot takes blocks wq, wq + 4, ...; PD blocks in flight per wave (register slots refilled in place
     // right after their codes have become gather addresses, as in k_pq_scan_rot; the prologue issues in slot order so that one
     // s_waitcnt serves the loop entry and the back edge)
@@ -908,7 +918,9 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
             }
         }
     }
+    PP4_MARK(3);
     __syncthreads();
+    PP4_MARK(4);
     // ---- k-th largest (sum + 1) of each slot's sample: two 8-bit radix rounds over the 16-bit values, the four slots side by side
     // with the same barriers.  ctl[slot]: [0] high byte, [1] remaining rank, [2] low byte / -1 = fewer than k vectors
     const int tg = (wq << 6) | lane;                     // thread within the slot
@@ -948,6 +960,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
     __syncthreads();
     if (wq == 0) { const int e = dhi >= 0 ? find_bin(want2) : -1; if (lane == 0) cs[2] = e; }
     __syncthreads();
+    PP4_MARK(5);
     // ---- the threshold (k_pq_prepass's arithmetic), the empty merge state, the candidate counter
     if (grp < np) {
         uint64_t* o = a.state + q * a.KP;
@@ -969,6 +982,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
             if (a.excl) a.excl[q] = (uint16_t)0;
         }
     }
+    PP4_MARK(6);
 }
 
 template <int NF, int NH>

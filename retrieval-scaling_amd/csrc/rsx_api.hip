@@ -1404,6 +1404,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, 0, h->st);
             tm.mark("group");
             a.qtiles = ls_qt;
+            if (ls_qt == 4) { chunk_rows *= 2; a.chunk_rows = (int)chunk_rows; }      // 64-query groups: 8 waves, 1024 rows per work item
             a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
             a.tau_key = state + (KP - 1); a.tau_stride = KP;
             a.cand = h->w_cand.as<uint64_t>(); a.cand_cnt = h->w_candcnt.as<unsigned long long>(); a.cand_cap = cand_cap;
@@ -1417,6 +1418,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             a.tau_key = nullptr; a.cand = nullptr; a.cand_cnt = nullptr; a.cand_cap = 0;
         }
         if (!filtered) {
+            if (a.qtiles == 4 && a.chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld)) {     // 64-query groups: 8 waves, 1024 rows per work item
+                a.chunk_rows *= 2;
+                a.max_chunks = (int)std::max<int64_t>(1, (maxlen + a.chunk_rows - 1) / a.chunk_rows);
+            }
             launch_list_scan(a, h->st);
             tm.mark("scan");
         }
