@@ -259,6 +259,52 @@ def test_ivfflat_skewed_lists_and_l2(gpu, orc):
                 assert np.allclose(D, Dr, rtol=0, atol=max(1e-30, np.abs(Dr[np.isfinite(Dr)]).max() * 2 ** -22))
 
 
+def test_round3_engine_knobs_never_change_a_result(gpu, orc):
+    """The round-3 kernels are alternatives to older ones behind engine parameters: candidate gather + select in one launch
+    (pq_gather), the four-queries-per-workgroup threshold pre-pass (pq_prepass4), 32 / 64 probing queries per IVF-Flat group
+    (ivf_qtiles).  Every combination must return the bits of the exact kernels."""
+    # IVF-PQ, rotated layout, a batch large enough for k_pq_prepass4 (>= 64 queries) and a ragged tail (130 = 32 x 4 + 2)
+    d, n, nlist, M, nq, k = 768, 90000, 16, 96, 130, 10
+    x = gpu.synth_vectors(d, 16, 1234, 10000, 0.5, 0, n)
+    q = gpu.synth_queries(d, 16, 1234, 10000, 0.5, n, 999, 0.1, 0, nq)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    ix.train(x[:20000]); ix.add(x); ix.nprobe = 8
+    ix.set_param("scan_kernel", 2)
+    De, Ie = ix.search(q, k)
+    ix.set_param("scan_kernel", 0)
+    for gather in (1, 0):
+        for pre4 in (1, 0):
+            for pre_rows in (4096, 2048):
+                ix.set_param("pq_gather", gather); ix.set_param("pq_prepass4", pre4); ix.set_param("pq_pre_rows", pre_rows)
+                D, I = ix.search(q, k)
+                assert_same_results(D, I, De, Ie, f"pq_gather={gather} pq_prepass4={pre4} pq_pre_rows={pre_rows}")
+                D, I = ix.search(q[:70], 100)          # 160 k > sample rows: the one-query-per-workgroup pre-pass whatever the knob says
+                ix.set_param("scan_kernel", 2); Dx, Ix = ix.search(q[:70], 100); ix.set_param("scan_kernel", 0)
+                assert_same_results(D, I, Dx, Ix, f"k=100 pq_gather={gather} pq_prepass4={pre4}")
+    # IVF-Flat, fp16 rows: 200 queries x nprobe 4 over 8 lists = 100 probing queries per list
+    rng = np.random.RandomState(11)
+    d, nlist, n, nq = 64, 8, 20000, 200
+    cen = rng.randn(nlist, d).astype(np.float32)
+    x = (cen[rng.randint(0, nlist, n)] + 0.4 * rng.randn(n, d)).astype(np.float16)
+    qf = (x[rng.randint(0, n, nq)].astype(np.float32) + 0.05 * rng.randn(nq, d)).astype(np.float32)
+    xf = x.astype(np.float32)
+    a, _ = orc.assign_ip(cen, xf)
+    lm = orc.ListMajor(a, np.arange(n), xf, nlist)
+    for metric in (0, 1):
+        ixf = gpu.IndexIVFFlat(None, d, nlist, metric)
+        ixf.set_centroids(cen); ixf.add(x)
+        assert ixf.storage_dtype == "float16"
+        for nprobe in (4, nlist, 1):
+            ixf.nprobe = nprobe
+            Dr, Ir = orc.ivfflat_search(metric, cen, lm, qf, nprobe, 10)
+            for qt in (1, 0, 2, 4):
+                for filt in (0, 2):
+                    ixf.set_param("ivf_qtiles", qt); ixf.set_param("ivf_filter", filt)
+                    D, I = ixf.search(qf, 10)
+                    assert np.array_equal(I, Ir), f"metric={metric} nprobe={nprobe} ivf_qtiles={qt} ivf_filter={filt}"
+                    assert np.allclose(D, Dr, rtol=0, atol=max(1e-30, np.abs(Dr[np.isfinite(Dr)]).max() * 2 ** -22))
+
+
 def test_train_matches_oracle(gpu, orc):
     """rsx_train == the oracle's k-means / PQ training, bit for bit (GPU assignment, host update)."""
     d, M, nlist, n = 64, 8, 8, 3000
