@@ -1,4 +1,4 @@
-// k_pq_rot.hip — IVF-PQ scans of the ROTATED code layout (rsx_internal.h: CB = 0; M in {32, 64, 96, 128}).
+// k_pq_rot.hip — IVF-PQ scans of the ROTATED code layout (rsx_internal.h: CB = 0; M in {16, 32, 64, 96, 128}).
 // Reference call site: IndexIVFPQ.search, src/indicies/ivf_pq.py:229-232 (IP, by_residual):
 //     score(q, v) = <q, centroid(list(v))> + sum_m T[q][m][code_v[m]].
 //
@@ -178,7 +178,8 @@ extern "C" int rsx_debug_rot_wave(uint32_t* out, int n_items) {
 }
 #endif
 
-template <int NF, int NH, bool FILTER>
+// NQ = 1: M = 16 (NF = NH = 0): 64-vector blocks, lane (g, i) = vector 16 g + i, every MFMA column used (column 4 g + q = vector group g, query q)
+template <int NF, int NH, bool FILTER, int NQ = 0>
 __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ seg_keys,
                                                       uint32_t* __restrict__ seg_cnt, uint32_t* xcd_ctr, uint32_t* prog, int seg_cap, int bpw, int pace_arg, int var_arg) {
 #ifdef RSX_MEASURE
@@ -186,13 +187,16 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 #else
     constexpr int var = 0;          // the shipped library has no measurement branches
 #endif
-    constexpr int M = 64 * NF + 32 * NH;
+    constexpr int M = 64 * NF + 32 * NH + 16 * NQ;
+    constexpr int BV = NQ ? 64 : 16;           // vectors per code block
+    constexpr int BB = NQ ? 1024 : 16 * M;     // bytes per code block
+    constexpr int NL = NQ ? 1 : NF;            // 16-byte code loads per lane and block
     constexpr int RD = NF >= 2 ? 2 : ROT_D;    // code blocks in flight per wave (M = 128: two 2 KiB blocks — four would not fit 128 VGPRs)
-    constexpr int NPH = NF + NH;               // phases = table planes
+    constexpr int NPH = NF + NH + NQ;          // phases = table planes
     constexpr int TAB = NPH * 65536;           // plane p at p * 64 KiB; row = code * 256; a half phase uses 128 B of the row
-    constexpr int NG = M / 4;                  // gathers per lane per block
+    constexpr int NG = NQ ? 16 : M / 4;        // gathers per lane per block
     constexpr int NR1 = NPH > 1 ? rot_nreg(1, NF >= 2 ? 16 : 8) : 0;
-    constexpr int NR0 = NF >= 1 ? 4 : rot_nreg(0, 8);     // M = 32: the half phase IS plane 0
+    constexpr int NR0 = (NF >= 1 || NQ) ? 4 : rot_nreg(0, 8);     // M = 32: the half phase IS plane 0
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) uint32_t rot_s[];
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 #pragma unroll
         for (int bb = 0; bb < 4; bb++) {
             const int s = r * 4 + bb;
-            const uint32_t rot = NF >= 1 ? (uint32_t)(64 * g + 4 * ((i + s) & 15))
+            const uint32_t rot = NQ ? (uint32_t)(64 * (g & 1) + 4 * ((i + s) & 15))           // M = 16: copy g & 1 of the 16 entries
+                               : NF >= 1 ? (uint32_t)(64 * g + 4 * ((i + s) & 15))
                                          : (uint32_t)(64 * (g & 1) + 4 * ((i + s + 8 * (g >> 1)) & 15));
             v |= rot << (8 * bb);
         }
@@ -259,7 +264,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         }
         R1[r] = v;
     }
-    const int bsel = n < 4 ? (1 << (8 * n)) : 0;
+    // B one-hot: K index 16 gK + 4 j + byte; column n picks byte n of every K group (n < 4) — or, M = 16, byte n & 3 of K group n >> 2 only
+    const int bsel = NQ ? (((n >> 2) == g) ? (1 << (8 * (n & 3))) : 0) : (n < 4 ? (1 << (8 * n)) : 0);
     const v4i Bm = {bsel, bsel, bsel, bsel};
     const int vo16 = lane * 16, vo8 = lane * 8;
     // Survivors leave the scan with PLAIN stores: every (item, wave, query) owns a segment of seg_cap keys in HBM, the slot of
@@ -268,7 +274,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     // the per-query candidate rows afterwards.  Nothing here returns a value: an LDS ds_add_rtn costs ~300 clk of the
     // whole CU's LDS pipe, and a returning global atomic sits in the wave's in-order vmcnt queue in front of the next item's
     // table loads (measured: 0.6 ms of a 3.8 ms scan for 1.9 M survivors).
-    const uint64_t QM = n < 4 ? (0x0001000100010001ull << n) : 0ull;   // the four lanes that own query n
+    const uint64_t QM = NQ ? (0x1111111111111111ull << (n & 3))         // M = 16: every lane with n & 3 == query
+                           : (n < 4 ? (0x0001000100010001ull << n) : 0ull);   // the four lanes that own query n
 
     int item = 0;
     if (w == 0) {
@@ -292,14 +299,14 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         const int np = np_raw & 15;
         const int64_t len = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->len >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->len);
         const int64_t base_row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->base_row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->base_row);
-        const int nblk = (int)(((len + 63) >> 6) << 2);     // 16-vector blocks of the list, slab padding included
+        const int nblk = NQ ? (int)((len + 63) >> 6) : (int)(((len + 63) >> 6) << 2);     // code blocks of the list, slab padding included
         const int tb0 = __builtin_amdgcn_readfirstlane(it->tile) * (16 * bpw);
-        const uint8_t* lp = a.codes + (base_row >> 4) * (int64_t)(16 * M);
+        const uint8_t* lp = a.codes + (base_row / BV) * (int64_t)BB;
         // ---- code loads: buffer instructions on a descriptor of THIS list's blocks (base + size in SGPRs, the block's byte
         // offset in an SGPR, lane * 16 in one constant VGPR): no address VALU, and a block past the list's end reads zeros
         // instead of needing a clamp (its sums are garbage that the pos < len test of the survivor path drops)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lp, 0, nblk * 16 * M, 0x00020000);
-        v4u ca[RD][NF > 0 ? NF : 1]; v2u cb[RD];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lp, 0, nblk * BB, 0x00020000);
+        v4u ca[RD][NL > 0 ? NL : 1]; v2u cb[RD];
         // ---- circular scan (round 3): the sibling groups of a list tile (the item's family: adjacent items, different CUs of this
         // XCD) read the same code lines, and a line lives ~5 us in the XCD's L2.  A workgroup that starts while a sibling is
         // already under way therefore does not begin at the tile's first block: it JOINS the most advanced running sibling at
@@ -366,6 +373,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 const int p = m < 64 * NF ? (m >> 6) : NF;
                 const int slot = m < 64 * NF ? (m & 63) : (m - 64 * NF);
                 *reinterpret_cast<uint4*>(sb + p * 65536 + c * 256 + slot * 4) = o;
+                if (NQ) *reinterpret_cast<uint4*>(sb + c * 256 + 64 + slot * 4) = o;      // M = 16: second copy for the odd lane groups
             }
             }
         }
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             if (lane == 0) { lds_wr32(i0_a, i0v); lds_wr32(chunk_a, (uint32_t)dyn_from); }
         }
         // ---- the lane's share of the item record: accumulator init, score parameters of the query it owns (n < 4)
-        const int cinit = FILTER ? (n < 4 ? it->cinit[nq4] : -(1 << 30)) : 0;
+        const int cinit = FILTER ? ((NQ || n < 4) ? it->cinit[nq4] : -(1 << 30)) : 0;
         const v4i Ci = {cinit, cinit, cinit, cinit};
         const float p_dis0 = it->dis0[nq4], p_scale = it->scale[nq4], p_bias = it->bias[nq4];
         const int64_t p_off = it->off[nq4];
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         const int nch = 16 * R + cl;
         int r0 = join_on ? (int)__builtin_amdgcn_readfirstlane((int)lds_rd32_volatile(i0_a)) : 0;
         if (r0 >= R) r0 = 0;
-        const int so_oob = nblk * (16 * M);                                        // past the descriptor's end: reads zeros
+        const int so_oob = nblk * BB;                                        // past the descriptor's end: reads zeros
         // sequence number -> byte offset of the chunk's first block (so_oob: no such chunk), its row, and whether it is on the second pass
         auto row_of = [&](int nseq, bool& wrapped) -> int {          // row of a valid sequence number, and whether it is on the second pass
             int r = nseq >> 4;
@@ -459,15 +467,17 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         auto chunk_of = [&](int nseq) -> int {
             if (nseq >= nch) return so_oob;
             bool wr_;
-            return (tb0 + (nseq & 15) + 16 * (row_of(nseq, wr_) * RD)) * (16 * M);
+            return (tb0 + (nseq & 15) + 16 * (row_of(nseq, wr_) * RD)) * BB;
         };
         int nA = w, nB = 16 + w, nC = 0x7fffffff;
         int soA = chunk_of(nA), soB = chunk_of(nB);
 #pragma unroll
         for (int dd = 0; dd < RD; dd++) {     // chunk A's blocks
-            const int so = soA == so_oob ? so_oob : soA + dd * 16 * (16 * M);
+            // (a chunk's RD blocks lie 16 apart in ONE column of the tile: with fewer than RD blocks per wave and tile — M = 16 at small
+            //  tiles — the later ones would belong to the next tile, which another item scans)
+            const int so = (soA == so_oob || soA / BB - tb0 + 16 * dd >= 16 * bpw) ? so_oob : soA + dd * 16 * BB;
 #pragma unroll
-            for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
+            for (int p = 0; p < NL; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
             if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
             // keep the issue order dd = 0 .. RD-1: the loop waits for slot dd with `vmcnt(loads of the RD-1 younger slots)`, and one
             // s_waitcnt serves both the loop entry and the back edge — with the scheduler's order (slot 0 LAST) the entry needs
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             // the chunk after next: drawn now, needed at the end of this iteration
             if (nB + 16 < dyn_from) nC = nB + 16;
             else if (lane == 0) nC = (int)__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + chunk_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int b0 = soA / (16 * M);                                         // first block of chunk A
+            const int b0 = soA / BB;                                         // first block of chunk A
             const int so_next = soB;
             if (prio_rot) {
                 // the four waves of a SIMD (w, w + 4, w + 8, w + 12) take turns at the top issue priority, one loop iteration each
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 const int b = b0 + 16 * dd;
                 uint32_t gv[NG];
                 // addresses: (plane << 16) | (code << 8) | rotation byte — one v_perm each
-                if (NF >= 1) {
+                if (NF >= 1 || NQ) {
                     const uint32_t cw[4] = {ca[dd][0].x, ca[dd][0].y, ca[dd][0].z, ca[dd][0].w};
 #pragma unroll
                     for (int s = 0; s < 16; s++)
@@ -536,9 +546,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 {   // the slot's code registers are dead: refill them in place
-                    const int so = so_next == so_oob ? so_oob : so_next + dd * 16 * (16 * M);
+                    const int so = (so_next == so_oob || so_next / BB - tb0 + 16 * dd >= 16 * bpw) ? so_oob : so_next + dd * 16 * BB;
 #pragma unroll
-                    for (int p = 0; p < NF; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
+                    for (int p = 0; p < NL; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
                     if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -557,9 +567,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                         for (int r = 0; r < 4; r++) {
                             const bool cnd = C[r] >= 0;
                             if (__builtin_amdgcn_ballot_w64(cnd)) {
-                                const int64_t pos = ((int64_t)b << 4) + 4 * g + r;
+                                const int64_t pos = NQ ? ((int64_t)b << 6) + 16 * (n >> 2) + 4 * g + r : ((int64_t)b << 4) + 4 * g + r;
                                 const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(C[r] - cinit + 128 * M), p_bias);
-                                const uint64_t key = (cnd && pos < len) ? make_key(sc, (uint32_t)p_off + (uint32_t)pos) : 0ull;
+                                const uint64_t key = (cnd && pos < len && b - tb0 < 16 * bpw) ? make_key(sc, (uint32_t)p_off + (uint32_t)pos) : 0ull;
                                 const bool pass = key > p_tau;
                                 const uint64_t mq = __builtin_amdgcn_ballot_w64(pass) & QM;      // this step's survivors of MY query
                                 if (pass) {
@@ -571,10 +581,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                         }
                     }
                 } else {
-                    if (n < np && b < nblk) {
+                    if ((NQ ? (n & 3) < np : n < np) && b < nblk && b - tb0 < 16 * bpw) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const int64_t pos = ((int64_t)b << 4) + 4 * g + r;
+                            const int64_t pos = NQ ? ((int64_t)b << 6) + 16 * (n >> 2) + 4 * g + r : ((int64_t)b << 4) + 4 * g + r;
                             const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(C[r] + 128 * M), p_bias);
                             a.temp[p_off + pos] = (pos < len) ? sc : -__builtin_inff();
                         }
@@ -670,17 +680,17 @@ __global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem*
     }
 }
 
-template <int NF, int NH, bool FILTER>
+template <int NF, int NH, bool FILTER, int NQ = 0>
 static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, int seg_cap, hipStream_t st) {
-    constexpr int M = 64 * NF + 32 * NH;
-    const size_t shm = (size_t)(NF + NH) * 65536 + 384 + 256;   // tables | 2 item records (176 B each) + pacing word | sibling progress [64]
+    constexpr int M = 64 * NF + 32 * NH + 16 * NQ;
+    const size_t shm = (size_t)(NF + NH + NQ) * 65536 + 384 + 256;   // tables | 2 item records (176 B each) + pacing word | sibling progress [64]
     static DevOnce once;
     static int ncu_of[64] = {};
     int& ncu = ncu_of[cur_device()];
     static std::atomic<int> failed{0};
     once.once([&] {
         int dev = 0; hipDeviceProp_t pr;
-        if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) { failed = 1; return; }
         ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     });
@@ -696,7 +706,7 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     // one persistent workgroup per CU (a multiple of 8: workgroup b serves XCD b % 8); never more than the work items
     int64_t grid = (ncu + 7) & ~7;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
-    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, xcd_ctr, prog,
+    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER, NQ>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, xcd_ctr, prog,
                        seg_cap, bpw, A.pace, var);
     if (FILTER && !A.qitems)     // with qitems the segments are consumed in place by k_pq_gather_select
         hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, seg_keys, seg_cnt, seg_cap,
@@ -722,6 +732,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
     switch (a.M) {
+        case 16: return f ? launch_pq_scan_rot_t<0, 0, true, 1>(A, vpl, item_ws, seg_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, seg_cap, st);   // 64-vector blocks
         case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, seg_cap, st);
         case 64: return f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, seg_cap, st);
         case 96: return f ? launch_pq_scan_rot_t<1, 1, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<1, 1, false>(A, bpw, item_ws, seg_cap, st);
@@ -994,7 +1005,7 @@ static void launch_pq_prepass4_t(const PQPrepassArgs& a, int64_t nq, hipStream_t
 }
 // sample rows the 4-query form can hold beside its tables (0: this M has no such kernel)
 int pq_prepass4_max_rows(int M) {
-    if (!pq_rot_applies(M)) return 0;
+    if (!pq_rot_applies(M) || M < 32) return 0;
     const int nph = (M >> 6) + ((M >> 5) & 1);
     const int64_t room = (int64_t)160 * 1024 - (int64_t)nph * 65536 - (1024 + 32) * 4 - 64 - 256;
     return room < 8 * 64 ? 0 : (int)(room / 8 / 64 * 64);

@@ -454,7 +454,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const float dis0 = a.probe_dis0[q * a.nprobe + j0];
     const int64_t col = a.seg_start[q * (a.nprobe + 1) + j0];
     const int nch = a.Mpad >> 4;
-    if (a.CB == 0) {
+    if (a.CB == 0 && a.Mpad == 16) {
+        // rotated layout, M = 16: 64-vector blocks, a lane owns a vector's 16 bytes (byte s: m = (lane + s) & 15); lut8 is [q][code][16]
+        const uint8_t* lb = a.codes + ((l >= 0 ? a.list_base[l] : 0) >> 6) * (int64_t)1024;
+        for (int sl = w; sl < nslab; sl += 16) {
+            const uint4 c = *reinterpret_cast<const uint4*>(lb + (int64_t)sl * 1024 + lane * 16);
+            const uint32_t wds[4] = {c.x, c.y, c.z, c.w};
+            uint32_t acc = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; s2++) acc += tab[((wds[s2 >> 2] >> (8 * (s2 & 3))) & 255u) * 16 + ((lane + s2) & 15)];
+            const int64_t pos = (int64_t)sl * 64 + lane;
+            sums[pos] = (pos < len) ? (uint16_t)(acc + 1u) : (uint16_t)0;
+        }
+    } else if (a.CB == 0) {
         // rotated layout: lut8 is [q][code][M]; lane (g, i) of a wave sums the entries of its 16 (+8) bytes of
         // vector i of a 16-vector block, the four lanes of a vector are added with two shuffles
         const int M = a.Mpad, NF = M >> 6, NH = (M >> 5) & 1;
@@ -1051,7 +1063,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             const float dis0 = a.probe_dis0[q * a.nprobe + lo];
             const int64_t slab = row >> 6; const int v = (int)(row & 63);
             const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-            const float sum = a.CB == 0 ? ((!T && a.dsub == 8) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
+            const float sum = a.CB == 0 ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
                                                                   : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub))
                             : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                          : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
@@ -1253,7 +1265,7 @@ __global__ __launch_bounds__(256) void k_pq_rescore_all(FinalizeArgs a, uint64_t
         const float dis0 = a.probe_dis0[q * a.nprobe + lo];
         const int64_t slab = row >> 6; const int v = (int)(row & 63);
         const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-        const float sum = a.CB == 0 ? ((!T && a.dsub == 8) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
+        const float sum = a.CB == 0 ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
                                                               : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub))
                         : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                      : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);

@@ -390,7 +390,7 @@ static rsx_index* create_common(int kind, int d, int nlist, int M, int nbits, in
         // rsx_set_param "pq_layout" switches an EMPTY index between the two
         h->CB_granule = h->CB;
         const char* e = getenv("RSX_PQ_LAYOUT");
-        if (pq_rot_applies(M) && !(e && atoi(e) == 0)) h->CB = 0;
+        if (pq_rot_applies(M) && M >= 32 && !(e && atoi(e) == 0)) h->CB = 0;      // M = 16: rotated on request only (pq_layout = 1): faster at small k, segment overflows at large k x nprobe
         if ((size_t)h->Mpad * 1024 > 160 * 1024) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: M = %d needs more than 160 KiB of LDS for the look-up table", M);
     }
     HIPCHECK(hipSetDevice(device));
@@ -2511,7 +2511,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_layout") {
             if (h->kind != KIND_IVFPQ) RSX_THROW(RSX_ERR_UNSUPPORTED, "pq_layout: IVFPQ only");
             if (h->ntotal + h->ndropped > 0) RSX_THROW(RSX_ERR_INVALID, "pq_layout must be set before the first add");
-            if ((int)value == 1 && !pq_rot_applies(h->M)) RSX_THROW(RSX_ERR_UNSUPPORTED, "pq_layout=1 (rotated) needs M in {32, 64, 96, 128}");
+            if ((int)value == 1 && !pq_rot_applies(h->M)) RSX_THROW(RSX_ERR_UNSUPPORTED, "pq_layout=1 (rotated) needs M in {16, 32, 64, 96, 128}");
             h->CB = (int)value == 1 ? 0 : h->CB_granule;
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;

@@ -86,6 +86,9 @@ constexpr int CCS = 16;   // counter stride in 8-byte words: cand_cnt[q * CCS]
 //             contiguous bytes at NF*1024 + lane*8 (byte s: m = 64NF + 16(g & 1) + ((i + s + 8(g >> 1)) & 15)).
 //             At every step the 32 lanes of a half-wave hold 32 different m % 32, so a table laid out [code][m]
 //             (bank = m % 32) is gathered without a single LDS bank conflict whatever the codes are (k_pq_scan_rot).
+//             M = 16: block of 64 vectors = 1 KiB; lane (g, i) owns vector 16 g + i and reads its 16 contiguous bytes at lane*16
+//             (byte s: m = (i + s) & 15); the table row of a code holds the 16 entries twice (bytes 0-63 and 64-127), lane groups
+//             of even / odd g use one copy each, so the 32 lanes of a half-wave again hit 32 different banks.
 // Lists start on 64-vector boundaries in both layouts and a 64-vector slab is 64*Mpad bytes in both.
 // ---------------------------------------------------------------------------------------
 __host__ __device__ inline int64_t pq_code_addr(int64_t row, int m, int Mpad, int CB) {
@@ -93,6 +96,10 @@ __host__ __device__ inline int64_t pq_code_addr(int64_t row, int m, int Mpad, in
         const int64_t slab = row >> 6; const int v = (int)(row & 63);
         const int g = m / CB, b = m - g * CB;
         return (slab * (Mpad / CB) + g) * (int64_t)(64 * CB) + v * CB + b;
+    }
+    if (Mpad == 16) {     // rotated, M = 16 (round 3): a block is 64 vectors = 1 KiB; vector v's 16 bytes sit together, byte s holds m = (v + s) & 15
+        const int v = (int)(row & 63);
+        return (row >> 6) * 1024 + v * 16 + ((m - v) & 15);
     }
     const int64_t base = (row >> 4) * (int64_t)(16 * Mpad);
     const int i = (int)(row & 15), NF = Mpad >> 6;
@@ -103,7 +110,7 @@ __host__ __device__ inline int64_t pq_code_addr(int64_t row, int m, int Mpad, in
     const int mm = m - 64 * NF, t = ((mm & 15) - i) & 15, g = (mm >> 4) + 2 * (t >> 3), s = t & 7;
     return base + NF * 1024 + (16 * g + i) * 8 + s;
 }
-__host__ __device__ inline bool pq_rot_applies(int M) { return M % 32 == 0 && M >= 32 && M <= 128; }
+__host__ __device__ inline bool pq_rot_applies(int M) { return M == 16 || (M % 32 == 0 && M >= 32 && M <= 128); }
 
 // Inverted-list directory on the device (one entry per list; Flat uses a single list 0).
 //   base : first storage row of the list (PQ: multiple of 64 = slab aligned; flat rows: of 16)

@@ -58,14 +58,14 @@ def test_golden_ivfflat(gpu, orc):
     assert_same_results(D2, I2, Dr, Ir, "nprobe>nlist")
 
 
-@pytest.mark.parametrize("name,layout", [("ivfpq_d64_m16", 0), ("ivfpq_d768_m96", 1), ("ivfpq_d768_m96", 0)])
+@pytest.mark.parametrize("name,layout", [("ivfpq_d64_m16", 1), ("ivfpq_d64_m16", 0), ("ivfpq_d768_m96", 1), ("ivfpq_d768_m96", 0)])
 def test_golden_ivfpq(gpu, orc, name, layout):
-    """layout 1 = the rotated code layout (k_pq_rot.hip: conflict-free table gathers, default for M in {32, 64, 96, 128}),
+    """layout 1 = the rotated code layout (k_pq_rot.hip: conflict-free table gathers, default for M in {32, 64, 96, 128}, on request (pq_layout = 1) for M = 16),
     layout 0 = the granule layout (k_pq.hip); both must give the oracle's bits through every scan variant."""
     g = load_golden(name)
     x, q = regen_gpu(gpu, g)
     ix = gpu.IndexIVFPQ(gpu.IndexFlatIP(g["d"]), g["d"], g["nlist"], g["M"], 8, gpu.METRIC_INNER_PRODUCT)
-    assert ix._get("pq_layout") == (1 if g["M"] % 32 == 0 else 0), "rotated layout is the default where it applies"
+    assert ix._get("pq_layout") == (1 if g["M"] % 32 == 0 else 0), "rotated layout is the default for M in {32, 64, 96, 128}; M = 16 on request"
     ix.set_param("pq_layout", layout)
     assert ix._get("pq_layout") == layout
     name = f"{name} layout={layout}"
@@ -146,11 +146,13 @@ def test_golden_ivfpq(gpu, orc, name, layout):
 
 
 @pytest.mark.parametrize("d,M,nlist", [(96, 12, 8), (64, 8, 4), (768, 16, 16), (128, 64, 8), (64, 16, 7), (320, 160, 4),
-                                       (256, 32, 8), (256, 128, 4), (192, 96, 5), (384, 64, 6)])
+                                       (256, 32, 8), (256, 128, 4), (192, 96, 5), (384, 64, 6), (768, -16, 16), (128, -16, 3)])
 def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
     """Other (d, M): 16-byte-granule and 4-byte-granule code layouts, dsub 8/2/48; M=160 is too large for the
     LDS-resident table build and takes the unfused table path; M = 32 / 64 / 96 / 128 take the rotated layout
     (half phase only, one full phase, full + half, two full phases of k_pq_scan_rot)."""
+    rot16 = M < 0            # M = -16: the rotated layout for M = 16 (on request: rsx_set_param pq_layout = 1)
+    M = abs(M)
     n, nq, k = 6000, 37, 20
     x = orc.synth_vectors(d, nlist, 61, 62, 0.5, 0, n)
     q = orc.synth_queries(d, nlist, 61, 62, 0.5, n, 63, 0.1, 0, nq)
@@ -161,6 +163,9 @@ def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
     codes = orc.pq_encode(cb, orc.residuals(cen, x32, a))
     lm = orc.ListMajor(a, np.arange(n), codes, nlist)
     ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    if rot16:
+        ix.set_param("pq_layout", 1)
+        assert ix._get("pq_layout") == 1
     ix.set_centroids(cen); ix.set_codebooks(cb)
     ix.add(x)
     for nprobe in (1, 3, nlist):
@@ -197,7 +202,9 @@ def test_ivfpq_many_survivors(gpu, orc, layout):
     assert_same_results(D, I, De, Ie, f"layout={layout} k=300")
 
 
-def test_ivfpq_large_k_and_ties(gpu, orc):
+@pytest.mark.parametrize("layout", [0, 1])
+def test_ivfpq_large_k_and_ties(gpu, orc, layout):
+    """layout 1: the rotated M = 16 form (64-vector blocks); two of the lists span two scan tiles of 1024 vectors."""
     d, M, nlist, n = 64, 16, 8, 5000
     x = orc.synth_vectors(d, nlist, 71, 72, 0.5, 0, n)
     x[100:140] = x[7]                    # 41 identical vectors -> identical codes -> exact score ties
@@ -208,9 +215,10 @@ def test_ivfpq_large_k_and_ties(gpu, orc):
     cb = orc.pq_train(orc.residuals(cen, x32, a)[:2000], M, 3, 1234)
     lm = orc.ListMajor(a, np.arange(n), orc.pq_encode(cb, orc.residuals(cen, x32, a)), nlist)
     ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    ix.set_param("pq_layout", layout)
     ix.set_centroids(cen); ix.set_codebooks(cb); ix.add(x)
     ix.nprobe = nlist
-    for k in (64, 1000, 2048, 4096):
+    for k in (64, 500, 1000, 2048, 4096):
         D, I = ix.search(q, k)
         Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, nlist, k)
         assert np.array_equal(D, Dr), f"k={k} scores"
