@@ -180,8 +180,8 @@ extern "C" int rsx_debug_rot_wave(uint32_t* out, int n_items) {
 
 // NQ = 1: M = 16 (NF = NH = 0): 64-vector blocks, lane (g, i) = vector 16 g + i, every MFMA column used (column 4 g + q = vector group g, query q)
 template <int NF, int NH, bool FILTER, int NQ = 0>
-__global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ seg_keys,
-                                                      uint32_t* __restrict__ seg_cnt, uint32_t* xcd_ctr, uint32_t* prog, int seg_cap, int bpw, int pace_arg, int var_arg) {
+__global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ log_keys,
+                                                      uint2* __restrict__ seg_desc, uint32_t* xcd_ctr, uint32_t* prog, int log_cap, int bpw, int pace_arg, int var_arg) {
 #ifdef RSX_MEASURE
     const int var = var_arg;        // tools/ builds only: cost-split variants (skip staging / scan / survivor path)
 #else
@@ -268,15 +268,23 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     const int bsel = NQ ? (((n >> 2) == g) ? (1 << (8 * (n & 3))) : 0) : (n < 4 ? (1 << (8 * n)) : 0);
     const v4i Bm = {bsel, bsel, bsel, bsel};
     const int vo16 = lane * 16, vo8 = lane * 8;
-    // Survivors leave the scan with PLAIN stores: every (item, wave, query) owns a segment of seg_cap keys in HBM, the slot of
-    // a survivor is the wave's running count for its query plus its rank among this step's survivors of the same query
-    // (ballot + mbcnt), and the count goes out with one store per wave and item.  k_pq_rot_compact appends the segments to
-    // the per-query candidate rows afterwards.  Nothing here returns a value: an LDS ds_add_rtn costs ~300 clk of the
-    // whole CU's LDS pipe, and a returning global atomic sits in the wave's in-order vmcnt queue in front of the next item's
-    // table loads (measured: 0.6 ms of a 3.8 ms scan for 1.9 M survivors).
+    // Survivors leave the scan with PLAIN stores into WAVE-PRIVATE LOGS (round 4): every (workgroup, wave, query slot) owns one
+    // append-only log of log_cap keys in HBM for the whole launch; the survivors of an item's query k go to the end of the wave's
+    // log k — slot = the wave's running count plus the survivor's rank among this step's survivors of the same query (ballot +
+    // mbcnt) — and one 8-byte descriptor {first key, count} per (item, wave, query) tells k_pq_gather_select / k_pq_rot_compact
+    // where the item's run lies.  Rounds 2-3 gave every (item, wave, query) its own fixed segment of seg_cap keys: with 8.4 M
+    // segments (the reference's nprobe 512) the pool allowed 128 keys each, and a query whose closest list is dense — 12 % of the
+    // queries at M = 16, every query at k >= 1000 — overflowed and was re-run exactly.  A log only overflows when ONE wave
+    // collects more than log_cap survivors of one slot in the whole launch (tens of thousands; counted, dropped, its queries
+    // re-run exactly — never silently lost).  Nothing here returns a value: an LDS ds_add_rtn costs ~300 clk of the whole CU's
+    // LDS pipe, and a returning global atomic sits in the wave's in-order vmcnt queue in front of the next item's table loads
+    // (measured: 0.6 ms of a 3.8 ms scan for 1.9 M survivors).
     const uint64_t QM = NQ ? (0x1111111111111111ull << (n & 3))         // M = 16: every lane with n & 3 == query
                            : (n < 4 ? (0x0001000100010001ull << n) : 0ull);   // the four lanes that own query n
 
+    const size_t mylog_i = ((size_t)blockIdx.x * 16 + (size_t)w) * 4 + (size_t)nq4;     // this lane's log (query slot nq4 of this wave)
+    uint64_t* const mylog = log_keys + mylog_i * (size_t)log_cap;
+    uint32_t lcur = 0;                    // keys appended to the lane's log so far (equal in all lanes of a query slot); persists across items
     int item = 0;
     if (w == 0) {
         if (lane == 0) { drawn = atomicAdd(ctr, 1u); }
@@ -377,7 +385,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             }
             }
         }
-        uint64_t* myseg = seg_keys + (((size_t)item * 16 + w) * 4 + nq4) * seg_cap;
         // ---- next item: drawn JUST IN TIME (round 3).  The XCD's item order is (list, tile, group), so the workgroups that
         // draw the sibling groups of a list tile are the ones that come free one after the other: they start within a few
         // microseconds of each other and stream the same code lines, the followers out of the XCD's L2 (a line lives ~5 us
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         const float p_dis0 = it->dis0[nq4], p_scale = it->scale[nq4], p_bias = it->bias[nq4];
         const int64_t p_off = it->off[nq4];
         const uint64_t p_tau = it->tau[nq4];
-        uint32_t qcnt = 0;                    // survivors of the lane's query so far (equal in the four lanes of a query)
+        const uint32_t qstart = lcur;         // the lane's log position at the start of this item
         __syncthreads();    // #2: table staged
 #ifdef RSX_MEASURE
         const uint64_t t_scan0 = wall_clock64();
@@ -573,10 +580,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                                 const bool pass = key > p_tau;
                                 const uint64_t mq = __builtin_amdgcn_ballot_w64(pass) & QM;      // this step's survivors of MY query
                                 if (pass) {
-                                    const uint32_t slot = qcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
-                                    if (slot < (uint32_t)seg_cap) myseg[slot] = key;   // beyond: counted, dropped -> the query is re-run exactly
+                                    const uint32_t slot = lcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                                    if (slot < (uint32_t)log_cap) mylog[slot] = key;   // beyond: counted, dropped -> the query is re-run exactly
                                 }
-                                qcnt += (uint32_t)__builtin_popcountll(mq);
+                                lcur += (uint32_t)__builtin_popcountll(mq);
                             }
                         }
                     }
@@ -595,10 +602,14 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             nB = __builtin_amdgcn_readfirstlane(nC);
             soB = chunk_of(nB);
         }
-        // ---- item epilogue: the wave's four survivor counts leave with one store (lanes 0..3 own queries 0..3); wave 0 parks
-        // the next record (or the end marker) and draws the index of the item after it
+        // ---- item epilogue: the wave's four run descriptors leave with one store (lanes 0..3 own queries 0..3): first key of the
+        // run in the log pool, keys stored, bit 31 = the log was full and keys were dropped; wave 0 parks the next record (or the
+        // end marker) and draws the index of the item after it
         __builtin_amdgcn_s_setprio(0);
-        if (FILTER && lane < 4) seg_cnt[((size_t)item * 16 + w) * 4 + lane] = qcnt;
+        if (FILTER && lane < 4) {
+            const uint32_t c0 = qstart < (uint32_t)log_cap ? qstart : (uint32_t)log_cap, c1 = lcur < (uint32_t)log_cap ? lcur : (uint32_t)log_cap;
+            seg_desc[((size_t)item * 16 + w) * 4 + lane] = make_uint2((uint32_t)(mylog_i * (size_t)log_cap) + c0, (c1 - c0) | (lcur > (uint32_t)log_cap ? 0x80000000u : 0u));
+        }
 #ifdef RSX_MEASURE
         if (lane == 0 && item < 16384) g_rot_wave[16 * item + w] = (uint32_t)(wall_clock64() - t_scan0);
         if (tid == 0 && item < 65536) g_rot_trace[4 * item + 1] = wall_clock64();
@@ -620,35 +631,34 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 // One wave per work item: append the item's (wave, query) survivor segments to the candidate rows of its queries — the only
 // atomics of the filtered scan live here, one reservation per (item, query), in a kernel with thousands of independent waves.
 __global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem* __restrict__ items, const int32_t* total_items,
-                                                       const uint64_t* __restrict__ seg_keys, const uint32_t* __restrict__ seg_cnt,
-                                                       int seg_cap, uint64_t* cand, unsigned long long* cand_cnt, int cand_cap) {
+                                                       const uint64_t* __restrict__ log_keys, const uint2* __restrict__ seg_desc,
+                                                       uint64_t* cand, unsigned long long* cand_cnt, int cand_cap) {
     const int item = blockIdx.x * ROT_CW + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (item >= *total_items) return;
     const int w = lane >> 2, k = lane & 3;
-    const uint32_t c0 = seg_cnt[(size_t)item * 64 + lane];                 // lane = (wave, query) segment
-    if (__builtin_amdgcn_ballot_w64(c0 != 0u) == 0ull) return;
-    const uint32_t c = c0 < (uint32_t)seg_cap ? c0 : (uint32_t)seg_cap;
+    const uint2 dsc = seg_desc[(size_t)item * 64 + lane];                  // lane = (wave, query) run of the item
+    const uint32_t c = dsc.y & 0x7fffffffu;
+    const uint64_t ovm = __builtin_amdgcn_ballot_w64((dsc.y >> 31) != 0u);        // runs that dropped keys (all 64 lanes vote)
+    if (__builtin_amdgcn_ballot_w64(c != 0u) == 0ull && ovm == 0ull) return;
     // exclusive prefix over the 16 waves of the same query (lanes k, k + 4, ...), and the query's total
     uint32_t incl = c;
 #pragma unroll
     for (int off = 4; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off); if (lane >= off) incl += y; }
     const uint32_t total = __shfl(incl, 60 + k);
-    const uint64_t ovm = __builtin_amdgcn_ballot_w64(c0 > (uint32_t)seg_cap);     // segments that dropped keys (all 64 lanes vote)
     const bool myover = (ovm & (0x1111111111111111ull << k)) != 0ull;              // ... any of them of MY query
     const int64_t q = items[item].q[k];
     unsigned long long base = 0;
     if (w == 0 && (total > 0 || myover)) {
-        // an overflowing segment dropped keys: push the row's count past its capacity so that k_finalize flags the query
+        // a full log dropped keys: push the row's count past its capacity so that k_finalize flags the query
         base = atomicAdd(&cand_cnt[q * CCS], (unsigned long long)total + (myover ? (unsigned long long)cand_cap + 1ull : 0ull));
     }
     base = __shfl(base, k) + (incl - c);
-    // copy-out.  Short segments — the usual case since the thresholds are tight: ~130 survivors per query, one or two per (wave,
-    // query) of an item — are moved by their own lane, all 64 segments in ONE round trip (round 3: the wave used to walk the
-    // non-empty segments one after the other, a dependent load + store per segment, ~50 us per batch).
+    // copy-out.  Short runs — the usual case since the thresholds are tight: one or two survivors per (wave, query) of an item —
+    // are moved by their own lane, all 64 runs in ONE round trip
     if (c != 0u && c <= 4u && base < (unsigned long long)cand_cap) {
         const unsigned long long room = (unsigned long long)cand_cap - base;
         const uint32_t ce = (unsigned long long)c < room ? c : (uint32_t)room;
-        const uint64_t* src = seg_keys + ((size_t)item * 64 + lane) * seg_cap;
+        const uint64_t* src = log_keys + dsc.x;
         uint64_t kk[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) kk[e] = (uint32_t)e < ce ? src[e] : 0ull;
@@ -656,16 +666,17 @@ __global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem*
 #pragma unroll
         for (int e = 0; e < 4; e++) if ((uint32_t)e < ce) dst[e] = kk[e];
     }
-    // longer segments: the wave walks them, all lanes on one segment at a time (coalesced 8-byte moves)
+    // longer runs: the wave walks them, all lanes on one run at a time (coalesced 8-byte moves)
     uint64_t live = __builtin_amdgcn_ballot_w64(c > 4u);
     while (live) {
         const int sgm = __builtin_ctzll(live);
         live &= live - 1;
         const uint32_t cs = __builtin_amdgcn_readlane(c, sgm);
+        const uint32_t st0 = __builtin_amdgcn_readlane(dsc.x, sgm);
         const unsigned long long bs = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), sgm) << 32) |
                                       (uint32_t)__builtin_amdgcn_readlane((int)base, sgm);
         const int64_t qs = items[item].q[sgm & 3];
-        const uint64_t* src = seg_keys + ((size_t)item * 64 + sgm) * seg_cap;
+        const uint64_t* src = log_keys + st0;
         // a row past its capacity is re-run exactly anyway (k_finalize flags it): nothing beyond cand_cap is moved
         if (bs >= (unsigned long long)cand_cap) continue;
         const uint32_t room = (uint32_t)((unsigned long long)cand_cap - bs);
@@ -680,36 +691,44 @@ __global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem*
     }
 }
 
+// persistent workgroups of the scan on the current device: one per CU, a multiple of 8 (workgroup b serves XCD b % 8)
+int pq_scan_rot_max_wgs() {
+    static int ncu_of[64] = {};
+    static DevOnce once;
+    int& ncu = ncu_of[cur_device()];
+    once.once([&] {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount;
+    });
+    if (ncu <= 0) ncu = 256;
+    return (ncu + 7) & ~7;
+}
+
 template <int NF, int NH, bool FILTER, int NQ = 0>
-static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, int seg_cap, hipStream_t st) {
+static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, int log_cap, hipStream_t st) {
     constexpr int M = 64 * NF + 32 * NH + 16 * NQ;
     const size_t shm = (size_t)(NF + NH + NQ) * 65536 + 384 + 256;   // tables | 2 item records (176 B each) + pacing word | sibling progress [64]
     static DevOnce once;
-    static int ncu_of[64] = {};
-    int& ncu = ncu_of[cur_device()];
     static std::atomic<int> failed{0};
     once.once([&] {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
-            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) { failed = 1; return; }
-        ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) failed = 1;
     });
     if (failed) return -1;
-    if (ncu <= 0) ncu = 256;
+    const int nwg = pq_scan_rot_max_wgs();
     PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
-    uint32_t* seg_cnt = pq_scan_rot_ws_cnt(desc_ws, A.max_items);
-    uint64_t* seg_keys = pq_scan_rot_ws_keys(desc_ws, A.max_items);
-    uint32_t* xcd_ctr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(seg_keys) + (size_t)(A.max_items + 8) * 64 * seg_cap * 8);
+    uint2* seg_desc = pq_scan_rot_ws_desc(desc_ws, A.max_items);
+    uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, A.max_items);
+    uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, A.max_items, log_cap, nwg);
     uint32_t* prog = xcd_ctr + 256;
     hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog);
     static const int var = measure_env("RSX_ROT_VARIANT", 0);
-    // one persistent workgroup per CU (a multiple of 8: workgroup b serves XCD b % 8); never more than the work items
-    int64_t grid = (ncu + 7) & ~7;
+    // one persistent workgroup per CU; never more than the work items
+    int64_t grid = nwg;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
-    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER, NQ>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, seg_keys, seg_cnt, xcd_ctr, prog,
-                       seg_cap, bpw, A.pace, var);
-    if (FILTER && !A.qitems)     // with qitems the segments are consumed in place by k_pq_gather_select
-        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, seg_keys, seg_cnt, seg_cap,
+    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER, NQ>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, prog,
+                       log_cap, bpw, A.pace, var);
+    if (FILTER && !A.qitems)     // with qitems the runs are consumed in place by k_pq_gather_select
+        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, log_keys, seg_desc,
                            A.cand, A.cand_cnt, A.cand_cap);
     return 0;
 }
@@ -719,9 +738,9 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws, int seg_cap, int prune, int pace, const uint16_t* excl, int32_t* qitems,
+                       int cand_cap, void* item_ws, int log_cap, int prune, int pace, const uint16_t* excl, int32_t* qitems,
                        int qitems_tmax, hipStream_t st) {
-    if (a.CB != 0 || !item_ws || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
+    if (a.CB != 0 || !item_ws || log_cap <= 0 || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8t; A.qp = (const PQQParam*)qparam;
     A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
@@ -732,11 +751,11 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
     switch (a.M) {
-        case 16: return f ? launch_pq_scan_rot_t<0, 0, true, 1>(A, vpl, item_ws, seg_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, seg_cap, st);   // 64-vector blocks
-        case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, seg_cap, st);
-        case 64: return f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, seg_cap, st);
-        case 96: return f ? launch_pq_scan_rot_t<1, 1, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<1, 1, false>(A, bpw, item_ws, seg_cap, st);
-        case 128: return f ? launch_pq_scan_rot_t<2, 0, true>(A, bpw, item_ws, seg_cap, st) : launch_pq_scan_rot_t<2, 0, false>(A, bpw, item_ws, seg_cap, st);
+        case 16: return f ? launch_pq_scan_rot_t<0, 0, true, 1>(A, vpl, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, log_cap, st);   // 64-vector blocks
+        case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, log_cap, st);
+        case 64: return f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, log_cap, st);
+        case 96: return f ? launch_pq_scan_rot_t<1, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 1, false>(A, bpw, item_ws, log_cap, st);
+        case 128: return f ? launch_pq_scan_rot_t<2, 0, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<2, 0, false>(A, bpw, item_ws, log_cap, st);
         default: return -1;
     }
 }

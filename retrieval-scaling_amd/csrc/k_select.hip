@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
 
 // ---------------------------------------------------------------------------------------
 // Candidate gather + selection for the rotated fast scan (PQGatherArgs, rsx_internal.h).  k_pq_scan_rot leaves a query's survivors
-// in (item, wave, slot) segments; k_pq_rot_compact appended them to the query's candidate row with one returning atomic per
+// in (item, wave, slot) runs of its waves' logs; k_pq_rot_compact appended them to the query's candidate row with one returning atomic per
 // (item, query) — ~40 dependent device-scope atomics on ONE counter per query, 40-50 us per batch whatever else the kernel did —
 // and k_select_radix then read the row back.  Here the query's workgroup finds its own segments (qitems: the inverse of the item
 // order, written by k_pq_rot_items), sums their counts, copies the keys behind what the pre-pass emitted and selects the K'
@@ -337,13 +337,13 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
             for (int u = 0; u < 8; u++) {
                 const int s2 = s0 + u * 256;
                 const int32_t slot = s2 < NS ? slots[s2 >> 4] : -1;
-                c[u] = slot >= 0 ? a.seg_cnt[(size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)] : 0u;
+                c[u] = slot >= 0 ? a.seg_desc[(size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)].y : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int s2 = s0 + u * 256;
                 if (s2 >= NS) break;
-                if (c[u] > (uint32_t)a.seg_cap) { over = true; c[u] = (uint32_t)a.seg_cap; }
+                if (c[u] >> 31) { over = true; c[u] &= 0x7fffffffu; }         // the wave's log was full: keys were dropped
                 cnts[s2] = (uint16_t)c[u];
             }
         }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
         const int c = cnts[s2];
         if (c == 0) continue;
         const int32_t slot = slots[s2 >> 4];
-        const uint64_t* src = a.seg_keys + ((size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)) * a.seg_cap;
+        const uint64_t* src = a.log_keys + a.seg_desc[(size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)].x;
         for (int e = 0; e < c; e += 4) {
             uint64_t kk[4];
 #pragma unroll

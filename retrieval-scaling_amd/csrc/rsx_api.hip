@@ -185,6 +185,7 @@ struct rsx_index {
     int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scan: 1 = choose 16 / 32 / 64 queries per group from the queries per list, 2 / 4 = force, 0 = always 16
     int pq_prepass4 = 1;     // rotated fast scan, small k, full batches: threshold pre-pass with four queries per workgroup on the scan's table format
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
+    int pq_log_cap = 0;      // rotated fast scan: keys per survivor log (0 = from the pool budget); tests shrink it to force the overflow path
     int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
     int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
@@ -210,9 +211,11 @@ struct rsx_index {
 
     // two-call search (rsx_search_prepass / rsx_search_scan: the caller exchanges the per-query thresholds between the calls,
     // e.g. an all-reduce(MAX) across the ranks of a LIST-sharded index).  The search runs on a worker thread that parks right
-    // after the threshold pre-pass; all of this is guarded by tc_mu.
+    // after the threshold pre-pass (only the worker thread ever parks: TwoCall::worker); parked / go / done / tau are guarded by
+    // TwoCall::mu, and every other entry point refuses the handle while `active` (refuse_while_two_call).
     struct TwoCall {
         std::thread th;
+        std::thread::id worker;     // the thread running the parked search: the only one allowed to park
         std::mutex mu;
         std::condition_variable cv;
         bool active = false, parked = false, go = false, done = false;
@@ -231,6 +234,12 @@ struct rsx_index {
 };
 
 static void use_device(rsx_index* h) { HIPCHECK(hipSetDevice(h->device)); }
+// A two-call search that is parked between rsx_search_prepass and rsx_search_scan owns the handle's workspaces (thresholds,
+// candidate rows, state): every other entry point refuses to touch the handle until rsx_search_scan has finished it.
+static void refuse_while_two_call(const rsx_index* h, const char* what) {
+    if (h && h->tc && h->tc->active)
+        RSX_THROW(RSX_ERR_INVALID, "%s: a two-call search is open on this handle (finish it with rsx_search_scan first)", what);
+}
 
 // HBM held by the search / add workspaces of one (unsharded) handle — grows with the largest batch served so far, is never
 // part of the index payload (hbm_bytes) and is released with the handle.  The largest single item is the IVF-PQ fast scan's
@@ -386,11 +395,12 @@ static rsx_index* create_common(int kind, int d, int nlist, int M, int nbits, in
             int nch = h->Mpad / 16;
             if (!(nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8)) h->CB = 4;
         }
-        // M in {32, 64, 96, 128}: the rotated layout (conflict-free table gathers, k_pq_rot.hip) unless RSX_PQ_LAYOUT=0;
-        // rsx_set_param "pq_layout" switches an EMPTY index between the two
+        // M in {16, 32, 64, 96, 128}: the rotated layout (conflict-free table gathers, k_pq_rot.hip) unless RSX_PQ_LAYOUT=0;
+        // rsx_set_param "pq_layout" switches an EMPTY index between the two.  (M = 16 — the reference's shipped IVF-PQ config,
+        // ric/conf/ivf_pq.yaml:64-78 — joined in round 4, once the survivors went to per-wave logs instead of fixed segments.)
         h->CB_granule = h->CB;
         const char* e = getenv("RSX_PQ_LAYOUT");
-        if (pq_rot_applies(M) && M >= 32 && !(e && atoi(e) == 0)) h->CB = 0;      // M = 16: rotated on request only (pq_layout = 1): faster at small k, segment overflows at large k x nprobe
+        if (pq_rot_applies(M) && !(e && atoi(e) == 0)) h->CB = 0;
         if ((size_t)h->Mpad * 1024 > 160 * 1024) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: M = %d needs more than 160 KiB of LDS for the look-up table", M);
     }
     HIPCHECK(hipSetDevice(device));
@@ -836,6 +846,16 @@ static int64_t max_scan_items(rsx_index* h, int64_t nq, int nprobe, int G, int t
 
 static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI, bool allow_fast = true);
 
+// Keys a query's candidate row can hold (filtered IVF-PQ fast scan).  The threshold is valid by construction, so the
+// row must hold every vector within 2 eps of the query's k-th best: ~700 keys at M = 96 / k = 10, but eps grows as the tables get
+// coarser — at M = 16 (48 dimensions per 8-bit table entry) the measured mean is 1800 and the maximum 23 000 at k = 10.  An
+// overflowing row sends its query to the exact re-run, so small M gets four times the room (8 B x nq x cap of HBM).
+static int64_t pq_cand_cap(int k, int M) {
+    int64_t cap = k > 512 ? 131072 : (k > 64 ? 65536 : 16384);
+    if (M <= 32) cap = std::min<int64_t>(cap * 4, 262144);
+    return cap;
+}
+
 // Queries whose certificate failed (h->w_uncertain, written by k_finalize) are re-run through the exact path of their index
 // kind and their result rows replaced — rare, and what makes the fast paths EXACT rather than "almost always right".
 // temp_bytes_per_query > 0 bounds the exact path's score buffer (Flat / IVF-Flat): the re-run proceeds in chunks.
@@ -1119,15 +1139,19 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
                            h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st);
             tm.mark("lut8");
-            int rot_seg_cap = 128;
-            auto rot_desc = [&](int64_t items, int v, int pre_rows_) -> void* {   // work-item records + survivor segments of the rotated-layout scan
-                rot_seg_cap = pq_scan_rot_seg_cap(1024 * v, KP, pre_rows_);
-                // the segment pool is (items x 64 segments x seg_cap keys): bounded by a quarter of the temp budget (4 GiB by
-                // default) — a smaller segment only means that an unusually dense (item, wave, query) overflows, is counted, and
-                // sends its query to the exact re-run; reported by rsx_get "workspace_bytes"
-                const int64_t pool_budget = std::max<int64_t>(h->temp_budget / 4, (int64_t)1 << 30);
-                while (rot_seg_cap > 128 && (items + 8) * 64 * (int64_t)rot_seg_cap * 8 > pool_budget) rot_seg_cap /= 2;
-                h->w_itemdesc.ensure(pq_scan_rot_ws(items, rot_seg_cap));
+            int rot_log_cap = 64;
+            auto rot_desc = [&](int64_t items) -> void* {   // work-item records + run descriptors + survivor logs of the rotated-layout scan
+                // the log pool = (persistent workgroups x 64 logs x log_cap keys): 1 / 2 / 4 GiB by k, never more than a quarter of the
+                // temp budget.  A log that fills up only sends the queries of its later runs to the exact re-run (counted); the pool is
+                // touched where survivors land, so its size costs nothing per batch; reported by rsx_get "workspace_bytes"
+                const int nwg = pq_scan_rot_max_wgs();
+                int64_t pool = (int64_t)(k <= 64 ? 1 : k <= 512 ? 2 : 4) << 30;
+                pool = std::min(pool, std::max<int64_t>(h->temp_budget / 4, (int64_t)64 << 20));
+                int64_t cap = pool / 8 / ((int64_t)nwg * 64);
+                cap = std::max<int64_t>(64, cap / 16 * 16);
+                if (h->pq_log_cap > 0) cap = h->pq_log_cap;            // tests starve the logs to force the overflow path
+                rot_log_cap = (int)std::min<int64_t>(cap, (int64_t)1 << 24);
+                h->w_itemdesc.ensure(pq_scan_rot_ws(items, rot_log_cap, nwg));
                 return h->w_itemdesc.p;
             };
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
@@ -1196,7 +1220,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 if (!fused_pre) pre_rows = 64 * 16 * pre_vpl;
             }
             if (fused_pre) {
-                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 512 ? 131072 : (k > 64 ? 65536 : 16384));
+                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), pq_cand_cap(k, h->M));
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 PQPrepassArgs pa{};
@@ -1216,7 +1240,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 if (!(pre4 && launch_pq_prepass4(pa, nq, h->st) == 0)) launch_pq_prepass(pa, nq, h->st);
                 fused_pre_used = true;
                 done = true;
-                if (h->tc && h->tc->active && allow_fast) {
+                if (h->tc && h->tc->active && allow_fast && std::this_thread::get_id() == h->tc->worker) {
                     // two-call search: the thresholds are final on the device; hand them to the caller and wait for rsx_search_scan
                     HIPCHECK(hipStreamSynchronize(h->st));
                     rsx_index::TwoCall& t = *h->tc;
@@ -1232,16 +1256,16 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
                 tm.mark("group");
                 const int64_t mi = filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows);
-                void* rws0 = rot ? rot_desc(mi, filtered ? pre_vpl : vpl, 0) : nullptr;
+                void* rws0 = rot ? rot_desc(mi) : nullptr;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
-                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_seg_cap, 0, 0, nullptr, nullptr, 0, h->st)
+                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_log_cap, 0, 0, nullptr, nullptr, 0, h->st)
                             : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                               total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
             }
             if (done && filtered) {
                 tm.mark("scan0");
-                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 512 ? 131072 : (k > 64 ? 65536 : 16384));
+                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), pq_cand_cap(k, h->M));
                 h->w_cand.ensure((size_t)nq * cand_cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 // multi-launch form: top-K' of the scored prefix of the closest list, row prefix
@@ -1259,7 +1283,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                    h->st);
                 tm.mark("group");
-                void* rws1 = rot ? rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, pre_rows) : nullptr;
+                void* rws1 = rot ? rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows)) : nullptr;
                 // threshold keys: one per query from the one-launch pre-pass, else the K'-th key the selection left in the state rows
                 const uint64_t* tau_ptr = fused_pre ? h->w_tau.as<uint64_t>() : state + (KP - 1);
                 const int64_t tau_stride = fused_pre ? 1 : KP;
@@ -1271,7 +1295,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     gs.probe_list = h->w_probelist.as<int32_t>(); gs.list_len = h->d_len.as<int64_t>(); gs.nprobe = nprobe;
                     gs.tile_rows = tile_rows; gs.tmax = gs_tmax; gs.qitems = h->w_qitems.as<int32_t>();
                     const int64_t mi = max_scan_items(h, nq, nprobe, 4, tile_rows);
-                    gs.seg_cnt = pq_scan_rot_ws_cnt(rws1, mi); gs.seg_keys = pq_scan_rot_ws_keys(rws1, mi); gs.seg_cap = rot_seg_cap;
+                    gs.seg_desc = pq_scan_rot_ws_desc(rws1, mi); gs.log_keys = pq_scan_rot_ws_keys(rws1, mi);
                     gs.cand = h->w_cand.as<uint64_t>(); gs.cand_cnt = h->w_candcnt.as<unsigned long long>(); gs.cand_cap = cand_cap;
                     gs.state = state; gs.KP = KP;
                 }
@@ -1279,7 +1303,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                                  total_groups, item_off, total_items, nlist,
                                                  max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rws1, rot_seg_cap, h->pq_prune, h->pq_pace, (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
+                                                 rws1, rot_log_cap, h->pq_prune, h->pq_pace, (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
                                                  use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
@@ -1973,6 +1997,9 @@ static void sharded_add_list(rsx_index* h, int64_t l, int64_t n, const void* cod
         if (hi > lo) add_list_impl(c, l, hi - lo, (const char*)codes + (size_t)lo * rowb, dtype, ids + lo);
     });
     h->ntotal += n;
+    // a later rsx_add without ids continues the sequence where the unsharded handle (and FAISS) would: at ntotal — a `.faiss`
+    // file re-sharded through rsx_add_list used to leave the counter at 0 and hand out ids 0..n-1 again
+    h->sh_next_id = std::max(h->sh_next_id, h->ntotal);
 }
 static void sharded_reserve(rsx_index* h, const int64_t* counts) {      // exact when every list arrives in ONE add_list call
     const int N = (int)h->shards.size();
@@ -2177,6 +2204,7 @@ int rsx_destroy(rsx_index_t* h) {
 int rsx_train(rsx_index_t* h, int64_t n, const void* x, int dtype) {
     return guarded([&] {
         if (!h || (!x && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "train");
         if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
         if (is_sharded(h)) {     // train once on the first shard, copy the parameters to the others
             HIPCHECK(hipSetDevice(h->shards[0]->device));
@@ -2191,6 +2219,7 @@ int rsx_train(rsx_index_t* h, int64_t n, const void* x, int dtype) {
 int rsx_set_centroids(rsx_index_t* h, const float* c) {
     return guarded([&] {
         if (!h || !c) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "set_centroids");
         if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "Flat has no centroids");
         if (h->ntotal) RSX_THROW(RSX_ERR_INVALID, "cannot replace centroids of a populated index");
         if (is_sharded(h)) {
@@ -2204,6 +2233,7 @@ int rsx_set_centroids(rsx_index_t* h, const float* c) {
 int rsx_set_codebooks(rsx_index_t* h, const float* c) {
     return guarded([&] {
         if (!h || !c) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "set_codebooks");
         if (h->kind != KIND_IVFPQ) RSX_THROW(RSX_ERR_INVALID, "only IVFPQ has codebooks");
         if (h->ntotal) RSX_THROW(RSX_ERR_INVALID, "cannot replace codebooks of a populated index");
         if (is_sharded(h)) {
@@ -2234,6 +2264,7 @@ int rsx_get_codebooks(rsx_index_t* h, float* out) {
 int rsx_add(rsx_index_t* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
     return guarded([&] {
         if (!h || (!x && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "add");
         if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
         if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "add before train");
         if (n <= 0) return;
@@ -2247,6 +2278,7 @@ int rsx_assign(rsx_index_t* h, int64_t n, const void* x, int dtype, int64_t* lab
         if (!h || (!x && n > 0) || (!labels && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
         if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
         if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "Flat has no coarse quantiser");
+        refuse_while_two_call(h, "assign");
         if (is_sharded(h)) h = h->shards[0];
         if (h->h_centroids.empty()) RSX_THROW(RSX_ERR_NOT_TRAINED, "assign before train");
         use_device(h);
@@ -2273,6 +2305,7 @@ int rsx_assign(rsx_index_t* h, int64_t n, const void* x, int dtype, int64_t* lab
 int rsx_reset(rsx_index_t* h) {
     return guarded([&] {
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "reset");
         if (is_sharded(h)) {
             for (auto* s : h->shards) {
                 HIPCHECK(hipSetDevice(s->device));
@@ -2294,6 +2327,7 @@ int rsx_reset(rsx_index_t* h) {
 int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts) {
     return guarded([&] {
         if (!h || !counts) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "reserve_lists");
         if (is_sharded(h)) { sharded_reserve(h, counts); return; }
         use_device(h);
         std::vector<int64_t> need(counts, counts + h->nlist);
@@ -2304,6 +2338,7 @@ int rsx_reserve_lists(rsx_index_t* h, const int64_t* counts) {
 int rsx_add_list(rsx_index_t* h, int64_t list_no, int64_t n, const void* codes, int dtype, const int64_t* ids) {
     return guarded([&] {
         if (!h || (!codes && n > 0)) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "add_list");
         if (is_sharded(h)) {
             if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "add_list before train");
             if (list_no < 0 || list_no >= h->nlist) RSX_THROW(RSX_ERR_INVALID, "list %lld out of range", (long long)list_no);
@@ -2337,6 +2372,7 @@ int rsx_get_list_sizes(rsx_index_t* h, int64_t* sizes) {
 int rsx_set_nprobe(rsx_index_t* h, int nprobe) {
     return guarded([&] {
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "set_nprobe");
         if (nprobe <= 0) RSX_THROW(RSX_ERR_INVALID, "nprobe must be positive (got %d)", nprobe);
         // FAISS accepts any nprobe and probes min(nprobe, nlist) lists; the effective value is bounded at search time
         h->nprobe = nprobe;
@@ -2347,6 +2383,7 @@ int rsx_set_nprobe(rsx_index_t* h, int nprobe) {
 int rsx_search(rsx_index_t* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
     return guarded([&] {
         if (!h) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "search");
         if (dtype != RSX_F32 && dtype != RSX_F16) RSX_THROW(RSX_ERR_INVALID, "bad dtype %d", dtype);
         if (is_sharded(h)) {
             if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "search before train");
@@ -2371,6 +2408,7 @@ int rsx_search_prepass(rsx_index_t* h, int64_t nq, const void* q, int dtype, int
         t.active = true; t.parked = false; t.go = false; t.done = false; t.status = 0; t.err.clear(); t.tau = nullptr; t.ntau = 0;
         t.th = std::thread([h, nq, q, dtype, k, D, I] {
             rsx_index::TwoCall& tt = *h->tc;
+            { std::lock_guard<std::mutex> lk(tt.mu); tt.worker = std::this_thread::get_id(); }
             int st_ = RSX_OK; std::string msg;
             try { HIPCHECK(hipSetDevice(h->device)); search_impl(h, nq, q, dtype, k, D, I); }
             catch (const RsxError& e) { st_ = e.code; msg = e.what(); }
@@ -2480,6 +2518,7 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
         else if (s == "code_size") *out = (h->kind == KIND_IVFPQ) ? h->M : (int64_t)h->d * (h->storage_f16 ? 2 : 4);
         else if (s == "device") *out = h->device;
         else if (s == "max_k") *out = 4096;
+        else if (s == "query_batch") *out = h->query_batch;
         else if (s == "pq_layout") *out = (h->kind == KIND_IVFPQ && h->CB == 0) ? 1 : 0;
         else if (s == "hbm_bytes") *out = (int64_t)(h->data.bytes + h->ids.bytes + h->norms.bytes);
         else if (s == "workspace_bytes") *out = workspace_bytes(h);
@@ -2489,6 +2528,7 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
 int rsx_set_param(rsx_index_t* h, const char* key, double value) {
     return guarded([&] {
         if (!h || !key) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "set_param");
         std::string s(key);
         if (is_sharded(h)) {     // knobs apply to every shard
             for (auto* c : h->shards) { int st_ = rsx_set_param(c, key, value); if (st_ != RSX_OK) throw RsxError(st_, g_err); }
@@ -2516,6 +2556,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
+        else if (s == "pq_log_cap") h->pq_log_cap = std::max(0, (int)value);
         else if (s == "pq_gather") h->pq_gather = (int)value;
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;
@@ -2546,6 +2587,7 @@ int rsx_get_timing(rsx_index_t* h, const char* key, double* ms) {
 int rsx_save(rsx_index_t* h, const char* path) {
     return guarded([&] {
         if (!h || !path) RSX_THROW(RSX_ERR_INVALID, "null pointer");
+        refuse_while_two_call(h, "save");
         if (is_sharded(h)) { sharded_save(h, path); return; }
         use_device(h);
         save_impl(h, path);

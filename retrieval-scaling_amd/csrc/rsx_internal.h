@@ -288,33 +288,28 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, seg_cap) bytes */, int seg_cap, int prune, int pace,
-                       const uint16_t* excl, int32_t* qitems /* non-null: fill it and leave the segments for k_pq_gather_select */,
+                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, log_cap, pq_scan_rot_max_wgs()) bytes */, int log_cap, int prune, int pace,
+                       const uint16_t* excl, int32_t* qitems /* non-null: fill it and leave the runs for k_pq_gather_select */,
                        int qitems_tmax, hipStream_t st);
-// survivor segment capacity per (item, wave, query): 4x what a query's CLOSEST list is expected to yield (a wave scans
-// tile/16 vectors of it, of which the pre-pass threshold lets about KP / pre_rows through), never less than 128 and never
-// more than the wave's whole share of the tile (at which point no overflow is possible)
-inline int pq_scan_rot_seg_cap(int tile_rows, int KP, int pre_rows) {
-    const int64_t share = tile_rows / 16;
-    int64_t c = pre_rows > 0 ? 4 * share * KP / pre_rows : share;
-    if (c < 128) c = 128;
-    if (c > share) c = share;
-    return (int)c;
+// Survivors of the filtered scan (round 4): every (persistent workgroup, wave, query slot) appends to its own LOG of log_cap keys;
+// an 8-byte descriptor per (item, wave, slot) = {index of the run's first key in the log pool, keys stored | bit 31: keys were
+// dropped because the log was full} lets the gather / compaction kernels find an item's runs.
+int pq_scan_rot_max_wgs();     // persistent workgroups of the scan on the current device (= logs / 64)
+inline size_t pq_scan_rot_ws(int64_t max_items, int log_cap, int nwg) {   // item records + run descriptors + logs + per-XCD counters + progress words
+    return (size_t)(max_items + 8) * (176 + 512 + 4) + (size_t)nwg * 64 * (size_t)log_cap * 8 + 1024;
 }
-inline size_t pq_scan_rot_ws(int64_t max_items, int seg_cap) {   // item records + segment counts + segment keys + per-XCD counters
-    return (size_t)(max_items + 8) * (176 + 256 + (size_t)64 * seg_cap * 8 + 4) + 1024;   // ... + per-item progress words (pacing)
+inline uint2* pq_scan_rot_ws_desc(void* ws, int64_t max_items) { return reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(ws) + (size_t)(max_items + 8) * 176); }
+inline uint64_t* pq_scan_rot_ws_keys(void* ws, int64_t max_items) { return reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(ws) + (size_t)(max_items + 8) * (176 + 512)); }
+inline uint32_t* pq_scan_rot_ws_ctr(void* ws, int64_t max_items, int log_cap, int nwg) {
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(pq_scan_rot_ws_keys(ws, max_items)) + (size_t)nwg * 64 * (size_t)log_cap * 8);
 }
-// the parts of that workspace: segment (item, wave w, slot k) has its count at seg_cnt[(item * 16 + w) * 4 + k] and its keys at
-// seg_keys[((item * 16 + w) * 4 + k) * seg_cap ...]
-inline uint32_t* pq_scan_rot_ws_cnt(void* ws, int64_t max_items) { return reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ws) + (size_t)(max_items + 8) * 176); }
-inline uint64_t* pq_scan_rot_ws_keys(void* ws, int64_t max_items) { return reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(ws) + (size_t)(max_items + 8) * (176 + 256)); }
 // Candidate gather + selection in one launch (round 3; replaces k_pq_rot_compact + the candidate merge when nprobe x tiles is small):
-// one workgroup per query walks the query's own survivor segments (through qitems), lays their keys end to end in the query's
-// candidate row behind what the pre-pass emitted, sets the row count (past the capacity when a segment overflowed, as the
-// compaction did) and writes the K' largest keys to the state row — no atomics, no second pass over the row.
+// one workgroup per query walks the query's own survivor runs (through qitems), lays their keys end to end in the query's
+// candidate row behind what the pre-pass emitted, sets the row count (past the capacity when a log overflowed, as the
+// compaction does) and writes the K' largest keys to the state row — no atomics, no second pass over the row.
 struct PQGatherArgs {
     const int32_t* probe_list; const int64_t* list_len; int nprobe; int tile_rows; int tmax;
-    const int32_t* qitems; const uint32_t* seg_cnt; const uint64_t* seg_keys; int seg_cap;
+    const int32_t* qitems; const uint2* seg_desc; const uint64_t* log_keys;
     uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
     uint64_t* state; int KP;
 };

@@ -76,20 +76,36 @@ class ShardedSearcher:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
     def _search_two_call(self, q, k):
+        """One all-reduce(MAX) of the per-query threshold keys between rsx_search_prepass and rsx_search_scan.  The library runs
+        ONE internal batch per two-call search, so a larger batch is cut into query_batch-sized pieces (every rank holds the
+        same batch and the same knob, hence issues the same sequence of collectives).  Whatever happens between the two calls
+        — a collective that times out, an allocation that fails — the parked search is always released with search_scan()
+        before the error propagates: a handle must never be left with an open two-call search."""
         import torch
         import torch.distributed as dist
+        qb = int(self.index._get("query_batch"))
+        if q.shape[0] > qb:
+            parts = [self._search_two_call(q[i:i + qb], k) for i in range(0, q.shape[0], qb)]
+            return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
         tau = self.index.search_prepass(q, k)
-        # every rank takes part in the collective, also one whose search has no pre-pass (it contributes "no threshold")
-        t = (tau ^ _SIGN) if tau is not None else torch.full((q.shape[0],), _SIGN, dtype=torch.int64, device=q.device)
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        else:                                   # gloo (CPU tests on a GPU box): through the host
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
-            t = h.to(q.device)
-        if tau is not None:
-            tau.copy_(t ^ _SIGN)
-            torch.cuda.current_stream(q.device).synchronize()     # the library's stream reads the keys next
+        try:
+            # every rank takes part in the collective, also one whose search has no pre-pass (it contributes "no threshold")
+            t = (tau ^ _SIGN) if tau is not None else torch.full((q.shape[0],), _SIGN, dtype=torch.int64, device=q.device)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            else:                                   # gloo (several ranks on one GPU, CPU tests): through the host
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                t = h.to(q.device)
+            if tau is not None:
+                tau.copy_(t ^ _SIGN)
+                torch.cuda.current_stream(q.device).synchronize()     # the library's stream reads the keys next
+        except BaseException:
+            try:
+                self.index.search_scan()            # release the parked worker; its result is discarded
+            except Exception:
+                pass
+            raise
         return self.index.search_scan()
 
     def search(self, q, k):
@@ -111,7 +127,12 @@ class ShardedSearcher:
             nq = D.shape[0]
             packed = rsx.pack_topk(D, I, self.id_offset)
             gathered = torch.empty((self.world_size, 2, nq, k), dtype=torch.int64, device=D.device)
-            dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+            else:                                   # gloo (several ranks sharing one GPU: RCCL refuses that): the same block through the host
+                hg = torch.empty((self.world_size, 2, nq, k), dtype=torch.int64)
+                dist.all_gather_into_tensor(hg.view(-1), packed.cpu().view(-1), group=self.group)
+                gathered.copy_(hg)
             return rsx.merge_packed(gathered, metric=self.metric)
         I = torch.where(I >= 0, I + self.id_offset, I)
         if self.world_size == 1 and not self.force_collective:

@@ -127,3 +127,16 @@ def test_hand_packed_iwpq(gpu, orc, tmp_path, sparse):
     assert sh.nshards == 2 and sh.ntotal == ntotal
     D2, I2 = sh.search(q, g["k"])
     assert_same_results(D2, I2, D, I, "hand-packed IwPQ re-sharded on load")
+    if not sparse:
+        # ... and keep growing like the single index: rows added WITHOUT ids continue the id sequence at ntotal on both (the
+        # re-sharded handle used to restart at 0 and collide with the imported ids — ADVICE r3)
+        extra = x[:50] * np.float16(1.0)
+        ix.add(extra); sh.add(extra)
+        assert ix.ntotal == sh.ntotal == ntotal + 50
+        qe = extra[:8]
+        ix.nprobe = sh.nprobe = nlist
+        De, Ie = ix.search(qe, 4)
+        Ds, Is = sh.search(qe, 4)
+        assert_same_results(Ds, Is, De, Ie, "add after a re-sharded load")
+        assert (Is >= ntotal).any(1).all(), "every query is one of the new rows: its duplicate must come back under a NEW id"
+        assert Is.max() == Ie.max() and Is.max() < ntotal + 50

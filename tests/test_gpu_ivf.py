@@ -60,12 +60,13 @@ def test_golden_ivfflat(gpu, orc):
 
 @pytest.mark.parametrize("name,layout", [("ivfpq_d64_m16", 1), ("ivfpq_d64_m16", 0), ("ivfpq_d768_m96", 1), ("ivfpq_d768_m96", 0)])
 def test_golden_ivfpq(gpu, orc, name, layout):
-    """layout 1 = the rotated code layout (k_pq_rot.hip: conflict-free table gathers, default for M in {32, 64, 96, 128}, on request (pq_layout = 1) for M = 16),
-    layout 0 = the granule layout (k_pq.hip); both must give the oracle's bits through every scan variant."""
+    """layout 1 = the rotated code layout (k_pq_rot.hip: conflict-free table gathers, the default for M in {16, 32, 64, 96, 128} — M = 16,
+    the reference's shipped IVF-PQ config, since round 4), layout 0 = the granule layout (k_pq.hip); both must give the oracle's
+    bits through every scan variant."""
     g = load_golden(name)
     x, q = regen_gpu(gpu, g)
     ix = gpu.IndexIVFPQ(gpu.IndexFlatIP(g["d"]), g["d"], g["nlist"], g["M"], 8, gpu.METRIC_INNER_PRODUCT)
-    assert ix._get("pq_layout") == (1 if g["M"] % 32 == 0 else 0), "rotated layout is the default for M in {32, 64, 96, 128}; M = 16 on request"
+    assert ix._get("pq_layout") == 1, "the rotated layout is the default for M in {16, 32, 64, 96, 128}"
     ix.set_param("pq_layout", layout)
     assert ix._get("pq_layout") == layout
     name = f"{name} layout={layout}"
@@ -151,7 +152,7 @@ def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
     """Other (d, M): 16-byte-granule and 4-byte-granule code layouts, dsub 8/2/48; M=160 is too large for the
     LDS-resident table build and takes the unfused table path; M = 32 / 64 / 96 / 128 take the rotated layout
     (half phase only, one full phase, full + half, two full phases of k_pq_scan_rot)."""
-    rot16 = M < 0            # M = -16: the rotated layout for M = 16 (on request: rsx_set_param pq_layout = 1)
+    gran16 = M < 0           # M = -16: the granule layout for M = 16 (on request since round 4: rsx_set_param pq_layout = 0)
     M = abs(M)
     n, nq, k = 6000, 37, 20
     x = orc.synth_vectors(d, nlist, 61, 62, 0.5, 0, n)
@@ -163,9 +164,10 @@ def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
     codes = orc.pq_encode(cb, orc.residuals(cen, x32, a))
     lm = orc.ListMajor(a, np.arange(n), codes, nlist)
     ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
-    if rot16:
-        ix.set_param("pq_layout", 1)
-        assert ix._get("pq_layout") == 1
+    assert ix._get("pq_layout") == (1 if M in (16, 32, 64, 96, 128) else 0)
+    if gran16:
+        ix.set_param("pq_layout", 0)
+        assert ix._get("pq_layout") == 0
     ix.set_centroids(cen); ix.set_codebooks(cb)
     ix.add(x)
     for nprobe in (1, 3, nlist):
@@ -193,6 +195,15 @@ def test_ivfpq_many_survivors(gpu, orc, layout):
             ix.set_param("pq_fast_kp", kp); ix.set_param("scan_chunk", chunk)
             D, I = ix.search(q, k)
             assert_same_results(D, I, De, Ie, f"layout={layout} K'={kp} scan_chunk={chunk}")
+    if layout == 1:
+        # round 4: survivors go to per-wave logs; starved logs (64 / 4 keys each) must flag every query that lost a key
+        ix.set_param("pq_fast_kp", 0); ix.set_param("scan_chunk", 0)
+        for cap in (64, 4):
+            ix.set_param("pq_log_cap", cap); ix.set_param("profile", 1)
+            D, I = ix.search(q, k)
+            assert_same_results(D, I, De, Ie, f"layout=1 pq_log_cap={cap}")
+        assert ix.get_timing("fallback_overflow_queries") > 0, "4-key logs cannot hold this batch's survivors"
+        ix.set_param("pq_log_cap", 0); ix.set_param("profile", 0)
     # k = 300 -> K' = 512 on its own
     ix.set_param("pq_fast_kp", 0); ix.set_param("scan_chunk", 0)
     ix.set_param("scan_kernel", 2)
@@ -505,3 +516,55 @@ def test_sharded_searcher_over_rccl_single_rank(gpu, orc):
         assert_same_results(D2, I2 - 1000, g["D"], g["I"], "sharded over RCCL (numpy)")
     finally:
         dist.destroy_process_group()
+
+
+def test_two_call_search_owns_the_handle(gpu, orc):
+    """between rsx_search_prepass and rsx_search_scan the parked search owns the handle's workspaces.  Every other
+    entry point must refuse the handle (it used to overwrite the parked search's thresholds — or park itself and hang), the
+    parked search must still finish with the single-call result, and ShardedSearcher must release it when the exchange fails."""
+    import torch
+    d, n, nlist, M, nq, k = 96, 9000, 8, 32, 40, 10
+    x = gpu.synth_vectors(d, 16, 77, 5000, 0.5, 0, n)
+    q = torch.from_numpy(gpu.synth_queries(d, 16, 77, 5000, 0.5, n, 31, 0.1, 0, nq)).cuda()
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    ix.train(x[:4000]); ix.add(x); ix.nprobe = 4
+    Dr, Ir = ix.search(q, k)
+    tau = ix.search_prepass(q, k)
+    assert tau is not None and tau.shape[0] == nq
+    for call in (lambda: ix.search(q, k), lambda: ix.add(x[:10]), lambda: ix.reset(), lambda: ix.set_param("pq_filter", 0),
+                 lambda: ix.train(x[:4000]), lambda: ix.search_prepass(q, k)):
+        with pytest.raises(RuntimeError, match="two-call"):
+            call()
+    D, I = ix.search_scan()
+    assert torch.equal(D, Dr) and torch.equal(I, Ir)
+    D2, I2 = ix.search(q, k)            # the handle is usable again
+    assert torch.equal(D2, Dr) and torch.equal(I2, Ir)
+    # a batch larger than query_batch goes through the two-call form in query_batch-sized pieces; a failing exchange releases the handle
+    import torch.distributed as dist
+    import sharded
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ss = sharded.ShardedSearcher(ix, exchange_thresholds=True, force_collective=True)
+        ix.set_param("query_batch", 16)
+        D3, I3 = ss._search_two_call(q, k)
+        assert torch.equal(D3, Dr) and torch.equal(I3, Ir)
+        ix.set_param("query_batch", 1024)
+        real = dist.all_reduce
+
+        def boom(*a, **kw):
+            raise RuntimeError("collective timed out")
+        dist.all_reduce = boom
+        try:
+            with pytest.raises(RuntimeError, match="timed out"):
+                ss._search_two_call(q, k)
+        finally:
+            dist.all_reduce = real
+        D4, I4 = ix.search(q, k)        # no parked worker left behind
+        assert torch.equal(D4, Dr) and torch.equal(I4, Ir)
+    finally:
+        if created:
+            dist.destroy_process_group()

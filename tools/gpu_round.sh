@@ -1,71 +1,94 @@
 #!/bin/bash
-# One GPU-box session: environment facts, GPU tests, smoke, bench, rocprof. Everything is logged under
-# gpurun_out/ so a single call returns as much evidence as possible.  Usage: tools/gpu_round.sh [stage ...]
+# ONE parameterised GPU-box session script (replaces the per-experiment tools/stage_*.sh of rounds 1-3).
+# Usage: [TAG=r04a] [PYTEST_ARGS=...] tools/gpu_round.sh stage [stage ...]      (everything lands in gpurun_out/)
+#   env        box facts (GPU, cores, RAM, import faiss)
+#   tests      pytest -m gpu (stop at first failure; PYTEST_ARGS narrows it)     tests_all: without -x
+#   smoke      __graft_entry__.smoke()
+#   bench      the default bench line (all configs)                               bench_fast: headline only
+#   prof       rocprofv3 --kernel-trace --stats of the headline bench  -> ${TAG}_rocprof_stats_ivfpq100M.md
+#   pmc_fetch  FETCH_SIZE pass -> ${TAG}_pmc_fetch_size.md + stamped pmc_traffic.json
+#   pmc_sq     two SQ counter passes of the scan kernel -> ${TAG}_pmc_sq_counters.md
+#   per_rank   one rank of an N = 2 / 4 / 8 run and of config 5 on this one GPU -> ${TAG}_per_rank_workloads.txt
+#   m16        the reference's shipped IVF-PQ point (M 16, nlist 8192, nprobe 512; k 10 and 1000)
+#   m16_pmc    SQ counters of that scan
+#   largek     the headline index at k = 100 / 1000 / 2000
+#   flat       Flat 10M (IP, L2, k 10 and 1000) + rocprof stats          ivfflat: IVF-Flat configs
+#   latency    single-query latency protocol
+#   cmd        run "$CMD" (free-form, logged to ${TAG}_cmd.log)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-STAGES="${*:-env tests smoke bench_small}"
-for s in $STAGES; do
+TAG=${TAG:-r04}
+O=$PWD/gpurun_out
+FAST="--cpu-queries 0 --no-recall --no-configs"
+prof() {  # prof <outdir> <rocprof args...> -- <cmd...>
+  local d=$1; shift
+  ( cd /tmp && timeout 700 rocprofv3 --kernel-trace "$@" ) ; }
+for s in "$@"; do
   case $s in
     env)
-      { rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; nproc; free -g | head -2; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; python -c "import faiss" 2>&1 | tail -1; } > gpurun_out/env.log 2>&1 ;;
+      { rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; nproc; free -g | head -2; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; python -c "import faiss" 2>&1 | tail -1; } > $O/${TAG}_gpu_box_env.txt 2>&1 ;;
     tests)
-      timeout 1500 python -m pytest tests -q -m gpu -x --timeout 600 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log ;;
+      timeout 1700 python -m pytest tests -q -m gpu -x --timeout 600 -p no:cacheprovider ${PYTEST_ARGS:-} > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $O/${TAG}_pytest_gpu.txt
+      tail -n 15 $O/${TAG}_pytest_gpu.txt | cut -c1-220 ;;
     tests_all)
-      timeout 1500 python -m pytest tests -q -m gpu --timeout 600 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log ;;
+      timeout 1700 python -m pytest tests -q -m gpu --timeout 600 -p no:cacheprovider ${PYTEST_ARGS:-} > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $O/${TAG}_pytest_gpu.txt
+      tail -n 15 $O/${TAG}_pytest_gpu.txt | cut -c1-220 ;;
     smoke)
-      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log ;;
-    bench_small)
-      timeout 900 python bench.py --n 4000000 --nlist 1024 --steps 5 --warmup 2 --cpu-queries 32 > gpurun_out/bench_small.json 2> gpurun_out/bench_small.log; echo "exit $?" >> gpurun_out/bench_small.log ;;
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; echo "smoke exit $?" >> $O/${TAG}_smoke.log ;;
     bench)
-      timeout 1700 python bench.py --steps 10 --warmup 3 --ab > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "exit $?" >> gpurun_out/bench.log ;;
-    diag)
-      timeout 300 python tools/diag_synth.py > gpurun_out/diag_synth.log 2>&1 ;;
-    configs)
-      timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log
-      timeout 900 python tools/bench_configs.py ivfflat > gpurun_out/cfg_ivfflat.json 2> gpurun_out/cfg_ivfflat.log; echo "exit $?" >> gpurun_out/cfg_ivfflat.log ;;
-    ivfflat100m)
-      timeout 1500 python tools/bench_configs.py ivfflat --n 100000000 > gpurun_out/cfg_ivfflat100m.json 2> gpurun_out/cfg_ivfflat100m.log; echo "exit $?" >> gpurun_out/cfg_ivfflat100m.log ;;
-    latency_ab)
-      timeout 900 python tools/bench_configs.py latency --param pq_filter=0 > gpurun_out/cfg_latency_ab.json 2> gpurun_out/cfg_latency_ab.log; echo "exit $?" >> gpurun_out/cfg_latency_ab.log ;;
-    latency)
-      timeout 900 python tools/bench_configs.py latency > gpurun_out/cfg_latency.json 2> gpurun_out/cfg_latency.log; echo "exit $?" >> gpurun_out/cfg_latency.log ;;
-    pmc_sq)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d "$OLDPWD/gpurun_out/pmc_sq_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --n 2000000 --check 0 --steps 2 > "$OLDPWD/gpurun_out/pmc_sq_flat.json" 2> "$OLDPWD/gpurun_out/pmc_sq_flat.log" ); echo "exit $?" >> gpurun_out/pmc_sq_flat.log
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d "$OLDPWD/gpurun_out/pmc_sq_pq" -o r01 -- python "$OLDPWD/bench.py" --n 20000000 --steps 2 --warmup 1 --cpu-queries 0 --no-recall --no-configs > "$OLDPWD/gpurun_out/pmc_sq_pq.json" 2> "$OLDPWD/gpurun_out/pmc_sq_pq.log" ); echo "exit $?" >> gpurun_out/pmc_sq_pq.log
-      rm -f gpurun_out/pmc_sq_summary.txt
-      python tools/pmc_summary.py gpurun_out/pmc_sq_flat/r01_results.db gpurun_out/pmc_sq_summary.txt '%k_flat_gemm%' '%k_select%'
-      python tools/pmc_summary.py gpurun_out/pmc_sq_pq/r01_results.db gpurun_out/pmc_sq_summary.txt '%k_pq_scan8%' '%k_pq_lut%' '%k_finalize%'
-      rm -rf gpurun_out/pmc_sq_flat gpurun_out/pmc_sq_pq ;;
-    cfg_flat_only)
-      timeout 900 python tools/bench_configs.py flat > gpurun_out/cfg_flat.json 2> gpurun_out/cfg_flat.log; echo "exit $?" >> gpurun_out/cfg_flat.log ;;
-    prof_flat)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_flat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" flat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_flat.json" 2> "$OLDPWD/gpurun_out/prof_flat.log" ); echo "exit $?" >> gpurun_out/prof_flat.log ;;
-    prof_ivfflat)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_ivfflat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" ivfflat --check 0 --steps 3 > "$OLDPWD/gpurun_out/prof_ivfflat.json" 2> "$OLDPWD/gpurun_out/prof_ivfflat.log" ); echo "exit $?" >> gpurun_out/prof_ivfflat.log ;;
-    pmc_ivfflat)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_ivfflat" -o r01 -- python "$OLDPWD/tools/bench_configs.py" ivfflat --check 0 --steps 2 > "$OLDPWD/gpurun_out/pmc_ivfflat.json" 2> "$OLDPWD/gpurun_out/pmc_ivfflat.log" ); echo "exit $?" >> gpurun_out/pmc_ivfflat.log
-      rm -f gpurun_out/pmc_ivfflat_summary.txt
-      python tools/pmc_summary.py gpurun_out/pmc_ivfflat/r01_results.db gpurun_out/pmc_ivfflat_summary.txt '%k_list_scan%' '%k_select%' '%k_finalize%'
-      rm -rf gpurun_out/pmc_ivfflat ;;
-    variants)
-      # cost split of k_pq_scan8 (unfiltered form): 0 = real kernel, 1 = gathers + ONE add, 2 = no LDS gather
-      for v in 0 1 2; do RSX_SCAN8_VARIANT=$v timeout 600 python bench.py --steps 5 --warmup 2 --cpu-queries 0 --no-recall --no-configs --param pq_filter=0 > gpurun_out/bench_var$v.json 2> gpurun_out/bench_var$v.log; done ;;
-    ab_lib)
-      # same-box A/B of two builds: retrieval-scaling_amd/csrc/librsx_head.so (copied there by hand) vs the current one
-      for r in 1 2; do
-        RSX_LIB=$PWD/retrieval-scaling_amd/csrc/librsx_head.so timeout 600 python bench.py --steps 10 --warmup 3 --cpu-queries 0 --no-recall --no-configs > gpurun_out/bench_ab_head$r.json 2> gpurun_out/bench_ab_head$r.log
-        timeout 600 python bench.py --steps 10 --warmup 3 --cpu-queries 0 --no-recall --no-configs > gpurun_out/bench_ab_new$r.json 2> gpurun_out/bench_ab_new$r.log
-      done ;;
-    bench_diag)
-      timeout 900 python bench.py --diag --no-recall --cpu-queries 0 > gpurun_out/bench_diag.json 2> gpurun_out/bench_diag.log; echo "exit $?" >> gpurun_out/bench_diag.log ;;
+      timeout 1500 python bench.py --steps ${STEPS:-20} --warmup 5 ${BENCH_ARGS:-} > $O/${TAG}_bench_ivfpq100M.json 2> $O/${TAG}_bench.log; echo "exit $?" >> $O/${TAG}_bench.log ;;
+    bench_fast)
+      timeout 600 python bench.py --steps ${STEPS:-20} --warmup 5 $FAST ${BENCH_ARGS:-} > $O/${TAG}_bench_fast.json 2> $O/${TAG}_bench_fast.log; echo "exit $?" >> $O/${TAG}_bench_fast.log
+      python tools/show_bench.py $O/${TAG}_bench_fast.json ;;
     prof)
-      ( cd /tmp && timeout 1700 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --cpu-queries 0 --no-recall --no-configs > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.log" ); echo "exit $?" >> gpurun_out/prof.log
-      find gpurun_out/prof -name "*stats*" | head >> gpurun_out/prof.log ;;
-    pmc)
-      ( cd /tmp && timeout 1700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o r01 -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --cpu-queries 0 --no-recall --no-configs > "$OLDPWD/gpurun_out/pmc_bench.json" 2> "$OLDPWD/gpurun_out/pmc.log" ); echo "exit $?" >> gpurun_out/pmc.log ;;
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG -- python $OLDPWD/bench.py --steps 5 --warmup 2 $FAST ${BENCH_ARGS:-} > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof.log ); echo "exit $?" >> $O/${TAG}_prof.log
+      python tools/rocprof_summary.py $O/prof/${TAG}_results.db $O/${TAG}_rocprof_stats_ivfpq100M.md "IVF-PQ 100M x 768, M=96, nlist=4096, nprobe=32, batch=1024 (python bench.py --steps 5 --warmup 2 $FAST ${BENCH_ARGS:-})"
+      rm -rf $O/prof ;;
+    pmc_fetch)
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc.log ); echo "exit $?" >> $O/${TAG}_pmc.log
+      rm -f $O/${TAG}_pmc_fetch_size.md
+      python tools/pmc_summary.py $O/pmc_fetch/${TAG}_results.db $O/${TAG}_pmc_fetch_size.md '%k_pq_scan%' '%k_pq_prepass%' '%k_pq_rot%'
+      python tools/update_pmc_traffic.py $O/pmc_fetch/${TAG}_results.db $O/pmc_traffic.json
+      rm -rf $O/pmc_fetch ;;
+    pmc_sq)
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $O/pmc_sq -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc_sq.log ); echo "exit $?" >> $O/${TAG}_pmc_sq.log
+      rm -f $O/${TAG}_pmc_sq_counters.md
+      python tools/pmc_summary.py $O/pmc_sq/${TAG}_results.db $O/${TAG}_pmc_sq_counters.md '%k_pq_scan%' '%k_pq_rot%' '%k_finalize%' '%k_pq_lut%'
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $O/pmc_sq2 -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc_sq2.log ); echo "exit $?" >> $O/${TAG}_pmc_sq2.log
+      python tools/pmc_summary.py $O/pmc_sq2/${TAG}_results.db $O/${TAG}_pmc_sq_counters.md '%k_pq_scan%'
+      rm -rf $O/pmc_sq $O/pmc_sq2 ;;
+    per_rank)
+      : > $O/${TAG}_per_rank_workloads.txt
+      for n in 50000000 25000000 12500000 125000000; do
+        timeout 600 python bench.py --n $n --steps 20 --warmup 5 $FAST ${BENCH_ARGS:-} > $O/${TAG}_n$n.json 2> $O/${TAG}_n$n.log
+        python tools/show_bench.py $O/${TAG}_n$n.json "n=$n batch=1024" >> $O/${TAG}_per_rank_workloads.txt
+      done
+      cat $O/${TAG}_per_rank_workloads.txt ;;
+    m16)
+      timeout 900 python tools/bench_configs.py ivfpq_ref --steps ${STEPS:-5} ${M16_ARGS:-} > $O/${TAG}_ivfpq_m16.json 2> $O/${TAG}_ivfpq_m16.log; echo "exit $?" >> $O/${TAG}_ivfpq_m16.log
+      cut -c1-2500 $O/${TAG}_ivfpq_m16.json; tail -n 3 $O/${TAG}_ivfpq_m16.log | cut -c1-300 ;;
+    m16_pmc)
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $O/pmc_m16 -o $TAG -- python $OLDPWD/tools/bench_configs.py ivfpq_ref --steps 2 --check 0 --ks 10 ${M16_ARGS:-} > /dev/null 2> $O/${TAG}_pmc_m16.log ); echo "exit $?" >> $O/${TAG}_pmc_m16.log
+      rm -f $O/${TAG}_pmc_sq_m16.md
+      python tools/pmc_summary.py $O/pmc_m16/${TAG}_results.db $O/${TAG}_pmc_sq_m16.md '%k_pq_scan%'
+      rm -rf $O/pmc_m16 ;;
+    largek)
+      timeout 900 python tools/bench_configs.py largek --steps ${STEPS:-5} > $O/${TAG}_largek.json 2> $O/${TAG}_largek.log; echo "exit $?" >> $O/${TAG}_largek.log
+      cut -c1-2500 $O/${TAG}_largek.json; tail -n 3 $O/${TAG}_largek.log | cut -c1-300 ;;
+    flat)
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d $O/prof_flat -o $TAG -- python $OLDPWD/tools/bench_configs.py flat --check 64 --steps 3 > $O/${TAG}_flat10M.json 2> $O/${TAG}_flat10M.log ); echo "exit $?" >> $O/${TAG}_flat10M.log
+      python tools/rocprof_summary.py $O/prof_flat/${TAG}_results.db $O/${TAG}_rocprof_stats_flat10M.md "Flat 10M x 768 batch 1024 (tools/bench_configs.py flat --check 64 --steps 3)"
+      rm -rf $O/prof_flat ;;
+    ivfflat)
+      timeout 900 python tools/bench_configs.py ivfflat ${IVFFLAT_ARGS:-} > $O/${TAG}_ivfflat.json 2> $O/${TAG}_ivfflat.log; echo "exit $?" >> $O/${TAG}_ivfflat.log
+      cut -c1-1500 $O/${TAG}_ivfflat.json ;;
+    latency)
+      timeout 500 python tools/bench_configs.py latency > $O/${TAG}_latency_ivfpq100M.json 2> $O/${TAG}_latency.log; echo "exit $?" >> $O/${TAG}_latency.log ;;
+    cmd)
+      timeout ${CMD_TIMEOUT:-900} bash -c "$CMD" > $O/${TAG}_cmd.log 2>&1; echo "exit $?" >> $O/${TAG}_cmd.log; tail -n ${CMD_TAIL:-40} $O/${TAG}_cmd.log | cut -c1-400 ;;
+    *) echo "unknown stage $s" ;;
   esac
 done
-ls -la gpurun_out > gpurun_out/ls.txt
-for f in gpurun_out/*.log; do echo "== $f"; tail -n 5 "$f"; done
+ls -la gpurun_out | tail -n 12
