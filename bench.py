@@ -70,6 +70,11 @@ def main():
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
                     help="engine parameter for an experiment (rsx_set_param), e.g. pq_filter=0; not for the reported line")
     ap.add_argument("--ab", action="store_true", help="also time the per-pair v1 scan kernel (same process, same index)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the default) or gloo (the same collectives routed "
+                         "through the host — what lets N ranks share one GPU in the dry-run test; RCCL refuses two ranks per device)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="dry run: rank r uses device r %% (visible GPUs) instead of requiring one GPU per rank (tests/test_gpu_bench_ranks.py)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -84,12 +89,30 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU search path)"
+    if args.share_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     os.environ["RSX_DEVICE"] = str(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    on_host = world > 1 and args.dist_backend != "nccl"     # gloo: every collective below goes through host memory
+
+    def bcast0(t):                       # rank 0's tensor to everyone, in place
+        if on_host:
+            h = t.cpu(); dist.broadcast(h, 0); t.copy_(h)
+        else:
+            dist.broadcast(t, 0)
+
+    def gather_all(t):                   # [world, *t.shape] on every rank
+        flat = (t.cpu() if on_host else t).contiguous().view(-1)      # flat views: gloo's all-gather wants [world * n], not [world, ...]
+        out = torch.empty(world * flat.numel(), dtype=t.dtype, device=flat.device)
+        dist.all_gather_into_tensor(out, flat)
+        return out.view((world,) + tuple(t.shape)).to(dev)
 
     n_total, nq, k = args.n, args.batch, args.k
     lo, hi = shard_range(n_total, rank, world)
@@ -117,7 +140,7 @@ def main():
     if world > 1:  # belt and braces: every shard must quantise with rank 0's parameters
         cen = torch.from_numpy(index.get_centroids()).to(dev)
         cb = torch.from_numpy(index.get_codebooks()).to(dev)
-        dist.broadcast(cen, 0); dist.broadcast(cb, 0)
+        bcast0(cen); bcast0(cb)
         fresh = rsx.IndexIVFPQ(rsx.IndexFlatIP(D), D, args.nlist, args.m, 8, rsx.METRIC_INNER_PRODUCT, device=local_rank)
         fresh.set_centroids(cen.cpu().numpy()); fresh.set_codebooks(cb.cpu().numpy())
         index = fresh
@@ -244,7 +267,7 @@ def main():
     stage_ms = {s: round(index.get_timing(s) / args.steps, 4) for s in
                 ("convert", "coarse", "select_probe", "lut", "lut8", "group", "scan0", "select0", "scan", "select", "finalize", "total")}
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     fallbacks = index.get_timing("fallback_queries") / max(1.0, index.get_timing("fast_queries"))
@@ -305,14 +328,13 @@ def main():
 
     # recall@k of the first timed batch against the exact streaming ground truth (all shards merged)
     D1, I1 = step(args.warmup)
+    import hashlib
+    result_sha = hashlib.sha256(D1.cpu().numpy().tobytes() + I1.cpu().numpy().tobytes()).hexdigest()   # equal for every N and both partitions
     recall = None
     recall_low = None
     if gtD is not None:
         if world > 1:
-            gD = torch.empty((world,) + tuple(gtD.shape), dtype=gtD.dtype, device=dev)
-            gI = torch.empty((world,) + tuple(gtI.shape), dtype=gtI.dtype, device=dev)
-            dist.all_gather_into_tensor(gD, gtD.contiguous()); dist.all_gather_into_tensor(gI, gtI.contiguous())
-            gtD, gtI = rsx.merge_topk(gD, gI)
+            gtD, gtI = rsx.merge_topk(gather_all(gtD), gather_all(gtI))
         gt = gtI.cpu().numpy()
         a, b = I1.cpu().numpy(), gt[:nq]
         recall = float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a, b)]))
@@ -465,13 +487,15 @@ def main():
             "dtype": "u8 codes; i8-table integer scan (MFMA-i8 adder tree), exact f32-table re-rank (certified)",
             "data": "synthetic",
             "recall_at_10": recall,
+            "first_timed_batch_sha256": result_sha,
             "recall_low_noise_queries": recall_low,
             "recall_informative": recall2,
             "config": {"workload": f"{n_total}x{D} IVF-PQ M={args.m} nbits=8 nlist={args.nlist} nprobe={args.nprobe} "
                                    f"batch={nq} k={k}, inner product, by_residual",
                        "vectors_per_gpu": n_local, "code_layout": "rotated" if rot else "granule",
                        "parallelism": (f"index sharded by inverted lists (l % {world} == rank) over {world} GPU(s)" if list_shards
-                                       else f"index sharded by id range over {world} GPU(s)")},
+                                       else f"index sharded by id range over {world} GPU(s)"),
+                       "dist_backend": (args.dist_backend if world > 1 else None)},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms_per_launch, 4),

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
     if (tid == 0) a.cand_cnt[q * CCS] = e0 + (unsigned long long)total + (over ? (unsigned long long)a.cand_cap + 1ull : 0ull);
     const unsigned long long nrow_ = e0c + (unsigned long long)total;
     const int nrow = (int)(nrow_ < (unsigned long long)a.cand_cap ? nrow_ : (unsigned long long)a.cand_cap);   // keys that fit the row
-    const bool in_lds = nrow_ <= (unsigned long long)GS_LCAP;
+    const bool in_lds = KP > 0 && nrow_ <= (unsigned long long)GS_LCAP;
     // 3. copy: segment keys -> candidate row (and LDS when the whole row fits)
     uint64_t* row = a.cand + q * a.cand_cap;
     if (in_lds) for (int i2 = tid; i2 < (int)e0c; i2 += 256) lkeys[i2] = row[i2];
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
         }
         pos += c;
     }
+    if (KP == 0) return;    // gather only: k_pq_final_tab works on the whole row
     __syncthreads();        // workgroup-scope release / acquire: the row (and lkeys) written above are visible to every thread
     // 4. the K' largest keys, sorted, to the state row
     if (in_lds) {
@@ -1275,6 +1276,234 @@ __global__ __launch_bounds__(256) void k_pq_rescore_all(FinalizeArgs a, uint64_t
 void launch_pq_rescore_all(const FinalizeArgs& a, uint64_t* cand, int cand_cap, hipStream_t st) {
     if (a.nq <= 0) return;
     hipLaunchKernelGGL(k_pq_rescore_all, dim3((unsigned)a.nq, 16), dim3(256), 0, st, a, cand, cand_cap);
+}
+
+// ---------------------------------------------------------------------------------------
+// IVF-PQ finalize from the COMPLETE candidate row (round 4): k_pq_final_tab.
+// With the threshold that is valid by construction (tau = a_k - 2 eps from the pre-pass sample) a query's candidate
+// row holds EVERY vector that can reach its top k.  Rounds 1-3 still cut the row to its K' best approximate keys, re-scored
+// those through the codebooks (K' x M dependent codeword loads per query: 1.5 ms per 1024 queries at K' = 4096 / M = 96, 4.9 ms
+// at M = 16 where an entry is a 48-term chain) and checked a certificate that fails for a quarter of the queries at M = 16 —
+// each of which then went through k_pq_rescore_all + a second selection + a second finalize.  Here ONE workgroup per query
+//   1. builds the query's fp32 table T[m][c] = <q_m, cb[m][c]> in LDS (M KiB; the table builder's fmaf chain: the oracle's bits),
+//   2. re-scores every key of the row in place: dis0 + (((0 + T[0][c0]) + T[1][c1]) + ...) — M LDS look-ups per candidate,
+//   3. finds the k-th largest exact score by a 4-round radix walk over the 32 score bits, collects the keys at or above it
+//      (all ties of the k-th included) into LDS, resolves their ids and sorts that handful by (score desc, id asc),
+//   4. emits k.  No certificate, no K', no second chance: a row is complete or it overflowed (flag 2 -> exact re-run).
+// Rotated code layout only (CB = 0, M in {16, 32, 64, 96, 128}); P = sort capacity (power of two >= k; more ties than that at
+// the k-th score send the query to the exact re-run).  row_filter != null: only the queries flagged 1 (second chance of the
+// K' path) are processed.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t* cand, int cand_cap, int P, uint64_t* tie_ws) {
+    extern __shared__ __attribute__((aligned(16))) float ft_T[];
+    const int M = a.M, dsub = a.dsub;
+    int64_t* sid = reinterpret_cast<int64_t*>(ft_T + (size_t)M * 256);     // [P]
+    uint32_t* sord = reinterpret_cast<uint32_t*>(sid + P);                 // [P]
+    uint64_t* tsel = reinterpret_cast<uint64_t*>(sord + P);                // [2]: the tie selection's id threshold
+    int32_t* hist = reinterpret_cast<int32_t*>(tsel + 2);                  // [256]
+    int32_t* ctl = hist + 256;                                             // [8]: 0 digit, 1 remaining, 2 valid, 3 cursor, 4 in-bin, 5 tie cursor, 6 exact-threshold flag
+    int32_t* ctl2 = ctl + 8;                                               // [8]: the tie selection's radix state
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t q = blockIdx.x;
+    if (a.row_filter && a.row_filter[q] != 1) return;
+    const unsigned long long n_raw = a.cand_cnt[q * CCS];
+    if (n_raw > (unsigned long long)cand_cap) {         // keys were dropped (row or log overflow): the exact re-run settles this query
+        if (tid == 0) a.uncertain[q] = 2;
+        return;
+    }
+    const int n = (int)n_raw;
+    uint64_t* row = cand + q * (int64_t)cand_cap;
+    const float* qv = a.Q32 + q * a.ldq;
+    // 1. the table
+    for (int e = tid; e < M * 256; e += 1024) {
+        const int m = e >> 8;
+        const float* qs = qv + m * dsub;
+        const float* cw = a.codebooks + (int64_t)e * dsub;
+        float t = 0.0f;
+        if ((dsub & 3) == 0) {
+            for (int tt = 0; tt < dsub; tt += 4) {
+                const float4 x = *reinterpret_cast<const float4*>(cw + tt);
+                t = __fmaf_rn(qs[tt], x.x, t); t = __fmaf_rn(qs[tt + 1], x.y, t); t = __fmaf_rn(qs[tt + 2], x.z, t); t = __fmaf_rn(qs[tt + 3], x.w, t);
+            }
+        } else {
+            for (int tt = 0; tt < dsub; tt++) t = __fmaf_rn(qs[tt], cw[tt], t);
+        }
+        ft_T[e] = t;
+    }
+    if (tid < 16) ctl[tid] = 0;
+    __syncthreads();
+    // candidate index -> storage row (the probed list that holds it, by bisection of the query's row offsets)
+    const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+    auto locate = [&](uint32_t idx, int& lo) -> int64_t {
+        lo = 0; int hi = a.nprobe;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
+        return a.list_base[a.probe_list[q * a.nprobe + lo]] + ((int64_t)idx - ss[lo]);
+    };
+    // 2. exact scores of the whole row, in place
+    const int NF = M >> 6, nrun = M >> 4;
+    int myvalid = 0;
+    for (int c = tid; c < n; c += 1024) {
+        const uint64_t key = row[c];
+        if (!key) continue;
+        const uint32_t idx = key_idx(key);
+        int lo;
+        const int64_t r = locate(idx, lo);
+        const float dis0 = a.probe_dis0[q * a.nprobe + lo];
+        float sum = 0.0f;
+        if (M == 16) {       // 64-vector blocks of 1 KiB: vector v's 16 bytes at v * 16, byte s = sub-quantiser (v + s) & 15
+            const uint4 cw4 = *reinterpret_cast<const uint4*>(a.codes + (r >> 6) * 1024 + (r & 63) * 16);
+            uint32_t w[4] = {cw4.x, cw4.y, cw4.z, cw4.w};
+            rot16_bytes(w, (int)(r & 15));
+#pragma unroll
+            for (int j = 0; j < 16; j++) sum += ft_T[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 255u)];
+        } else {             // 16-vector blocks (pq_exact_sum_rot_wide's pieces), 16 sub-quantisers per run in m order
+            const int i = (int)(r & 15);
+            const uint8_t* base = a.codes + (r >> 4) * (int64_t)(16 * M);
+            for (int run = 0; run < nrun; run++) {
+                const uint8_t* p0; const uint8_t* p1;
+                if (run < 4 * NF) { p0 = base + (run >> 2) * 1024 + ((run & 3) * 16 + i) * 16; p1 = p0 + 8; }
+                else { const int h = run & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
+                const uint2 lo2 = *reinterpret_cast<const uint2*>(p0), hi2 = *reinterpret_cast<const uint2*>(p1);
+                uint32_t w[4] = {lo2.x, lo2.y, hi2.x, hi2.y};
+                rot16_bytes(w, i);
+                const float* Tr = ft_T + run * 16 * 256;
+#pragma unroll
+                for (int j = 0; j < 16; j++) sum += Tr[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 255u)];
+            }
+        }
+        const uint64_t nk = make_key(dis0 + sum, idx);
+        row[c] = nk;
+        myvalid += nk != 0ull;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) myvalid += __shfl_xor(myvalid, off);
+    if (lane == 0 && myvalid) atomicAdd(&ctl[2], myvalid);
+    __syncthreads();        // workgroup-scope release / acquire: every thread sees the re-scored row
+    // 3. threshold = the k-th largest 32-bit score word (ties counted with multiplicity)
+    const int V = ctl[2];
+    uint32_t thr = 1u;      // fewer than k valid keys: take every valid one
+    if (V > a.k) {
+        uint32_t prefix = 0;
+        if (tid == 0) ctl[1] = a.k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i2 = tid; i2 < 256; i2 += 1024) hist[i2] = 0;
+            __syncthreads();
+            for (int c = tid; c < n; c += 1024) {
+                const uint64_t key = row[c];
+                const uint32_t o = (uint32_t)(key >> 32);
+                if (key != 0ull && (shift == 24 || (o >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&hist[(o >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const int sum4 = h0 + h1 + h2 + h3;
+                int suf = sum4;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_down(suf, off); if (lane + off < 64) suf += y; }
+                const int remaining = ctl[1];
+                const uint64_t mk = __ballot(suf >= remaining);
+                const int L = 63 - __clzll((unsigned long long)mk);
+                if (lane == L) {
+                    int run = suf - sum4;
+                    const int hb[4] = {h0, h1, h2, h3};
+                    int d = 4 * L, rem = remaining, inbin = 0;
+                    for (int b = 3; b >= 0; b--) {
+                        if (run + hb[b] >= remaining) { d = 4 * L + b; rem = remaining - run; inbin = hb[b]; break; }
+                        run += hb[b];
+                    }
+                    ctl[0] = d; ctl[1] = rem; ctl[4] = inbin;
+                    if (shift == 0 && rem != inbin) ctl[6] = 1;     // thr is the k-th score itself and its ties straddle rank k
+                }
+            }
+            __syncthreads();
+            prefix |= (uint32_t)ctl[0] << shift;
+            const bool all_in = ctl[1] == ctl[4];       // every key under this prefix is selected: no need to refine it
+            __syncthreads();
+            if (all_in) break;
+        }
+        thr = prefix;
+    }
+    // 4. collect.  Usually the keys at or above the threshold are just k (+ a few ties) and all of them go to the sort.  PQ codes
+    // are coarse, though: vectors with IDENTICAL codes in one list have bit-equal scores (at M = 16 on the bench mixture whole
+    // data clusters do: 40 % of adjacent results tie, up to 16 000 vectors at one score), and the order among them is id
+    // ascending.  When the ties of the k-th score do not fit the sort, their ids go to a scratch row, the t-th smallest id is
+    // found by a second radix walk (ids are distinct), and only the t ties at or below it join the keys above the threshold.
+    const bool straddle = ctl[6] != 0;
+    const int t_need = ctl[1], g_ties = ctl[4];                      // (straddle only) ties wanted / ties present
+    const bool tie_select = straddle && (a.k - t_need) + g_ties > P;
+    for (int i2 = tid; i2 < P; i2 += 1024) { sord[i2] = 0u; sid[i2] = INT64_MAX; }
+    __syncthreads();
+    uint64_t* tws = tie_ws + q * (int64_t)cand_cap;
+    for (int c = tid; c < n; c += 1024) {
+        const uint64_t key = row[c];
+        const uint32_t o = (uint32_t)(key >> 32);
+        if (key == 0ull || o < thr) continue;
+        int lo;
+        const int64_t r = locate(key_idx(key), lo);
+        const int64_t id = a.ids ? a.ids[r] : r;
+        if (tie_select && o == thr) {
+            tws[atomicAdd(&ctl[5], 1)] = ~((uint64_t)id ^ 0x8000000000000000ull);      // larger = smaller id; never 0 (id != INT64_MAX)
+        } else {
+            const int pos = atomicAdd(&ctl[3], 1);
+            if (pos < P) { sord[pos] = o; sid[pos] = id; }
+        }
+    }
+    __syncthreads();
+    if (tie_select) {
+        auto key_at = [&](int i2) -> uint64_t { return tws[i2]; };
+        radix_topk_wg<1024, true>(key_at, g_ties, t_need, tsel, hist, ctl2);      // tsel[0]: the t-th largest of the flipped ids (0: take all)
+        const uint64_t kth = tsel[0];
+        for (int c = tid; c < g_ties; c += 1024) {
+            const uint64_t f = tws[c];
+            if (f < kth) continue;
+            const int pos = atomicAdd(&ctl[3], 1);
+            if (pos < P) { sord[pos] = thr; sid[pos] = (int64_t)((~f) ^ 0x8000000000000000ull); }
+        }
+        __syncthreads();
+    }
+    if (ctl[3] > P) {        // cannot happen with the tie selection; kept as a guard: the exact re-run (full-row selection) settles it
+        if (tid == 0) a.uncertain[q] = 2 | 4 | (int)((unsigned)(ctl[3] > 0xfffff ? 0xfffff : ctl[3]) << 8);    // bit 2 + the count: diagnostics
+        return;
+    }
+    int ns = 2;              // sort only the power of two that holds the keys
+    while (ns < ctl[3]) ns <<= 1;
+    for (int size = 2; size <= ns; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (ns >> 1); t += 1024) {
+                const int i2 = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                const int j2 = i2 + stride;
+                const bool desc = ((i2 & size) == 0);
+                const uint32_t oi = sord[i2], oj = sord[j2];
+                const int64_t ii = sid[i2], ij = sid[j2];
+                const bool i_worse = (oi < oj) || (oi == oj && ii > ij);
+                if (i_worse == desc) { sord[i2] = oj; sord[j2] = oi; sid[i2] = ij; sid[j2] = ii; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < a.k; j += 1024) {
+        const bool valid = j < ns && sord[j] != 0u && sid[j] != INT64_MAX;
+        a.D[q * a.k + j] = valid ? ord2f(sord[j]) : -__builtin_inff();
+        a.I[q * a.k + j] = valid ? sid[j] : -1;
+    }
+    if (tid == 0) a.uncertain[q] = 0;
+}
+// sort capacity of k_pq_final_tab for this (M, k), 0 when the kernel does not apply (layout, or the table + sort do not fit the LDS)
+int pq_final_tab_capacity(int M, int CB, int k) {
+    if (CB != 0 || !pq_rot_applies(M)) return 0;
+    const auto fits = [&](int P) { return (size_t)M * 1024 + (size_t)P * 12 + 16 + (256 + 16) * 4 + 64 <= (size_t)160 * 1024; };
+    int P = 64; while (P < k + 16) P <<= 1;
+    if (fits(P)) return P;
+    P = 64; while (P < k) P <<= 1;
+    return fits(P) ? P : 0;
+}
+void launch_pq_final_tab(const FinalizeArgs& a, uint64_t* cand, int cand_cap, uint64_t* tie_ws, hipStream_t st) {
+    if (a.nq <= 0) return;
+    const int P = pq_final_tab_capacity(a.M, a.CB, a.k);
+    const size_t shm = (size_t)a.M * 1024 + (size_t)P * 12 + 16 + (256 + 16) * 4 + 64;
+    static DevSize attr;
+    attr.grow(shm, [&] { (void)hipFuncSetAttribute((const void*)k_pq_final_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
+    hipLaunchKernelGGL(k_pq_final_tab, dim3((unsigned)a.nq), dim3(1024), shm, st, a, cand, cand_cap, P, tie_ws);
 }
 
 void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {

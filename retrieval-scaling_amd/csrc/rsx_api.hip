@@ -185,6 +185,7 @@ struct rsx_index {
     int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scan: 1 = choose 16 / 32 / 64 queries per group from the queries per list, 2 / 4 = force, 0 = always 16
     int pq_prepass4 = 1;     // rotated fast scan, small k, full batches: threshold pre-pass with four queries per workgroup on the scan's table format
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
+    int pq_final_tab = 1;    // rotated fast scan: finalize from the complete candidate row with the fp32 table in LDS (1 = when K' >= 512 or dsub > 8 and as the second chance, 2 = always, 0 = never)
     int pq_log_cap = 0;      // rotated fast scan: keys per survivor log (0 = from the pool budget); tests shrink it to force the overflow path
     int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
@@ -196,7 +197,7 @@ struct rsx_index {
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart, w_qitems;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart, w_qitems, w_tiews;
     std::map<std::string, double> timing;
 
     // Flat / IVF-Flat: largest |x|^2 ever added (certificate of the MFMA scan); device copy is the running atomic max
@@ -248,7 +249,7 @@ static int64_t workspace_bytes(const rsx_index* h) {
     const DevBuf* bufs[] = {&h->w_q32, &h->w_q16, &h->w_coarse, &h->w_keys1, &h->w_probekeys, &h->w_probelist, &h->w_dis0, &h->w_segstart,
                             &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
                             &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
-                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->w_qitems, &h->sh_D, &h->sh_I, &h->sh_q,
+                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->w_qitems, &h->w_tiews, &h->sh_D, &h->sh_I, &h->sh_q,
                             &h->sh_oD, &h->sh_oI};
     int64_t t = 0;
     for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
@@ -846,6 +847,13 @@ static int64_t max_scan_items(rsx_index* h, int64_t nq, int nprobe, int G, int t
 
 static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI, bool allow_fast = true);
 
+// The IVF-PQ fast scan with in-kernel filtering and the one-launch threshold pre-pass never writes a score row (search_batch):
+// such a search needs no [nq, sum of the nprobe longest lists] score buffer, and its internal batch is not bounded by one.
+static bool pq_search_needs_score_rows(const rsx_index* h, int nprobe) {
+    const bool fast = h->pq_fast != 0 && h->scan_kernel == 0 && (h->CB == 16 || h->CB == 0) && h->M * 255 < 65536;
+    return !(h->kind == KIND_IVFPQ && fast && nprobe > 1 && h->pq_filter != 0 && h->pq_prepass_fused != 0);
+}
+
 // Keys a query's candidate row can hold (filtered IVF-PQ fast scan).  The threshold is valid by construction, so the
 // row must hold every vector within 2 eps of the query's k-th best: ~700 keys at M = 96 / k = 10, but eps grows as the tables get
 // coarser — at M = 16 (48 dimensions per 8-bit table entry) the measured mean is 1800 and the maximum 23 000 at k = 10.  An
@@ -890,7 +898,10 @@ static void rerun_uncertified(rsx_index* h, int64_t nq, const void* dq, int dtyp
     const size_t esz = dtype == RSX_F16 ? 2 : 4;
     std::vector<int64_t> badq;
     int64_t n_over = 0;
-    for (int64_t q = 0; q < nq; q++) if (bad[(size_t)q]) { badq.push_back(q); n_over += (bad[(size_t)q] & 2) != 0; }
+    for (int64_t q = 0; q < nq; q++) if (bad[(size_t)q]) {
+        badq.push_back(q); n_over += (bad[(size_t)q] & 2) != 0;
+        if (bad[(size_t)q] & 4) { h->timing["fallback_tie_queries"] += 1.0; h->timing["fallback_tie_max"] = std::max(h->timing["fallback_tie_max"], (double)(bad[(size_t)q] >> 8)); }
+    }
     h->timing["fallback_overflow_queries"] += (double)n_over;     // of the fallbacks: candidate buffer / survivor segment overflows
     const int64_t nbad = (int64_t)badq.size();
     h->timing["fallback_queries"] += (double)nbad;
@@ -1106,7 +1117,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     int64_t tmax = padded.first, maxlen = padded.second;
     tmax = std::max<int64_t>(round_up(tmax, 256), 256);
     if (tmax >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "probed lists exceed 2^32 vectors per query");
-    h->w_temp.ensure((size_t)nq * tmax * 4);
+    // score rows [nq, tmax]: every path but the filtered IVF-PQ fast scan with the one-launch pre-pass fills (part of) them.  At the
+    // reference's nprobe 512 a row is 35 MB: allocating it unconditionally used to cut a 1024-query batch into four internal
+    // batches (round 4: 4x the fixed stages, a quarter of the queries per list group)
+    if (allow_fast ? pq_search_needs_score_rows(h, nprobe) : true) h->w_temp.ensure((size_t)nq * tmax * 4);
     bool filtered = false;   // fast path with in-kernel candidate filtering (no full score buffer)
     bool use_gather = false; int gs_tmax = 0; PQGatherArgs gs{};   // ... whose candidates are gathered and selected in one launch
     bool fused_pre_used = false;   // ... whose threshold came from the one-launch pre-pass (complete candidate rows: second chance)
@@ -1251,6 +1265,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     t.parked = false; t.tau = nullptr; t.ntau = 0;
                 }
             } else {
+                h->w_temp.ensure((size_t)nq * tmax * 4);       // this form scores a prefix / everything into the score rows
+                a.temp = h->w_temp.as<float>();
                 launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
                                    pairs_sorted, h->d_len.as<int64_t>(), pre_rows, item_off, total_items, nprobe, 0,
                                    filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
@@ -1450,9 +1466,16 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             tm.mark("scan");
         }
     }
+    // IVF-PQ, rotated layout, threshold by construction: finalize straight from the complete candidate row (k_pq_final_tab) when K'
+    // is large or a table entry is a long chain (M = 16: dsub 48) — the K' cut, its certificate and the second chance disappear
+    const int tabP = (fast && filtered && fused_pre_used && rot && h->pq_final_tab != 0) ? pq_final_tab_capacity(h->M, h->CB, k) : 0;
+    const bool use_tab = tabP > 0 && (h->pq_final_tab == 2 || KP >= 512 || h->dsub > 8);
     // 3. per-query k-selection over the score rows
     if (filtered && use_gather) {
+        if (use_tab) gs.KP = 0;        // gather only
         launch_pq_gather_select(gs, nq, h->st);
+    } else if (filtered && use_tab) {
+        // the compaction has laid the survivors end to end in the candidate rows already
     } else if (filtered) {
         // merge the filtered candidates (keys) into state0: one wave per query, the whole buffer in one segment
         SelectArgs b{};
@@ -1485,11 +1508,20 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         fa.uncertain = h->w_uncertain.as<int32_t>();
         if (filtered) { fa.cand_cnt = h->w_candcnt.as<unsigned long long>(); fa.cand_cap = cand_cap; }
     }
-    launch_finalize(fa, h->st);
+    if (tabP > 0) h->w_tiews.ensure((size_t)nq * cand_cap * 8);
+    if (use_tab) launch_pq_final_tab(fa, h->w_cand.as<uint64_t>(), cand_cap, h->w_tiews.as<uint64_t>(), h->st);
+    else launch_finalize(fa, h->st);
     tm.mark("finalize");
     tm.finish();
     std::function<void()> second;
-    if (fast && filtered && fused_pre_used) {
+    if (fast && filtered && fused_pre_used && !use_tab && tabP > 0) {
+        second = [&]() {       // the flagged queries' candidate rows are complete: settle them from there (k_pq_final_tab)
+            h->timing["rescore_all_launches"] += 1;
+            FinalizeArgs fr = fa;
+            fr.row_filter = h->w_uncertain.as<int32_t>();
+            launch_pq_final_tab(fr, h->w_cand.as<uint64_t>(), cand_cap, h->w_tiews.as<uint64_t>(), h->st);
+        };
+    } else if (fast && filtered && fused_pre_used && !use_tab) {
         second = [&]() {
             // the flagged queries' candidate rows are complete (threshold by construction) and did not overflow: score every
             // candidate exactly in place, then the best K2 >= k + 64 of them by (exact score, index) go through k_finalize for
@@ -1513,7 +1545,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             launch_finalize(f2, h->st);
         };
     }
-    if (fast || certify) rerun_uncertified(h, nq, dq, dtype, k, dD, dI, fast ? 0 : (size_t)tmax * 4, second);
+    if (fast || certify) rerun_uncertified(h, nq, dq, dtype, k, dD, dI, (size_t)tmax * 4, second);     // the re-run fills score rows: chunked by the budget
 }
 
 // L2 ranking bias  -|x|^2/2  from the stored squared norms
@@ -1552,7 +1584,7 @@ static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int 
         const int pad_to = (h->kind == KIND_IVFPQ) ? 64 : 16;
         int64_t tmax = top_probe_sum(h, nprobe, pad_to, pad_to).first;
         tmax = std::max<int64_t>(round_up(tmax, 256), 256);
-        qb = std::max<int64_t>(1, std::min<int64_t>(qb, h->temp_budget / (tmax * 4)));
+        if (pq_search_needs_score_rows(h, nprobe)) qb = std::max<int64_t>(1, std::min<int64_t>(qb, h->temp_budget / (tmax * 4)));
     } else if (nq <= 32) {
         qb = 32;
     }
@@ -2557,6 +2589,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_log_cap") h->pq_log_cap = std::max(0, (int)value);
+        else if (s == "pq_final_tab") h->pq_final_tab = (int)value;
         else if (s == "pq_gather") h->pq_gather = (int)value;
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;

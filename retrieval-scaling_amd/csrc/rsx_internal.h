@@ -397,6 +397,11 @@ struct FinalizeArgs {
 void launch_finalize(const FinalizeArgs& a, hipStream_t st);
 // exact scores for every candidate key of the queries with a.row_filter[q] == 1, in place (a.cand_cnt gives the row lengths)
 void launch_pq_rescore_all(const FinalizeArgs& a, uint64_t* cand, int cand_cap, hipStream_t st);
+// IVF-PQ finalize from the complete candidate row (k_select.hip: k_pq_final_tab): exact re-score of EVERY key of the row with the
+// query's fp32 table in LDS, top k by (score, id) — no K', no certificate.  capacity 0: does not apply.  a.cand_cnt / a.uncertain
+// / a.row_filter as in FinalizeArgs (row_filter: second chance of the K' path).
+int pq_final_tab_capacity(int M, int CB, int k);
+void launch_pq_final_tab(const FinalizeArgs& a, uint64_t* cand, int cand_cap, uint64_t* tie_ws /* [nq, cand_cap]: ids of score ties */, hipStream_t st);
 // Exact scores of the uncertified queries (fallback of the certificate above): fp64 dot product of the query with EVERY row
 // the query may see (Flat: all rows; IVF-Flat: the rows of its probed lists, laid out by seg_start), rounded once to fp32 —
 // the canonical score — into temp[q * tstride + column]; invalid columns get -inf.

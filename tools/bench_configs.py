@@ -123,7 +123,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
     return res
 
 
-def measure_ivfpq(n=100_000_000, M=16, nlist=8192, nprobe=512, ks=(10, 1000), steps=3, batch=1024, check=4):
+def measure_ivfpq(n=100_000_000, M=16, nlist=8192, nprobe=512, ks=(10, 1000), steps=3, batch=1024, check=4, params=()):
     """The reference's shipped IVF-PQ operating point (ric/conf/ivf_pq.yaml:64-78: n_subquantizers 16, ncentroids 8192,
     probe 512, n_docs 1000) on n synthetic vectors: ms per batch for each k, fallbacks, oracle spot check."""
     import torch, rsx
@@ -140,6 +140,8 @@ def measure_ivfpq(n=100_000_000, M=16, nlist=8192, nprobe=512, ks=(10, 1000), st
         rsx.synth_vectors(D, NC, SC, SX, 0.5, (b * stride) % max(1, n - nb), nb, out=xt[b:b + nb])
     ix.train(xt); del xt
     ix.nprobe = nprobe
+    for name, val in params:
+        ix.set_param(name, val)
     buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
     for c0 in range(0, n, buf.shape[0]):
         nb = min(buf.shape[0], n - c0)
@@ -162,7 +164,12 @@ def measure_ivfpq(n=100_000_000, M=16, nlist=8192, nprobe=512, ks=(10, 1000), st
         r = {"ms_per_step": round(el * 1e3, 3), "queries_per_s": round(nq / el, 1),
              "stage_ms": {x: round(ix.get_timing(x) / steps, 4) for x in ("coarse", "select_probe", "lut8", "group", "scan0", "scan", "select", "finalize", "total")},
              "exact_fallback_queries_per_step": round(ix.get_timing("fallback_queries") / steps, 2),
+             "of_them_overflows_per_step": round(ix.get_timing("fallback_overflow_queries") / steps, 2),
              "reranked_from_candidate_row_per_step": round(ix.get_timing("second_chance_queries") / steps, 2)}
+        r["outside_stages_ms"] = round(r["ms_per_step"] - r["stage_ms"]["total"], 3)
+        ix.set_param("profile", 2)
+        ix.search(Q[:nq], k)
+        r["filter_survivors_per_query"] = {"mean": round(ix.get_timing("cand_keys") / nq, 1), "max": ix.get_timing("cand_keys_max")}
         ix.set_param("profile", 0)
         if check:
             qs = Q[steps * nq:steps * nq + check].cpu().numpy().astype(np.float32)
@@ -190,21 +197,30 @@ def measure_ivfpq(n=100_000_000, M=16, nlist=8192, nprobe=512, ks=(10, 1000), st
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", choices=["flat", "ivfflat", "latency", "ivfpq_ref"])
+    ap.add_argument("which", choices=["flat", "ivfflat", "latency", "ivfpq_ref", "largek"])
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--nlist", type=int, default=4096)
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--check", type=int, default=4, help="queries verified against the CPU oracle")
-    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="latency: engine parameter A/B")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="latency / ivfpq_ref / largek: engine parameter A/B")
+    ap.add_argument("--ks", default="", help="ivfpq_ref / largek: comma-separated k values")
+    ap.add_argument("--k", type=int, default=10, help="flat / ivfflat: results per query")
+    ap.add_argument("--metric", default="ip", choices=["ip", "l2"])
     a = ap.parse_args()
+    params = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.param]
     if a.which == "latency":
         return latency(a)
     if a.which == "ivfpq_ref":
-        print(json.dumps(measure_ivfpq(a.n or 100_000_000, steps=a.steps, check=a.check)), flush=True)
+        ks = tuple(int(t) for t in a.ks.split(",")) if a.ks else (10, 1000)
+        print(json.dumps(measure_ivfpq(a.n or 100_000_000, ks=ks, steps=a.steps, check=a.check, params=params)), flush=True)
         return
-    print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check)), flush=True)
+    if a.which == "largek":      # the headline index (M = 96, nlist 4096, nprobe 32) at the reference's n_docs
+        ks = tuple(int(t) for t in a.ks.split(",")) if a.ks else (10, 100, 1000, 2000)
+        print(json.dumps(measure_ivfpq(a.n or 100_000_000, 96, 4096, 32, ks=ks, steps=a.steps, check=a.check, params=params)), flush=True)
+        return
+    print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check, metric=a.metric, k=a.k)), flush=True)
 
 
 def latency(a):

@@ -10,7 +10,7 @@
 #   pmc_sq     two SQ counter passes of the scan kernel -> ${TAG}_pmc_sq_counters.md
 #   per_rank   one rank of an N = 2 / 4 / 8 run and of config 5 on this one GPU -> ${TAG}_per_rank_workloads.txt
 #   m16        the reference's shipped IVF-PQ point (M 16, nlist 8192, nprobe 512; k 10 and 1000)
-#   m16_pmc    SQ counters of that scan
+#   m16_prof   rocprofv3 kernel stats of it              m16_pmc: SQ counters of its scan
 #   largek     the headline index at k = 100 / 1000 / 2000
 #   flat       Flat 10M (IP, L2, k 10 and 1000) + rocprof stats          ivfflat: IVF-Flat configs
 #   latency    single-query latency protocol
@@ -22,9 +22,6 @@ export TMPDIR=/tmp
 TAG=${TAG:-r04}
 O=$PWD/gpurun_out
 FAST="--cpu-queries 0 --no-recall --no-configs"
-prof() {  # prof <outdir> <rocprof args...> -- <cmd...>
-  local d=$1; shift
-  ( cd /tmp && timeout 700 rocprofv3 --kernel-trace "$@" ) ; }
 for s in "$@"; do
   case $s in
     env)
@@ -69,13 +66,17 @@ for s in "$@"; do
     m16)
       timeout 900 python tools/bench_configs.py ivfpq_ref --steps ${STEPS:-5} ${M16_ARGS:-} > $O/${TAG}_ivfpq_m16.json 2> $O/${TAG}_ivfpq_m16.log; echo "exit $?" >> $O/${TAG}_ivfpq_m16.log
       cut -c1-2500 $O/${TAG}_ivfpq_m16.json; tail -n 3 $O/${TAG}_ivfpq_m16.log | cut -c1-300 ;;
+    m16_prof)
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d $O/prof_m16 -o $TAG -- python $OLDPWD/tools/bench_configs.py ivfpq_ref --steps 3 --check 0 ${M16_ARGS:-} > /dev/null 2> $O/${TAG}_prof_m16.log ); echo "exit $?" >> $O/${TAG}_prof_m16.log
+      python tools/rocprof_summary.py $O/prof_m16/${TAG}_results.db $O/${TAG}_rocprof_stats_ivfpq_m16.md "IVF-PQ 100M x 768, M=16, nlist=8192, nprobe=512, batch=1024, k = 10 and 1000 (tools/bench_configs.py ivfpq_ref --steps 3 --check 0 ${M16_ARGS:-})"
+      rm -rf $O/prof_m16; head -n 40 $O/${TAG}_rocprof_stats_ivfpq_m16.md | cut -c1-200 ;;
     m16_pmc)
-      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $O/pmc_m16 -o $TAG -- python $OLDPWD/tools/bench_configs.py ivfpq_ref --steps 2 --check 0 --ks 10 ${M16_ARGS:-} > /dev/null 2> $O/${TAG}_pmc_m16.log ); echo "exit $?" >> $O/${TAG}_pmc_m16.log
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $O/pmc_m16 -o $TAG -- python $OLDPWD/tools/bench_configs.py ivfpq_ref --steps 2 --check 0 --ks ${M16_PMC_K:-10} ${M16_ARGS:-} > /dev/null 2> $O/${TAG}_pmc_m16.log ); echo "exit $?" >> $O/${TAG}_pmc_m16.log
       rm -f $O/${TAG}_pmc_sq_m16.md
       python tools/pmc_summary.py $O/pmc_m16/${TAG}_results.db $O/${TAG}_pmc_sq_m16.md '%k_pq_scan%'
       rm -rf $O/pmc_m16 ;;
     largek)
-      timeout 900 python tools/bench_configs.py largek --steps ${STEPS:-5} > $O/${TAG}_largek.json 2> $O/${TAG}_largek.log; echo "exit $?" >> $O/${TAG}_largek.log
+      timeout 900 python tools/bench_configs.py largek --steps ${STEPS:-5} ${LARGEK_ARGS:-} > $O/${TAG}_largek.json 2> $O/${TAG}_largek.log; echo "exit $?" >> $O/${TAG}_largek.log
       cut -c1-2500 $O/${TAG}_largek.json; tail -n 3 $O/${TAG}_largek.log | cut -c1-300 ;;
     flat)
       ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d $O/prof_flat -o $TAG -- python $OLDPWD/tools/bench_configs.py flat --check 64 --steps 3 > $O/${TAG}_flat10M.json 2> $O/${TAG}_flat10M.log ); echo "exit $?" >> $O/${TAG}_flat10M.log
