@@ -428,6 +428,7 @@ void launch_pq_gather_select(const PQGatherArgs& a, int64_t nq, hipStream_t st) 
 // writes it as the query's threshold (state[q][KP-1], the other slots zero) and resets the candidate counter.
 // Replaces pair grouping + k_pq_scan8<unfiltered> + selection (5 launches) for that step.
 // ---------------------------------------------------------------------------------------
+constexpr int PP_MAXSEG = 8;      // lists a threshold sample may span (k_pq_prepass)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pq_prepass(PQPrepassArgs a) {   // <= 64 VGPRs: two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) uint64_t pp_smem[];
     uint64_t* obuf = pp_smem;                                        // [2]
@@ -531,6 +532,56 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         sums[pos] = (pos < len) ? (uint16_t)(acc + 1u) : (uint16_t)0;
     }
     __syncthreads();
+    // Round 4 — a closest list SHORTER than 8 k vectors: the sample continues in the next closest lists (at most PP_MAXSEG - 1 more,
+    // until it holds min(pre_rows, 8 k) rows).  A query whose closest list held fewer than k vectors used to get no threshold at
+    // all, kept every vector of every probed list (781 k survivors on the bench index, 6.6 M at nprobe 512) and was re-run
+    // exactly.  A vector of list j enters with the integer sum S + floor((dis0_j - dis0_0) / scale) - 2: dis0_0 + fma(scale, that,
+    // bias) is a LOWER bound of its approximate score (vectors whose shifted sum would be negative are left out), so the k-th
+    // largest of the sample's sums still yields a valid a_k — the sample holds k vectors whose approximate scores reach it.
+    // Rare, so simple: one thread per vector, byte loads through pq_code_addr.
+    int ntot = nslab * 64;
+    {
+        int32_t* seg = reinterpret_cast<int32_t*>(sums + a.pre_rows);      // [PP_MAXSEG][4]: list, rows, first sample slot, shift; then the count
+        const int want = a.pre_rows < 8 * a.k ? a.pre_rows : 8 * a.k;
+        if (tid == 0) {
+            int ns = 0, off = ntot;
+            if (l >= 0 && scale > 0.0f)
+                for (int j = j0 + 1; j < a.nprobe && ns < PP_MAXSEG - 1 && off < want; j++) {
+                    const int32_t lj = a.probe_list[q * a.nprobe + j];
+                    if (lj < 0) continue;
+                    const int64_t len_j = a.list_len[lj];
+                    if (len_j <= 0) continue;
+                    const float sh = floorf((a.probe_dis0[q * a.nprobe + j] - dis0) / scale) - 2.0f;
+                    if (!(sh > -1.0e9f)) break;
+                    const int rows = (int)(len_j < (int64_t)(a.pre_rows - off) ? len_j : (int64_t)(a.pre_rows - off));
+                    seg[4 * ns + 0] = lj; seg[4 * ns + 1] = rows; seg[4 * ns + 2] = off; seg[4 * ns + 3] = sh < 0.0f ? (int)sh : 0;
+                    off += (rows + 63) & ~63;
+                    ns++;
+                }
+            seg[4 * PP_MAXSEG] = ns; seg[4 * PP_MAXSEG + 1] = off;
+        }
+        __syncthreads();
+        const int nseg = seg[4 * PP_MAXSEG];
+        for (int sg = 0; sg < nseg; sg++) {
+            const int32_t ls = seg[4 * sg];
+            const int rows = seg[4 * sg + 1], off = seg[4 * sg + 2], shift = seg[4 * sg + 3];
+            const int64_t row0 = a.list_base[ls];
+            for (int pos = tid; pos < ((rows + 63) & ~63); pos += 1024) {
+                int v = -1;
+                if (pos < rows) {
+                    uint32_t acc = 0;
+                    for (int m = 0; m < a.Mpad; m++) {
+                        const uint32_t code = a.codes[pq_code_addr(row0 + pos, m, a.Mpad, a.CB)];
+                        acc += a.CB == 0 ? tab[code * a.Mpad + m] : tab[m * 256 + code];
+                    }
+                    v = (int)acc + shift;
+                }
+                sums[off + pos] = v >= 0 ? (uint16_t)(v + 1) : (uint16_t)0;
+            }
+        }
+        ntot = seg[4 * PP_MAXSEG + 1];
+    }
+    __syncthreads();
     // The approximate score dis0 + fma(scale, S, bias) is monotone in the integer sum S: the k-th best score of the sample
     // is the score of the k-th largest S (a 16-bit radix walk).  Round 3 — threshold by CONSTRUCTION instead of by the K'-th
     // sample key: the sample holds k vectors with approximate score >= a_k, hence exact score >= a_k - eps, so the query's
@@ -538,7 +589,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // < a_k - eps and cannot be among the top k.  Every vector the scan drops is therefore provably irrelevant, for any k,
     // and the candidate count is what the data needs (measured: ~130 for k = 10, ~2300 for k = 1000) instead of a guess.
     auto key_at = [&](int i) -> uint64_t { return (uint64_t)sums[i] << 48; };
-    radix_topk_wg<1024, true>(key_at, nslab * 64, a.k, obuf, hist, ctl);
+    radix_topk_wg<1024, true>(key_at, ntot, a.k, obuf, hist, ctl);
     uint64_t* o = a.state + q * a.KP;
     for (int i = tid; i < a.KP; i += 1024) o[i] = 0ull;              // the candidate merge starts from an empty state
     if (tid == 0) {
@@ -594,7 +645,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 }
 void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
     if (nq <= 0) return;
-    size_t shm = 16 + 264 * 4 + (size_t)a.Mpad * 256 + (size_t)a.pre_rows * 2 + 64;
+    size_t shm = 16 + 264 * 4 + (size_t)a.Mpad * 256 + (size_t)a.pre_rows * 2 + (4 * PP_MAXSEG + 4) * 4 + 64;
     static DevSize attr;
     attr.grow(shm, [&] { hipFuncSetAttribute((const void*)k_pq_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
     hipLaunchKernelGGL(k_pq_prepass, dim3((unsigned)nq), dim3(1024), shm, st, a);

@@ -568,3 +568,40 @@ def test_two_call_search_owns_the_handle(gpu, orc):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M", [16, 96])
+def test_threshold_sample_spans_short_lists(gpu, orc, M):
+    """Round 4: a query whose closest list holds fewer than k vectors used to get NO filter threshold (every vector of every probed
+    list survived, the candidate row overflowed, the query was re-run exactly).  The pre-pass now continues its sample in the next
+    closest lists with integer sums shifted down by the coarse-score difference (a lower bound of the approximate score): same
+    results, no overflow, no exact re-run."""
+    d, nlist, nq, k = 768 if M == 96 else 64, 12, 24, 40
+    rng = np.random.RandomState(3)
+    cen = rng.randn(nlist, d).astype(np.float32)
+    cen /= np.linalg.norm(cen, axis=1, keepdims=True)
+    # lists 0..3 hold 7 / 20 / 33 / 5 vectors (fewer than k), the others thousands
+    sizes = [7, 20, 33, 5] + [3000] * (nlist - 4)
+    xs = [(cen[l] * 4 + 0.3 * rng.randn(sz, d)).astype(np.float16) for l, sz in enumerate(sizes)]
+    x = np.concatenate(xs, 0)
+    perm = rng.permutation(len(x)); x = x[perm]
+    x32 = x.astype(np.float32)
+    a, _ = orc.assign_ip(cen, x32)
+    assert np.bincount(a, minlength=nlist)[:4].max() < k
+    # queries next to the short lists' centroids (their closest list is short) and a few ordinary ones
+    q = np.concatenate([(cen[l] * 4 + 0.2 * rng.randn(5, d)) for l in range(4)] + [(cen[7] * 4 + 0.2 * rng.randn(4, d))], 0).astype(np.float16)
+    assert len(q) == nq
+    cb = orc.pq_train(orc.residuals(cen, x32, a)[:4000], M, 3, 1234)
+    lm = orc.ListMajor(a, np.arange(len(x)), orc.pq_encode(cb, orc.residuals(cen, x32, a)), nlist)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    ix.set_centroids(cen); ix.set_codebooks(cb); ix.add(x)
+    for nprobe in (3, nlist):
+        ix.nprobe = nprobe
+        ix.set_param("profile", 2)
+        D, I = ix.search(q, k)
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q.astype(np.float32), nprobe, k)
+        assert_same_results(D, I, Dr, Ir, f"short closest lists, M={M} nprobe={nprobe}")
+        assert ix.get_timing("fallback_overflow_queries") == 0
+        if nprobe == nlist:     # a threshold exists: far fewer survivors than the vectors of the probed lists
+            assert ix.get_timing("cand_keys_max") < 0.5 * len(x), ix.get_timing("cand_keys_max")
+    ix.set_param("profile", 0)
