@@ -340,7 +340,16 @@ def main():
         recall = float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a, b)]))
         _, I2 = step_q(Qlow)
         a2, b2 = I2.cpu().numpy(), gt[nq:]
+        by_np = {}
+        for npb in sorted({1, 8, args.nprobe}):      # the metric's second half read off the benchmarked index itself (task 8)
+            index.nprobe = npb
+            _, Ix = step_q(Qlow)
+            ax = Ix.cpu().numpy()
+            by_np[f"nprobe{npb}"] = {"recall_at_10": round(float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(ax, b2)])), 4),
+                                     "recall_at_1": round(float(np.mean(ax[:, 0] == b2[:, 0])), 4)}
+        index.nprobe = args.nprobe
         recall_low = {"recall_at_10": round(float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a2, b2)])), 4),
+                      "by_nprobe": by_np,
                       "recall_at_1": round(float(np.mean(a2[:, 0] == b2[:, 0])), 4),
                       "recall_at_1_prescribed_queries": round(float(np.mean(a[:, 0] == b[:, 0])), 4),
                       "queries": "base vector + 0.02 noise (seed 1000), same 100M index, same nprobe; ground truth = exact streaming Flat search"}
@@ -453,14 +462,15 @@ def main():
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import bench_configs
         configs = {}
-        for name, kw in (("flat_10M_batch1024", dict(which="flat", n=10_000_000, steps=5, check=4, small_batches=False)),
+        # every index also at k = 1000, the reference's default n_docs (ric/conf/default.yaml:84)
+        for name, kw in (("flat_10M_batch1024", dict(which="flat", n=10_000_000, steps=5, check=4, small_batches=False, extra_ks=(1000,))),
                          # BASELINE config 2 as written ("exact L2"): the same 10M through the L2 metric
                          ("flat_10M_batch1024_L2", dict(which="flat", n=10_000_000, steps=5, check=4, small_batches=False, metric="l2")),
-                         ("ivfflat_100M_nlist4096_nprobe32", dict(which="ivfflat", n=100_000_000, steps=5, check=2)),
+                         ("ivfflat_100M_nlist4096_nprobe32", dict(which="ivfflat", n=100_000_000, steps=5, check=2, extra_ks=(1000,))),
                          # the reference's own shipped operating points: ric/conf/example_config.yaml:70-76 (IVFFlat, ncentroids
                          # 2048, probe 128; 20M vectors here to bound the run) and ric/conf/ivf_pq.yaml:64-78 (IVFPQ, M 16,
                          # ncentroids 8192, probe 512, n_docs 1000)
-                         ("ivfflat_20M_nlist2048_nprobe128", dict(which="ivfflat", n=20_000_000, nlist=2048, nprobe=128, steps=3, check=2)),
+                         ("ivfflat_20M_nlist2048_nprobe128", dict(which="ivfflat", n=20_000_000, nlist=2048, nprobe=128, steps=3, check=2, extra_ks=(1000,))),
                          ("ivfpq_100M_M16_nlist8192_nprobe512", dict(which="ivfpq_ref"))):
             t0 = time.time()
             try:

@@ -606,8 +606,9 @@ size_t pq_lut8_fused_lds(int M, int Mpad, int dsub) { return ((size_t)Mpad * 256
 
 void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
                     int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8, void* qparam, void* ws, int transposed,
-                    hipStream_t st) {
+                    hipStream_t st, int phase) {
     if (nq <= 0) return;
+    if (phase != 0 && !(ws && dsub == 8 && !lut32)) return;     // only the tiled build splits into tables (1) + per-query parameters (2)
     if (lut32) {
         hipLaunchKernelGGL(k_pq_lut8, dim3((unsigned)nq), dim3(256), 0, st, lut32, M, Mpad, probe_dis0, nprobe, lut8,
                            (PQQParam*)qparam, transposed);
@@ -621,10 +622,13 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
         const size_t osm = transposed ? (size_t)LT_QC * 256 * LT_MB : 0;
         static DevOnce once;
         if (osm) once.once([&] { hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm); });
-        hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
-        hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), osm, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
-        hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)nq), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0, nprobe,
-                           (PQQParam*)qparam);
+        if (phase != 2) {
+            hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
+            hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), osm, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
+        }
+        if (phase != 1)
+            hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)nq), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0, nprobe,
+                               (PQQParam*)qparam);
         return;
     }
     const size_t lds = pq_lut8_fused_lds(M, Mpad, dsub);

@@ -151,6 +151,15 @@ struct rsx_index {
     bool trained = false;
     int64_t ntotal = 0;
     hipStream_t st = nullptr;
+    // side stream of a search batch (round 4): stages that do not depend on each other run beside the main chain — the table build
+    // beside the coarse quantiser + probe selection, the pair grouping beside the threshold pre-pass
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_probe = nullptr, ev_lut = nullptr, ev_group = nullptr;
+    int overlap = 1;          // 0 = everything on one stream
+    ~rsx_index() {
+        if (st2) { (void)hipSetDevice(device); (void)hipStreamDestroy(st2); }
+        for (hipEvent_t e : {ev_fork, ev_probe, ev_lut, ev_group}) if (e) (void)hipEventDestroy(e);
+    }
     PinBuf pin_q, pin_out, pin_flags;     // latency path: pinned staging of queries / results / certificate flags
 
     // trained parameters
@@ -235,6 +244,11 @@ struct rsx_index {
 };
 
 static void use_device(rsx_index* h) { HIPCHECK(hipSetDevice(h->device)); }
+static void ensure_side_stream(rsx_index* h) {
+    if (h->st2) return;
+    HIPCHECK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&h->ev_fork, &h->ev_probe, &h->ev_lut, &h->ev_group}) HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+}
 // A two-call search that is parked between rsx_search_prepass and rsx_search_scan owns the handle's workspaces (thresholds,
 // candidate rows, state): every other entry point refuses to touch the handle until rsx_search_scan has finished it.
 static void refuse_while_two_call(const rsx_index* h, const char* what) {
@@ -952,6 +966,22 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     h->w_state.ensure((size_t)nq * KP * 8);
     uint64_t* state = h->w_state.as<uint64_t>();
     tm.mark("convert");
+    // Round 4: the 8-bit tables depend on the queries only — their build (k_pq_lut_tiled<0/1>, ~80 us per 1024 queries) starts here
+    // on the side stream and runs beside the coarse quantiser and the probe selection (~115 us); the per-query parameters
+    // (k_pq_qparam: they need the coarse scores) follow on the main stream once both have finished.
+    const bool pq_fused_lut = h->kind == KIND_IVFPQ && fast && pq_lut8_fused_lds(h->M, h->Mpad, h->dsub) <= 160 * 1024 - 64;
+    const bool side_lut = pq_fused_lut && h->overlap != 0 && h->dsub == 8 && h->lut_tiled != 0 && nq >= 64;
+    if (side_lut) {
+        ensure_side_stream(h);
+        h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
+        h->w_qparam.ensure((size_t)nq * 16);
+        h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad));
+        HIPCHECK(hipEventRecord(h->ev_fork, h->st));
+        HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        launch_pq_lut8(nullptr, h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad, nullptr, 0,
+                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, rot ? 1 : 0, h->st2, 1);
+        HIPCHECK(hipEventRecord(h->ev_lut, h->st2));
+    }
 
     FinalizeArgs fa{};
     fa.kind = h->kind; fa.metric = h->metric; fa.state = state; fa.KP = KP; fa.k = k; fa.nq = nq;
@@ -1095,6 +1125,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     h->w_segstart.ensure((size_t)nq * (nprobe + 1) * 8);
     launch_probe_setup(h->w_probekeys.as<uint64_t>(), KPp, nq, nprobe, h->d_len.as<int64_t>(), pad_to,
                        h->w_probelist.as<int32_t>(), h->w_dis0.as<float>(), h->w_segstart.as<int64_t>(), h->st);
+    if (side_lut) HIPCHECK(hipEventRecord(h->ev_probe, h->st));
     tm.mark("select_probe");
     if (h->profile >= 2) {
         std::vector<int32_t> pl((size_t)nq * nprobe);
@@ -1126,7 +1157,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     bool fused_pre_used = false;   // ... whose threshold came from the one-launch pre-pass (complete candidate rows: second chance)
     int cand_cap = 0;
     // the exact kernels gather fp32 table entries; the fast path builds the table in LDS (when it fits)
-    const bool fused_lut = h->kind == KIND_IVFPQ && fast && pq_lut8_fused_lds(h->M, h->Mpad, h->dsub) <= 160 * 1024 - 64;
+    const bool fused_lut = pq_fused_lut;
 
     if (h->kind == KIND_IVFPQ) {
         if (!fused_lut) {
@@ -1150,8 +1181,9 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             h->w_uncertain.ensure((size_t)nq * 4);
             void* lut_ws = nullptr;
             if (fused_lut && h->dsub == 8 && h->lut_tiled != 0) { h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad)); lut_ws = h->w_lutws.p; }
+            if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_lut, 0));     // the tables were built beside the probe selection
             launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
-                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st);
+                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st, side_lut ? 2 : 0);
             tm.mark("lut8");
             int rot_log_cap = 64;
             auto rot_desc = [&](int64_t items) -> void* {   // work-item records + run descriptors + survivor logs of the rotated-layout scan
@@ -1214,6 +1246,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // else grouping + scan of the prefix + selection (K'-th key of the prefix as the threshold)
             bool fused_pre = filtered && h->pq_prepass_fused != 0;
             bool pre4 = false;
+            bool grouped_early = false;
             if (fused_pre) {
                 // the sample's k-th best score is the threshold: the sample must be a large part of the closest list once k is large
                 // (measured at 24k-vector lists: a 2048-vector prefix gives ~1000 candidates per query for k = 10 but ~20000 for
@@ -1250,6 +1283,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 if (rot) {       // the sample's own candidates leave from the pre-pass; the scan drops that (query, list, tile 0)
                     h->w_excl.ensure((size_t)nq * 2);
                     pa.cand = h->w_cand.as<uint64_t>(); pa.cand_cap = cand_cap; pa.tile_rows = tile_rows; pa.excl = h->w_excl.as<uint16_t>();
+                }
+                if (side_lut) {       // the (list, tile, group) work items of the scan: built beside the pre-pass (they need the probes only)
+                    HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_probe, 0));
+                    launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
+                                       pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
+                                       h->st2);
+                    HIPCHECK(hipEventRecord(h->ev_group, h->st2));
+                    grouped_early = true;
                 }
                 if (!(pre4 && launch_pq_prepass4(pa, nq, h->st) == 0)) launch_pq_prepass(pa, nq, h->st);
                 fused_pre_used = true;
@@ -1295,9 +1336,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // arrive twice (the prefix keys above the threshold come back through the candidate buffer).
                 // (the selection wrote only the K'-th key of each query and reset the query's candidate counter)
                 tm.mark("select0");
-                launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
-                                   pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
-                                   h->st);
+                if (grouped_early) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_group, 0));
+                else launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
+                                        pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
+                                        h->st);
                 tm.mark("group");
                 void* rws1 = rot ? rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows)) : nullptr;
                 // threshold keys: one per query from the one-launch pre-pass, else the K'-th key the selection left in the state rows
@@ -2590,6 +2632,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_log_cap") h->pq_log_cap = std::max(0, (int)value);
         else if (s == "pq_final_tab") h->pq_final_tab = (int)value;
+        else if (s == "overlap") h->overlap = (int)value;
         else if (s == "pq_gather") h->pq_gather = (int)value;
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;

@@ -14,7 +14,7 @@ D, NC = 768, 4096
 SC, SX, SQ = 1234, 10000, 999
 
 
-def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, small_batches=True, metric="ip", k=10):
+def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, small_batches=True, metric="ip", k=10, extra_ks=()):
     """One non-headline config on cuda:0 -> result dict (the same object bench.py embeds under "configs")."""
     import torch, rsx
     from oracle import oracle as orc
@@ -49,34 +49,71 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
         ix.add(buf[:nb])
     torch.cuda.synchronize()
     build_s = time.time() - t0
-    ix.search(Q[:nq], k)
-    ix.set_param("profile", 2 if which == "ivfflat" else 1)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for s in range(1, steps + 1):
-        Dq, Iq = ix.search(Q[s * nq:(s + 1) * nq], k)
-    torch.cuda.synchronize(); el = time.perf_counter() - t0
-    scan_ms = ix.get_timing("scan") / steps
-    res = {"config": f"{which} {n}x{D} batch={nq} k={k}" + (f" nlist={nlist} nprobe={nprobe}" if which == "ivfflat" else f" metric={'L2' if mcode else 'IP'}"),
-           "queries_per_s": round(steps * nq / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
-           "scan_ms": round(scan_ms, 3), "select_ms": round(ix.get_timing("select") / steps, 3),
-           "finalize_ms": round(ix.get_timing("finalize") / steps, 3), "build_s": round(build_s, 1),
-           "storage_dtype": ix.storage_dtype,
-           "certificate_fallback_queries_per_step": round(ix.get_timing("fallback_queries") / steps, 3)}
-    if which == "flat":
-        fl = 2.0 * nq * n * D
-        res["roofline"] = {"bound": "mfma", "kernel": "k_flat_gemm2", "achieved": round(fl / (scan_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
-                           "unit": "TFLOP/s", "frac": round(fl / (scan_ms * 1e-3) / 2.5e15, 4),
-                           "note": "2*nq*N*d flop / scan stage (k_flat_gemm2 + the first chunk's k_select; HIP events on the library stream)"}
-    else:
-        rows = ix.get_timing("scanned_vectors") / steps
-        uniq = ix.get_timing("scanned_unique_vectors") / steps
-        res["roofline"] = {"bound": "hbm", "kernel": "k_list_scan2", "achieved": round(uniq * D * 2 / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
-                           "unit": "GB/s", "frac": round(uniq * D * 2 / (scan_ms * 1e-3) / 8e12, 4),
-                           "algorithmic_bytes_per_step": uniq * D * 2, "logical_bytes_per_step": rows * D * 2,
-                           "effective_GBs": round(rows * D * 2 / (scan_ms * 1e-3) / 1e9, 1),
-                           "note": "achieved = rows of every list probed at least once x d x 2 B (each must cross HBM once per batch) / scan "
-                                   "stage; logical = sum over (query, probed list) of len*d*2 B (SURVEY 8d), served from one HBM read per "
-                                   "group of <=16 probing queries"}
+    lm_cache = {}
+
+    def run_k(k):
+        ix.search(Q[:nq], k)
+        ix.set_param("profile", 2 if which == "ivfflat" else 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for s in range(1, steps + 1):
+            Dq, Iq = ix.search(Q[s * nq:(s + 1) * nq], k)
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        scan_ms = ix.get_timing("scan") / steps
+        res = {"config": f"{which} {n}x{D} batch={nq} k={k}" + (f" nlist={nlist} nprobe={nprobe}" if which == "ivfflat" else f" metric={'L2' if mcode else 'IP'}"),
+               "queries_per_s": round(steps * nq / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+               "scan_ms": round(scan_ms, 3), "select_ms": round(ix.get_timing("select") / steps, 3),
+               "finalize_ms": round(ix.get_timing("finalize") / steps, 3), "build_s": round(build_s, 1),
+               "storage_dtype": ix.storage_dtype,
+               "certificate_fallback_queries_per_step": round(ix.get_timing("fallback_queries") / steps, 3)}
+        if which == "flat":
+            fl = 2.0 * nq * n * D
+            res["roofline"] = {"bound": "mfma", "kernel": "k_flat_gemm2", "achieved": round(fl / (scan_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
+                               "unit": "TFLOP/s", "frac": round(fl / (scan_ms * 1e-3) / 2.5e15, 4),
+                               "note": "2*nq*N*d flop / scan stage (k_flat_gemm2 + the first chunk's k_select; HIP events on the library stream)"}
+        else:
+            rows = ix.get_timing("scanned_vectors") / steps
+            uniq = ix.get_timing("scanned_unique_vectors") / steps
+            res["roofline"] = {"bound": "hbm", "kernel": "k_list_scan2", "achieved": round(uniq * D * 2 / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                               "unit": "GB/s", "frac": round(uniq * D * 2 / (scan_ms * 1e-3) / 8e12, 4),
+                               "algorithmic_bytes_per_step": uniq * D * 2, "logical_bytes_per_step": rows * D * 2,
+                               "effective_GBs": round(rows * D * 2 / (scan_ms * 1e-3) / 1e9, 1),
+                               "note": "achieved = rows of every list probed at least once x d x 2 B (each must cross HBM once per batch) / scan "
+                                       "stage; logical = sum over (query, probed list) of len*d*2 B (SURVEY 8d), served from one HBM read per "
+                                       "group of <=16 probing queries"}
+        ix.set_param("profile", 0)
+        # parity spot check against the oracle (exact arithmetic) on a few queries of the last batch
+        if check:
+            qs = Q[steps * nq:steps * nq + check].cpu().numpy().astype(np.float32)
+            if which == "flat":
+                best = None
+                for c0 in range(0, n, buf.shape[0]):
+                    nb = min(buf.shape[0], n - c0)
+                    rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb])
+                    Dc, Ic = orc.flat_search(qs, buf[:nb].cpu().numpy().astype(np.float32), k, mcode)
+                    Ic = Ic + c0
+                    best = (Dc, Ic) if best is None else orc.merge_topk(np.stack([best[0], Dc]), np.stack([best[1], Ic]), mcode)
+                ok = bool(np.array_equal(best[1], Iq[:check].cpu().numpy()) and np.array_equal(best[0], Dq[:check].cpu().numpy()))
+            else:
+                cen = ix.get_centroids()
+                if "lm" not in lm_cache:
+                    pid, _ = orc.coarse_probe(cen, qs, nprobe)
+                    need = np.unique(pid)
+                    off = np.zeros(nlist + 1, np.int64); lens = np.zeros(nlist, np.int64); pay = []; ids = []
+                    for l in need:
+                        v, i = ix.get_list(int(l)); pay.append(v); ids.append(i); lens[l] = len(i)
+                    np.cumsum(lens, out=off[1:])
+
+                    class LM: pass
+                    lm = LM(); lm.list_off = off; lm.payload = np.concatenate(pay); lm.ids = np.concatenate(ids)
+                    lm_cache["lm"] = lm
+                Dr, Ir = orc.ivfflat_search(0, cen, lm_cache["lm"], qs, nprobe, k)
+                ok = bool(np.array_equal(Ir, Iq[:check].cpu().numpy()) and np.array_equal(Dr, Dq[:check].cpu().numpy()))
+            res["oracle_parity_ids_and_scores"] = ok
+            res["oracle_checked_queries"] = int(check)
+        return res
+
+    res = run_k(k)
+    if which == "ivfflat":
         ls = ix.list_sizes()
         res["list_length"] = {"min": int(ls.min()), "p50": int(np.percentile(ls, 50)), "p95": int(np.percentile(ls, 95)), "max": int(ls.max())}
     if which == "flat" and small_batches:
@@ -91,33 +128,11 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
             ms = (time.perf_counter() - t0) / 5 * 1e3
             small[f"batch{b}"] = {"ms": round(ms, 3), "db_GBps": round(n * D * 2 / (ms * 1e-3) / 1e9, 1)}
         res["small_batch"] = small
-    # parity spot check against the oracle (exact arithmetic) on a few queries of the last batch
-    if check:
-        qs = Q[steps * nq:steps * nq + check].cpu().numpy().astype(np.float32)
-        if which == "flat":
-            best = None
-            for c0 in range(0, n, buf.shape[0]):
-                nb = min(buf.shape[0], n - c0)
-                rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb])
-                Dc, Ic = orc.flat_search(qs, buf[:nb].cpu().numpy().astype(np.float32), k, mcode)
-                Ic = Ic + c0
-                best = (Dc, Ic) if best is None else orc.merge_topk(np.stack([best[0], Dc]), np.stack([best[1], Ic]), mcode)
-            ok = bool(np.array_equal(best[1], Iq[:check].cpu().numpy()) and np.array_equal(best[0], Dq[:check].cpu().numpy()))
-        else:
-            cen = ix.get_centroids()
-            pid, _ = orc.coarse_probe(cen, qs, nprobe)
-            need = np.unique(pid)
-            off = np.zeros(nlist + 1, np.int64); lens = np.zeros(nlist, np.int64); pay = []; ids = []
-            for l in need:
-                v, i = ix.get_list(int(l)); pay.append(v); ids.append(i); lens[l] = len(i)
-            np.cumsum(lens, out=off[1:])
-
-            class LM: pass
-            lm = LM(); lm.list_off = off; lm.payload = np.concatenate(pay); lm.ids = np.concatenate(ids)
-            Dr, Ir = orc.ivfflat_search(0, cen, lm, qs, nprobe, k)
-            ok = bool(np.array_equal(Ir, Iq[:check].cpu().numpy()) and np.array_equal(Dr, Dq[:check].cpu().numpy()))
-        res["oracle_parity_ids_and_scores"] = ok
-        res["oracle_checked_queries"] = int(check)
+    # the reference's own n_docs (ric/conf/default.yaml:84: 1000) on the same index
+    for kk in extra_ks:
+        r2 = run_k(kk)
+        res[f"k{kk}"] = {key: r2[key] for key in ("queries_per_s", "ms_per_step", "scan_ms", "select_ms", "finalize_ms", "certificate_fallback_queries_per_step",
+                                                 "roofline", "oracle_parity_ids_and_scores", "oracle_checked_queries") if key in r2}
     del ix, buf, Q
     torch.cuda.synchronize()
     return res
@@ -220,7 +235,8 @@ def main():
         ks = tuple(int(t) for t in a.ks.split(",")) if a.ks else (10, 100, 1000, 2000)
         print(json.dumps(measure_ivfpq(a.n or 100_000_000, 96, 4096, 32, ks=ks, steps=a.steps, check=a.check, params=params)), flush=True)
         return
-    print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check, metric=a.metric, k=a.k)), flush=True)
+    extra = tuple(int(t) for t in a.ks.split(",")) if a.ks else ()
+    print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check, metric=a.metric, k=a.k, extra_ks=extra)), flush=True)
 
 
 def latency(a):
