@@ -1190,7 +1190,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // the log pool = (persistent workgroups x 64 logs x log_cap keys): 1 / 2 / 4 GiB by k, never more than a quarter of the
                 // temp budget.  A log that fills up only sends the queries of its later runs to the exact re-run (counted); the pool is
                 // touched where survivors land, so its size costs nothing per batch; reported by rsx_get "workspace_bytes"
-                const int nwg = pq_scan_rot_max_wgs();
+                const int nwg = pq_scan_rot_max_wgs(h->M);
                 int64_t pool = (int64_t)(k <= 64 ? 1 : k <= 512 ? 2 : 4) << 30;
                 pool = std::min(pool, std::max<int64_t>(h->temp_budget / 4, (int64_t)64 << 20));
                 int64_t cap = pool / 8 / ((int64_t)nwg * 64);

@@ -289,13 +289,13 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
-                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, log_cap, pq_scan_rot_max_wgs()) bytes */, int log_cap, int prune, int pace,
+                       int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, log_cap, pq_scan_rot_max_wgs(M)) bytes */, int log_cap, int prune, int pace,
                        const uint16_t* excl, int32_t* qitems /* non-null: fill it and leave the runs for k_pq_gather_select */,
                        int qitems_tmax, hipStream_t st);
 // Survivors of the filtered scan (round 4): every (persistent workgroup, wave, query slot) appends to its own LOG of log_cap keys;
 // an 8-byte descriptor per (item, wave, slot) = {index of the run's first key in the log pool, keys stored | bit 31: keys were
 // dropped because the log was full} lets the gather / compaction kernels find an item's runs.
-int pq_scan_rot_max_wgs();     // persistent workgroups of the scan on the current device (= logs / 64)
+int pq_scan_rot_max_wgs(int M);     // persistent workgroups of the scan on the current device (= logs / 64)
 inline size_t pq_scan_rot_ws(int64_t max_items, int log_cap, int nwg) {   // item records + run descriptors + logs + per-XCD counters + progress words
     return (size_t)(max_items + 8) * (176 + 512 + 4) + (size_t)nwg * 64 * (size_t)log_cap * 8 + 1024;
 }
