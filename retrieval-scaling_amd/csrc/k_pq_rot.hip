@@ -36,10 +36,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define ROT_DEPTH 4
 #endif
 constexpr int ROT_D = ROT_DEPTH;   // 16-vector code blocks in flight per wave (16 M bytes each); must divide the tile's blocks per wave
-#ifndef ROT_PIPE
-#define ROT_PIPE 0          // 1 = the software-pipelined block loop of k_pq_scan_rot (round 4 experiment, profiles/r04_scan_experiments.md:
-                            // +1-2 % at M = 96 — inside the box-to-box noise — and -50 % at M = 16, whose items are 12 blocks per wave)
-#endif
 #ifndef ROT_CW
 #define ROT_CW 4              // items (waves) per workgroup of k_pq_rot_compact
 #endif
@@ -496,37 +492,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             // vmcnt(0), so every iteration drained all RD refills it had just issued (prefetch distance one block instead of RD)
             __builtin_amdgcn_sched_barrier(0);
         }
-#if ROT_PIPE
-        // gather address of look-up s of the block whose codes sit in slot sl: (plane << 16) | (code << 8) | rotation byte — one v_perm
-        auto gather_addr = [&](int sl, int s) -> uint32_t {
-            if ((NF >= 1 || NQ) && s < 16) {
-                const uint32_t cw[4] = {ca[sl][0].x, ca[sl][0].y, ca[sl][0].z, ca[sl][0].w};
-                return __builtin_amdgcn_perm(cw[s >> 2], R0[s >> 2], 0x0c0c0000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s & 3));
-            }
-            if (NF >= 2 && s < 32) {
-                const int s1 = s - 16;
-                const uint32_t cw[4] = {ca[sl][NF - 1].x, ca[sl][NF - 1].y, ca[sl][NF - 1].z, ca[sl][NF - 1].w};
-                return __builtin_amdgcn_perm(cw[s1 >> 2], R1[s1 / 3], 0x0c030000u | ((uint32_t)(4 + (s1 & 3)) << 8) | (uint32_t)(s1 % 3));
-            }
-            const int s1 = s - 16 * NF;        // the half phase's eight look-ups
-            const uint32_t cw[2] = {cb[sl].x, cb[sl].y};
-            if (NF == 0) return __builtin_amdgcn_perm(cw[s1 >> 2], R0[s1 >> 2], 0x0c0c0000u | ((uint32_t)(4 + (s1 & 3)) << 8) | (uint32_t)(s1 & 3));
-            return __builtin_amdgcn_perm(cw[s1 >> 2], R1[s1 / 3], 0x0c030000u | ((uint32_t)(4 + (s1 & 3)) << 8) | (uint32_t)(s1 % 3));
-        };
-        uint32_t gd[NG];
-        {   // the item's first block is looked up here, unoverlapped (once per item); slot 0 then takes the next chunk's first block
-#pragma unroll
-            for (int s2 = 0; s2 < NG; s2++) gd[s2] = gather_addr(0, s2);
-            __builtin_amdgcn_sched_barrier(0);
-            const int so = (soB == so_oob) ? so_oob : soB;
-#pragma unroll
-            for (int p = 0; p < NL; p++) ca[0][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
-            if (NH) cb[0] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s2 = 0; s2 < NG; s2++) gd[s2] = lds_rd32(gd[s2]);
-        }
-#endif
 #pragma unroll 1
         for (int k = 0; nA < nch; k++) {
             // the chunk after next: drawn now, needed at the end of this iteration
@@ -560,76 +525,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 }
                 if (dstate == 0 && nA >= nch - 48) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }
             }
-#if ROT_PIPE
-            // ---- software-pipelined form (round 4).  gd[] holds the LDS look-ups of the CURRENT block (issued one block ago); while
-            // the matrix core adds quad t of it, the addresses of the FOLLOWING block's quad t are formed and its look-ups issued into
-            // the very registers that MFMA has just consumed.  The straight-line form (perms -> look-ups -> MFMAs per block) left the
-            // four waves of a SIMD in lock step — all forming addresses, then all waiting for the LDS, then all on the matrix core:
-            // 371 clk per block where the VALU needs ~110, the matrix core ~100 and the LDS pipe ~50.  The order is pinned with
-            // scheduling barriers (the scheduler regroups the three instruction kinds otherwise, as it did with round 2's source-level
-            // attempt).  The following block = slot dd + 1 of this chunk, or slot 0, which already holds the NEXT chunk's first block
-            // (it was refilled at the end of the previous iteration); a slot is refilled as soon as its codes have become addresses.
-            int soC = so_oob;
-#pragma unroll
-            for (int dd = 0; dd < RD; dd++) {
-                const int b = b0 + 16 * dd;
-                constexpr int dummy_ = 0; (void)dummy_;
-                const int nd = dd + 1 < RD ? dd + 1 : 0;
-                if (dd == RD - 1) soC = chunk_of(__builtin_amdgcn_readfirstlane(nC));
-                v4i C = Ci;
-#pragma unroll
-                for (int t = 0; t < NG / 4; t++) {
-                    const v4i Av = {(int)gd[4 * t], (int)gd[4 * t + 1], (int)gd[4 * t + 2], (int)gd[4 * t + 3]};
-                    C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) gd[4 * t + j] = gather_addr(nd, 4 * t + j);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) gd[4 * t + j] = lds_rd32(gd[4 * t + j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                {   // slot nd's code registers are dead: refill them in place (the next chunk's block nd; slot 0: the chunk after next's first block)
-                    const int sb_ = nd != 0 ? so_next : soC;
-                    const int so = (sb_ == so_oob || sb_ / BB - tb0 + 16 * nd >= 16 * bpw) ? so_oob : sb_ + nd * 16 * BB;
-#pragma unroll
-                    for (int p = 0; p < NL; p++) ca[nd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
-                    if (NH) cb[nd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // C[r] (lanes n < 4) = cinit + sum over m of (u8 - 128) for vector 4 g + r of the block and query n
-                if (FILTER) {
-                    if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0) && !(var & 1)) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const bool cnd = C[r] >= 0;
-                            if (__builtin_amdgcn_ballot_w64(cnd)) {
-                                const float p_dis0 = it->dis0[nq4], p_scale = it->scale[nq4], p_bias = it->bias[nq4];
-                                const int64_t p_off = it->off[nq4];
-                                const uint64_t p_tau = it->tau[nq4];
-                                const int64_t pos = NQ ? ((int64_t)b << 6) + 16 * (n >> 2) + 4 * g + r : ((int64_t)b << 4) + 4 * g + r;
-                                const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(C[r] - cinit + 128 * M), p_bias);
-                                const uint64_t key = (cnd && pos < len && b - tb0 < 16 * bpw) ? make_key(sc, (uint32_t)p_off + (uint32_t)pos) : 0ull;
-                                const bool pass = key > p_tau;
-                                const uint64_t mq = __builtin_amdgcn_ballot_w64(pass) & QM;      // this step's survivors of MY query
-                                if (pass) {
-                                    const uint32_t slot = lcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
-                                    if (slot < (uint32_t)log_cap) mylog[slot] = key;   // beyond: counted, dropped -> the query is re-run exactly
-                                }
-                                lcur += (uint32_t)__builtin_popcountll(mq);
-                            }
-                        }
-                    }
-                } else {
-                    if ((NQ ? (n & 3) < np : n < np) && b < nblk && b - tb0 < 16 * bpw) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int64_t pos = NQ ? ((int64_t)b << 6) + 16 * (n >> 2) + 4 * g + r : ((int64_t)b << 4) + 4 * g + r;
-                            const float sc = p_dis0_u + __fmaf_rn(p_scale_u, (float)(C[r] + 128 * M), p_bias_u);
-                            a.temp[p_off_u + pos] = (pos < len) ? sc : -__builtin_inff();
-                        }
-                    }
-                }
-            }
-#else
 #pragma unroll
             for (int dd = 0; dd < RD; dd++) {
                 const int b = b0 + 16 * dd;
@@ -707,7 +602,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                     }
                 }
             }
-#endif
             nA = nB; soA = soB;
             nB = __builtin_amdgcn_readfirstlane(nC);
             soB = chunk_of(nB);
