@@ -95,12 +95,15 @@ struct __attribute__((aligned(16))) PQRotItem {
 };
 static_assert(sizeof(PQRotItem) == 176, "PQRotItem is copied as 11 x 16 bytes");
 
+// ngq = records per work item: 1, or — M = 16, filtered scan (k_pq_scan_rot16) — 4: a work item is then a group of up to 16 probing
+// queries of a list tile, described by four consecutive 4-query records (a record without queries has np = 0).
 template <int M, bool FILTER>
-__global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* items, uint32_t* xcd_ctr, uint32_t* prog) {
+__global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* items, uint32_t* xcd_ctr, uint32_t* prog, int ngq) {
     const PQScanArgs& a = A.b;
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item < 8) xcd_ctr[item * 32] = 0u;     // the scan's per-XCD work counters (one per 128-byte line)
+    const int rec = blockIdx.x * 256 + threadIdx.x;
+    if (rec < 8) xcd_ctr[rec * 32] = 0u;     // the scan's per-XCD work counters (one per 128-byte line)
     const int ti = *A.total_items;
+    const int item = rec / ngq, h = rec - item * ngq;
     if (item >= ti) return;
     int lo = 0, hi = A.nlist;   // largest l with item_off[l] <= item
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.item_off[mid] <= item) lo = mid; else hi = mid; }
@@ -108,22 +111,24 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
     const int r = item - A.item_off[lo];
     const int tile = r / ng, gi = r - tile * ng;
     const int cnt = A.pair_off[lo + 1] - A.pair_off[lo];
-    const int pair0 = A.pair_off[lo] + 4 * gi;
+    const int first = 4 * (gi * ngq + h);                 // this record's first pair within the list's sorted pairs
+    int npr = cnt - first; if (npr > 4) npr = 4; if (npr < 0) npr = 0;
+    const int pair0 = A.pair_off[lo] + (npr > 0 ? first : 0);
     PQRotItem d;
-    d.l = lo; d.tile = tile; d.np = (cnt - 4 * gi) > 4 ? 4 : (cnt - 4 * gi); d.pad0 = 0;
+    d.l = lo; d.tile = tile; d.np = npr; d.pad0 = 0;
     // the item's FAMILY = the ng query groups of one list tile, adjacent in the item order: [item - gi, item - gi + ng)
     const int fam = ((gi < 0x3fff ? gi : 0x3fff) << 4) | ((ng < 0x3fff ? ng : 0x3fff) << 18);
-    prog[item] = 0u;
+    if (h == 0) prog[item] = 0u;
     d.len = a.list_len[lo]; d.base_row = a.list_base[lo];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int pi = A.pairs_sorted[pair0 + (k < d.np ? k : 0)];
+        const int pi = A.pairs_sorted[pair0 + (k < npr ? k : 0)];
         const int64_t q = pi / a.nprobe;
         const PQQParam p = A.qp[q];
         const int64_t col = a.seg_start[q * (a.nprobe + 1) + (pi - (int)q * a.nprobe)];
         const float dis0 = a.probe_dis0[pi];
         d.q[k] = (int32_t)q; d.dis0[k] = dis0; d.scale[k] = p.scale; d.bias[k] = p.bias;
-        if (FILTER && A.qitems && k < d.np && tile < A.qitems_tmax) A.qitems[(int64_t)pi * A.qitems_tmax + tile] = item * 4 + k;
+        if (FILTER && A.qitems && k < npr && tile < A.qitems_tmax) A.qitems[(int64_t)pi * A.qitems_tmax + tile] = rec * 4 + k;
         d.off[k] = FILTER ? col : q * a.tstride + col;
         const uint64_t tau = FILTER ? A.tau_key[q * A.tau_stride] : 0ull;
         d.tau[k] = tau;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
         // scored with, monotone in S) reaches the threshold key's score.  The MFMA accumulates C = S - 128 M starting from
         // cinit = -(that threshold - 128 M): the block's result is then >= 0 exactly for the survivors.
         int thr = INT_MIN;
-        if (k >= d.np) thr = INT_MAX;
+        if (k >= npr) thr = INT_MAX;
         else if (FILTER && tile == 0 && A.excl && A.excl[q] == (uint16_t)(0x8000 | (pi - (int)q * a.nprobe))) thr = INT_MAX;   // emitted by the pre-pass
         else if (FILTER && tau != 0ull) {
             const float ts = key_score(tau);
@@ -152,10 +157,10 @@ __global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* 
     }
     // opt-in pair pruning (rsx_set_param "pq_prune"): no query of the group can produce a survivor here -> the scan skips
     // the item (no table staging, no gathers).  Exact: the bound is on the very integer sums the scan would compute.
-    if (FILTER && A.prune && d.cinit[0] == -(1 << 30) && d.cinit[1] == -(1 << 30) && d.cinit[2] == -(1 << 30) && d.cinit[3] == -(1 << 30))
+    if (FILTER && A.prune && ngq == 1 && d.cinit[0] == -(1 << 30) && d.cinit[1] == -(1 << 30) && d.cinit[2] == -(1 << 30) && d.cinit[3] == -(1 << 30))
         d.l = -2;
     d.np |= fam;
-    items[item] = d;
+    items[rec] = d;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -466,24 +471,29 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         int r0 = join_on ? (int)__builtin_amdgcn_readfirstlane((int)lds_rd32_volatile(i0_a)) : 0;
         if (r0 >= R) r0 = 0;
         const int so_oob = nblk * BB;                                        // past the descriptor's end: reads zeros
-        // sequence number -> byte offset of the chunk's first block (so_oob: no such chunk), its row, and whether it is on the second pass
+        constexpr int BK_OOB = 0x3fffff00;                                   // "no such chunk" as a block index (any comparison against the tile's end fails)
+        const int bk_end = tb0 + 16 * bpw;                                   // first block past this tile
+        // Round 4: chunks are tracked as BLOCK indices (their byte offsets used to be divided by the block size again for every
+        // block — ~16 scalar instructions per block, and the counters say the loop issues ONE instruction per 4 clk and SIMD whatever
+        // its kind: SQ_INSTS_{VALU,LDS,SALU,VMEM} = 1.23e9 per 4.77e9 SIMD cycles, profiles/r03z_pmc_sq_counters.md)
+        // sequence number -> first block of the chunk (BK_OOB: no such chunk), its row, and whether it is on the second pass
         auto row_of = [&](int nseq, bool& wrapped) -> int {          // row of a valid sequence number, and whether it is on the second pass
             int r = nseq >> 4;
             if (r < R) { r += r0; wrapped = r >= R; if (wrapped) r -= R; } else { r = R; wrapped = r0 > 0; }
             return r;
         };
         auto chunk_of = [&](int nseq) -> int {
-            if (nseq >= nch) return so_oob;
+            if (nseq >= nch) return BK_OOB;
             bool wr_;
-            return (tb0 + (nseq & 15) + 16 * (row_of(nseq, wr_) * RD)) * BB;
+            return tb0 + (nseq & 15) + 16 * (row_of(nseq, wr_) * RD);
         };
         int nA = w, nB = 16 + w, nC = 0x7fffffff;
-        int soA = chunk_of(nA), soB = chunk_of(nB);
+        int bkA = chunk_of(nA), bkB = chunk_of(nB);
 #pragma unroll
         for (int dd = 0; dd < RD; dd++) {     // chunk A's blocks
             // (a chunk's RD blocks lie 16 apart in ONE column of the tile: with fewer than RD blocks per wave and tile — M = 16 at small
             //  tiles — the later ones would belong to the next tile, which another item scans)
-            const int so = (soA == so_oob || soA / BB - tb0 + 16 * dd >= 16 * bpw) ? so_oob : soA + dd * 16 * BB;
+            const int so = (bkA + 16 * dd >= bk_end) ? so_oob : (bkA + 16 * dd) * BB;
 #pragma unroll
             for (int p = 0; p < NL; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
             if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
@@ -497,8 +507,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             // the chunk after next: drawn now, needed at the end of this iteration
             if (nB + 16 < dyn_from) nC = nB + 16;
             else if (lane == 0) nC = (int)__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + chunk_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int b0 = soA / BB;                                         // first block of chunk A
-            const int so_next = soB;
+            const int b0 = bkA;                                              // first block of chunk A
+            const int bk_next = bkB;
             if (prio_rot) {
                 // the four waves of a SIMD (w, w + 4, w + 8, w + 12) take turns at the top issue priority, one loop iteration each
                 switch ((k + (w >> 2)) & 3) {
@@ -554,12 +564,35 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 {   // the slot's code registers are dead: refill them in place
-                    const int so = (so_next == so_oob || so_next / BB - tb0 + 16 * dd >= 16 * bpw) ? so_oob : so_next + dd * 16 * BB;
+                    const int so = (bk_next + 16 * dd >= bk_end) ? so_oob : (bk_next + 16 * dd) * BB;
 #pragma unroll
                     for (int p = 0; p < NL; p++) ca[dd][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16 + p * 1024, so, 0);
                     if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef RSX_MEASURE
+                // cost split (tools/ builds only): 16 = no table look-ups (the addresses stand in for the data), 32 = no MFMAs (one VALU
+                // add per quad instead), 64 = no address formation (the code words stand in for the addresses, masked into the table)
+                if (var & 64) {
+#pragma unroll
+                    for (int s = 0; s < NG; s++) gv[s] = (NF >= 1 || NQ ? ca[dd][0].x : cb[dd].x) & 0xfffcu;
+                }
+                if (!(var & 16)) {
+#pragma unroll
+                    for (int s = 0; s < NG; s++) gv[s] = lds_rd32(gv[s]);
+                }
+                v4i C = Ci;
+                if (var & 32) {
+#pragma unroll
+                    for (int t = 0; t < NG / 4; t++) C[t & 3] += (int)(gv[4 * t] ^ gv[4 * t + 1] ^ gv[4 * t + 2] ^ gv[4 * t + 3]) >> 31;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NG / 4; t++) {
+                        const v4i Av = {(int)gv[4 * t], (int)gv[4 * t + 1], (int)gv[4 * t + 2], (int)gv[4 * t + 3]};
+                        C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
+                    }
+                }
+#else
 #pragma unroll
                 for (int s = 0; s < NG; s++) gv[s] = lds_rd32(gv[s]);
                 v4i C = Ci;
@@ -568,6 +601,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                     const v4i Av = {(int)gv[4 * t], (int)gv[4 * t + 1], (int)gv[4 * t + 2], (int)gv[4 * t + 3]};
                     C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
                 }
+#endif
                 // C[r] (lanes n < 4) = cinit + sum over m of (u8 - 128) for vector 4 g + r of the block and query n
                 if (FILTER) {
                     if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0) && !(var & 1)) {
@@ -602,9 +636,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                     }
                 }
             }
-            nA = nB; soA = soB;
+            nA = nB; bkA = bkB;
             nB = __builtin_amdgcn_readfirstlane(nC);
-            soB = chunk_of(nB);
+            bkB = chunk_of(nB);
         }
         // ---- item epilogue: the wave's four run descriptors leave with one store (lanes 0..3 own queries 0..3): first key of the
         // run in the log pool, keys stored, bit 31 = the log was full and keys were dropped; wave 0 parks the next record (or the
@@ -632,13 +666,248 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// M = 16, filtered scan: SIXTEEN queries per pass over a list tile (round 4) — k_pq_scan_rot16.
+// The reference's shipped IVF-PQ point (ric/conf/ivf_pq.yaml:64-78: M 16, 8192 lists, 512 probes) has ~64 probing queries per
+// list and batch: sixteen 4-query groups, each of which re-read the list's codes in k_pq_scan_rot<0,0,true,1> — 27.7 GB through
+// the L2s per batch for 1.6 GB of codes, 6.7 TB/s at 4.1 ms: bound by that traffic, not by the CUs (two workgroups per CU changed
+// nothing: profiles/r04_scan_experiments.md).  Here a work item carries FOUR records = up to 16 queries (k_pq_rot_items, ngq = 4)
+// and every 64-vector code block is loaded once and looked up in four tables: a table row is 256 bytes and a 4-query group needs
+// 128 of them (its 16 entries twice: lane groups of even / odd g use one copy each), so a 64 KiB plane holds TWO groups — bytes
+// 0-127 map to banks 0-31, bytes 128-255 to banks 32-63, every gather stays conflict-free — and two planes (128 KiB) hold four.
+// Survivors, logs and run descriptors are per RECORD, exactly as k_pq_scan_rot leaves them: the compaction / gather kernels and
+// everything behind them are unchanged.  Simpler than the general kernel on purpose: static block columns, no circular join (a
+// list has 4 sibling items instead of 16), items drawn one ahead.
+// ---------------------------------------------------------------------------------------
+constexpr int R16_G = 4;
+__global__ __launch_bounds__(1024) void k_pq_scan_rot16(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ log_keys,
+                                                        uint2* __restrict__ seg_desc, uint32_t* xcd_ctr, int log_cap, int bpw) {
+    constexpr int M = 16, BB = 1024, RD = 4, G = R16_G;
+    constexpr int TAB = 2 * 65536;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) uint32_t rot16_s[];
+    uint8_t* sb = reinterpret_cast<uint8_t*>(rot16_s);
+    PQRotItem* islot = reinterpret_cast<PQRotItem*>(sb + TAB);                  // [2][G] current / next item's records
+    const PQScanArgs& a = A.b;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15, n = lane & 15, nq4 = n & 3;
+    // ---- items: XCD b % 8 owns a contiguous range of the list-major item order, its workgroups draw from one counter, an exhausted
+    // range steals from the next XCD's (as k_pq_scan_rot)
+    const int ti = *A.total_items;
+    const int per_xcd = (ti + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    int xlo = xcd * per_xcd;
+    int xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
+    if (xlo >= xhi) return;
+    uint32_t* ctr = xcd_ctr + xcd * 32;
+    int cx = xcd, hops = 0;
+    unsigned drawn = 0;
+    auto resolve_draw = [&]() -> int {
+        for (;;) {
+            const int i2 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+            if (i2 < xhi) return i2;
+            if (hops >= 7) return 0x7fffffff;
+            hops++;
+            cx = (cx + 1) & 7;
+            xlo = cx * per_xcd;
+            xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
+            ctr = xcd_ctr + cx * 32;
+            if (xlo >= xhi) { drawn = 0u; xlo = 0; xhi = 0; continue; }
+            if (lane == 0) drawn = atomicAdd(ctr, 1u);
+        }
+    };
+    // ---- per-lane constants: rotation bytes (lane (g, i) = vector 16 g + i reaches sub-quantiser (i + s) & 15 at step s, copy g & 1
+    // of the code's 16 entries), for the two row halves (+128) and the two planes (plane 1: three rotation bytes + the plane byte)
+    uint32_t R00[4], R01[4], R10[6], R11[6];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) v |= (uint32_t)(64 * (g & 1) + 4 * ((i + r * 4 + bb) & 15)) << (8 * bb);
+        R00[r] = v; R01[r] = v | 0x80808080u;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        uint32_t v = 0x01000000u;     // byte 3 = plane 1 -> address bit 16
+#pragma unroll
+        for (int bb = 0; bb < 3; bb++) { const int s2 = r * 3 + bb; if (s2 < 16) v |= (uint32_t)(64 * (g & 1) + 4 * ((i + s2) & 15)) << (8 * bb); }
+        R10[r] = v; R11[r] = v | 0x00808080u;
+    }
+    // B one-hot: column n = (vector group n >> 2, query n & 3) takes byte n & 3 of K group n >> 2
+    const int bsel = ((n >> 2) == g) ? (1 << (8 * (n & 3))) : 0;
+    const v4i Bm = {bsel, bsel, bsel, bsel};
+    const int vo16 = lane * 16;
+    const uint64_t QM = 0x1111111111111111ull << (n & 3);                // every lane with n & 3 == my query slot
+    const size_t mylog_0 = ((size_t)blockIdx.x * 16 + (size_t)w) * (4 * G) + (size_t)nq4;      // + 4 gq: the log of (record gq, slot nq4) of this wave
+    uint32_t lcur[G];
+#pragma unroll
+    for (int gq = 0; gq < G; gq++) lcur[gq] = 0u;
+    const auto load_records = [&](int it_) -> uint4 {       // lanes 0 .. 11 G - 1: the item's G records, 16 bytes per lane
+        uint4 r0 = make_uint4(0xffffffffu, 0, 0, 0);        // l = -1: end marker
+        if (lane < 11 * G && it_ != 0x7fffffff) r0 = reinterpret_cast<const uint4*>(&items[(size_t)it_ * G])[lane];
+        return r0;
+    };
+    int item = 0;
+    if (w == 0) {
+        if (lane == 0) drawn = atomicAdd(ctr, 1u);
+        item = resolve_draw();
+        const uint4 r0 = load_records(item);
+        if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
+        if (lane == 0) islot[0].pad0 = item;
+    }
+    int buf = 0;
+#pragma unroll 1
+    for (;; buf ^= 1) {
+        __syncthreads();    // #1: every wave has left the previous item's scan (tables free), the records are in LDS
+        const PQRotItem* it0 = &islot[buf * G];
+        const int item_l = __builtin_amdgcn_readfirstlane(it0->l);
+        if (item_l == -1) break;
+        item = __builtin_amdgcn_readfirstlane(it0->pad0);
+        const int64_t len = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it0->len >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it0->len);
+        const int64_t base_row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it0->base_row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it0->base_row);
+        const int nblk = (int)((len + 63) >> 6);
+        const int tb0 = __builtin_amdgcn_readfirstlane(it0->tile) * (16 * bpw);
+        int npg[G];
+#pragma unroll
+        for (int gq = 0; gq < G; gq++) npg[gq] = __builtin_amdgcn_readfirstlane(islot[buf * G + gq].np) & 15;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.codes + (base_row >> 6) * (int64_t)BB), 0, nblk * BB, 0x00020000);
+        const int so_oob = nblk * BB;
+        // my blocks: tb0 + w, tb0 + w + 16, ... inside the tile and the list
+        int bend = tb0 + 16 * bpw; if (bend > nblk) bend = nblk;
+        int nmine = (bend - (tb0 + w) + 15) >> 4; if (nmine < 0) nmine = 0;
+        // the first code blocks travel while the tables are staged
+        v4u ca[RD];
+#pragma unroll
+        for (int dd = 0; dd < RD; dd++) {
+            ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, dd < nmine ? (tb0 + w + 16 * dd) * BB : so_oob, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (w == 0 && lane == 0) drawn = atomicAdd(ctr, 1u);      // the next item's index: resolved after the staging
+        // ---- stage the tables, a plane (two groups) at a time: thread e -> (code e >> 4 + 64 pass, half (e >> 3) & 1, copy (e >> 2) & 1,
+        // four sub-quantisers e & 3): 16 consecutive lanes write the 16 different 16-byte bank slots of ONE row — no bank conflict
+        // (the 4-query form wrote 4 slots of every row: SQ_LDS_BANK_CONFLICT 4.5 % of the kernel's LDS cycles)
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            const int m4 = tid & 3, cp = (tid >> 2) & 1, hf = (tid >> 3) & 1;
+            const PQRotItem* itg = &islot[buf * G + 2 * pl + hf];
+            const int npq = itg->np & 15;
+            const int64_t q0 = itg->q[0], q1 = itg->q[1], q2 = itg->q[2], q3 = itg->q[3];
+            uint32_t in[4][4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) {
+                const int c = ps * 64 + (tid >> 4);
+                in[ps][0] = npq > 0 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q0 * 256 + c) * M + m4 * 4) : 0u;
+                in[ps][1] = npq > 1 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q1 * 256 + c) * M + m4 * 4) : 0u;
+                in[ps][2] = npq > 2 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q2 * 256 + c) * M + m4 * 4) : 0u;
+                in[ps][3] = npq > 3 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q3 * 256 + c) * M + m4 * 4) : 0u;
+            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) {
+                const int c = ps * 64 + (tid >> 4);
+                const uint32_t t0 = __builtin_amdgcn_perm(in[ps][1], in[ps][0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[ps][1], in[ps][0], 0x07030602u);
+                const uint32_t u0 = __builtin_amdgcn_perm(in[ps][3], in[ps][2], 0x05010400u), u1 = __builtin_amdgcn_perm(in[ps][3], in[ps][2], 0x07030602u);
+                uint4 o;
+                o.x = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
+                o.y = __builtin_amdgcn_perm(u0, t0, 0x07060302u) ^ 0x80808080u;
+                o.z = __builtin_amdgcn_perm(u1, t1, 0x05040100u) ^ 0x80808080u;
+                o.w = __builtin_amdgcn_perm(u1, t1, 0x07060302u) ^ 0x80808080u;
+                *reinterpret_cast<uint4*>(sb + pl * 65536 + c * 256 + hf * 128 + cp * 64 + m4 * 16) = o;
+            }
+        }
+        // ---- the next item's records: requested now (the draw has returned), parked after the scan
+        uint4 pre = make_uint4(0xffffffffu, 0, 0, 0);
+        int i1 = 0x7fffffff;
+        if (w == 0) { i1 = resolve_draw(); pre = load_records(i1); }
+        int cin[G];
+        uint32_t qstart[G];
+#pragma unroll
+        for (int gq = 0; gq < G; gq++) { cin[gq] = islot[buf * G + gq].cinit[nq4]; qstart[gq] = lcur[gq]; }
+        __syncthreads();    // #2: tables staged
+        // ---- scan: RD code blocks in flight per wave; a block's 16 bytes per lane become 16 look-ups in each live group's table
+#pragma unroll 1
+        for (int j = 0; j < nmine; j += RD) {
+#pragma unroll
+            for (int dd = 0; dd < RD; dd++) {
+                const int b = tb0 + w + 16 * (j + dd);
+                const uint32_t cw[4] = {ca[dd].x, ca[dd].y, ca[dd].z, ca[dd].w};
+                __builtin_amdgcn_sched_barrier(0);
+                ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, j + dd + RD < nmine ? (b + 16 * RD) * BB : so_oob, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + dd >= nmine) continue;          // wave-uniform
+#pragma unroll
+                for (int gq = 0; gq < G; gq++) {
+                    if (npg[gq] == 0) continue;          // wave-uniform: no query in this record
+                    uint32_t gv[16];
+                    if (gq < 2) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 16; s2++)
+                            gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], gq == 0 ? R00[s2 >> 2] : R01[s2 >> 2], 0x0c0c0000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 & 3));
+                    } else {
+#pragma unroll
+                        for (int s2 = 0; s2 < 16; s2++)
+                            gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], gq == 2 ? R10[s2 / 3] : R11[s2 / 3], 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; s2++) gv[s2] = lds_rd32(gv[s2]);
+                    const int cinit = cin[gq];
+                    v4i C = {cinit, cinit, cinit, cinit};
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const v4i Av = {(int)gv[4 * t], (int)gv[4 * t + 1], (int)gv[4 * t + 2], (int)gv[4 * t + 3]};
+                        C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
+                    }
+                    // C[r] = cinit + sum over m of (u8 - 128) for vector 16 (n >> 2) + 4 g + r of the block and query n & 3 of record gq
+                    if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0)) {
+                        const PQRotItem* itg = &islot[buf * G + gq];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const bool cnd = C[r] >= 0;
+                            if (__builtin_amdgcn_ballot_w64(cnd)) {
+                                const float p_dis0 = itg->dis0[nq4], p_scale = itg->scale[nq4], p_bias = itg->bias[nq4];
+                                const int64_t p_off = itg->off[nq4];
+                                const uint64_t p_tau = itg->tau[nq4];
+                                const int64_t pos = ((int64_t)b << 6) + 16 * (n >> 2) + 4 * g + r;
+                                const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(C[r] - cinit + 128 * M), p_bias);
+                                const uint64_t key = (cnd && pos < len) ? make_key(sc, (uint32_t)p_off + (uint32_t)pos) : 0ull;
+                                const bool pass = key > p_tau;
+                                const uint64_t mq = __builtin_amdgcn_ballot_w64(pass) & QM;      // this step's survivors of MY query
+                                if (pass) {
+                                    const uint32_t slot = lcur[gq] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                                    if (slot < (uint32_t)log_cap) log_keys[(mylog_0 + 4 * gq) * (size_t)log_cap + slot] = key;   // beyond: counted, dropped -> exact re-run
+                                }
+                                lcur[gq] += (uint32_t)__builtin_popcountll(mq);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- item epilogue: the wave's 4 G run descriptors (lane 4 gq + k owns record gq, query slot k; its lcur / qstart are those
+        // of its own n & 3 = k), then wave 0 parks the next item's records
+        if (lane < 4 * G) {
+            const int gq = lane >> 2;
+            uint32_t l1 = lcur[0], l0 = qstart[0];
+#pragma unroll
+            for (int x = 1; x < G; x++) if (gq == x) { l1 = lcur[x]; l0 = qstart[x]; }
+            const uint32_t c0 = l0 < (uint32_t)log_cap ? l0 : (uint32_t)log_cap, c1 = l1 < (uint32_t)log_cap ? l1 : (uint32_t)log_cap;
+            seg_desc[(((size_t)item * G + gq) * 16 + w) * 4 + (lane & 3)] =
+                make_uint2((uint32_t)((mylog_0 - nq4 + lane) * (size_t)log_cap) + c0, (c1 - c0) | (l1 > (uint32_t)log_cap ? 0x80000000u : 0u));
+        }
+        if (w == 0) {
+            if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[(buf ^ 1) * G])[lane] = pre;
+            if (lane == 0) islot[(buf ^ 1) * G].pad0 = i1;
+        }
+    }
+}
+
 // One wave per work item: append the item's (wave, query) survivor segments to the candidate rows of its queries — the only
 // atomics of the filtered scan live here, one reservation per (item, query), in a kernel with thousands of independent waves.
-__global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem* __restrict__ items, const int32_t* total_items,
+__global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem* __restrict__ items, const int32_t* total_items, int ngq,
                                                        const uint64_t* __restrict__ log_keys, const uint2* __restrict__ seg_desc,
                                                        uint64_t* cand, unsigned long long* cand_cnt, int cand_cap) {
-    const int item = blockIdx.x * ROT_CW + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (item >= *total_items) return;
+    const int item = blockIdx.x * ROT_CW + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;     // item = RECORD here (ngq records per work item)
+    if (item >= *total_items * ngq) return;
     const int w = lane >> 2, k = lane & 3;
     const uint2 dsc = seg_desc[(size_t)item * 64 + lane];                  // lane = (wave, query) run of the item
     const uint32_t c = dsc.y & 0x7fffffffu;
@@ -727,7 +996,7 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, A.max_items);
     uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, A.max_items, log_cap, nwg);
     uint32_t* prog = xcd_ctr + 256;
-    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog);
+    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, 1);
     static const int var = measure_env("RSX_ROT_VARIANT", 0);
     // one persistent workgroup per CU; never more than the work items
     int64_t grid = nwg;
@@ -735,7 +1004,35 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER, NQ>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, prog,
                        log_cap, bpw, A.pace, var);
     if (FILTER && !A.qitems)     // with qitems the runs are consumed in place by k_pq_gather_select
-        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, log_keys, seg_desc,
+        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, 1, log_keys, seg_desc,
+                           A.cand, A.cand_cnt, A.cand_cap);
+    return 0;
+}
+
+// M = 16, filtered: sixteen queries per work item (k_pq_scan_rot16); A.max_items counts WORK ITEMS, the workspace holds R16_G records each
+int pq_scan_rot_ngq(int M, bool filtered) { return (M == 16 && filtered) ? R16_G : 1; }
+static int launch_pq_scan_rot16(const PQScan8Args& A, int bpw, void* desc_ws, int log_cap, hipStream_t st) {
+    constexpr int G = R16_G;
+    const size_t shm = (size_t)2 * 65536 + (size_t)2 * G * 176 + 64;
+    static DevOnce once;
+    static std::atomic<int> failed{0};
+    once.once([&] {
+        if (hipFuncSetAttribute((const void*)k_pq_scan_rot16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) failed = 1;
+    });
+    if (failed) return -1;
+    const int nwg = pq_scan_rot_max_wgs(16);
+    const int64_t recs = (int64_t)A.max_items * G;
+    PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
+    uint2* seg_desc = pq_scan_rot_ws_desc(desc_ws, recs);
+    uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, recs);
+    uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
+    uint32_t* prog = xcd_ctr + 256;
+    hipLaunchKernelGGL((k_pq_rot_items<16, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
+    int64_t grid = nwg;
+    if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
+    hipLaunchKernelGGL(k_pq_scan_rot16, dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, bpw);
+    if (!A.qitems)
+        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((recs + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, G, log_keys, seg_desc,
                            A.cand, A.cand_cnt, A.cand_cap);
     return 0;
 }
@@ -758,7 +1055,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
     switch (a.M) {
-        case 16: return f ? launch_pq_scan_rot_t<0, 0, true, 1>(A, vpl, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, log_cap, st);   // 64-vector blocks
+        case 16: return f ? launch_pq_scan_rot16(A, vpl, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, log_cap, st);   // 64-vector blocks
         case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, log_cap, st);
         case 64: return f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, log_cap, st);
         case 96: return f ? launch_pq_scan_rot_t<1, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 1, false>(A, bpw, item_ws, log_cap, st);

@@ -1186,20 +1186,21 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                            h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st, side_lut ? 2 : 0);
             tm.mark("lut8");
             int rot_log_cap = 64;
-            auto rot_desc = [&](int64_t items) -> void* {   // work-item records + run descriptors + survivor logs of the rotated-layout scan
+            auto rot_desc = [&](int64_t items, int ngq) -> void* {   // work-item records + run descriptors + survivor logs of the rotated-layout scan
                 // the log pool = (persistent workgroups x 64 logs x log_cap keys): 1 / 2 / 4 GiB by k, never more than a quarter of the
                 // temp budget.  A log that fills up only sends the queries of its later runs to the exact re-run (counted); the pool is
                 // touched where survivors land, so its size costs nothing per batch; reported by rsx_get "workspace_bytes"
-                const int nwg = pq_scan_rot_max_wgs(h->M);
+                const int nwg = pq_scan_rot_max_wgs(h->M) * ngq;
                 int64_t pool = (int64_t)(k <= 64 ? 1 : k <= 512 ? 2 : 4) << 30;
                 pool = std::min(pool, std::max<int64_t>(h->temp_budget / 4, (int64_t)64 << 20));
                 int64_t cap = pool / 8 / ((int64_t)nwg * 64);
                 cap = std::max<int64_t>(64, cap / 16 * 16);
                 if (h->pq_log_cap > 0) cap = h->pq_log_cap;            // tests starve the logs to force the overflow path
                 rot_log_cap = (int)std::min<int64_t>(cap, (int64_t)1 << 24);
-                h->w_itemdesc.ensure(pq_scan_rot_ws(items, rot_log_cap, nwg));
+                h->w_itemdesc.ensure(pq_scan_rot_ws(items * ngq, rot_log_cap, nwg));
                 return h->w_itemdesc.p;
             };
+            const int ngq = rot ? pq_scan_rot_ngq(h->M, true) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             // rotated layout: persistent workgroups draw items dynamically, so the tile is the whole (average) list — one table
             // staging per (list, query group) — as long as that leaves a few thousand items to balance over 256 CUs
@@ -1286,7 +1287,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 }
                 if (side_lut) {       // the (list, tile, group) work items of the scan: built beside the pre-pass (they need the probes only)
                     HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_probe, 0));
-                    launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
+                    launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4 * ngq, cnt, cursor, pair_off, group_off, total_groups,
                                        pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                        h->st2);
                     HIPCHECK(hipEventRecord(h->ev_group, h->st2));
@@ -1313,7 +1314,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                    filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
                 tm.mark("group");
                 const int64_t mi = filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows);
-                void* rws0 = rot ? rot_desc(mi) : nullptr;
+                void* rws0 = rot ? rot_desc(mi, 1) : nullptr;
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
                                                  nullptr, 0, nullptr, nullptr, 0, rws0, rot_log_cap, 0, 0, nullptr, nullptr, 0, h->st)
@@ -1337,11 +1338,12 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // (the selection wrote only the K'-th key of each query and reset the query's candidate counter)
                 tm.mark("select0");
                 if (grouped_early) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_group, 0));
-                else launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
+                else launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4 * ngq, cnt, cursor, pair_off, group_off, total_groups,
                                         pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                         h->st);
                 tm.mark("group");
-                void* rws1 = rot ? rot_desc(max_scan_items(h, nq, nprobe, 4, tile_rows)) : nullptr;
+                const int64_t mi_main = max_scan_items(h, nq, nprobe, 4 * ngq, tile_rows);
+                void* rws1 = rot ? rot_desc(mi_main, ngq) : nullptr;
                 // threshold keys: one per query from the one-launch pre-pass, else the K'-th key the selection left in the state rows
                 const uint64_t* tau_ptr = fused_pre ? h->w_tau.as<uint64_t>() : state + (KP - 1);
                 const int64_t tau_stride = fused_pre ? 1 : KP;
@@ -1352,14 +1354,13 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     h->w_qitems.ensure((size_t)nq * nprobe * gs_tmax * 4);
                     gs.probe_list = h->w_probelist.as<int32_t>(); gs.list_len = h->d_len.as<int64_t>(); gs.nprobe = nprobe;
                     gs.tile_rows = tile_rows; gs.tmax = gs_tmax; gs.qitems = h->w_qitems.as<int32_t>();
-                    const int64_t mi = max_scan_items(h, nq, nprobe, 4, tile_rows);
-                    gs.seg_desc = pq_scan_rot_ws_desc(rws1, mi); gs.log_keys = pq_scan_rot_ws_keys(rws1, mi);
+                    gs.seg_desc = pq_scan_rot_ws_desc(rws1, mi_main * ngq); gs.log_keys = pq_scan_rot_ws_keys(rws1, mi_main * ngq);
                     gs.cand = h->w_cand.as<uint64_t>(); gs.cand_cnt = h->w_candcnt.as<unsigned long long>(); gs.cand_cap = cand_cap;
                     gs.state = state; gs.KP = KP;
                 }
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist,
-                                                 max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,
+                                                 mi_main, vpl, tau_ptr, tau_stride,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
                                                  rws1, rot_log_cap, h->pq_prune, h->pq_pace, (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
                                                  use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st)
