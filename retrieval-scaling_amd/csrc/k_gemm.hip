@@ -843,8 +843,8 @@ __global__ __launch_bounds__(64 * NW) void k_list_scan2(ListScanArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* ring = ls_smem + NQG * qstride + 24 * NQG + w * (D * 2048);
-    const int g = blockIdx.x;
-    const int chunk = blockIdx.y;
+    int g = blockIdx.x;
+    int chunk = blockIdx.y;
 
     int64_t base, len;
     int np;
@@ -854,11 +854,17 @@ __global__ __launch_bounds__(64 * NW) void k_list_scan2(ListScanArgs a) {
         np = a.nq - NQG * g; if (np > NQG) np = NQG;
         if (np <= 0) return;
     } else {
-        if (g >= *a.total_groups) return;
-        int lo = 0, hi = a.nlist;  // largest l with group_off[l] <= g
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.group_off[mid] <= g) lo = mid; else hi = mid; }
-        const int l = lo;
-        int gi = g - a.group_off[l];
+        int l, gi;
+        if (a.item_off) {           // 1-D grid over (list, chunk, group) items: the groups of a list chunk share an XCD and a moment
+            if (!pq_decode_item(a.item_off, a.group_off, *a.total_items, a.nlist, l, gi, chunk)) return;
+            g = a.group_off[l] + gi;
+        } else {
+            if (g >= *a.total_groups) return;
+            int lo = 0, hi = a.nlist;  // largest l with group_off[l] <= g
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.group_off[mid] <= g) lo = mid; else hi = mid; }
+            l = lo;
+            gi = g - a.group_off[l];
+        }
         int cnt = a.pair_off[l + 1] - a.pair_off[l];
         np = cnt - NQG * gi; if (np > NQG) np = NQG;
         pair0 = a.pair_off[l] + NQG * gi;
@@ -1045,6 +1051,7 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
     const int base_rows = list_scan2_chunk_rows(a.x_f16, a.ld);
     if (base_rows > 0 && (a.chunk_rows == base_rows || (a.qtiles == 4 && a.chunk_rows == 2 * base_rows))) {
+        if (a.item_off && !a.flat_mode && a.max_items > 0) grid = dim3((unsigned)((a.max_items + 7) & ~7), 1);   // XCD-aware item order
         // the grouping was made for 16 x qtiles queries per group: qtiles is binding (a smaller kernel would misread the groups)
         const int qt = (a.qtiles == 2 || a.qtiles == 4) && !a.flat_mode ? a.qtiles : 1;
         const bool wide = qt == 4 && a.chunk_rows == 2 * base_rows;        // 8 waves x 3 stages, 1024 rows per work item

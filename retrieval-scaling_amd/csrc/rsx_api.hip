@@ -1424,13 +1424,15 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     } else {
         // group (query, probe) pairs by list, then list-major MFMA scan
         int64_t npairs = nq * nprobe;
-        h->w_pairs.ensure((size_t)(npairs + 4 * (size_t)(nlist + 1) + 4) * 4);
+        h->w_pairs.ensure((size_t)(npairs + 5 * (size_t)(nlist + 1) + 8) * 4);
         int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
         int32_t* cnt = pairs_sorted + npairs;
         int32_t* cursor = cnt + (nlist + 1);
         int32_t* pair_off = cursor + (nlist + 1);
         int32_t* group_off = pair_off + (nlist + 1);
-        int32_t* total_groups = group_off + (nlist + 1);
+        int32_t* item_off = group_off + (nlist + 1);
+        int32_t* total_groups = item_off + (nlist + 1);
+        int32_t* total_items = total_groups + 1;
         // query tiles per group of the LDS-DMA list scan: with ~64 probing queries per list (nlist 2048 / nprobe 128) groups of 16 read
         // every list four times; 32 / 64 queries per group read it twice / once (k_list_scan2<_, QT>)
         int ls_qt = 1;
@@ -1440,8 +1442,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             ls_qt = std::min(ls_qt == 3 ? 2 : ls_qt, list_scan2_max_qtiles(ld));
             if (ls_qt != 2 && ls_qt != 4) ls_qt = 1;
         }
+        // (list, chunk, group) work items in list-major order for the LDS-DMA scan's XCD-aware 1-D grid (round 4): the groups of a
+        // list chunk run on one XCD at the same moment and its rows cross HBM once — at nlist 2048 / nprobe 128 half of the lists
+        // are probed by more than 64 queries, i.e. by two groups, which used to land on different XCDs (two fetches)
+        const int ls2_rows = list_scan2_chunk_rows(h->storage_f16, ld);
+        const int item_rows = (h->scan_chunk <= 0 && ls2_rows > 0) ? (ls_qt == 4 ? 2 * ls2_rows : ls2_rows) : 0;
         launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,
-                           pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, 0, h->st);
+                           pairs_sorted, item_rows ? h->d_len.as<int64_t>() : nullptr, item_rows, item_rows ? item_off : nullptr,
+                           item_rows ? total_items : nullptr, nprobe, 0, nprobe, 0, h->st);
         tm.mark("group");
         const float* bias = nullptr;
         if (h->metric == RSX_METRIC_L2) { bias = h->w_misc.as<float>(); }
@@ -1484,11 +1492,13 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                         h->w_candcnt.as<unsigned long long>());
             tm.mark("select0");
             launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, nprobe, 0, h->st);
+                               pairs_sorted, item_rows ? h->d_len.as<int64_t>() : nullptr, item_rows, item_rows ? item_off : nullptr,
+                               item_rows ? total_items : nullptr, nprobe, 0, nprobe, 0, h->st);
             tm.mark("group");
             a.qtiles = ls_qt;
             if (ls_qt == 4) { chunk_rows *= 2; a.chunk_rows = (int)chunk_rows; }      // 64-query groups: 8 waves, 1024 rows per work item
             a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
+            if (item_rows == (int)chunk_rows) { a.item_off = item_off; a.total_items = total_items; a.max_items = (int)max_scan_items(h, nq, nprobe, 16 * ls_qt, item_rows); }
             a.tau_key = state + (KP - 1); a.tau_stride = KP;
             a.cand = h->w_cand.as<uint64_t>(); a.cand_cnt = h->w_candcnt.as<unsigned long long>(); a.cand_cap = cand_cap;
             launch_list_scan(a, h->st);
@@ -1504,6 +1514,9 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             if (a.qtiles == 4 && a.chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld)) {     // 64-query groups: 8 waves, 1024 rows per work item
                 a.chunk_rows *= 2;
                 a.max_chunks = (int)std::max<int64_t>(1, (maxlen + a.chunk_rows - 1) / a.chunk_rows);
+            }
+            if (!want_filter && item_rows > 0 && item_rows == a.chunk_rows) {     // (after a filtered attempt the grouping in place is the filtered scan's: same items)
+                a.item_off = item_off; a.total_items = total_items; a.max_items = (int)max_scan_items(h, nq, nprobe, 16 * ls_qt, item_rows);
             }
             launch_list_scan(a, h->st);
             tm.mark("scan");

@@ -201,6 +201,11 @@ struct ListScanArgs {
     // filtered output (k_list_scan2 only; tau_key != null): keys > tau_key[q * tau_stride] are appended to
     // cand[q][0..cand_cap) (count in cand_cnt[q]) instead of storing every score
     const uint64_t* tau_key; int64_t tau_stride; uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
+    // k_list_scan2, optional (round 4): a 1-D grid over the (list, chunk, group) work items in list-major order, decoded XCD-aware
+    // (pq_decode_item below) — the query groups of one list chunk then run on ONE XCD at the same time and the chunk's rows are
+    // fetched from HBM once (with the 2-D grid the groups of a list landed on different XCDs: one fetch per group).  item_off /
+    // total_items from launch_group_pairs(tile_rows = chunk_rows); max_items = the grid.
+    const int32_t* item_off; const int32_t* total_items; int max_items;
 };
 int list_scan2_chunk_rows(int x_f16, int ld);   // work-item rows of the LDS-DMA list scan, 0 if it does not apply
 int list_scan2_max_qtiles(int ld);              // ... and the 16-query tiles per group its LDS holds

@@ -1,6 +1,6 @@
 #!/bin/bash
 # ONE parameterised GPU-box session script (replaces the per-experiment tools/stage_*.sh of rounds 1-3).
-# Usage: [TAG=r04a] [PYTEST_ARGS=...] tools/gpu_round.sh stage [stage ...]      (everything lands in gpurun_out/)
+# Usage: [TAG=r04a] [PYTEST_ARGS=...] [PYTEST_K='expr with spaces'] tools/gpu_round.sh stage [stage ...]      (everything lands in gpurun_out/)
 #   env        box facts (GPU, cores, RAM, import faiss)
 #   tests      pytest -m gpu (stop at first failure; PYTEST_ARGS narrows it)     tests_all: without -x
 #   smoke      __graft_entry__.smoke()
@@ -27,10 +27,10 @@ for s in "$@"; do
     env)
       { rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; nproc; free -g | head -2; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; python -c "import faiss" 2>&1 | tail -1; } > $O/${TAG}_gpu_box_env.txt 2>&1 ;;
     tests)
-      timeout 1700 python -m pytest tests -q -m gpu -x --timeout 600 -p no:cacheprovider ${PYTEST_ARGS:-} > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $O/${TAG}_pytest_gpu.txt
+      timeout 1700 python -m pytest tests -q -m gpu -x --timeout 600 -p no:cacheprovider ${PYTEST_ARGS:-} ${PYTEST_K:+-k "$PYTEST_K"} > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $O/${TAG}_pytest_gpu.txt
       tail -n 15 $O/${TAG}_pytest_gpu.txt | cut -c1-220 ;;
     tests_all)
-      timeout 1700 python -m pytest tests -q -m gpu --timeout 600 -p no:cacheprovider ${PYTEST_ARGS:-} > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $O/${TAG}_pytest_gpu.txt
+      timeout 1700 python -m pytest tests -q -m gpu --timeout 600 -p no:cacheprovider ${PYTEST_ARGS:-} ${PYTEST_K:+-k "$PYTEST_K"} > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $O/${TAG}_pytest_gpu.txt
       tail -n 15 $O/${TAG}_pytest_gpu.txt | cut -c1-220 ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; echo "smoke exit $?" >> $O/${TAG}_smoke.log ;;
