@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64 * NW) void k_list_scan2(ListScanArgs a) {
             else {
                 int pidx = a.pairs_sorted[pair0 + tid];
                 int64_t q = pidx / a.nprobe; int j = pidx % a.nprobe;
-                off = q * a.tstride + a.seg_start[q * (a.nprobe + 1) + j];
+                off = q * a.tstride + ((!FILTER && a.pre_stride) ? (int64_t)j * a.pre_stride : a.seg_start[q * (a.nprobe + 1) + j]);
             }
         }
         segoff[tid] = off;

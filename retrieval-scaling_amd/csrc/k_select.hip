@@ -659,7 +659,9 @@ static bool select_radix_applies(const SelectArgs& a) {
     // ... unless only a few rows are in flight (latency path): 256 threads per row instead of one wave
     // ... or many keys are kept (nprobe 512 of 8192 lists: one wave re-sorted its 1024-key buffer for 1.07 ms per 1024 rows)
     return !off && (a.keep_last || a.in_is_keys || a.nrows <= 16 || a.KP >= 256) && a.nseg == 1 && a.seg_base == 0 && !a.tau_ptr && a.n_uniform > 0 &&
-           (a.n_uniform <= 16384 || (a.in_is_keys && a.row_n && a.n_uniform <= 131072)) && a.KP <= 4096;
+           (a.n_uniform <= 16384 || (a.in_is_keys && a.row_n && a.n_uniform <= 131072) || (a.KP >= 1024 && a.n_uniform <= 131072)) && a.KP <= 4096;
+    // (K' >= 1024: one wave per 32 k-score segment re-sorts a 4096-key buffer over and over — 3 ms per 1024 x 65536 scores; the radix walk
+    //  reads the row eight times from L2 instead)
 }
 
 void launch_select(const SelectArgs& a, hipStream_t st) {
@@ -1570,6 +1572,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
     if (a.rank_sort) shm = base20 + (size_t)a.KP * 12 + 16;       // the second copy shares the table-entry region (used earlier)
     if (a.par_entries) { shm = std::max(shm, par_shm); waves = 16; }
     else if (a.kind != KIND_IVFPQ && a.nq <= 64) waves = std::min(16, std::max(waves, a.KP / 4));   // one wave per candidate re-score
+    else if (a.KP >= 1024) waves = 16;     // the reference's n_docs = 1000: 2048 candidates per query to re-score and sort (4 waves: 3.2 ms per 1024 queries)
     static DevSize big;
     if (shm > 48 * 1024) big.grow(shm, [&] { hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)a.nq), dim3(64 * waves), shm, st, a);

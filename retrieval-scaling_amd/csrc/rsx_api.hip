@@ -789,6 +789,7 @@ static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, c
                         bool merge_state, unsigned long long* threshold_only_cnt = nullptr) {
     int64_t seg_len = std::max<int64_t>(4096, (int64_t)8 * BUF);
     seg_len = round_up(seg_len, 256);
+    if (KP >= 1024 && n_max <= 131072) seg_len = round_up(n_max, 256);     // one segment: the radix selection (launch_select)
     int nseg = (int)std::max<int64_t>(1, (n_max + seg_len - 1) / seg_len);
     SelectArgs a{};
     a.in = scores; a.in_is_keys = 0; a.row_stride = row_stride;
@@ -1062,13 +1063,18 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                  h->w_temp.as<float>(), CH, h->st);
                 select_rows(h, h->w_temp.as<float>(), CH, nullptr, 0, nv, (uint32_t)v0, nq, KP, BUF, KP, state, true);
             };
-            chunk_pass(0);
-            done_rows = std::min<int64_t>(CH, N);
+            // threshold phase: the K'-th key of the first rows is a FIXED threshold for everything behind them, so the filtered pass
+            // keeps ~N K' / rows-so-far keys per query.  One 65536-row chunk is right for k = 10 (K' = 32: 5 k keys at 10M rows);
+            // for the reference's n_docs = 1000 (K' = 2048) it let 310 k keys through, overflowed every candidate row and fell back
+            // to 153 chunk passes — 550 ms per batch (round 4: measured once k = 1000 joined the bench).  Now 320 K' rows.
+            const int64_t n0 = std::min<int64_t>((N + CH - 1) / CH, std::max<int64_t>(1, ((int64_t)KP * 320 + CH - 1) / CH));
+            for (int64_t c = 0; c < n0; c++) chunk_pass(c * CH);
+            done_rows = std::min<int64_t>(n0 * CH, N);
             tm.mark("scan0");
             bool filtered_ok = true;
             if (done_rows < N && h->flat_filter != 0) {
                 // the rest in ONE GEMM launch whose epilogue keeps only keys beating the running K'-th key
-                const int cap = 32768;
+                const int cap = KP <= 64 ? 32768 : 131072;
                 h->w_cand.ensure((size_t)nq * cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8 * CCS);
                 HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8 * CCS, h->st));
@@ -1474,21 +1480,38 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         // (never seen at the bench sizes) falls back to the score-buffer path, so the result is always exact.
         // (ivf_filter: 1 = when the score rows would exceed ~2 GB — below that the second grouping pass and the
         //  count read-back cost more than the row traffic they save; 2 = always; 0 = never)
+        // (round 4: for large k the pre-pass scores the first 4 K' rows of the closest list — up to 32 chunks — instead of giving up
+        //  the filter when K' no longer fits one chunk: k = 1000 at nlist 2048 / nprobe 128 wrote and re-read 10 GB of score rows)
+        const int64_t pre_chunks = std::max<int64_t>(1, ((int64_t)KP * 4 + chunk_rows - 1) / chunk_rows);
         bool want_filter = h->ivf_filter != 0 && nprobe > 1 && chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld) &&
-                           (int64_t)KP * 4 <= chunk_rows && (h->ivf_filter > 1 || nq * tmax >= (int64_t)500000000);
+                           pre_chunks <= 32 && (h->ivf_filter > 1 || nq * tmax >= (int64_t)500000000);
         if (want_filter) {
-            a.max_chunks = 1;                                      // the first chunk of ...
+            // ... of the closest list — of the EIGHT closest lists when K' is large: a query whose closest list holds fewer than K'
+            // rows would get no threshold, keep every row of its 128 lists and overflow (the prefix of its score row then runs on
+            // into the next lists' first rows)
+            const int pre_lists = (KP >= 256 && (int64_t)8 * pre_chunks * chunk_rows <= tmax) ? std::min(8, nprobe) : 1;
+            a.max_chunks = (int)pre_chunks;                        // the first chunk(s) of ...
             a.qtiles = 1;                                          // (groups of 16 there: most lists are the closest of at most a few queries)
+            const int64_t pre_stride = pre_lists > 1 ? pre_chunks * chunk_rows : 0;    // several lists: one slice of the sample buffer each
+            if (pre_stride) {
+                a.pre_stride = pre_stride; a.tstride = pre_lists * pre_stride;
+                launch_fill_f32(h->w_temp.as<float>(), nq * a.tstride, -INFINITY, h->st);
+            }
             launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, 1, 0, h->st);   // ... the closest list only
+                               pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, pre_lists, 0, h->st);   // ... the closest list(s) only
             launch_list_scan(a, h->st);
             tm.mark("scan0");
-            cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), 16384);
+            cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 512 ? 131072 : (k > 64 ? 65536 : 16384));
             h->w_cand.ensure((size_t)nq * cand_cap * 8);
             h->w_candcnt.ensure((size_t)nq * 8 * CCS);
             // the pre-pass is only a threshold (see the IVF-PQ path): the K'-th key, candidate counters reset
+            if (pre_stride) {
+                select_rows(h, h->w_temp.as<float>(), a.tstride, nullptr, 0, a.tstride, 0, nq, KP, BUF, KP, state, false,
+                            h->w_candcnt.as<unsigned long long>());
+                a.pre_stride = 0; a.tstride = tmax;
+            } else
             select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
-                        std::min<int64_t>(maxlen, chunk_rows), 0, nq, KP, BUF, KP, state, false,
+                        std::min<int64_t>(maxlen, pre_chunks * chunk_rows), 0, nq, KP, BUF, KP, state, false,
                         h->w_candcnt.as<unsigned long long>());
             tm.mark("select0");
             launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,

@@ -206,6 +206,9 @@ struct ListScanArgs {
     // fetched from HBM once (with the 2-D grid the groups of a list landed on different XCDs: one fetch per group).  item_off /
     // total_items from launch_group_pairs(tile_rows = chunk_rows); max_items = the grid.
     const int32_t* item_off; const int32_t* total_items; int max_items;
+    // unfiltered k_list_scan2, optional: the scores of (query q, probe rank j) go to temp[q * tstride + j * pre_stride + row] instead of
+    // the query's concatenated row (threshold pre-pass over the first rows of several lists: every list gets its own slice)
+    int64_t pre_stride;
 };
 int list_scan2_chunk_rows(int x_f16, int ld);   // work-item rows of the LDS-DMA list scan, 0 if it does not apply
 int list_scan2_max_qtiles(int ld);              // ... and the 16-query tiles per group its LDS holds
