@@ -1126,28 +1126,32 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         __syncthreads();
     }
     if (a.kind != KIND_IVFPQ) {
+        // one wave per candidate, lanes over the dimensions; FOUR candidates per wave in flight (round 4: at the reference's n_docs =
+        // 1000 a query re-scores 2048 rows of 1.5 KB that sit anywhere in HBM — one row at a time per wave was 3.2 ms per 1024 queries)
         const float* qv = a.Q32 + q * a.ldq;
-        for (int c = wv; c < KP; c += nwv) {   // one wave per candidate, lanes over the dimensions
-            int64_t row = srow[c];
-            if (row < 0) continue;  // wave-uniform (LDS value)
-            double acc = 0.0;
-            if (a.x_f16) {
-                const __half* xv = (const __half*)a.X + row * a.ld;
-                for (int t = lane; t < a.d; t += 64) {
-                    double qd = (double)qv[t], xd = (double)__half2float(xv[t]);
-                    if (a.metric == 0) acc += qd * xd; else { double df = qd - xd; acc += df * df; }
+        for (int c0 = 4 * wv; c0 < KP; c0 += 4 * nwv) {
+            int64_t rows[4]; double acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { rows[u] = c0 + u < KP ? srow[c0 + u] : -1; acc[u] = 0.0; }   // wave-uniform (LDS values)
+            for (int t = lane; t < a.d; t += 64) {
+                const double qd = (double)qv[t];
+                double xd[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    xd[u] = 0.0;
+                    if (rows[u] >= 0) xd[u] = a.x_f16 ? (double)__half2float(((const __half*)a.X)[rows[u] * a.ld + t]) : (double)((const float*)a.X)[rows[u] * a.ld + t];
                 }
-            } else {
-                const float* xv = (const float*)a.X + row * a.ld;
-                for (int t = lane; t < a.d; t += 64) {
-                    double qd = (double)qv[t], xd = (double)xv[t];
-                    if (a.metric == 0) acc += qd * xd; else { double df = qd - xd; acc += df * df; }
-                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { if (a.metric == 0) acc[u] += qd * xd[u]; else { const double df = qd - xd[u]; acc[u] += df * df; } }
             }
-            acc = wave_sum_f64(acc);
-            if (lane == 0) {
-                float s = (float)acc;
-                sord[c] = f2ord((a.metric == 0 ? s : 0.0f - s) + 0.0f);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (rows[u] < 0) continue;
+                const double sacc = wave_sum_f64(acc[u]);
+                if (lane == 0) {
+                    const float sc = (float)sacc;
+                    sord[c0 + u] = f2ord((a.metric == 0 ? sc : 0.0f - sc) + 0.0f);
+                }
             }
         }
         __syncthreads();
