@@ -605,3 +605,36 @@ def test_threshold_sample_spans_short_lists(gpu, orc, M):
         if nprobe == nlist:     # a threshold exists: far fewer survivors than the vectors of the probed lists
             assert ix.get_timing("cand_keys_max") < 0.5 * len(x), ix.get_timing("cand_keys_max")
     ix.set_param("profile", 0)
+
+
+@pytest.mark.parametrize("M,d", [(16, 768), (32, 256)])
+def test_ivfpq_bulk_ties_at_the_kth_score(gpu, orc, M, d):
+    """Round 4 (k_pq_final_tab): PQ ties come in bulk — vectors with identical codes in one list have bit-equal scores (at M = 16 whole
+    data clusters do on the bench mixture: up to 16 000 candidates at one score) — and the order among them is id ascending.  Here
+    3000 copies of one vector (scattered ids) straddle rank k: far more ties than the kernel's sort holds, so the tied candidates'
+    ids go through the second radix selection.  Every k must reproduce the oracle's ids and scores; M = 16 takes the
+    finalize-from-the-row path by default (dsub 48), M = 32 is forced onto it."""
+    nlist, n = 8, 12000
+    rng = np.random.RandomState(9)
+    x = orc.synth_vectors(d, nlist, 91, 92, 0.5, 0, n)
+    dup = rng.choice(n, 3000, replace=False)
+    x[dup] = x[dup[0]]
+    q = np.concatenate([x[dup[:1]], orc.synth_queries(d, nlist, 91, 92, 0.5, n, 93, 0.1, 0, 6)], 0)
+    x32, q32 = x.astype(np.float32), q.astype(np.float32)
+    cen = orc.kmeans(0, x32, nlist, 4, 1234)
+    a, _ = orc.assign_ip(cen, x32)
+    cb = orc.pq_train(orc.residuals(cen, x32, a)[:3000], M, 3, 1234)
+    lm = orc.ListMajor(a, np.arange(n), orc.pq_encode(cb, orc.residuals(cen, x32, a)), nlist)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    ix.set_centroids(cen); ix.set_codebooks(cb); ix.add(x)
+    ix.set_param("pq_final_tab", 2)
+    ix.nprobe = nlist
+    for k in (10, 100, 1000, 2500, 4096):
+        ix.set_param("profile", 1)
+        D, I = ix.search(q, k)
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, nlist, k)
+        assert np.array_equal(D, Dr), f"M={M} k={k} scores"
+        assert np.array_equal(I, Ir), f"M={M} k={k} ids (ties by id ascending)"
+        assert ix.get_timing("fallback_queries") == 0, f"M={M} k={k}: settled from the candidate row, not by the exact re-run"
+    ties = (Dr[0, 1:] == Dr[0, :-1]).sum()
+    assert ties > 2000, "the fixture must tie in bulk"
