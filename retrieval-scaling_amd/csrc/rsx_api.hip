@@ -196,6 +196,7 @@ struct rsx_index {
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
     int pq_final_tab = 1;    // rotated fast scan: finalize from the complete candidate row with the fp32 table in LDS (1 = when K' >= 512 or dsub > 8 and as the second chance, 2 = always, 0 = never)
     int pq_log_cap = 0;      // rotated fast scan: keys per survivor log (0 = from the pool budget); tests shrink it to force the overflow path
+    int pq_pre_mult = 160, pq_pre_max = 16384;   // ... and for larger k: pq_pre_mult x k rows, at most pq_pre_max (<= 32768: 64 KiB of 16-bit sums in LDS; 16384 measured best overall on the headline index at k = 100 / 1000 / 2000, profiles/r04u_pre_sweep.jsonl)
     int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
     int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
@@ -1263,7 +1264,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // the best total for a full batch, a few queries keep the cheaper 2048)
                 int64_t base_rows = h->pq_pre_rows > 0 ? h->pq_pre_rows : 2048;
                 if (nq <= 64) base_rows = std::min<int64_t>(base_rows, 2048);
-                int64_t want_rows = std::max<int64_t>(base_rows, std::min<int64_t>(32768, (int64_t)160 * k));
+                int64_t want_rows = std::max<int64_t>(base_rows, std::min<int64_t>(h->pq_pre_max, (int64_t)h->pq_pre_mult * k));
                 want_rows = std::min<int64_t>(round_up(want_rows, 64), round_up(std::max<int64_t>(maxlen, 64), 64));
                 // small k, full batch, rotated layout: the 4-queries-per-workgroup form (k_pq_prepass4) — its sample is what fits the LDS
                 // beside the four-query table image (3520 rows at M = 96)
@@ -2668,6 +2669,8 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_log_cap") h->pq_log_cap = std::max(0, (int)value);
+        else if (s == "pq_pre_mult") h->pq_pre_mult = std::max(1, (int)value);
+        else if (s == "pq_pre_max") h->pq_pre_max = std::min(32768, std::max(64, (int)value));
         else if (s == "pq_final_tab") h->pq_final_tab = (int)value;
         else if (s == "overlap") h->overlap = (int)value;
         else if (s == "pq_gather") h->pq_gather = (int)value;
