@@ -1208,6 +1208,10 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             if (!(a_last + eps < s_k)) bad = 1;
         }
         if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad |= 2;  // candidates were dropped (reason bit 1: overflow)
+        // second chance without a certificate (the K2 best of a complete, exactly scored row, selected by (score, INDEX)): when the
+        // selection was full and its last candidate ties with the k-th score, a lower-ID vector of the same score may have been cut
+        // (identical codes in one list tie exactly) -> the exact re-run settles the query
+        if (a.no_cert && last != 0 && sord[a.k - 1] != 0 && sord[KP - 1] == sord[a.k - 1]) bad |= 2;
         a.uncertain[q] = bad;
     }
     if (a.kind != KIND_IVFPQ && a.uncertain) {
