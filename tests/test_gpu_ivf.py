@@ -638,3 +638,26 @@ def test_ivfpq_bulk_ties_at_the_kth_score(gpu, orc, M, d):
         assert ix.get_timing("fallback_queries") == 0, f"M={M} k={k}: settled from the candidate row, not by the exact re-run"
     ties = (Dr[0, 1:] == Dr[0, :-1]).sum()
     assert ties > 2000, "the fixture must tie in bulk"
+
+
+@pytest.mark.parametrize("M,d", [(96, 768), (16, 768), (64, 256)])
+def test_round4_engine_knobs_never_change_a_result(gpu, orc, M, d):
+    """Round 4's alternatives behind engine parameters: one or two streams per search batch (overlap), finalize from the complete
+    candidate row or through the K' cut (pq_final_tab 0 / 1 / 2), the size of the large-k threshold sample (pq_pre_mult / pq_pre_max).
+    Every combination must return the bits of the exact kernel, for small and large k."""
+    n, nlist, nq = 60000, 16, 130
+    x = gpu.synth_vectors(d, 16, 1234, 10000, 0.5, 0, n)
+    q = gpu.synth_queries(d, 16, 1234, 10000, 0.5, n, 999, 0.1, 0, nq)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    ix.train(x[:20000]); ix.add(x); ix.nprobe = 8
+    for k in (10, 300):
+        ix.set_param("scan_kernel", 2)
+        De, Ie = ix.search(q, k)
+        ix.set_param("scan_kernel", 0)
+        for overlap in (1, 0):
+            for tab in (1, 2, 0):
+                for mult, mx in ((160, 16384), (8, 2048)):
+                    ix.set_param("overlap", overlap); ix.set_param("pq_final_tab", tab)
+                    ix.set_param("pq_pre_mult", mult); ix.set_param("pq_pre_max", mx)
+                    D, I = ix.search(q, k)
+                    assert_same_results(D, I, De, Ie, f"M={M} k={k} overlap={overlap} pq_final_tab={tab} sample={mult}x/{mx}")
