@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int 
 template <int DSUB>   // 8: two float4 loads per codeword; 0: generic dsub
 __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, const float* codebooks, int dsub, int M,
                                                   int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
-                                                  PQQParam* qp, int transposed) {
+                                                  PQQParam* qp, int transposed, float* lut32_out) {
     extern __shared__ float sm_lut8f[];
     float* T = sm_lut8f;                 // [Mpad][256]
     float* s_q = T + Mpad * 256;         // [M*dsub]
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
             for (int t = 0; t < dsub; t++) s = __fmaf_rn(qs[t], cw[t], s);
         }
         T[m * 256 + c] = s;
+        if (lut32_out) lut32_out[(q * Mpad + m) * 256 + c] = s;      // the fp32 table for k_pq_final_tab (round 4): M KiB per query
     }
     for (int m = M; m < Mpad; m++) T[m * 256 + c] = 0.0f;
     __syncthreads();
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
 #endif
 template <int PASS>
 __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq, const float* codebooks, int M, int Mpad,
-                                                      int64_t nq, float* mnmx, float* errb, uint8_t* lut8, int transposed) {
+                                                      int64_t nq, float* mnmx, float* errb, uint8_t* lut8, int transposed, float* lut32_out) {
     __shared__ float s_q[LT_QC * LT_MB * 8];     // the tile's query slices
     __shared__ float s_scale[2 * LT_QC];         // scale, 1 / scale
     __shared__ float s_mn[LT_QC * LT_MB];
@@ -530,6 +531,10 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
             } else {
                 const float mn = s_mn[qi * LT_MB + mi], scale = s_scale[qi], inv = s_scale[LT_QC + qi];
                 float err = 0.0f;
+                if (lut32_out && m < M) {         // the fp32 table for k_pq_final_tab (round 4): 256-byte runs per (query, m, j)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) lut32_out[(q * Mpad + m) * 256 + lane + 64 * j] = v[j];
+                }
                 // transposed ([q][code][m], the rotated-layout scans): bytes collect in LDS and leave as 8-byte runs of the
                 // tile's 8 sub-quantisers (a byte store per entry at stride M costs 0.1 ms per batch)
                 uint8_t* o = transposed ? lt_obuf + ((size_t)qi * 256 + lane) * LT_MB + mi : lut8 + (q * Mpad + m) * 256 + lane;
@@ -606,7 +611,7 @@ size_t pq_lut8_fused_lds(int M, int Mpad, int dsub) { return ((size_t)Mpad * 256
 
 void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
                     int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8, void* qparam, void* ws, int transposed,
-                    hipStream_t st, int phase) {
+                    hipStream_t st, int phase, float* lut32_out) {
     if (nq <= 0) return;
     if (phase != 0 && !(ws && dsub == 8 && !lut32)) return;     // only the tiled build splits into tables (1) + per-query parameters (2)
     if (lut32) {
@@ -623,8 +628,8 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
         static DevOnce once;
         if (osm) once.once([&] { hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm); });
         if (phase != 2) {
-            hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
-            hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), osm, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed);
+            hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed, (float*)nullptr);
+            hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), osm, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed, lut32_out);
         }
         if (phase != 1)
             hipLaunchKernelGGL(k_pq_qparam, dim3((unsigned)nq), dim3(64), 0, st, nq, M, Mpad, mnmx, errb, probe_dis0, nprobe,
@@ -636,7 +641,7 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
     static DevOnce once8, once0;
     (dsub == 8 ? once8 : once0).once([&] { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), lds, st, Q32, ldq, codebooks, dsub, M, Mpad, probe_dis0, nprobe,
-                       lut8, (PQQParam*)qparam, transposed);
+                       lut8, (PQQParam*)qparam, transposed, lut32_out);
 }
 
 // LDS byte offset (code * 4) of byte K of w in ONE instruction: the SDWA form of v_lshlrev selects the

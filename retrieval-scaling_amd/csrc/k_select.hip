@@ -1375,7 +1375,11 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     const int n = (int)n_raw;
     uint64_t* row = cand + q * (int64_t)cand_cap;
     const float* qv = a.Q32 + q * a.ldq;
-    // 1. the table
+    // 1. the table: copied when the table builder stored it (lut32: the same fmaf chains), else built here from the codebooks
+    if (a.lut32) {
+        const float4* src = reinterpret_cast<const float4*>(a.lut32 + q * (int64_t)a.Mpad * 256);
+        for (int e = tid; e < M * 64; e += 1024) reinterpret_cast<float4*>(ft_T)[e] = src[e];
+    } else
     for (int e = tid; e < M * 256; e += 1024) {
         const int m = e >> 8;
         const float* qs = qv + m * dsub;

@@ -973,6 +973,13 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     // (k_pq_qparam: they need the coarse scores) follow on the main stream once both have finished.
     const bool pq_fused_lut = h->kind == KIND_IVFPQ && fast && pq_lut8_fused_lds(h->M, h->Mpad, h->dsub) <= 160 * 1024 - 64;
     const bool side_lut = pq_fused_lut && h->overlap != 0 && h->dsub == 8 && h->lut_tiled != 0 && nq >= 64;
+    // the finalize-from-the-row kernel (k_pq_final_tab) will serve this batch: let the table builder store the fp32 tables for it
+    // (M KiB per query, 100 MB at M = 96 / batch 1024) instead of every query's workgroup re-deriving its table from the 786 KB codebook
+    const bool tab_expected = pq_fused_lut && rot && h->pq_final_tab != 0 && (h->pq_final_tab == 2 || KP >= 512 || h->dsub > 8) &&
+                              std::min(h->nprobe, h->nlist) > 1 && h->pq_filter != 0 && h->pq_prepass_fused != 0 &&
+                              pq_final_tab_capacity(h->M, h->CB, k) > 0;
+    float* lut32_out = nullptr;
+    if (tab_expected) { h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4); lut32_out = h->w_lut.as<float>(); }
     if (side_lut) {
         ensure_side_stream(h);
         h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
@@ -981,7 +988,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         HIPCHECK(hipEventRecord(h->ev_fork, h->st));
         HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
         launch_pq_lut8(nullptr, h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad, nullptr, 0,
-                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, rot ? 1 : 0, h->st2, 1);
+                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, rot ? 1 : 0, h->st2, 1, lut32_out);
         HIPCHECK(hipEventRecord(h->ev_lut, h->st2));
     }
 
@@ -1190,7 +1197,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             if (fused_lut && h->dsub == 8 && h->lut_tiled != 0) { h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad)); lut_ws = h->w_lutws.p; }
             if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_lut, 0));     // the tables were built beside the probe selection
             launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
-                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st, side_lut ? 2 : 0);
+                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st, side_lut ? 2 : 0,
+                           fused_lut ? lut32_out : nullptr);
             tm.mark("lut8");
             int rot_log_cap = 64;
             auto rot_desc = [&](int64_t items, int ngq) -> void* {   // work-item records + run descriptors + survivor logs of the rotated-layout scan
@@ -1589,7 +1597,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         if (filtered) { fa.cand_cnt = h->w_candcnt.as<unsigned long long>(); fa.cand_cap = cand_cap; }
     }
     if (tabP > 0) h->w_tiews.ensure((size_t)nq * cand_cap * 8);
-    if (use_tab) launch_pq_final_tab(fa, h->w_cand.as<uint64_t>(), cand_cap, h->w_tiews.as<uint64_t>(), h->st);
+    if (use_tab) { FinalizeArgs ft = fa; if (lut32_out) ft.lut32 = lut32_out; launch_pq_final_tab(ft, h->w_cand.as<uint64_t>(), cand_cap, h->w_tiews.as<uint64_t>(), h->st); }
     else launch_finalize(fa, h->st);
     tm.mark("finalize");
     tm.finish();

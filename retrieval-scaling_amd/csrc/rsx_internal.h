@@ -240,7 +240,8 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
                     void* qparam /* [nq] {scale, bias, eps, pad} */,
                     void* ws /* pq_lut8_tiled_ws(nq, Mpad) bytes -> tiled build (dsub 8), or null */,
                     int transposed /* 0: lut8 [nq][Mpad][256]; 1: [nq][256][Mpad] (rotated-layout scans) */, hipStream_t st,
-                    int phase = 0 /* tiled build only: 1 = the tables (independent of the probe selection), 2 = the per-query parameters */);
+                    int phase = 0 /* tiled build only: 1 = the tables (independent of the probe selection), 2 = the per-query parameters */,
+                    float* lut32_out = nullptr /* fused forms only: also store the fp32 tables [nq][Mpad][256] (k_pq_final_tab reads them) */);
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad);
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
                     const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
