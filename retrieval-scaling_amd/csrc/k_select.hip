@@ -1355,7 +1355,7 @@ void launch_pq_rescore_all(const FinalizeArgs& a, uint64_t* cand, int cand_cap, 
 // the k-th score send the query to the exact re-run).  row_filter != null: only the queries flagged 1 (second chance of the
 // K' path) are processed.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t* cand, int cand_cap, int P, uint64_t* tie_ws) {
+__global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t* cand, int cand_cap, int P, uint64_t* tie_ws, int stage_probes) {
     extern __shared__ __attribute__((aligned(16))) float ft_T[];
     const int M = a.M, dsub = a.dsub;
     int64_t* sid = reinterpret_cast<int64_t*>(ft_T + (size_t)M * 256);     // [P]
@@ -1364,6 +1364,11 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     int32_t* hist = reinterpret_cast<int32_t*>(tsel + 2);                  // [256]
     int32_t* ctl = hist + 256;                                             // [8]: 0 digit, 1 remaining, 2 valid, 3 cursor, 4 in-bin, 5 tie cursor, 6 exact-threshold flag
     int32_t* ctl2 = ctl + 8;                                               // [8]: the tie selection's radix state
+    // the query's probe table in LDS (stage_probes): row offsets, list bases, coarse scores — a candidate's list is found by bisection,
+    // five dependent L2 round trips per candidate when it runs on global memory
+    int64_t* s_ss = reinterpret_cast<int64_t*>(ctl2 + 8);                   // [nprobe + 1]
+    int64_t* s_lb = s_ss + (a.nprobe + 1);                                 // [nprobe]
+    float* s_d0 = reinterpret_cast<float*>(s_lb + a.nprobe);               // [nprobe]
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t q = blockIdx.x;
     if (a.row_filter && a.row_filter[q] != 1) return;
@@ -1396,13 +1401,22 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         ft_T[e] = t;
     }
     if (tid < 16) ctl[tid] = 0;
+    const int64_t* ss_g = a.seg_start + q * (a.nprobe + 1);
+    if (stage_probes) {
+        for (int j = tid; j <= a.nprobe; j += 1024) s_ss[j] = ss_g[j];
+        for (int j = tid; j < a.nprobe; j += 1024) {
+            const int32_t l = a.probe_list[q * a.nprobe + j];
+            s_lb[j] = l >= 0 ? a.list_base[l] : 0;
+            s_d0[j] = a.probe_dis0[q * a.nprobe + j];
+        }
+    }
     __syncthreads();
     // candidate index -> storage row (the probed list that holds it, by bisection of the query's row offsets)
-    const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+    const int64_t* ss = stage_probes ? s_ss : ss_g;
     auto locate = [&](uint32_t idx, int& lo) -> int64_t {
         lo = 0; int hi = a.nprobe;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
-        return a.list_base[a.probe_list[q * a.nprobe + lo]] + ((int64_t)idx - ss[lo]);
+        return (stage_probes ? s_lb[lo] : a.list_base[a.probe_list[q * a.nprobe + lo]]) + ((int64_t)idx - ss[lo]);
     };
     // 2. exact scores of the whole row, in place
     const int NF = M >> 6, nrun = M >> 4;
@@ -1413,7 +1427,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         const uint32_t idx = key_idx(key);
         int lo;
         const int64_t r = locate(idx, lo);
-        const float dis0 = a.probe_dis0[q * a.nprobe + lo];
+        const float dis0 = stage_probes ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
         float sum = 0.0f;
         if (M == 16) {       // 64-vector blocks of 1 KiB: vector v's 16 bytes at v * 16, byte s = sub-quantiser (v + s) & 15
             const uint4 cw4 = *reinterpret_cast<const uint4*>(a.codes + (r >> 6) * 1024 + (r & 63) * 16);
@@ -1565,10 +1579,13 @@ int pq_final_tab_capacity(int M, int CB, int k) {
 void launch_pq_final_tab(const FinalizeArgs& a, uint64_t* cand, int cand_cap, uint64_t* tie_ws, hipStream_t st) {
     if (a.nq <= 0) return;
     const int P = pq_final_tab_capacity(a.M, a.CB, a.k);
-    const size_t shm = (size_t)a.M * 1024 + (size_t)P * 12 + 16 + (256 + 16) * 4 + 64;
+    size_t shm = (size_t)a.M * 1024 + (size_t)P * 12 + 16 + (256 + 16) * 4 + 64;
+    const size_t probes = (size_t)(a.nprobe + 1) * 8 + (size_t)a.nprobe * 12 + 16;
+    const int stage_probes = shm + probes <= (size_t)160 * 1024 ? 1 : 0;
+    if (stage_probes) shm += probes;
     static DevSize attr;
     attr.grow(shm, [&] { (void)hipFuncSetAttribute((const void*)k_pq_final_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
-    hipLaunchKernelGGL(k_pq_final_tab, dim3((unsigned)a.nq), dim3(1024), shm, st, a, cand, cand_cap, P, tie_ws);
+    hipLaunchKernelGGL(k_pq_final_tab, dim3((unsigned)a.nq), dim3(1024), shm, st, a, cand, cand_cap, P, tie_ws, stage_probes);
 }
 
 void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
