@@ -1047,6 +1047,22 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
     const int64_t q = blockIdx.x;
     if (a.row_filter && a.row_filter[q] != 1) return;
+    // IVF: the query's probe table in LDS (round 4) — a candidate's list is found by bisection of the row offsets, which on global
+    // memory is five dependent L2 round trips per candidate, twice (location, then the coarse score of the re-score)
+    const bool plds = a.probe_lds_off != 0 && a.kind != KIND_FLAT;
+    int64_t* s_ss = reinterpret_cast<int64_t*>(reinterpret_cast<unsigned char*>(fin_buf) + a.probe_lds_off);   // [nprobe + 1]
+    int64_t* s_lb = s_ss + (a.nprobe + 1);                                                                       // [nprobe]
+    float* s_d0 = reinterpret_cast<float*>(s_lb + a.nprobe);                                                     // [nprobe]
+    if (plds) {
+        for (int j = tid; j <= a.nprobe; j += nt) s_ss[j] = a.seg_start[q * (a.nprobe + 1) + j];
+        for (int j = tid; j < a.nprobe; j += nt) {
+            const int32_t l = a.probe_list[q * a.nprobe + j];
+            s_lb[j] = l >= 0 ? a.list_base[l] : 0;
+            s_d0[j] = a.probe_dis0 ? a.probe_dis0[q * a.nprobe + j] : 0.0f;
+        }
+        __syncthreads();
+    }
+    const int64_t* ssq = plds ? s_ss : a.seg_start + q * (a.nprobe + 1);
 
     for (int c = tid; c < KP; c += nt) {
         uint64_t key = a.state[q * KP + c];
@@ -1057,11 +1073,10 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             if (a.kind == KIND_FLAT) {
                 row = idx;
             } else {
-                const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+                const int64_t* ss = ssq;
                 int lo = 0, hi = a.nprobe;  // find j with ss[j] <= idx < ss[j+1]
                 while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
-                int32_t l = a.probe_list[q * a.nprobe + lo];
-                row = a.list_base[l] + ((int64_t)idx - ss[lo]);
+                row = (plds ? s_lb[lo] : a.list_base[a.probe_list[q * a.nprobe + lo]]) + ((int64_t)idx - ss[lo]);
             }
             id = a.ids ? a.ids[row] : row;
             ord = (uint32_t)(key >> 32);
@@ -1094,10 +1109,10 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         for (int c = tid; c < KP; c += nt) {
             if (srow[c] < 0) continue;
             const uint32_t idx = key_idx(a.state[q * KP + c]);
-            const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+            const int64_t* ss = ssq;
             int lo = 0, hi = a.nprobe;
             while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
-            const float dis0 = a.probe_dis0[q * a.nprobe + lo];
+            const float dis0 = plds ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
             float sum = 0.0f;
             for (int m = 0; m < M; m++) sum += ent[c * es + m];
             sord[c] = f2ord((dis0 + sum) + 0.0f);
@@ -1111,10 +1126,10 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             int64_t row = srow[c];
             if (row < 0) continue;
             uint32_t idx = key_idx(a.state[q * KP + c]);
-            const int64_t* ss = a.seg_start + q * (a.nprobe + 1);
+            const int64_t* ss = ssq;
             int lo = 0, hi = a.nprobe;
             while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
-            const float dis0 = a.probe_dis0[q * a.nprobe + lo];
+            const float dis0 = plds ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
             const int64_t slab = row >> 6; const int v = (int)(row & 63);
             const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
             const float sum = a.CB == 0 ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
@@ -1602,6 +1617,11 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
     if (a.par_entries) { shm = std::max(shm, par_shm); waves = 16; }
     else if (a.kind != KIND_IVFPQ && a.nq <= 64) waves = std::min(16, std::max(waves, a.KP / 4));   // one wave per candidate re-score
     else if (a.KP >= 1024) waves = 16;     // the reference's n_docs = 1000: 2048 candidates per query to re-score and sort (4 waves: 3.2 ms per 1024 queries)
+    a.probe_lds_off = 0;
+    if (a.kind != KIND_FLAT && a.nprobe <= 1024) {      // the probe table behind everything else (20 bytes per probe)
+        a.probe_lds_off = (int)((shm + 15) / 16 * 16);
+        shm = (size_t)a.probe_lds_off + (size_t)(a.nprobe + 1) * 8 + (size_t)a.nprobe * 12 + 16;
+    }
     static DevSize big;
     if (shm > 48 * 1024) big.grow(shm, [&] { hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)a.nq), dim3(64 * waves), shm, st, a);

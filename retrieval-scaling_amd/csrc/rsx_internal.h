@@ -403,6 +403,7 @@ struct FinalizeArgs {
     float* D; int64_t* I;
     const int32_t* row_filter;     // optional: only queries with row_filter[q] == 1 are processed (second-chance pass)
     int no_cert;                   // the state keys are the best of a COMPLETE, exactly scored candidate row: nothing to certify
+    int probe_lds_off;             // set by launch_finalize: byte offset of the query's probe table in the dynamic LDS (0 = keep it in global memory)
     int par_entries;               // set by launch_finalize: parallel table-entry form of the IVF-PQ re-score (small batches)
     int rank_sort;                 // set by launch_finalize: order the candidates by counting (K' <= 1024) instead of a bitonic network
 };
