@@ -1148,6 +1148,27 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             int64_t rows[4]; double acc[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) { rows[u] = c0 + u < KP ? srow[c0 + u] : -1; acc[u] = 0.0; }   // wave-uniform (LDS values)
+            if (a.x_f16 && (a.ldq & 7) == 0 && a.ldq >= a.ld) {
+                // fp16 rows: 16 bytes (8 values) per lane and load — a 1536-byte row is 1.5 wave loads instead of 12 two-byte ones (the
+                // rows' zero padding up to ld contributes exact zeros; fp64 sums of products of fp16-valued numbers do not depend on the order)
+                for (int c8 = lane; c8 < (a.ld >> 3); c8 += 64) {
+                    const float4 qa = *reinterpret_cast<const float4*>(qv + 8 * c8), qb = *reinterpret_cast<const float4*>(qv + 8 * c8 + 4);
+                    const float qf[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+                    uint4 xr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) xr[u] = rows[u] >= 0 ? *reinterpret_cast<const uint4*>((const __half*)a.X + rows[u] * a.ld + 8 * c8) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t wds[4] = {xr[u].x, xr[u].y, xr[u].z, xr[u].w};
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const __half hx = __ushort_as_half((unsigned short)((wds[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+                            const double qd = (double)qf[e], xd = (double)__half2float(hx);
+                            if (a.metric == 0) acc[u] += qd * xd; else { const double df = qd - xd; acc[u] += df * df; }
+                        }
+                    }
+                }
+            } else
             for (int t = lane; t < a.d; t += 64) {
                 const double qd = (double)qv[t];
                 double xd[4];

@@ -1074,8 +1074,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // threshold phase: the K'-th key of the first rows is a FIXED threshold for everything behind them, so the filtered pass
             // keeps ~N K' / rows-so-far keys per query.  One 65536-row chunk is right for k = 10 (K' = 32: 5 k keys at 10M rows);
             // for the reference's n_docs = 1000 (K' = 2048) it let 310 k keys through, overflowed every candidate row and fell back
-            // to 153 chunk passes — 550 ms per batch (round 4: measured once k = 1000 joined the bench).  Now 320 K' rows.
-            const int64_t n0 = std::min<int64_t>((N + CH - 1) / CH, std::max<int64_t>(1, ((int64_t)KP * 320 + CH - 1) / CH));
+            // to 153 chunk passes — 550 ms per batch (round 4: measured once k = 1000 joined the bench).  Now 160 K' rows (320: the radix selections of the threshold phase cost more than the extra keys).
+            const int64_t n0 = std::min<int64_t>((N + CH - 1) / CH, std::max<int64_t>(1, ((int64_t)KP * 160 + CH - 1) / CH));
             for (int64_t c = 0; c < n0; c++) chunk_pass(c * CH);
             done_rows = std::min<int64_t>(n0 * CH, N);
             tm.mark("scan0");
