@@ -191,6 +191,7 @@ struct rsx_index {
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
+    int ivf_wide2 = 0;       // IVF-Flat LDS-DMA scan, 32-query groups: 8 waves x 6-stage rings (experiment)
     int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scan: 1 = choose 16 / 32 / 64 queries per group from the queries per list, 2 / 4 = force, 0 = always 16
     int pq_prepass4 = 1;     // rotated fast scan, small k, full batches: threshold pre-pass with four queries per workgroup on the scan's table format
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
@@ -1461,7 +1462,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         // list chunk run on one XCD at the same moment and its rows cross HBM once — at nlist 2048 / nprobe 128 half of the lists
         // are probed by more than 64 queries, i.e. by two groups, which used to land on different XCDs (two fetches)
         const int ls2_rows = list_scan2_chunk_rows(h->storage_f16, ld);
-        const int item_rows = (h->scan_chunk <= 0 && ls2_rows > 0) ? (ls_qt == 4 ? 2 * ls2_rows : ls2_rows) : 0;
+        const bool ls_wide = ls_qt == 4 || (ls_qt == 2 && h->ivf_wide2 != 0);     // 8-wave forms: 1024 rows per work item
+        const int item_rows = (h->scan_chunk <= 0 && ls2_rows > 0) ? (ls_wide ? 2 * ls2_rows : ls2_rows) : 0;
         launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,
                            pairs_sorted, item_rows ? h->d_len.as<int64_t>() : nullptr, item_rows, item_rows ? item_off : nullptr,
                            item_rows ? total_items : nullptr, nprobe, 0, nprobe, 0, h->st);
@@ -1528,7 +1530,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                item_rows ? total_items : nullptr, nprobe, 0, nprobe, 0, h->st);
             tm.mark("group");
             a.qtiles = ls_qt;
-            if (ls_qt == 4) { chunk_rows *= 2; a.chunk_rows = (int)chunk_rows; }      // 64-query groups: 8 waves, 1024 rows per work item
+            if (ls_wide) { chunk_rows *= 2; a.chunk_rows = (int)chunk_rows; }      // 8 waves, 1024 rows per work item
             a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
             if (item_rows == (int)chunk_rows) { a.item_off = item_off; a.total_items = total_items; a.max_items = (int)max_scan_items(h, nq, nprobe, 16 * ls_qt, item_rows); }
             a.tau_key = state + (KP - 1); a.tau_stride = KP;
@@ -1543,7 +1545,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             a.tau_key = nullptr; a.cand = nullptr; a.cand_cnt = nullptr; a.cand_cap = 0;
         }
         if (!filtered) {
-            if (a.qtiles == 4 && a.chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld)) {     // 64-query groups: 8 waves, 1024 rows per work item
+            if (ls_wide && a.chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld)) {     // 8 waves, 1024 rows per work item
                 a.chunk_rows *= 2;
                 a.max_chunks = (int)std::max<int64_t>(1, (maxlen + a.chunk_rows - 1) / a.chunk_rows);
             }
@@ -2684,6 +2686,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_gather") h->pq_gather = (int)value;
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;
+        else if (s == "ivf_wide2") h->ivf_wide2 = (int)value;
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;

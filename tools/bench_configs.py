@@ -14,7 +14,7 @@ D, NC = 768, 4096
 SC, SX, SQ = 1234, 10000, 999
 
 
-def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, small_batches=True, metric="ip", k=10, extra_ks=()):
+def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, small_batches=True, metric="ip", k=10, extra_ks=(), params=()):
     """One non-headline config on cuda:0 -> result dict (the same object bench.py embeds under "configs")."""
     import torch, rsx
     from oracle import oracle as orc
@@ -49,6 +49,8 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
         ix.add(buf[:nb])
     torch.cuda.synchronize()
     build_s = time.time() - t0
+    for name, val in params:
+        ix.set_param(name, val)
     lm_cache = {}
 
     def run_k(k):
@@ -236,7 +238,7 @@ def main():
         print(json.dumps(measure_ivfpq(a.n or 100_000_000, 96, 4096, 32, ks=ks, steps=a.steps, check=a.check, params=params)), flush=True)
         return
     extra = tuple(int(t) for t in a.ks.split(",")) if a.ks else ()
-    print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check, metric=a.metric, k=a.k, extra_ks=extra)), flush=True)
+    print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check, metric=a.metric, k=a.k, extra_ks=extra, params=params)), flush=True)
 
 
 def latency(a):
