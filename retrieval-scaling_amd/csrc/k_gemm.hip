@@ -1033,181 +1033,6 @@ __global__ __launch_bounds__(64 * NW) void k_list_scan2(ListScanArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// k_list_scan3 (round 4): the 64-query form with the db rows loaded STRAIGHT INTO REGISTERS.  In k_list_scan2<_, 4, 8, 3> the 64 staged
-// queries own 99 KiB of the LDS and leave 48 KiB for the DMA rings: 48 KiB of rows in flight per CU, which at ~2.8 us of loaded HBM
-// latency is 4.5 TB/s — where that kernel sits at nlist 2048 / nprobe 128 now that the sibling re-reads are gone (PMC: 32.0 GB fetched
-// for 30.7 GB of rows).  A list row is read by exactly ONE wave here (unlike the Flat GEMM's db tile, where the LDS fan-out to several
-// waves is what makes the LDS path win: profiles/r04_flat_gemm5_prototype.md), so its B fragments can go global -> VGPR directly: lane
-// (lr, kg) of a wave needs bytes [16 kg, 16 kg + 16) and [64 + 16 kg, ...) of row lr's 128-byte K slice — two global_load_dwordx4 —
-// and a register ring of LS3_PF K steps per wave replaces the LDS ring: 8 waves x LS3_PF x 2 KiB in flight per CU with no LDS behind it.
-// Same work decomposition, query staging, MFMA shape, filter epilogue and results as k_list_scan2<_, 4, 8, _>.
-// ---------------------------------------------------------------------------------------
-#define LS3_PF 6
-template <bool FILTER>
-__global__ __launch_bounds__(512) void k_list_scan3(ListScanArgs a) {
-    constexpr int QT = 4, NW = 8;
-    constexpr int NQG = 16 * QT;
-    constexpr int NT = 64 * NW;
-    constexpr int BR = 16 * NW;
-    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
-    const int qstride = (a.ld + 8) * 2;
-    unsigned char* Qs = ls_smem;
-    int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + NQG * qstride);
-    int64_t* sq = segoff + NQG;
-    uint64_t* stau = reinterpret_cast<uint64_t*>(sq + NQG);
-    int32_t* sqn = reinterpret_cast<int32_t*>(stau + NQG);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int g = blockIdx.x;
-    int chunk = blockIdx.y;
-    int l, gi;
-    if (a.item_off) {
-        if (!pq_decode_item(a.item_off, a.group_off, *a.total_items, a.nlist, l, gi, chunk)) return;
-        g = a.group_off[l] + gi;
-    } else {
-        if (g >= *a.total_groups) return;
-        int lo = 0, hi = a.nlist;
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.group_off[mid] <= g) lo = mid; else hi = mid; }
-        l = lo; gi = g - a.group_off[l];
-    }
-    const int cnt = a.pair_off[l + 1] - a.pair_off[l];
-    int np = cnt - NQG * gi; if (np > NQG) np = NQG;
-    const int pair0 = a.pair_off[l] + NQG * gi;
-    const int64_t base = a.list_base[l], len = a.list_len[l];
-    const int64_t len_pad = (len + 15) & ~15ll;
-    const int64_t c0 = (int64_t)chunk * (BR * LS2_NB);
-    if (c0 >= len_pad) return;
-    int64_t c1 = c0 + BR * LS2_NB; if (c1 > len_pad) c1 = len_pad;
-    // this wave's blocks: rows c0 + 16 w + BR i, i < nb; their first K steps travel while the queries are staged
-    const int64_t r0 = c0 + 16 * w;
-    const int nb = r0 < c1 ? (int)((c1 - r0 + BR - 1) / BR) : 0;
-    const int KT = a.ld >> 6;
-    const int T = nb * KT;
-    const int lr = lane & 15, kg = lane >> 4;
-    const char* xb = reinterpret_cast<const char*>(reinterpret_cast<const __half*>(a.X) + (base + r0 + lr) * a.ld) + kg * 16;
-    const int64_t blk_bytes = (int64_t)BR * a.ld * 2;
-    v4u x0[LS3_PF], x1[LS3_PF];
-    int i_kt = 0; int64_t i_boff = 0; int i_left = T;          // issue position (branch-free advance; past the end the last piece is fetched again)
-    auto issue = [&](int slot) {
-        const char* gsrc = xb + i_boff + (int64_t)i_kt * 128;
-        x0[slot] = *reinterpret_cast<const v4u*>(gsrc);
-        x1[slot] = *reinterpret_cast<const v4u*>(gsrc + 64);
-        const bool adv = i_left > 1;
-        i_left -= adv ? 1 : 0;
-        i_kt += adv ? 1 : 0;
-        const bool wrap = i_kt == KT;
-        i_kt = wrap ? 0 : i_kt;
-        i_boff += wrap ? blk_bytes : 0;
-    };
-    if (nb > 0) {
-#pragma unroll
-        for (int d = 0; d < LS3_PF; d++) { issue(d); __builtin_amdgcn_sched_barrier(0); }
-    }
-    // stage the group's queries and their offsets (as k_list_scan2)
-    if (tid < NQG) sqn[tid] = tid < np ? (int32_t)(a.pairs_sorted[pair0 + tid] / a.nprobe) : -1;
-    __syncthreads();
-    {
-        const int ppr = a.ld >> 3;
-        const int npc = NQG * ppr;
-        for (int p0 = tid; p0 < npc; p0 += NT * 8) {
-            uint4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int pc = p0 + u * NT;
-                const int i = pc < npc ? pc / ppr : 0, t = pc < npc ? pc - i * ppr : 0;
-                const int q = sqn[i];
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (pc < npc && q >= 0) v[u] = *reinterpret_cast<const uint4*>(a.Q16 + (int64_t)q * a.ld + t * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int pc = p0 + u * NT;
-                if (pc >= npc) break;
-                const int i = pc / ppr, t = pc - i * ppr;
-                *reinterpret_cast<uint4*>(Qs + i * qstride + t * 16) = v[u];
-            }
-        }
-    }
-    if (tid < NQG) {
-        int64_t off = 0;
-        if (tid < np) {
-            const int pidx = a.pairs_sorted[pair0 + tid];
-            const int64_t q = pidx / a.nprobe; const int j = pidx % a.nprobe;
-            off = q * a.tstride + a.seg_start[q * (a.nprobe + 1) + j];
-        }
-        segoff[tid] = off;
-        if (FILTER) {
-            int64_t q = 0; uint64_t t = ~0ull;
-            if (tid < np) {
-                q = a.pairs_sorted[pair0 + tid] / a.nprobe;
-                t = a.tau_key[q * a.tau_stride];
-                segoff[tid] = off - q * a.tstride;
-            }
-            sq[tid] = q; stau[tid] = t;
-        }
-    }
-    __syncthreads();
-    if (nb == 0) return;
-    const unsigned char* qa_base = Qs + lr * qstride + (8 * kg) * 2;
-    int kt = 0, blk = 0;
-    floatx4 acc[QT];
-#pragma unroll
-    for (int t = 0; t < QT; t++) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-    for (int s0 = 0; s0 < T; s0 += LS3_PF) {
-#pragma unroll
-        for (int j = 0; j < LS3_PF; j++) {
-            if (s0 + j < T) {              // wave-uniform
-                const half8 xa = __builtin_bit_cast(half8, x0[j]), xc = __builtin_bit_cast(half8, x1[j]);
-                __builtin_amdgcn_sched_barrier(0);
-                issue(j);                  // the slot's registers are consumed: refill them LS3_PF steps ahead
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < QT; t++) {
-                    const half8 q0 = *reinterpret_cast<const half8*>(qa_base + t * 16 * qstride + (kt * 64) * 2);
-                    const half8 q1 = *reinterpret_cast<const half8*>(qa_base + t * 16 * qstride + (kt * 64 + 32) * 2);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0, xa, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q1, xc, acc[t], 0, 0, 0);
-                }
-                kt++;
-                if (kt == KT) {            // the block is complete: epilogue, next block
-                    kt = 0;
-                    const int64_t rloc = r0 + (int64_t)BR * blk + lr;
-                    const float bv = (a.bias && rloc < len) ? a.bias[base + rloc] : 0.0f;
-#pragma unroll
-                    for (int t = 0; t < QT; t++) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int qi = t * 16 + kg * 4 + r;
-                            if (!FILTER) {
-                                if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[t][r] + bv : -__builtin_inff();
-                            } else {
-                                const uint64_t key = (rloc < len && qi < np) ? make_key(acc[t][r] + bv, (uint32_t)(segoff[qi] + rloc)) : 0ull;
-                                const bool pass = key > stau[qi];
-                                const uint64_t mask = __ballot(pass);
-                                const uint64_t mine = (mask >> (16 * kg)) & 0xffffull;
-                                if (mine) {   // one atomic per query per block
-                                    const int64_t q = sq[qi];
-                                    unsigned long long slot0 = 0;
-                                    const int leader = (__ffsll((unsigned long long)mine) - 1) + 16 * kg;
-                                    if (lane == leader) slot0 = atomicAdd(&a.cand_cnt[(int64_t)q * CCS], (unsigned long long)__popcll(mine));
-                                    slot0 = __shfl(slot0, leader);
-                                    const unsigned long long slot = slot0 + __popcll(mine & ((1ull << lr) - 1ull));
-                                    if (pass && slot < (unsigned long long)a.cand_cap) a.cand[q * a.cand_cap + slot] = key;
-                                }
-                            }
-                        }
-                        acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-                    }
-                    blk++;
-                }
-            }
-        }
-    }
-}
-
 // rows per work item k_list_scan2 is built for (0: it does not apply to this storage)
 int list_scan2_chunk_rows(int x_f16, int ld) {
     static const int off = measure_env("RSX_LIST_SCAN_V1", 0);
@@ -1246,17 +1071,7 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 2, 8, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 2, 8, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-        static const int scan3_off = measure_env("RSX_LIST_SCAN3_OFF", 0);
-        if (wide && !scan3_off && !a.pre_stride && a.scan3) {
-            const size_t shm3 = (size_t)64 * (a.ld + 8) * 2 + 28 * 64 + 64;
-            static DevOnce once3;
-            once3.once([&] {
-                (void)hipFuncSetAttribute((const void*)k_list_scan3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)k_list_scan3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            });
-            if (a.tau_key) hipLaunchKernelGGL((k_list_scan3<true>), grid, dim3(512), shm3, st, a);
-            else hipLaunchKernelGGL((k_list_scan3<false>), grid, dim3(512), shm3, st, a);
-        } else if (wide) {
+        if (wide) {
             if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 4, 8, 3>), grid, dim3(512), shm2, st, a);
             else hipLaunchKernelGGL((k_list_scan2<false, 4, 8, 3>), grid, dim3(512), shm2, st, a);
         } else if (wide2) {

@@ -191,7 +191,6 @@ struct rsx_index {
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
-    int ivf_scan3 = 1;       // IVF-Flat, 64-query groups: db rows straight into registers (k_list_scan3) instead of the LDS-DMA rings
     int ivf_wide2 = 0;       // IVF-Flat LDS-DMA scan, 32-query groups: 8 waves x 6-stage rings (experiment)
     int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scan: 1 = choose 16 / 32 / 64 queries per group from the queries per list, 2 / 4 = force, 0 = always 16
     int pq_prepass4 = 1;     // rotated fast scan, small k, full batches: threshold pre-pass with four queries per workgroup on the scan's table format
@@ -1485,7 +1484,6 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         if (h->scan_chunk <= 0 && list_scan2_chunk_rows(h->storage_f16, ld) > 0) chunk_rows = list_scan2_chunk_rows(h->storage_f16, ld);
         a.chunk_rows = (int)chunk_rows;
         a.qtiles = ls_qt;
-        a.scan3 = h->ivf_scan3;
         a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
         // Same two-stage shape as the IVF-PQ fast path when the LDS-DMA kernel applies: score a prefix of every
         // query's closest list, take its K'-th key as the query's threshold, then scan everything with the keys
@@ -2689,7 +2687,6 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;
         else if (s == "ivf_wide2") h->ivf_wide2 = (int)value;
-        else if (s == "ivf_scan3") h->ivf_scan3 = (int)value;
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;

@@ -209,7 +209,6 @@ struct ListScanArgs {
     // unfiltered k_list_scan2, optional: the scores of (query q, probe rank j) go to temp[q * tstride + j * pre_stride + row] instead of
     // the query's concatenated row (threshold pre-pass over the first rows of several lists: every list gets its own slice)
     int64_t pre_stride;
-    int scan3;      // 64-query groups: 1 = rows straight into registers (k_list_scan3), 0 = LDS-DMA rings (k_list_scan2<_, 4, 8, 3>)
 };
 int list_scan2_chunk_rows(int x_f16, int ld);   // work-item rows of the LDS-DMA list scan, 0 if it does not apply
 int list_scan2_max_qtiles(int ld);              // ... and the 16-query tiles per group its LDS holds
