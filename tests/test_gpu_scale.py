@@ -210,3 +210,46 @@ def test_ivf_nlist4096_nprobe32_batch_1024(gpu, orc, kind):
         ix.set_param("pq_prune", 1)
         Dp, Ip = ix.search(q, k)
         assert torch.equal(Dp, D) and torch.equal(Ip, I), "pair pruning is exact"
+
+
+def test_m16_reference_shape_mid_scale(gpu, orc):
+    """The reference's shipped IVF-PQ shape (M = 16, many probes per query: ric/conf/ivf_pq.yaml:64-78) at a size where the round-4
+    M = 16 scan (k_pq_scan_rot16: 16 queries per work item, four records, work stealing across XCD ranges, lists of several tiles
+    when scan_chunk shrinks them) runs thousands of work items: every query of the batch against the exact list-major kernel,
+    a sample against the CPU oracle, for the reference's n_docs too; no exact re-run may be needed."""
+    import torch
+    d, n, nlist, M, nq, nprobe = 768, 2_000_000, 256, 16, 256, 64
+    dev = torch.device("cuda", 0)
+    x = torch.empty((n, d), dtype=torch.float16, device=dev)
+    gpu.synth_vectors(d, 512, 1234, 10000, 0.5, 0, n, out=x)
+    q = torch.empty((nq, d), dtype=torch.float16, device=dev)
+    gpu.synth_queries(d, 512, 1234, 10000, 0.5, n, 999, 0.1, 0, nq, out=q)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    assert ix._get("pq_layout") == 1
+    ix.train(x[:65536]); ix.add(x); ix.nprobe = nprobe
+    del x
+    qs = q[:6].cpu().numpy().astype(np.float32)
+    cen, cb = ix.get_centroids(), ix.get_codebooks()
+    pid, _ = orc.coarse_probe(cen, qs, nprobe)
+    need = np.unique(pid[pid >= 0])
+    ls = ix.list_sizes()
+    lens = np.zeros(nlist, np.int64); lens[need] = ls[need]
+    off = np.zeros(nlist + 1, np.int64); np.cumsum(lens, out=off[1:])
+
+    class LM: pass
+    lm = LM(); lm.list_off = off
+    lm.payload = np.empty((int(off[-1]), M), np.uint8); lm.ids = np.empty(int(off[-1]), np.int64)
+    for l in need:
+        c, i = ix.get_list(int(l)); lm.payload[off[l]:off[l + 1]] = c; lm.ids[off[l]:off[l + 1]] = i
+    for k in (10, 1000):
+        ix.set_param("scan_kernel", 2)
+        De, Ie = ix.search(q, k)
+        ix.set_param("scan_kernel", 0)
+        for chunk in (0, 2048):          # 2048: every list becomes several tiles
+            ix.set_param("scan_chunk", chunk); ix.set_param("profile", 1)
+            D, I = ix.search(q, k)
+            assert torch.equal(I, Ie) and torch.equal(D, De), f"k={k} scan_chunk={chunk}: fast scan vs exact kernel"
+            assert ix.get_timing("fallback_queries") == 0, f"k={k} scan_chunk={chunk}"
+        ix.set_param("scan_chunk", 0); ix.set_param("profile", 0)
+        Do, Io = orc.ivfpq_search(cen, cb, lm, qs, nprobe, k)
+        assert np.array_equal(Io, I[:6].cpu().numpy()) and np.array_equal(Do, D[:6].cpu().numpy()), f"k={k}: oracle sample"
