@@ -415,9 +415,20 @@ __global__ __launch_bounds__(256) void k_flat_gemm(const __half* Q16, const void
 // ---------------------------------------------------------------------------------------
 #define FG2_STAGE 65536
 
+// Cache policy of the LDS-DMA row streams (aux bits of the load; 2 = nt, "streamed once"), measured per kernel on one box
+// (profiles/r04_nt_loads.md): the IVF-Flat / small-batch row stream is read by ONE workgroup once per launch — nt: +5 % at
+// nprobe 32, +1 % at nprobe 128; a Flat db tile is re-read by the 4 workgroups that walk it on one XCD — nt: -12 %; the
+// IVF-PQ code stream is re-read by sibling query groups out of the L2 — nt: -9 % (k_pq_rot.hip keeps the default policy).
+#ifndef RSX_NT_FLAT
+#define RSX_NT_FLAT 0
+#endif
+#ifndef RSX_NT_LIST
+#define RSX_NT_LIST 2
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void fg2_dma16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
 }
 
 template <bool FILTER>
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
             int64_t xrow = i_vt + ((4 * w + j) * 8 + r8);
             xrow = xrow > vlast ? vlast : xrow;
             fg2_dma16(srcA[j] + i_aoff + (int64_t)i_kt * 128, sa + j * 1024);
-            fg2_dma16(xb[j & 1] + (uint64_t)(uint32_t)xrow * ld2 + (int64_t)i_kt * 128, sb + j * 1024);
+            fg2_dma16<RSX_NT_FLAT>(xb[j & 1] + (uint64_t)(uint32_t)xrow * ld2 + (int64_t)i_kt * 128, sb + j * 1024);
         }
         // branch-free advance (a branch here would split the scheduling region the interleave below pins)
         i_kt += advance ? 1 : 0;
@@ -951,8 +962,8 @@ __global__ __launch_bounds__(64 * NW) void k_list_scan2(ListScanArgs a) {
     auto issue = [&]() {
         const char* gsrc = xb + i_boff + (int64_t)i_kt * 128;
         unsigned char* dst = ring + i_slot * 2048;
-        fg2_dma16(gsrc + off0, dst);
-        fg2_dma16(gsrc + off1, dst + 1024);
+        fg2_dma16<RSX_NT_LIST>(gsrc + off0, dst);
+        fg2_dma16<RSX_NT_LIST>(gsrc + off1, dst + 1024);
         // branch-free advance; past the last step the last (valid) piece is fetched again into a slot nobody reads
         const bool adv = i_left > 1;
         i_left -= adv ? 1 : 0;
