@@ -287,6 +287,31 @@ def main():
                 "note": "numpy fp16 queries in, numpy D/I out: 1.57 MB H2D + 0.12 MB D2H per step inside the timed loop"}
         del Qh
 
+    # ---- the reference's call shape (src/search.py:296: ALL queries in one index.search): four batches in one call, as the
+    # sequential loop over internal batches and through the batch pipeline (rsx_api.hip: search_impl).  A side key, never `value`.
+    one_call = None
+    nb4 = min(4, args.steps)
+    if world == 1 and nb4 >= 2:
+        Q4 = Q[args.warmup * nq:(args.warmup + nb4) * nq]
+        one_call = {"queries": nb4 * nq, "k": k}
+        outs = {}
+        for name, pl in (("sequential", 0), ("pipelined", 1)):
+            index.set_param("pipeline", pl)
+            index.search(Q4, k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                outs[name] = index.search(Q4, k)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / 3 * 1e3
+            one_call[name] = {"ms": round(ms, 4), "queries_per_s": round(nb4 * nq / ms * 1e3, 1)}
+        index.set_param("pipeline", 0)      # the default: the pipeline does not pay on this hardware (profiles/r04_pipeline.md)
+        one_call["same_ids_and_scores"] = bool(torch.equal(outs["sequential"][0], outs["pipelined"][0]) and torch.equal(outs["sequential"][1], outs["pipelined"][1]))
+        one_call["note"] = ("one index.search call of %d queries (query_batch 1024): internal batches alternate between the handle and its "
+                            "pipeline view on two host threads, the scan grid leaves 16 CUs to the neighbouring batches' small kernels (engine parameter "
+                            "pipeline = 1; off by default: measured, no gain — profiles/r04_pipeline.md)" % (nb4 * nq))
+        del outs, Q4
+
     ab = None
     if args.ab:
         ab = {}
@@ -526,6 +551,7 @@ def main():
                                  "stream, rank 0; traffic = PMC FETCH_SIZE x 2 of the same kernel (profiles/pmc_traffic.json, refused when "
                                  "the kernel sources changed since it was measured)"},
             "pcie_inclusive": pcie,
+            "one_call_all_queries": one_call,
             "list_length_histogram": hist,
             "stage_ms_per_step": stage_ms,
             "certificate_fallback_fraction": fallbacks,

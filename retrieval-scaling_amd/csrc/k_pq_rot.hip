@@ -998,8 +998,10 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint32_t* prog = xcd_ctr + 256;
     hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, 1);
     static const int var = measure_env("RSX_ROT_VARIANT", 0);
-    // one persistent workgroup per CU; never more than the work items
-    int64_t grid = nwg;
+    // one persistent workgroup per CU; never more than the work items; a pipelined search (rsx_api.hip: search_impl) leaves
+    // 8 x (bits 16-19 of pace) CUs to the kernels of the neighbouring batches
+    int64_t grid = nwg - 8 * ((A.pace >> 16) & 15);
+    if (grid < 8) grid = 8;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
     hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER, NQ>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, prog,
                        log_cap, bpw, A.pace, var);
@@ -1028,7 +1030,8 @@ static int launch_pq_scan_rot16(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
     uint32_t* prog = xcd_ctr + 256;
     hipLaunchKernelGGL((k_pq_rot_items<16, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
-    int64_t grid = nwg;
+    int64_t grid = nwg - 8 * ((A.pace >> 16) & 15);
+    if (grid < 8) grid = 8;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
     hipLaunchKernelGGL(k_pq_scan_rot16, dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, bpw);
     if (!A.qitems)

@@ -67,8 +67,10 @@ static int guarded(F&& f) {
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool borrowed = false;      // a pipeline view's alias of its parent's buffer (refresh_view): never freed, never grown here
     void ensure(size_t n) {
         if (n <= bytes) return;
+        if (borrowed) throw std::logic_error("DevBuf: a borrowed buffer cannot grow");
         release();
         size_t want = n + n / 8;
         if (hipMalloc(&p, want) != hipSuccess) {
@@ -80,9 +82,10 @@ struct DevBuf {
         bytes = want;
     }
     void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
+        if (p && !borrowed) (void)hipFree(p);
+        p = nullptr; bytes = 0; borrowed = false;
     }
+    void borrow(const DevBuf& o) { release(); p = o.p; bytes = o.bytes; borrowed = o.p != nullptr; }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
     ~DevBuf() { release(); }
     DevBuf() = default;
@@ -156,6 +159,20 @@ struct rsx_index {
     hipStream_t st2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_probe = nullptr, ev_lut = nullptr, ev_group = nullptr;
     int overlap = 1;          // 0 = everything on one stream
+    // Batch pipeline (round 4, VERDICT r3 task 4b; the reference hands ALL its queries to one index.search call, src/search.py:296):
+    // a search of several internal batches alternates them between this handle and a VIEW of it — a second handle that borrows
+    // the index payload (codes, ids, directory, trained parameters) and owns its own streams and workspaces — driven by a second
+    // host thread, so that the query-side stages of batch i+1 and the selection / re-rank of batch i-1 can run beside batch i's
+    // scan; the scan's persistent grid leaves `pipeline_reserve` CUs (a multiple of 8) free meanwhile.  Results are those of the
+    // sequential loop (every batch is still one search_batch call).  MEASURED AND OFF BY DEFAULT (profiles/r04_pipeline.md):
+    // 4096 queries take 11.4 ms sequentially and 11.4-11.8 ms pipelined for any reserve — a kernel of another queue makes no
+    // progress on the CUs a 240-workgroup scan leaves free unless EVERY shader engine of every XCD has room (32 CUs = 12.5 % of
+    // the scan's throughput, as much as the fixed cost it hides), and without a reserve the neighbouring batches' small kernels
+    // only meet between two scans, where they slow each other by what the overlap saves.
+    int pipeline = 0;         // 1 = IVF-PQ rotated fast scan, >= 2 internal batches, no profiling; 0 = never (default)
+    int pipeline_reserve = 16;
+    int scan_reserve_now = 0; // CUs the scan grid leaves free in the call under way (set by search_impl)
+    rsx_index* pipe_view = nullptr;
     ~rsx_index() {
         if (st2) { (void)hipSetDevice(device); (void)hipStreamDestroy(st2); }
         for (hipEvent_t e : {ev_fork, ev_probe, ev_lut, ev_group}) if (e) (void)hipEventDestroy(e);
@@ -1378,7 +1395,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                                  total_groups, item_off, total_items, nlist,
                                                  mi_main, vpl, tau_ptr, tau_stride,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rws1, rot_log_cap, h->pq_prune, h->pq_pace, (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
+                                                 rws1, rot_log_cap, h->pq_prune, (h->pq_pace & 0xffff) | ((h->scan_reserve_now >> 3) << 16), (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
                                                  use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
@@ -1644,6 +1661,42 @@ __global__ void k_bias_from_norms(const float* norms, float* bias, int64_t n) {
     if (i < n) bias[i] = -0.5f * norms[i];
 }
 
+// The pipeline view of an (unsharded) index: same configuration and knobs, the parent's payload BORROWED (refreshed at the start
+// of every pipelined search: an add may have re-laid the lists out since the last one), its own streams and workspaces.
+static void free_view(rsx_index* h) {
+    rsx_index* v = h->pipe_view;
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->st) { (void)hipStreamSynchronize(v->st); (void)hipStreamDestroy(v->st); }
+    delete v;
+    h->pipe_view = nullptr;
+}
+static rsx_index* refresh_view(rsx_index* h) {
+    if (!h->pipe_view) {
+        std::unique_ptr<rsx_index> v(new rsx_index());
+        v->device = h->device;
+        HIPCHECK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
+        h->pipe_view = v.release();
+    }
+    rsx_index* v = h->pipe_view;
+    v->kind = h->kind; v->d = h->d; v->metric = h->metric; v->nlist = h->nlist; v->M = h->M; v->nbits = h->nbits; v->Mpad = h->Mpad;
+    v->CB = h->CB; v->dsub = h->dsub; v->CB_granule = h->CB_granule; v->nprobe = h->nprobe; v->trained = h->trained; v->ntotal = h->ntotal;
+    v->ld = h->ld; v->storage_f16 = h->storage_f16; v->storage_decided = h->storage_decided; v->custom_ids = h->custom_ids;
+    v->total_cap = h->total_cap; v->max_norm2 = h->max_norm2; v->flat_cert = h->flat_cert;
+    v->h_base = h->h_base; v->h_len = h->h_len; v->h_cap = h->h_cap;          // nlist x 8 bytes each
+    v->dir_gen = h->dir_gen;                                                   // its memoised bounds carry the generation they were made for
+    v->d_centroids.borrow(h->d_centroids); v->d_codebooks.borrow(h->d_codebooks); v->data.borrow(h->data); v->ids.borrow(h->ids);
+    v->norms.borrow(h->norms); v->d_base.borrow(h->d_base); v->d_len.borrow(h->d_len); v->d_maxnorm.borrow(h->d_maxnorm);
+    // knobs
+    v->overlap = h->overlap; v->query_batch = h->query_batch; v->scan_chunk = h->scan_chunk; v->scan_kernel = h->scan_kernel;
+    v->pq_fast = h->pq_fast; v->pq_fast_kp = h->pq_fast_kp; v->pq_filter = h->pq_filter; v->pq_pace = h->pq_pace; v->pq_prune = h->pq_prune;
+    v->lut_tiled = h->lut_tiled; v->pq_prepass_fused = h->pq_prepass_fused; v->ivf_wide2 = h->ivf_wide2; v->ivf_qtiles = h->ivf_qtiles;
+    v->pq_prepass4 = h->pq_prepass4; v->pq_gather = h->pq_gather; v->pq_final_tab = h->pq_final_tab; v->pq_log_cap = h->pq_log_cap;
+    v->pq_pre_mult = h->pq_pre_mult; v->pq_pre_max = h->pq_pre_max; v->pq_pre_rows = h->pq_pre_rows; v->flat_filter = h->flat_filter;
+    v->ivf_filter = h->ivf_filter; v->profile = 0; v->temp_budget = h->temp_budget; v->pipeline = 0;
+    return v;
+}
+
 static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
     if (nq < 0 || k <= 0) RSX_THROW(RSX_ERR_INVALID, "search: nq=%lld k=%d", (long long)nq, k);
     if (k > 4096) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: k = %d exceeds this build's maximum of 4096 (the reference backends' default k)", k);
@@ -1678,7 +1731,10 @@ static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int 
     } else if (nq <= 32) {
         qb = 32;
     }
-    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+    // e: the handle that executes (h itself, or its pipeline view); batches first, first + stride, ...
+    auto run_batches = [&](rsx_index* e, int64_t first, int64_t stride) {
+    rsx_index* const h = e;
+    for (int64_t q0 = first * qb; q0 < nq; q0 += stride * qb) {
         int64_t nb = std::min(qb, nq - q0);
         const void* dq;
         const bool small = nb <= 64;      // latency path: stage through pinned memory (see PinBuf)
@@ -1712,6 +1768,30 @@ static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int 
             memcpy(D + q0 * k, h->pin_out.p, dbytes);
             memcpy(I + q0 * k, h->pin_out.as<char>() + round_up(dbytes, 16), ibytes);
         }
+    }
+    };
+    const bool piped = h->pipeline == 1 && nq > qb && h->kind == KIND_IVFPQ && h->CB == 0 && h->pq_fast && h->pq_filter && h->scan_kernel == 0 &&
+                       h->profile == 0 && !(h->tc && h->tc->active);
+    if (!piped) {
+        run_batches(h, 0, 1);
+    } else {
+        rsx_index* v = refresh_view(h);
+        const int res = std::max(0, std::min(120, h->pipeline_reserve)) & ~7;
+        h->scan_reserve_now = res; v->scan_reserve_now = res;
+        std::exception_ptr verr;
+        std::string verr_msg;
+        std::thread th([&] {
+            try {
+                HIPCHECK(hipSetDevice(v->device));
+                run_batches(v, 1, 2);
+            } catch (...) { verr = std::current_exception(); }
+        });
+        std::exception_ptr herr;
+        try { run_batches(h, 0, 2); } catch (...) { herr = std::current_exception(); }
+        th.join();
+        h->scan_reserve_now = 0; v->scan_reserve_now = 0;
+        if (herr) std::rethrow_exception(herr);
+        if (verr) std::rethrow_exception(verr);
     }
     HIPCHECK(hipGetLastError());
 }
@@ -2148,7 +2228,8 @@ static void sharded_save(rsx_index* h, const char* path) {
 
 static void destroy_handle(rsx_index* h) {
     if (!h) return;
-    for (auto* c : h->shards) { if (c->st) { (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->st); } delete c; }
+    for (auto* c : h->shards) { free_view(c); if (c->st) { (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->st); } delete c; }
+    free_view(h);
     if (h->st) { (void)hipSetDevice(h->device); (void)hipStreamDestroy(h->st); }
     delete h;
 }
@@ -2313,11 +2394,13 @@ int rsx_destroy(rsx_index_t* h) {
         }
         for (auto* c : h->shards) {
             (void)hipSetDevice(c->device);
+            free_view(c);
             if (c->st) { (void)hipStreamSynchronize(c->st); (void)hipStreamDestroy(c->st); }
             delete c;
         }
         h->shards.clear();
         (void)hipSetDevice(h->device);
+        free_view(h);
         if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
         delete h;
     });
@@ -2643,7 +2726,7 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
         else if (s == "query_batch") *out = h->query_batch;
         else if (s == "pq_layout") *out = (h->kind == KIND_IVFPQ && h->CB == 0) ? 1 : 0;
         else if (s == "hbm_bytes") *out = (int64_t)(h->data.bytes + h->ids.bytes + h->norms.bytes);
-        else if (s == "workspace_bytes") *out = workspace_bytes(h);
+        else if (s == "workspace_bytes") *out = workspace_bytes(h) + (h->pipe_view ? workspace_bytes(h->pipe_view) : 0);
         else RSX_THROW(RSX_ERR_INVALID, "unknown property '%s'", key);
     });
 }
@@ -2683,6 +2766,8 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_pre_max") h->pq_pre_max = std::min(32768, std::max(64, (int)value));
         else if (s == "pq_final_tab") h->pq_final_tab = (int)value;
         else if (s == "overlap") h->overlap = (int)value;
+        else if (s == "pipeline") h->pipeline = (int)value;
+        else if (s == "pipeline_reserve") h->pipeline_reserve = std::max(0, (int)value);
         else if (s == "pq_gather") h->pq_gather = (int)value;
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;

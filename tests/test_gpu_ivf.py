@@ -661,3 +661,42 @@ def test_round4_engine_knobs_never_change_a_result(gpu, orc, M, d):
                     ix.set_param("pq_pre_mult", mult); ix.set_param("pq_pre_max", mx)
                     D, I = ix.search(q, k)
                     assert_same_results(D, I, De, Ie, f"M={M} k={k} overlap={overlap} pq_final_tab={tab} sample={mult}x/{mx}")
+
+
+@pytest.mark.parametrize("M", [96, 16])
+def test_pipelined_batches_equal_the_sequential_loop(gpu, M):
+    """One index.search call with several internal batches (the reference hands ALL its queries to one call, src/search.py:296)
+    alternates the batches between the handle and its pipeline view on two host threads (rsx_api.hip: search_impl).  The results
+    must be those of the sequential loop (pipeline = 0) — CUDA-tensor and host queries, ragged last batch, any reserve — also
+    after the index grew between two calls (the view borrows the payload and must pick up the re-laid-out lists), and the
+    exact kernel's."""
+    import torch
+    d, n, nlist, nq = 768, 80000, 32, 64 * 7 + 19
+    x = gpu.synth_vectors(d, 64, 1234, 10000, 0.5, 0, n + 40000)
+    q = gpu.synth_queries(d, 64, 1234, 10000, 0.5, n, 999, 0.1, 0, nq)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    ix.train(x[:20000]); ix.add(x[:n]); ix.nprobe = 8
+    ix.set_param("query_batch", 64)
+    qd = torch.from_numpy(q).cuda()
+    for round_ in range(2):
+        for k in (10, 200):
+            ix.set_param("pipeline", 0)
+            Ds, Is = ix.search(q, k)
+            ws0 = ix._get("workspace_bytes")
+            ix.set_param("pipeline", 1)
+            for reserve in (16, 0, 64):
+                ix.set_param("pipeline_reserve", reserve)
+                D, I = ix.search(q, k)
+                assert_same_results(D, I, Ds, Is, f"M={M} k={k} reserve={reserve} host queries, round {round_}")
+                Dd, Id = ix.search(qd, k)
+                assert_same_results(Dd.cpu().numpy(), Id.cpu().numpy(), Ds, Is, f"M={M} k={k} reserve={reserve} device queries, round {round_}")
+            if round_ == 0 and k == 10:
+                assert ix._get("workspace_bytes") > ws0, "the pipeline view's workspaces are reported"
+            D1, I1 = ix.search(q[:64], k)          # a single batch never takes the pipeline
+            assert_same_results(D1, I1, Ds[:64], Is[:64], f"M={M} k={k} one batch")
+        ix.set_param("scan_kernel", 2); ix.set_param("pipeline", 1)
+        De, Ie = ix.search(q, 10)
+        ix.set_param("scan_kernel", 0)
+        D, I = ix.search(q, 10)
+        assert_same_results(D, I, De, Ie, f"M={M} pipelined vs the exact kernel, round {round_}")
+        ix.add(x[n:])                              # lists overflow: the payload moves

@@ -16,3 +16,7 @@ r = j.get("roofline") or {}
 print(f"{label}: {j['ms_per_step']:.3f} ms/step, scan {scan:.3f}, stage total {s.get('total', 0.0):.3f}, fixed {j['ms_per_step'] - scan:.3f} "
       f"(stages {s.get('total', 0.0) - scan:.3f}), {j['value']:.0f} q/s, frac {r.get('frac')}, fallbacks {j.get('certificate_fallback_fraction')}")
 print("   stages:", {k: v for k, v in s.items() if v})
+oc = j.get("one_call_all_queries")
+if oc:
+    print(f"   one call of {oc['queries']} queries: sequential {oc['sequential']['ms']:.3f} ms ({oc['sequential']['queries_per_s']:.0f} q/s), "
+          f"pipelined {oc['pipelined']['ms']:.3f} ms ({oc['pipelined']['queries_per_s']:.0f} q/s), same results {oc['same_ids_and_scores']}")
