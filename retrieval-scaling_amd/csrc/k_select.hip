@@ -774,17 +774,36 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
                                                     const int64_t* list_len, int tile_rows, int tile_cap,
                                                     int32_t* item_off, int32_t* total_items) {
     __shared__ int32_t sp[48], sg[3];
+    // This single workgroup runs on the side stream BESIDE the threshold pre-pass, whose 1024-thread workgroups fill every CU: alone
+    // it takes 10 us, sharing a CU's issue slots 75 us — and the item records (hence the scan) wait for it.  Top issue priority, the
+    // tile counts kept in registers between the two passes, and a 32-bit division where the list length allows (always, in practice).
+    __builtin_amdgcn_s_setprio(3);
     // tiles of list l that become work items (tile_cap > 0 limits them, e.g. to the first tile only)
     auto ntiles = [&](int l) {
-        int32_t t = (int32_t)((list_len[l] + tile_rows - 1) / tile_rows);
+        const int64_t len = list_len[l];
+        int32_t t = len <= 0x7ffffffe - tile_rows ? (int32_t)(((uint32_t)len + (uint32_t)tile_rows - 1u) / (uint32_t)tile_rows)
+                                                  : (int32_t)((len + tile_rows - 1) / tile_rows);
         return (tile_cap > 0 && t > tile_cap) ? tile_cap : t;
     };
     int t = threadIdx.x;
     int per = (nlist + 1023) / 1024;
     int lo = t * per, hi = lo + per;
     if (hi > nlist) hi = nlist;
+    constexpr int KEEP = 8;                     // lists per thread whose counts stay in registers (nlist <= 8192)
+    int32_t c_[KEEP], n_[KEEP];
     int32_t ap = 0, ag = 0, ai = 0;
-    for (int l = lo; l < hi; l++) {
+#pragma unroll
+    for (int j = 0; j < KEEP; j++) {
+        const int l = lo + j;
+        c_[j] = 0; n_[j] = 0;
+        if (l < hi) {
+            c_[j] = cnt[l];
+            const int ng = (c_[j] + G - 1) / G;
+            if (tile_rows > 0) n_[j] = ng * ntiles(l);
+            ap += c_[j]; ag += ng; ai += n_[j];
+        }
+    }
+    for (int l = lo + KEEP; l < hi; l++) {
         int ng = (cnt[l] + G - 1) / G;
         ap += cnt[l]; ag += ng;
         if (tile_rows > 0) ai += ng * ntiles(l);
@@ -794,7 +813,17 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
         pair_off[nlist] = sg[0]; group_off[nlist] = sg[1]; *total_groups = sg[1];
         if (tile_rows > 0) { item_off[nlist] = sg[2]; *total_items = sg[2]; }
     }
-    for (int l = lo; l < hi; l++) {
+#pragma unroll
+    for (int j = 0; j < KEEP; j++) {
+        const int l = lo + j;
+        if (l < hi) {
+            const int ng = (c_[j] + G - 1) / G;
+            pair_off[l] = ap; group_off[l] = ag;
+            if (tile_rows > 0) { item_off[l] = ai; ai += n_[j]; }
+            ap += c_[j]; ag += ng;
+        }
+    }
+    for (int l = lo + KEEP; l < hi; l++) {
         int ng = (cnt[l] + G - 1) / G;
         pair_off[l] = ap; group_off[l] = ag;
         if (tile_rows > 0) { item_off[l] = ai; ai += ng * ntiles(l); }
