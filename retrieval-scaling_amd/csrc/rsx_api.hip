@@ -218,8 +218,11 @@ struct rsx_index {
     int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
     int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
-    int flat_filter = 1;  // Flat: one filtered GEMM launch after the first chunk (0 = score buffer per chunk)
+    int flat_filter = 1;  // Flat: filtered GEMM launches after the threshold phase (0 = score buffer per chunk)
+    int flat_pre_mult = 32;  // Flat: rows of the threshold phase per K' (through the score buffer), rounded up to 65536-row chunks
+    int flat_stages = 0;     // Flat: filtered stages behind the threshold phase (0 = from K' and the row count; see search_batch)
     int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
+    int ivf_pre_lists = 0;   // IVF-Flat threshold sample at large K': closest lists sampled (0 = 2)
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
 
@@ -766,10 +769,10 @@ static void train_impl(rsx_index* h, int64_t n, const void* x, int dtype) {
 // ---------------------------------------------------------------------------------------
 struct StageTimer {
     rsx_index* h; bool on; std::string prefix;
-    hipEvent_t ev[16]; const char* name[16]; int n = 0;
+    hipEvent_t ev[64]; const char* name[64]; int n = 0;
     StageTimer(rsx_index* hh, const char* pre = "") : h(hh), on(hh->profile != 0), prefix(pre) {}
     void mark(const char* nm) {
-        if (!on || n >= 16) return;
+        if (!on || n >= 64) return;
         (void)hipEventCreate(&ev[n]);
         (void)hipEventRecord(ev[n], h->st);
         name[n] = nm; n++;
@@ -1083,50 +1086,68 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             launch_fill_u64(state, nq * KP, 0, h->st);
             // chunk 0 through the score buffer: its top-K' gives every query a running threshold
             int64_t done_rows = 0;
-            auto chunk_pass = [&](int64_t v0) {
-                int64_t nv = std::min<int64_t>(CH, N - v0);
+            auto chunk_pass = [&](int64_t v0, int64_t vend) {
+                int64_t nv = std::min<int64_t>(CH, vend - v0);
                 launch_flat_gemm(h->w_q16.as<__half>(), (int)nq_pad, h->data.p, h->storage_f16, v0, nv, ld, bias,
                                  h->w_temp.as<float>(), CH, h->st);
                 select_rows(h, h->w_temp.as<float>(), CH, nullptr, 0, nv, (uint32_t)v0, nq, KP, BUF, KP, state, true);
             };
-            // threshold phase: the K'-th key of the first rows is a FIXED threshold for everything behind them, so the filtered pass
-            // keeps ~N K' / rows-so-far keys per query.  One 65536-row chunk is right for k = 10 (K' = 32: 5 k keys at 10M rows);
-            // for the reference's n_docs = 1000 (K' = 2048) it let 310 k keys through, overflowed every candidate row and fell back
-            // to 153 chunk passes — 550 ms per batch (round 4: measured once k = 1000 joined the bench).  Now 160 K' rows (320: the radix selections of the threshold phase cost more than the extra keys).
-            const int64_t n0 = std::min<int64_t>((N + CH - 1) / CH, std::max<int64_t>(1, ((int64_t)KP * 160 + CH - 1) / CH));
-            for (int64_t c = 0; c < n0; c++) chunk_pass(c * CH);
+            // Threshold phase: the K'-th key of the first rows is a threshold for everything behind them, so a filtered pass over
+            // the rows [a, b) keeps ~K' (b - a) / a keys per query.  One 65536-row chunk is right for k = 10 (K' = 32: 5 k keys at
+            // 10M rows).  For the reference's n_docs = 1000 (K' = 2048) one chunk let 310 k keys through, overflowed every candidate row
+            // and fell back to 153 chunk passes (550 ms per batch, round 4); 160 K' rows and ONE filtered launch over the rest still
+            // emitted 62 k keys per query — 64 M atomically placed keys, the filtered GEMM 27.8 instead of 17.4 ms — behind five
+            // chunk selections of 0.93 ms.  Now: flat_pre_mult x K' rows through the score buffer (default 32: one chunk), then the rest
+            // in STAGES of geometrically growing row ranges, each one filtered launch + one selection that tightens the threshold for
+            // the next: S stages of ratio r = (N / first)^(1/S) emit ~S K' (r - 1) keys.  Measured at 10M x 768, batch 1024
+            // (profiles/r04_flat_staged_filter.md): k = 1000 36.5 -> 23.3 ms (S = 5), k = 10 18.9 -> 17.2 ms (S = 2: even 5 k keys
+            // per query cost the single filtered launch 1.6 ms), k = 100 17.8 ms.
+            const int64_t nchunks = (N + CH - 1) / CH;
+            const int64_t n0 = std::min<int64_t>(nchunks, std::max<int64_t>(1, ((int64_t)KP * std::max(1, h->flat_pre_mult) + CH - 1) / CH));
+            for (int64_t c = 0; c < n0; c++) chunk_pass(c * CH, N);
             done_rows = std::min<int64_t>(n0 * CH, N);
             tm.mark("scan0");
-            bool filtered_ok = true;
             if (done_rows < N && h->flat_filter != 0) {
-                // the rest in ONE GEMM launch whose epilogue keeps only keys beating the running K'-th key
+                int S = h->flat_stages;
+                if (S <= 0) S = KP <= 64 ? 2 : std::min(6, std::max(1, (int)lround(log((double)nchunks / (double)n0) / log(3.0))));
+                const double r = pow((double)nchunks / (double)n0, 1.0 / S);
                 const int cap = KP <= 64 ? 32768 : 131072;
                 h->w_cand.ensure((size_t)nq * cap * 8);
                 h->w_candcnt.ensure((size_t)nq * 8 * CCS);
-                HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8 * CCS, h->st));
-                launch_flat_gemm_filter(h->w_q16.as<__half>(), (int)nq_pad, (int)nq, h->data.p, h->storage_f16, done_rows,
-                                        N - done_rows, ld, bias, state + (KP - 1), KP, h->w_cand.as<uint64_t>(),
-                                        h->w_candcnt.as<unsigned long long>(), cap, h->st);
-                tm.mark("scan");
                 std::vector<unsigned long long> cnts((size_t)nq * CCS);
-                HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
-                HIPCHECK(hipStreamSynchronize(h->st));
-                for (int64_t qi = 0; qi < nq; qi++) if (cnts[(size_t)qi * CCS] > (unsigned long long)cap) { filtered_ok = false; break; }
-                if (filtered_ok) {
-                    SelectArgs b{};
-                    b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cap;
-                    b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cap;
-                    b.seg_len = cap; b.nseg = 1; b.idx_base = 0;
-                    b.init = state; b.out = state; b.out_row_stride = KP;
-                    b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;
-                    launch_select(b, h->st);
-                    tm.mark("select");
-                } else {
-                    h->timing["flat_filter_overflows"] += 1;   // adversarial order: redo the rest chunk by chunk
+                for (int st_ = 0; st_ < S && done_rows < N; st_++) {
+                    // stage boundaries on chunk multiples (the database tiles of the GEMM stay aligned)
+                    int64_t endc = st_ == S - 1 ? nchunks : std::min<int64_t>(nchunks, std::max<int64_t>(done_rows / CH + 1, (int64_t)llround((double)n0 * pow(r, st_ + 1))));
+                    const int64_t end = std::min<int64_t>(N, endc * CH);
+                    // ONE GEMM launch over the stage's rows whose epilogue keeps only keys beating the running K'-th key
+                    HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8 * CCS, h->st));
+                    launch_flat_gemm_filter(h->w_q16.as<__half>(), (int)nq_pad, (int)nq, h->data.p, h->storage_f16, done_rows,
+                                            end - done_rows, ld, bias, state + (KP - 1), KP, h->w_cand.as<uint64_t>(),
+                                            h->w_candcnt.as<unsigned long long>(), cap, h->st);
+                    tm.mark("scan");
+                    HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
+                    HIPCHECK(hipStreamSynchronize(h->st));
+                    bool filtered_ok = true;
+                    for (int64_t qi = 0; qi < nq; qi++) if (cnts[(size_t)qi * CCS] > (unsigned long long)cap) { filtered_ok = false; break; }
+                    if (filtered_ok) {
+                        SelectArgs b{};
+                        b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cap;
+                        b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cap;
+                        b.seg_len = cap; b.nseg = 1; b.idx_base = 0;
+                        b.init = state; b.out = state; b.out_row_stride = KP;
+                        b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;
+                        launch_select(b, h->st);
+                        tm.mark("select");
+                    } else {
+                        h->timing["flat_filter_overflows"] += 1;   // adversarial order: redo this stage's rows chunk by chunk
+                        for (int64_t v0 = done_rows; v0 < end; v0 += CH) chunk_pass(v0, end);
+                        tm.mark("scan");
+                    }
+                    done_rows = end;
                 }
             }
-            if (done_rows < N && (h->flat_filter == 0 || !filtered_ok)) {
-                for (int64_t v0 = done_rows; v0 < N; v0 += CH) chunk_pass(v0);
+            if (done_rows < N) {       // flat_filter = 0
+                for (int64_t v0 = done_rows; v0 < N; v0 += CH) chunk_pass(v0, N);
                 tm.mark("scan");
             }
         }
@@ -1517,7 +1538,11 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // ... of the closest list — of the EIGHT closest lists when K' is large: a query whose closest list holds fewer than K'
             // rows would get no threshold, keep every row of its 128 lists and overflow (the prefix of its score row then runs on
             // into the next lists' first rows)
-            const int pre_lists = (KP >= 256 && (int64_t)8 * pre_chunks * chunk_rows <= tmax) ? std::min(8, nprobe) : 1;
+            // (round 4: two lists, not eight — with 64 probing queries per list nearly every list is among some query's eight closest,
+            //  and the 'sample' read 26 of the 31 GB: 3.4 + 0.8 ms of a 13.2 ms batch at nlist 2048 / nprobe 128 / k 1000; two lists
+            //  leave 11.3 ms and as few candidates; ONE list overflows the queries whose closest list is short: profiles/r04_n_docs_1000.md)
+            const int pre_want = h->ivf_pre_lists > 0 ? h->ivf_pre_lists : 2;
+            const int pre_lists = (KP >= 256 && (int64_t)pre_want * pre_chunks * chunk_rows <= tmax) ? std::min(pre_want, nprobe) : 1;
             a.max_chunks = (int)pre_chunks;                        // the first chunk(s) of ...
             a.qtiles = 1;                                          // (groups of 16 there: most lists are the closest of at most a few queries)
             const int64_t pre_stride = pre_lists > 1 ? pre_chunks * chunk_rows : 0;    // several lists: one slice of the sample buffer each
@@ -1692,8 +1717,8 @@ static rsx_index* refresh_view(rsx_index* h) {
     v->pq_fast = h->pq_fast; v->pq_fast_kp = h->pq_fast_kp; v->pq_filter = h->pq_filter; v->pq_pace = h->pq_pace; v->pq_prune = h->pq_prune;
     v->lut_tiled = h->lut_tiled; v->pq_prepass_fused = h->pq_prepass_fused; v->ivf_wide2 = h->ivf_wide2; v->ivf_qtiles = h->ivf_qtiles;
     v->pq_prepass4 = h->pq_prepass4; v->pq_gather = h->pq_gather; v->pq_final_tab = h->pq_final_tab; v->pq_log_cap = h->pq_log_cap;
-    v->pq_pre_mult = h->pq_pre_mult; v->pq_pre_max = h->pq_pre_max; v->pq_pre_rows = h->pq_pre_rows; v->flat_filter = h->flat_filter;
-    v->ivf_filter = h->ivf_filter; v->profile = 0; v->temp_budget = h->temp_budget; v->pipeline = 0;
+    v->pq_pre_mult = h->pq_pre_mult; v->pq_pre_max = h->pq_pre_max; v->pq_pre_rows = h->pq_pre_rows; v->flat_filter = h->flat_filter; v->flat_pre_mult = h->flat_pre_mult; v->flat_stages = h->flat_stages;
+    v->ivf_filter = h->ivf_filter; v->ivf_pre_lists = h->ivf_pre_lists; v->profile = 0; v->temp_budget = h->temp_budget; v->pipeline = 0;
     return v;
 }
 
@@ -2760,6 +2785,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
             h->CB = (int)value == 1 ? 0 : h->CB_granule;
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
+        else if (s == "ivf_pre_lists") h->ivf_pre_lists = std::max(0, (int)value);
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_log_cap") h->pq_log_cap = std::max(0, (int)value);
         else if (s == "pq_pre_mult") h->pq_pre_mult = std::max(1, (int)value);
@@ -2775,6 +2801,8 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;
+        else if (s == "flat_pre_mult") h->flat_pre_mult = std::max(1, (int)value);
+        else if (s == "flat_stages") h->flat_stages = std::max(0, (int)value);
         else if (s == "flat_cert") h->flat_cert = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
         else if (s == "temp_budget_mb") h->temp_budget = (int64_t)value << 20;

@@ -253,3 +253,68 @@ def test_m16_reference_shape_mid_scale(gpu, orc):
         ix.set_param("scan_chunk", 0); ix.set_param("profile", 0)
         Do, Io = orc.ivfpq_search(cen, cb, lm, qs, nprobe, k)
         assert np.array_equal(Io, I[:6].cpu().numpy()) and np.array_equal(Do, D[:6].cpu().numpy()), f"k={k}: oracle sample"
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_flat_staged_filter_at_the_reference_n_docs(gpu, orc, metric):
+    """Flat at the reference's n_docs (ric/conf/default.yaml:70,84: Flat, n_docs 1000) behind the staged threshold: the rows
+    behind the threshold phase are scanned in stages of growing row ranges, each filtered by the running K'-th key and followed
+    by a selection that tightens it (rsx_api.hip: search_batch).  Any number of stages and any threshold-phase size must
+    return the oracle's ids and scores; the default must take more than one stage here."""
+    import torch
+    d, n, nq = 128, 1_000_000, 160
+    x = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    gpu.synth_vectors(d, 256, 1234, 10000, 0.5, 0, n, out=x)
+    q = torch.empty((nq, d), dtype=torch.float16, device="cuda")
+    gpu.synth_queries(d, 256, 1234, 10000, 0.5, n, 999, 0.1, 0, nq, out=q)
+    ix = gpu.IndexFlat(d, metric); ix.add(x)
+    sample = [0, 63, 64, 159]
+    xs = x.cpu().numpy().astype(np.float32)
+    for k in (1000, 100):
+        Dr, Ir = orc.flat_search(q[sample].cpu().numpy().astype(np.float32), xs, k, metric)
+        ref = None
+        for mult, stages in ((32, 0), (64, 1), (1, 4), (16, 2), (160, 3)):
+            ix.set_param("flat_pre_mult", mult); ix.set_param("flat_stages", stages); ix.set_param("profile", 1)
+            D, I = ix.search(q, k)
+            assert ix.get_timing("fallback_queries") == 0 and ix.get_timing("flat_filter_overflows") == 0
+            Dn, In = D.cpu().numpy(), I.cpu().numpy()
+            assert_same_results(Dn[sample], In[sample], Dr, Ir, f"flat k={k} metric {metric} pre_mult={mult} stages={stages} vs oracle")
+            if ref is None:
+                ref = (Dn, In)
+            assert np.array_equal(ref[1], In) and np.array_equal(ref[0], Dn), f"k={k} pre_mult={mult} stages={stages}: staging must be invisible"
+        ix.set_param("flat_pre_mult", 32); ix.set_param("flat_stages", 0); ix.set_param("profile", 0)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_ivfflat_filter_at_the_reference_n_docs(gpu, orc, metric):
+    """IVF-Flat at the reference's n_docs (ric/conf: n_docs 1000) behind the in-kernel filter: the threshold comes from a sample of
+    the first rows of the query's closest list(s) — 1, 2, 4 or 8 of them (ivf_pre_lists) — and lists of very different lengths
+    (some shorter than one scan chunk or than K', some of 20+ chunks) must neither lose a result nor change one: the oracle's ids,
+    the scores within the fp16-scan tolerance of the other IVF-Flat tests, identical results across the settings and with the
+    unfiltered scan."""
+    rng = np.random.RandomState(5)
+    d, nlist, n, nq, nprobe = 128, 24, 260_000, 130, 12
+    cen = rng.randn(nlist, d).astype(np.float32)
+    pl = rng.dirichlet(np.full(nlist, 0.6))                 # skewed list sizes: a few hundred to tens of thousands of rows
+    x = (cen[rng.choice(nlist, n, p=pl)] + 0.5 * rng.randn(n, d)).astype(np.float16)
+    qf = (x[rng.randint(0, n, nq)].astype(np.float32) + 0.1 * rng.randn(nq, d)).astype(np.float32)
+    xf = x.astype(np.float32)
+    a, _ = orc.assign_ip(cen, xf)
+    lm = orc.ListMajor(a, np.arange(n), xf, nlist)
+    ix = gpu.IndexIVFFlat(None, d, nlist, metric)
+    ix.set_centroids(cen); ix.add(x); ix.nprobe = nprobe
+    ls = ix.list_sizes()
+    assert ls.min() < 1024 and ls.max() > 16 * 1024, "the test wants short and long lists"
+    for k in (1000, 300):
+        Dr, Ir = orc.ivfflat_search(metric, cen, lm, qf[:6], nprobe, k)
+        ix.set_param("ivf_filter", 0)
+        Du, Iu = ix.search(qf, k)
+        assert np.array_equal(Iu[:6], Ir), f"metric={metric} k={k} unfiltered vs oracle"
+        assert np.allclose(Du[:6], Dr, rtol=0, atol=max(1e-30, np.abs(Dr[np.isfinite(Dr)]).max() * 2 ** -22))
+        ix.set_param("ivf_filter", 2)
+        for pre_lists in (0, 1, 2, 4):
+            ix.set_param("ivf_pre_lists", pre_lists); ix.set_param("profile", 1)
+            D, I = ix.search(qf, k)
+            assert ix.get_timing("fallback_queries") == 0
+            assert np.array_equal(Iu, I) and np.array_equal(Du, D), f"metric={metric} k={k} ivf_pre_lists={pre_lists}: the filter must be invisible"
+        ix.set_param("profile", 0); ix.set_param("ivf_pre_lists", 0)
