@@ -1083,9 +1083,21 @@ extern "C" int rsx_debug_pp4_trace(uint64_t* out) { return hipMemcpyFromSymbol(o
 #else
 #define PP4_MARK(i)
 #endif
-template <int NF, int NH>
+// BIG (round 4, the reference's n_docs = 1000 / 2000 on the headline index): samples of any size, spanning several lists.  The
+// 16-bit sums are not kept — every (sum + 1) goes straight into a per-query histogram of (sum + 1) >> PP4_SH (16-bit counters,
+// two per dword: a sample holds <= 32768 rows) and the threshold is taken at the LOWER EDGE of the bin that holds the k-th
+// largest: a lower bound of the k-th largest sum (<= 7 of ~24 k integer units below it), hence still a valid a_k.  A sample that
+// the closest list cannot fill continues in the next closest lists with k_pq_prepass's shifted sums (a lower bound of the
+// vector's approximate score relative to the closest list's dis0).  k_pq_prepass scores such samples with byte gathers on a
+// per-query byte table: 0.77 ms per 1024 queries x 16384 rows; this form shares the table image between four queries and uses
+// the scan's conflict-free gathers and the MFMA adder.
+constexpr int PP4_MAXSEG = 8;
+template <int NF, int NH, bool BIG = false>
 __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t nq) {
     constexpr int M = 64 * NF + 32 * NH;
+    constexpr int PP4_SH = M > 96 ? 4 : 3;
+    constexpr int NB = ((255 * M + 1) >> PP4_SH) + 1;        // bins of (sum + 1) >> PP4_SH
+    constexpr int NBW = (NB + 1) / 2;                        // dwords of one query's histogram
     constexpr int NPH = NF + NH;
     constexpr int TAB = NPH * 65536;
     constexpr int NG = M / 4;
@@ -1096,8 +1108,9 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
     extern __shared__ __attribute__((aligned(16))) uint32_t pp4_s[];
     uint8_t* sb = reinterpret_cast<uint8_t*>(pp4_s);
     uint16_t* sums = reinterpret_cast<uint16_t*>(sb + TAB);                               // [4][pre_rows]: integer sum + 1, 0 = no vector
-    int32_t* hist = reinterpret_cast<int32_t*>(sb + TAB + (size_t)4 * a.pre_rows * 2);    // [4][256]
-    int32_t* ctl = hist + 1024;                                                           // [4][8]
+    int32_t* hist = reinterpret_cast<int32_t*>(sb + TAB + (BIG ? (size_t)0 : (size_t)4 * a.pre_rows * 2));    // [4][256] | BIG: [4][NBW] packed 16-bit counters
+    int32_t* ctl = hist + (BIG ? 4 * NBW : 1024);                                         // [4][8]
+    int32_t* segs = ctl + 32;                                                             // BIG: [4][PP4_MAXSEG][4] list, rows, shift, -; then [4] counts
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15, n = lane & 15;
@@ -1168,7 +1181,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
             *reinterpret_cast<uint4*>(sb + p * 65536 + c * 256 + slot * 4) = o;
         }
     }
-    for (int t = tid; t < 1024 + 32; t += 1024) hist[t] = 0;
+    for (int t = tid; t < (BIG ? 4 * NBW : 1024) + 32; t += 1024) hist[t] = 0;
     // ---- my query's closest probed list that holds vectors here (wave-uniform)
     int32_t l = -1; int64_t len = 0; int j0 = 0;
     if (grp < np) {
@@ -1178,13 +1191,53 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
         }
     }
     l = __builtin_amdgcn_readfirstlane(l); j0 = __builtin_amdgcn_readfirstlane(j0);
-    const int nrows = (int)(len < a.pre_rows ? len : a.pre_rows);
-    const int nblk = __builtin_amdgcn_readfirstlane((nrows + 15) >> 4);
+    int nrows = (int)(len < a.pre_rows ? len : a.pre_rows);
+    int nblk = __builtin_amdgcn_readfirstlane((nrows + 15) >> 4);
     const uint8_t* lp = a.codes + ((l >= 0 ? a.list_base[l] : 0) >> 4) * (int64_t)(16 * M);
     uint16_t* mysum = sums + (size_t)grp * a.pre_rows;
+    int nseg = 1;
+    if (BIG) {
+        // the slot's sample: the closest list first, then (k_pq_prepass's rule) the next closest ones until it holds min(pre_rows, 8 k) rows
+        int32_t* sg = segs + grp * (PP4_MAXSEG * 4);
+        if (wq == 0 && lane == 0) {
+            int ns = 0, off = 0;
+            if (l >= 0 && grp < np) {
+                sg[0] = l; sg[1] = nrows; sg[2] = 0; ns = 1; off = nrows;
+                const float scale = a.qparam[q * 4 + 0];
+                const float dis0 = a.probe_dis0[q * a.nprobe + j0];
+                const int want = a.pre_rows < 8 * a.k ? a.pre_rows : 8 * a.k;
+                if (scale > 0.0f)
+                    for (int j = j0 + 1; j < a.nprobe && ns < PP4_MAXSEG && off < want; j++) {
+                        const int32_t lj = a.probe_list[q * a.nprobe + j];
+                        if (lj < 0) continue;
+                        const int64_t len_j = a.list_len[lj];
+                        if (len_j <= 0) continue;
+                        const float sh = floorf((a.probe_dis0[q * a.nprobe + j] - dis0) / scale) - 2.0f;
+                        if (!(sh > -1.0e9f)) break;
+                        const int rows = (int)(len_j < (int64_t)(a.pre_rows - off) ? len_j : (int64_t)(a.pre_rows - off));
+                        sg[4 * ns + 0] = lj; sg[4 * ns + 1] = rows; sg[4 * ns + 2] = sh < 0.0f ? (int)sh : 0;
+                        off += rows;
+                        ns++;
+                    }
+            }
+            segs[4 * PP4_MAXSEG * 4 + grp] = ns;
+        }
+    }
     PP4_MARK(1);
     __syncthreads();        // tables staged, histograms zero
     PP4_MARK(2);
+    if (BIG) nseg = __builtin_amdgcn_readfirstlane(segs[4 * PP4_MAXSEG * 4 + grp]);
+    int shift = 0;
+    uint32_t* hq = reinterpret_cast<uint32_t*>(hist) + grp * NBW;
+#pragma unroll 1
+    for (int sgi = 0; sgi < nseg; sgi++) {
+    if (BIG) {
+        const int32_t* sg = segs + grp * (PP4_MAXSEG * 4) + 4 * sgi;
+        const int32_t ls = __builtin_amdgcn_readfirstlane(sg[0]);
+        nrows = __builtin_amdgcn_readfirstlane(sg[1]); shift = __builtin_amdgcn_readfirstlane(sg[2]);
+        nblk = (nrows + 15) >> 4;
+        lp = a.codes + (a.list_base[ls] >> 4) * (int64_t)(16 * M);
+    }
     // ---- scan: wave wq of the slot takes blocks wq, wq + 4, ...; PD blocks in flight per wave (register slots refilled in place
     // right after their codes have become gather addresses, as in k_pq_scan_rot; the prologue issues in slot order so that one
     // s_waitcnt serves the loop entry and the back edge)
@@ -1249,12 +1302,18 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int pos = b * 16 + 4 * g + r;
-                        mysum[pos] = pos < len ? (uint16_t)(C[r] + 128 * M + 1) : (uint16_t)0;
+                        if (BIG) {
+                            const int v = C[r] + 128 * M + 1 + shift;          // shifted sum + 1; < 1: below every score the bound could certify
+                            if (pos < nrows && v >= 1) atomicAdd(&hq[(v >> PP4_SH) >> 1], 1u << (16 * ((v >> PP4_SH) & 1)));
+                        } else {
+                            mysum[pos] = pos < len ? (uint16_t)(C[r] + 128 * M + 1) : (uint16_t)0;
+                        }
                     }
                 }
             }
         }
     }
+    }       // segments
     PP4_MARK(3);
     __syncthreads();
     PP4_MARK(4);
@@ -1285,18 +1344,47 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
         }
         return res;
     };
-    for (int t = tg; t < N; t += 256) { const int v = mysum[t]; if (v) atomicAdd(&hs[v >> 8], 1); }
-    __syncthreads();
-    if (wq == 0) { const int d = find_bin(a.k); if (lane == 0) cs[0] = d; }
-    __syncthreads();
-    const int dhi = cs[0], want2 = cs[1];
-    __syncthreads();
-    for (int t = tg; t < 256; t += 256) hs[t] = 0;
-    __syncthreads();
-    if (dhi >= 0) for (int t = tg; t < N; t += 256) { const int v = mysum[t]; if (v && (v >> 8) == dhi) atomicAdd(&hs[v & 255], 1); }
-    __syncthreads();
-    if (wq == 0) { const int e = dhi >= 0 ? find_bin(want2) : -1; if (lane == 0) cs[2] = e; }
-    __syncthreads();
+    int kth = -1;                           // (k-th largest integer sum) + 1 — BIG: a lower bound of it; -1: fewer than k vectors in the sample
+    if (BIG) {
+        // the highest bin B whose suffix count reaches k: wave 0 of the slot, lane i owns bins [i per, (i + 1) per)
+        if (wq == 0) {
+            constexpr int per = (NB + 63) / 64;
+            auto cnt_of = [&](int bin) -> int { return bin < NB ? (int)((hq[bin >> 1] >> (16 * (bin & 1))) & 0xffffu) : 0; };
+            int mine = 0;
+            for (int t = 0; t < per; t++) mine += cnt_of(lane * per + t);
+            int suf = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_down(suf, off); if (lane + off < 64) suf += y; }
+            const uint64_t mk = __builtin_amdgcn_ballot_w64(suf >= a.k);
+            int B = -1;
+            if (mk != 0ull) {
+                const int L = 63 - __builtin_clzll((unsigned long long)mk);
+                int run = __shfl(suf - mine, L);
+                if (lane == L)
+                    for (int t = per - 1; t >= 0; t--) { run += cnt_of(L * per + t); if (run >= a.k) { B = L * per + t; break; } }
+                B = __shfl(B, L);
+            }
+            if (lane == 0) cs[0] = B;
+        }
+        __syncthreads();
+        const int B = cs[0];
+        if (B >= 0) { kth = B << PP4_SH; if (kth < 1) kth = 1; }       // the bin's lower edge (values are >= 1)
+    } else {
+        for (int t = tg; t < N; t += 256) { const int v = mysum[t]; if (v) atomicAdd(&hs[v >> 8], 1); }
+        __syncthreads();
+        if (wq == 0) { const int d = find_bin(a.k); if (lane == 0) cs[0] = d; }
+        __syncthreads();
+        const int dhi = cs[0], want2 = cs[1];
+        __syncthreads();
+        for (int t = tg; t < 256; t += 256) hs[t] = 0;
+        __syncthreads();
+        if (dhi >= 0) for (int t = tg; t < N; t += 256) { const int v = mysum[t]; if (v && (v >> 8) == dhi) atomicAdd(&hs[v & 255], 1); }
+        __syncthreads();
+        if (wq == 0) { const int e = dhi >= 0 ? find_bin(want2) : -1; if (lane == 0) cs[2] = e; }
+        __syncthreads();
+        const int dlo = cs[2];
+        if (dhi >= 0 && dlo >= 0) kth = (dhi << 8) | dlo;
+    }
     PP4_MARK(5);
     // ---- the threshold (k_pq_prepass's arithmetic), the empty merge state, the candidate counter
     if (grp < np) {
@@ -1304,11 +1392,9 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
         for (int t = tg; t < a.KP; t += 256) o[t] = 0ull;
         if (tg == 0) {
             uint64_t tau = 0ull;
-            const int dlo = cs[2];
-            if (dhi >= 0 && dlo >= 0 && l >= 0) {
+            if (kth >= 0 && l >= 0) {
                 const float scale = a.qparam[q * 4 + 0], bias = a.qparam[q * 4 + 1], eps = a.qparam[q * 4 + 2];
                 const float dis0 = a.probe_dis0[q * a.nprobe + j0];
-                const int kth = (dhi << 8) | dlo;                                         // = (k-th largest integer sum) + 1
                 const float a_k = dis0 + __fmaf_rn(scale, (float)(kth - 1), bias);
                 float t = __fmaf_rn(-2.0002f, eps, a_k);
                 t -= fabsf(t) * 4.8e-7f + 1e-30f;
@@ -1328,6 +1414,27 @@ static void launch_pq_prepass4_t(const PQPrepassArgs& a, int64_t nq, hipStream_t
     static DevSize attr;
     attr.grow(shm, [&] { (void)hipFuncSetAttribute((const void*)k_pq_prepass4<NF, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
     hipLaunchKernelGGL((k_pq_prepass4<NF, NH>), dim3((unsigned)((nq + 3) / 4)), dim3(1024), shm, st, a, nq);
+}
+template <int NF, int NH>
+static void launch_pq_prepass4_big_t(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
+    constexpr int M = 64 * NF + 32 * NH;
+    constexpr int NBW = ((((255 * M + 1) >> (M > 96 ? 4 : 3)) + 1) + 1) / 2;
+    const size_t shm = (size_t)(NF + NH) * 65536 + (size_t)(4 * NBW + 32 + 4 * PP4_MAXSEG * 4 + 4) * 4 + 64;
+    static DevOnce once;
+    once.once([&] { (void)hipFuncSetAttribute((const void*)k_pq_prepass4<NF, NH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
+    hipLaunchKernelGGL((k_pq_prepass4<NF, NH, true>), dim3((unsigned)((nq + 3) / 4)), dim3(1024), shm, st, a, nq);
+}
+// the BIG form (histogram of the sums, samples of any size over several lists): 0 on launch, -1 when it does not apply
+int launch_pq_prepass4_big(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
+    if (nq <= 0) return 0;
+    if (a.CB != 0 || a.pre_rows <= 0 || a.pre_rows > 32768) return -1;        // 16-bit counters
+    switch (a.Mpad) {
+        case 32: launch_pq_prepass4_big_t<0, 1>(a, nq, st); return 0;
+        case 64: launch_pq_prepass4_big_t<1, 0>(a, nq, st); return 0;
+        case 96: launch_pq_prepass4_big_t<1, 1>(a, nq, st); return 0;
+        case 128: launch_pq_prepass4_big_t<2, 0>(a, nq, st); return 0;
+        default: return -1;
+    }
 }
 // sample rows the 4-query form can hold beside its tables (0: this M has no such kernel)
 int pq_prepass4_max_rows(int M) {

@@ -210,7 +210,7 @@ struct rsx_index {
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
     int ivf_wide2 = 0;       // IVF-Flat LDS-DMA scan, 32-query groups: 8 waves x 6-stage rings (experiment)
     int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scan: 1 = choose 16 / 32 / 64 queries per group from the queries per list, 2 / 4 = force, 0 = always 16
-    int pq_prepass4 = 1;     // rotated fast scan, small k, full batches: threshold pre-pass with four queries per workgroup on the scan's table format
+    int pq_prepass4 = 1;     // rotated fast scan, full batches: threshold pre-pass with four queries per workgroup on the scan's table format (1 = small and large k, 2 = small k only, 0 = never)
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
     int pq_final_tab = 1;    // rotated fast scan: finalize from the complete candidate row with the fp32 table in LDS (1 = when K' >= 512 or dsub > 8 and as the second chance, 2 = always, 0 = never)
     int pq_log_cap = 0;      // rotated fast scan: keys per survivor log (0 = from the pool budget); tests shrink it to force the overflow path
@@ -223,6 +223,7 @@ struct rsx_index {
     int flat_stages = 0;     // Flat: filtered stages behind the threshold phase (0 = from K' and the row count; see search_batch)
     int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
     int ivf_pre_lists = 0;   // IVF-Flat threshold sample at large K': closest lists sampled (0 = 2)
+    int ivf_pre_mult = 4;    // ... and rows of each per K'
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
 
@@ -1347,7 +1348,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     HIPCHECK(hipEventRecord(h->ev_group, h->st2));
                     grouped_early = true;
                 }
-                if (!(pre4 && launch_pq_prepass4(pa, nq, h->st) == 0)) launch_pq_prepass(pa, nq, h->st);
+                // large k: the histogram form of the four-query pre-pass (any sample size, several lists; pq_prepass4 = 2 keeps k_pq_prepass)
+                const bool pre4big = rot && !pre4 && h->pq_prepass4 == 1 && nq >= 64 && h->Mpad >= 32 && pre_rows <= 32768;
+                if (!(pre4 && launch_pq_prepass4(pa, nq, h->st) == 0) && !(pre4big && launch_pq_prepass4_big(pa, nq, h->st) == 0))
+                    launch_pq_prepass(pa, nq, h->st);
                 fused_pre_used = true;
                 done = true;
                 if (h->tc && h->tc->active && allow_fast && std::this_thread::get_id() == h->tc->worker) {
@@ -1531,7 +1535,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         //  count read-back cost more than the row traffic they save; 2 = always; 0 = never)
         // (round 4: for large k the pre-pass scores the first 4 K' rows of the closest list — up to 32 chunks — instead of giving up
         //  the filter when K' no longer fits one chunk: k = 1000 at nlist 2048 / nprobe 128 wrote and re-read 10 GB of score rows)
-        const int64_t pre_chunks = std::max<int64_t>(1, ((int64_t)KP * 4 + chunk_rows - 1) / chunk_rows);
+        const int64_t pre_chunks = std::max<int64_t>(1, ((int64_t)KP * std::max(1, h->ivf_pre_mult) + chunk_rows - 1) / chunk_rows);
         bool want_filter = h->ivf_filter != 0 && nprobe > 1 && chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld) &&
                            pre_chunks <= 32 && (h->ivf_filter > 1 || nq * tmax >= (int64_t)500000000);
         if (want_filter) {
@@ -1718,7 +1722,7 @@ static rsx_index* refresh_view(rsx_index* h) {
     v->lut_tiled = h->lut_tiled; v->pq_prepass_fused = h->pq_prepass_fused; v->ivf_wide2 = h->ivf_wide2; v->ivf_qtiles = h->ivf_qtiles;
     v->pq_prepass4 = h->pq_prepass4; v->pq_gather = h->pq_gather; v->pq_final_tab = h->pq_final_tab; v->pq_log_cap = h->pq_log_cap;
     v->pq_pre_mult = h->pq_pre_mult; v->pq_pre_max = h->pq_pre_max; v->pq_pre_rows = h->pq_pre_rows; v->flat_filter = h->flat_filter; v->flat_pre_mult = h->flat_pre_mult; v->flat_stages = h->flat_stages;
-    v->ivf_filter = h->ivf_filter; v->ivf_pre_lists = h->ivf_pre_lists; v->profile = 0; v->temp_budget = h->temp_budget; v->pipeline = 0;
+    v->ivf_filter = h->ivf_filter; v->ivf_pre_lists = h->ivf_pre_lists; v->ivf_pre_mult = h->ivf_pre_mult; v->profile = 0; v->temp_budget = h->temp_budget; v->pipeline = 0;
     return v;
 }
 
@@ -2786,6 +2790,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "ivf_pre_lists") h->ivf_pre_lists = std::max(0, (int)value);
+        else if (s == "ivf_pre_mult") h->ivf_pre_mult = std::max(1, (int)value);
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_log_cap") h->pq_log_cap = std::max(0, (int)value);
         else if (s == "pq_pre_mult") h->pq_pre_mult = std::max(1, (int)value);

@@ -372,6 +372,7 @@ void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
 // returns -1 when it does not apply (layout, M, or a sample larger than pq_prepass4_max_rows(M))
 int pq_prepass4_max_rows(int M);
 int launch_pq_prepass4(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
+int launch_pq_prepass4_big(const PQPrepassArgs& a, int64_t nq, hipStream_t st);   // large samples (<= 32768 rows, several lists): histogram form
 void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
                         int pad_to, int32_t* probe_list, float* probe_dis0, int64_t* seg_start, hipStream_t st);
 // tile_rows > 0: also build the (list, tile, group) work-item table: item_off[nlist+1], total_items

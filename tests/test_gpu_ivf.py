@@ -700,3 +700,34 @@ def test_pipelined_batches_equal_the_sequential_loop(gpu, M):
         D, I = ix.search(q, 10)
         assert_same_results(D, I, De, Ie, f"M={M} pipelined vs the exact kernel, round {round_}")
         ix.add(x[n:])                              # lists overflow: the payload moves
+
+
+@pytest.mark.parametrize("M,d", [(96, 768), (32, 256), (64, 256), (128, 256)])
+def test_large_k_prepass_histogram_form(gpu, M, d):
+    """Large k on the rotated layout: the threshold pre-pass in its four-queries-per-workgroup histogram form
+    (k_pq_prepass4<.., BIG>: samples of up to 32768 rows spanning up to eight lists, the threshold at the lower edge of the
+    histogram bin that holds the k-th largest integer sum) against the one-query form (pq_prepass4 = 2), no pre-pass kernel of
+    this family (0) and the exact kernel.  Lists from a few rows to tens of thousands: closest lists shorter than k, than the
+    sample, longer than it.  No query may need the exact re-run."""
+    rng = np.random.RandomState(3)
+    nlist, n, nq = 40, 200_000, 133
+    cen = rng.randn(nlist, d).astype(np.float32)
+    pl = rng.dirichlet(np.full(nlist, 0.3))                 # very uneven lists
+    x = (cen[rng.choice(nlist, n, p=pl)] + 0.6 * rng.randn(n, d)).astype(np.float16)
+    q = (x[rng.randint(0, n, nq)].astype(np.float32) + 0.2 * rng.randn(nq, d)).astype(np.float16)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    assert ix._get("pq_layout") == 1
+    ix.train(x[:40000]); ix.add(x); ix.nprobe = 16
+    ls = ix.list_sizes()
+    assert ls.min() < 1000 and ls.max() > 5000, "the test wants lists shorter than k and lists longer than the sample"
+    for k in (100, 1000, 2000):
+        ix.set_param("scan_kernel", 2)
+        De, Ie = ix.search(q, k)
+        ix.set_param("scan_kernel", 0)
+        for pre4 in (1, 2, 0):
+            for mult, mx in ((160, 16384), (160, 32768), (4, 1024)):
+                ix.set_param("pq_prepass4", pre4); ix.set_param("pq_pre_mult", mult); ix.set_param("pq_pre_max", mx); ix.set_param("profile", 1)
+                D, I = ix.search(q, k)
+                assert_same_results(D, I, De, Ie, f"M={M} k={k} pq_prepass4={pre4} sample={mult}x/{mx}")
+                assert ix.get_timing("fallback_queries") == 0, f"M={M} k={k} pq_prepass4={pre4} sample={mult}x/{mx}"
+        ix.set_param("profile", 0); ix.set_param("pq_prepass4", 1); ix.set_param("pq_pre_mult", 160); ix.set_param("pq_pre_max", 16384)

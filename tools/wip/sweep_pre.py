@@ -20,8 +20,9 @@ del buf
 Q = torch.empty((nq * 6, D), dtype=torch.float16, device=dev); rsx.synth_queries(D, NC, SC, SX, 0.5, n, SQ, 0.1, 0, nq * 6, out=Q)
 ref = {}
 for k in (100, 1000, 2000):
-    for mult, mx in ((160, 32768), (160, 16384), (160, 8192), (40, 32768), (40, 16384), (16, 16384), (16, 8192)):
-        ix.set_param("pq_pre_mult", mult); ix.set_param("pq_pre_max", mx)
+  for pre4 in (2, 1):
+    for mult, mx in ((160, 32768), (160, 16384), (160, 8192), (16, 4096)):
+        ix.set_param("pq_prepass4", pre4); ix.set_param("pq_pre_mult", mult); ix.set_param("pq_pre_max", mx)
         ix.search(Q[:nq], k)
         ix.set_param("profile", 1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -32,4 +33,4 @@ for k in (100, 1000, 2000):
         ix.set_param("profile", 2); ix.search(Q[:nq], k); cand = ix.get_timing("cand_keys") / nq; ix.set_param("profile", 0)
         key = (Dq.cpu().numpy().tobytes(), Iq.cpu().numpy().tobytes())
         same = ref.setdefault(k, key) == key
-        print(json.dumps({"k": k, "mult": mult, "max": mx, "ms": round(el * 1e3, 3), "stages": st, "fallbacks": fb, "cand_mean": round(cand), "same_results": same}), flush=True)
+        print(json.dumps({"k": k, "pq_prepass4": pre4, "mult": mult, "max": mx, "ms": round(el * 1e3, 3), "stages": st, "fallbacks": fb, "cand_mean": round(cand), "same_results": same}), flush=True)
