@@ -291,7 +291,7 @@ def main():
     # sequential loop over internal batches and through the batch pipeline (rsx_api.hip: search_impl).  A side key, never `value`.
     one_call = None
     nb4 = min(4, args.steps)
-    if world == 1 and nb4 >= 2:
+    if world == 1 and nb4 >= 2 and not args.no_configs:      # (--no-configs: the profiled runs must hold the timed loop's kernels only)
         Q4 = Q[args.warmup * nq:(args.warmup + nb4) * nq]
         one_call = {"queries": nb4 * nq, "k": k}
         outs = {}
