@@ -733,13 +733,37 @@ __global__ void k_zero_i32(int32_t* p, int n) {
     if (i < n) p[i] = 0;
 }
 // jmin/jmax: only pairs whose probe rank j = i % nprobe lies in [jmin, jmax) take part
-__global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int nprobe, int jmin, int jmax, int32_t* cnt) {
+// (jmax_q non-null: the query's own upper rank, jmax_q[q] <= jmax — the IVF-Flat threshold sample takes as many of a query's closest
+//  lists as it needs rows)
+__global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int nprobe, int jmin, int jmax, int32_t* cnt, const uint8_t* jmax_q) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npairs) {
         int j = (int)(i % nprobe);
         int32_t l = probe_list[i];
-        if (l >= 0 && j >= jmin && j < jmax) atomicAdd(&cnt[l], 1);
+        const int jm = jmax_q ? (int)jmax_q[i / nprobe] : jmax;
+        if (l >= 0 && j >= jmin && j < jm) atomicAdd(&cnt[l], 1);
     }
+}
+// per query: the number of its closest lists (min_lists .. max_lists) whose first `rows` vectors make a threshold sample of at least
+// min_lists x rows vectors, and the length of its sample row (lists x stride) for the selection
+__global__ void k_sample_ranks(const int32_t* probe_list, const int64_t* list_len, int64_t nq, int nprobe, int64_t rows, int min_lists, int max_lists,
+                               int64_t stride, uint8_t* jmax_q, int64_t* row_n) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int64_t have = 0; int j = 0;
+    while (j < max_lists && j < nprobe && (j < min_lists || have < (int64_t)min_lists * rows)) {
+        const int32_t l = probe_list[q * nprobe + j];
+        if (l >= 0) { const int64_t len = list_len[l]; have += len < rows ? len : rows; }
+        j++;
+    }
+    jmax_q[q] = (uint8_t)j;
+    row_n[q] = (int64_t)j * stride;
+}
+void launch_sample_ranks(const int32_t* probe_list, const int64_t* list_len, int64_t nq, int nprobe, int64_t rows, int min_lists, int max_lists,
+                         int64_t stride, uint8_t* jmax_q, int64_t* row_n, hipStream_t st) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_sample_ranks, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, probe_list, list_len, nq, nprobe, rows, min_lists,
+                       max_lists, stride, jmax_q, row_n);
 }
 // Exclusive scan of three per-thread values over a 1024-thread workgroup (wave shuffles + one LDS hop);
 // tot[0..2] receive the workgroup totals.  scratch: 3 * 16 ints of LDS.
@@ -831,12 +855,13 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
     }
 }
 __global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, int nprobe, int jmin, int jmax,
-                               const int32_t* pair_off, int32_t* cursor, int32_t* pairs_sorted) {
+                               const int32_t* pair_off, int32_t* cursor, int32_t* pairs_sorted, const uint8_t* jmax_q) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npairs) {
         int j = (int)(i % nprobe);
         int32_t l = probe_list[i];
-        if (l >= 0 && j >= jmin && j < jmax) { int s = atomicAdd(&cursor[l], 1); pairs_sorted[pair_off[l] + s] = (int32_t)i; }
+        const int jm = jmax_q ? (int)jmax_q[i / nprobe] : jmax;
+        if (l >= 0 && j >= jmin && j < jm) { int s = atomicAdd(&cursor[l], 1); pairs_sorted[pair_off[l] + s] = (int32_t)i; }
     }
 }
 // The same grouping in ONE launch of one workgroup (histogram and cursors in LDS) for the sizes a search batch
@@ -846,7 +871,7 @@ __global__ __launch_bounds__(1024) void k_group_pairs_1wg(const int32_t* probe_l
                                                           int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                                                           int32_t* pairs_sorted, const int64_t* list_len, int tile_rows,
                                                           int32_t* item_off, int32_t* total_items, int nprobe, int jmin,
-                                                          int jmax, int tile_cap) {
+                                                          int jmax, int tile_cap, const uint8_t* jmax_q) {
     extern __shared__ int32_t gp_lds[];
     int32_t* cnt = gp_lds;                 // [nlist] histogram, then running cursor
     int32_t* sp = gp_lds + nlist;          // [48] scan scratch
@@ -861,7 +886,8 @@ __global__ __launch_bounds__(1024) void k_group_pairs_1wg(const int32_t* probe_l
     for (int i = t; i < npairs; i += 1024) {
         const int j = i % nprobe;
         const int32_t l = probe_list[i];
-        if (l >= 0 && j >= jmin && j < jmax) atomicAdd(&cnt[l], 1);
+        const int jm = jmax_q ? (int)jmax_q[i / nprobe] : jmax;
+        if (l >= 0 && j >= jmin && j < jm) atomicAdd(&cnt[l], 1);
     }
     __syncthreads();
     const int per = (nlist + 1023) / 1024;
@@ -890,20 +916,21 @@ __global__ __launch_bounds__(1024) void k_group_pairs_1wg(const int32_t* probe_l
     for (int i = t; i < npairs; i += 1024) {
         const int j = i % nprobe;
         const int32_t l = probe_list[i];
-        if (l >= 0 && j >= jmin && j < jmax) pairs_sorted[atomicAdd(&cnt[l], 1)] = (int32_t)i;
+        const int jm = jmax_q ? (int)jmax_q[i / nprobe] : jmax;
+        if (l >= 0 && j >= jmin && j < jm) pairs_sorted[atomicAdd(&cnt[l], 1)] = (int32_t)i;
     }
 }
 
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                         int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
-                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st) {
+                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st, const uint8_t* jmax_q) {
     if (nlist <= GP1_MAX_LISTS && npairs <= 8192) {   // larger batches: the multi-launch form is parallel and faster (32 k pairs: 45 vs 65 us)
         size_t shm = ((size_t)nlist + 64) * 4;
         if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_group_pairs_1wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         hipLaunchKernelGGL(k_group_pairs_1wg, dim3(1), dim3(1024), shm, st, probe_list, (int)npairs, nlist, group_size, pair_off,
                            group_off, total_groups, pairs_sorted, list_len, tile_rows, item_off, total_items, nprobe, jmin, jmax,
-                           tile_cap);
+                           tile_cap, jmax_q);
         return;
     }
     if (cursor == cnt + (nlist + 1)) {      // the callers lay the two arrays end to end: one launch
@@ -912,11 +939,11 @@ void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, in
         hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
         hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
     }
-    hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, nprobe, jmin, jmax, cnt);
+    hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, nprobe, jmin, jmax, cnt, jmax_q);
     hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, group_size, pair_off, group_off, total_groups,
                        list_len, tile_rows, tile_cap, item_off, total_items);
     hipLaunchKernelGGL(k_pair_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs,
-                       nprobe, jmin, jmax, pair_off, cursor, pairs_sorted);
+                       nprobe, jmin, jmax, pair_off, cursor, pairs_sorted, jmax_q);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -223,13 +223,14 @@ struct rsx_index {
     int flat_stages = 0;     // Flat: filtered stages behind the threshold phase (0 = from K' and the row count; see search_batch)
     int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
     int ivf_pre_lists = 0;   // IVF-Flat threshold sample at large K': closest lists sampled (0 = 2)
+    int ivf_pre_adaptive = 0;   // ... 1 = two, and up to two more per query when its closest lists are short
     int ivf_pre_mult = 4;    // ... and rows of each per K'
     int profile = 0;
     int64_t temp_budget = (int64_t)16 << 30;
 
     // workspace
     DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart, w_qitems, w_tiews;
+        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart, w_qitems, w_tiews, w_samp;
     std::map<std::string, double> timing;
 
     // Flat / IVF-Flat: largest |x|^2 ever added (certificate of the MFMA scan); device copy is the running atomic max
@@ -286,7 +287,7 @@ static int64_t workspace_bytes(const rsx_index* h) {
     const DevBuf* bufs[] = {&h->w_q32, &h->w_q16, &h->w_coarse, &h->w_keys1, &h->w_probekeys, &h->w_probelist, &h->w_dis0, &h->w_segstart,
                             &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
                             &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
-                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->w_qitems, &h->w_tiews, &h->sh_D, &h->sh_I, &h->sh_q,
+                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->w_qitems, &h->w_tiews, &h->w_samp, &h->sh_D, &h->sh_I, &h->sh_q,
                             &h->sh_oD, &h->sh_oI};
     int64_t t = 0;
     for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
@@ -1545,17 +1546,30 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // (round 4: two lists, not eight — with 64 probing queries per list nearly every list is among some query's eight closest,
             //  and the 'sample' read 26 of the 31 GB: 3.4 + 0.8 ms of a 13.2 ms batch at nlist 2048 / nprobe 128 / k 1000; two lists
             //  leave 11.3 ms and as few candidates; ONE list overflows the queries whose closest list is short: profiles/r04_n_docs_1000.md)
-            const int pre_want = h->ivf_pre_lists > 0 ? h->ivf_pre_lists : 2;
+            // ivf_pre_lists = 0 (default): the query's TWO closest lists.  ONE list is not enough even when it is long: at nlist 2048 /
+            // nprobe 128 its K'-th key lets > 131072 keys of some queries through (the score-row pass follows: 27 instead of 11.7 ms); at
+            // 100M / nprobe 32 it would do (28.7 against 29.8 ms) — two is the setting that is safe at both (profiles/r04_n_docs_1000.md).
+            // ivf_pre_adaptive = 1: two lists, and up to two more for the queries whose two closest lists are short (a batch with ONE
+            // query that has no threshold takes the score-row pass as a whole); costs 1-2 % on the bench configs, off by default.
+            const int pre_want = h->ivf_pre_lists > 0 ? h->ivf_pre_lists : (h->ivf_pre_adaptive ? 4 : 2);
             const int pre_lists = (KP >= 256 && (int64_t)pre_want * pre_chunks * chunk_rows <= tmax) ? std::min(pre_want, nprobe) : 1;
             a.max_chunks = (int)pre_chunks;                        // the first chunk(s) of ...
             a.qtiles = 1;                                          // (groups of 16 there: most lists are the closest of at most a few queries)
             const int64_t pre_stride = pre_lists > 1 ? pre_chunks * chunk_rows : 0;    // several lists: one slice of the sample buffer each
+            const bool pre_adaptive = pre_stride && h->ivf_pre_lists == 0 && h->ivf_pre_adaptive != 0;
             if (pre_stride) {
                 a.pre_stride = pre_stride; a.tstride = pre_lists * pre_stride;
                 launch_fill_f32(h->w_temp.as<float>(), nq * a.tstride, -INFINITY, h->st);
             }
+            const uint8_t* jmax_q = nullptr;
+            if (pre_adaptive) {
+                h->w_samp.ensure((size_t)nq * 8 + (size_t)round_up(nq, 8));
+                launch_sample_ranks(h->w_probelist.as<int32_t>(), h->d_len.as<int64_t>(), nq, nprobe, pre_stride, std::min(2, pre_lists), pre_lists, pre_stride,
+                                    reinterpret_cast<uint8_t*>(h->w_samp.as<int64_t>() + nq), h->w_samp.as<int64_t>(), h->st);
+                jmax_q = reinterpret_cast<const uint8_t*>(h->w_samp.as<int64_t>() + nq);
+            }
             launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, pre_lists, 0, h->st);   // ... the closest list(s) only
+                               pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, pre_lists, 0, h->st, jmax_q);   // ... the closest list(s) only
             launch_list_scan(a, h->st);
             tm.mark("scan0");
             cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 512 ? 131072 : (k > 64 ? 65536 : 16384));
@@ -1563,8 +1577,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             h->w_candcnt.ensure((size_t)nq * 8 * CCS);
             // the pre-pass is only a threshold (see the IVF-PQ path): the K'-th key, candidate counters reset
             if (pre_stride) {
-                select_rows(h, h->w_temp.as<float>(), a.tstride, nullptr, 0, a.tstride, 0, nq, KP, BUF, KP, state, false,
-                            h->w_candcnt.as<unsigned long long>());
+                select_rows(h, h->w_temp.as<float>(), a.tstride, pre_adaptive ? h->w_samp.as<int64_t>() : nullptr, pre_adaptive ? 1 : 0, a.tstride, 0,
+                            nq, KP, BUF, KP, state, false, h->w_candcnt.as<unsigned long long>());
                 a.pre_stride = 0; a.tstride = tmax;
             } else
             select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
@@ -1722,7 +1736,7 @@ static rsx_index* refresh_view(rsx_index* h) {
     v->lut_tiled = h->lut_tiled; v->pq_prepass_fused = h->pq_prepass_fused; v->ivf_wide2 = h->ivf_wide2; v->ivf_qtiles = h->ivf_qtiles;
     v->pq_prepass4 = h->pq_prepass4; v->pq_gather = h->pq_gather; v->pq_final_tab = h->pq_final_tab; v->pq_log_cap = h->pq_log_cap;
     v->pq_pre_mult = h->pq_pre_mult; v->pq_pre_max = h->pq_pre_max; v->pq_pre_rows = h->pq_pre_rows; v->flat_filter = h->flat_filter; v->flat_pre_mult = h->flat_pre_mult; v->flat_stages = h->flat_stages;
-    v->ivf_filter = h->ivf_filter; v->ivf_pre_lists = h->ivf_pre_lists; v->ivf_pre_mult = h->ivf_pre_mult; v->profile = 0; v->temp_budget = h->temp_budget; v->pipeline = 0;
+    v->ivf_filter = h->ivf_filter; v->ivf_pre_lists = h->ivf_pre_lists; v->ivf_pre_adaptive = h->ivf_pre_adaptive; v->ivf_pre_mult = h->ivf_pre_mult; v->profile = 0; v->temp_budget = h->temp_budget; v->pipeline = 0;
     return v;
 }
 
@@ -2790,6 +2804,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "ivf_pre_lists") h->ivf_pre_lists = std::max(0, (int)value);
+        else if (s == "ivf_pre_adaptive") h->ivf_pre_adaptive = (int)value;
         else if (s == "ivf_pre_mult") h->ivf_pre_mult = std::max(1, (int)value);
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_log_cap") h->pq_log_cap = std::max(0, (int)value);

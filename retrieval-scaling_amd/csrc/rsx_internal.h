@@ -379,7 +379,12 @@ void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int npr
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                         int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
-                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st);
+                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st,
+                        const uint8_t* jmax_q = nullptr /* per-query upper probe rank (<= jmax) instead of jmax */);
+// per query: how many of its closest lists (min_lists .. max_lists) give a threshold sample of min_lists x rows vectors from their first
+// `rows` each; row_n[q] = that count x stride (the length of the query's sample row)
+void launch_sample_ranks(const int32_t* probe_list, const int64_t* list_len, int64_t nq, int nprobe, int64_t rows, int min_lists, int max_lists,
+                         int64_t stride, uint8_t* jmax_q, int64_t* row_n, hipStream_t st);
 struct FinalizeArgs {
     int kind; int metric;
     const uint64_t* state; int KP; int k; int64_t nq;
