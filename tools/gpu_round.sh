@@ -12,7 +12,7 @@
 #   m16        the reference's shipped IVF-PQ point (M 16, nlist 8192, nprobe 512; k 10 and 1000)
 #   m16_prof   rocprofv3 kernel stats of it              m16_pmc: SQ counters of its scan
 #   largek     the headline index at k = 100 / 1000 / 2000
-#   flat       Flat 10M (IP, L2, k 10 and 1000) + rocprof stats          ivfflat: IVF-Flat configs
+#   flat       Flat 10M (k 10 and 1000) + rocprof stats          ivfflat: IVF-Flat configs     ivfflat_prof: nlist 2048 / nprobe 128 + rocprof stats
 #   latency    single-query latency protocol
 #   cmd        run "$CMD" (free-form, logged to ${TAG}_cmd.log)
 set -u
@@ -79,9 +79,13 @@ for s in "$@"; do
       timeout 900 python tools/bench_configs.py largek --steps ${STEPS:-5} ${LARGEK_ARGS:-} > $O/${TAG}_largek.json 2> $O/${TAG}_largek.log; echo "exit $?" >> $O/${TAG}_largek.log
       cut -c1-2500 $O/${TAG}_largek.json; tail -n 3 $O/${TAG}_largek.log | cut -c1-300 ;;
     flat)
-      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d $O/prof_flat -o $TAG -- python $OLDPWD/tools/bench_configs.py flat --check 64 --steps 3 > $O/${TAG}_flat10M.json 2> $O/${TAG}_flat10M.log ); echo "exit $?" >> $O/${TAG}_flat10M.log
-      python tools/rocprof_summary.py $O/prof_flat/${TAG}_results.db $O/${TAG}_rocprof_stats_flat10M.md "Flat 10M x 768 batch 1024 (tools/bench_configs.py flat --check 64 --steps 3)"
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d $O/prof_flat -o $TAG -- python $OLDPWD/tools/bench_configs.py flat --check 64 --steps 3 --ks 1000 > $O/${TAG}_flat10M.json 2> $O/${TAG}_flat10M.log ); echo "exit $?" >> $O/${TAG}_flat10M.log
+      python tools/rocprof_summary.py $O/prof_flat/${TAG}_results.db $O/${TAG}_rocprof_stats_flat10M.md "Flat 10M x 768 batch 1024, k = 10 and 1000, + the small-batch searches (tools/bench_configs.py flat --check 64 --steps 3 --ks 1000)"
       rm -rf $O/prof_flat ;;
+    ivfflat_prof)
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d $O/prof_ivf -o $TAG -- python $OLDPWD/tools/bench_configs.py ivfflat --nlist 2048 --nprobe 128 --check 2 --steps 3 --ks 1000 > $O/${TAG}_ivfflat20M_nprobe128.json 2> $O/${TAG}_ivfflat_prof.log ); echo "exit $?" >> $O/${TAG}_ivfflat_prof.log
+      python tools/rocprof_summary.py $O/prof_ivf/${TAG}_results.db $O/${TAG}_rocprof_stats_ivfflat20M_nprobe128.md "IVF-Flat 20M x 768, nlist 2048, nprobe 128, batch 1024, k = 10 and 1000 (tools/bench_configs.py ivfflat --nlist 2048 --nprobe 128 --check 2 --steps 3 --ks 1000)"
+      rm -rf $O/prof_ivf ;;
     ivfflat)
       timeout 900 python tools/bench_configs.py ivfflat ${IVFFLAT_ARGS:-} > $O/${TAG}_ivfflat.json 2> $O/${TAG}_ivfflat.log; echo "exit $?" >> $O/${TAG}_ivfflat.log
       cut -c1-1500 $O/${TAG}_ivfflat.json ;;
