@@ -1822,7 +1822,6 @@ static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int 
         const int res = std::max(0, std::min(120, h->pipeline_reserve)) & ~7;
         h->scan_reserve_now = res; v->scan_reserve_now = res;
         std::exception_ptr verr;
-        std::string verr_msg;
         std::thread th([&] {
             try {
                 HIPCHECK(hipSetDevice(v->device));
