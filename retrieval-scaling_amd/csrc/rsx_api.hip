@@ -205,6 +205,7 @@ struct rsx_index {
                           // lines), bits 8-11 = join offset in tile rows (0 = 2), bits 12-15 = the last n rows of a tile are handed to
                           // the waves dynamically (default 4; 0 = static columns), bit 4 = every chunk dynamic, bit 6 = no issue-
                           // priority rotation
+    int pq_rot8 = 0;      // rotated fast scan, M = 64: EIGHT queries per pass over a list tile (k_pq_scan_rot64x2: two 4-query records per work item, one table plane each); opt-in, measured in profiles/r04_rot8_m64.md
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
@@ -1256,7 +1257,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 h->w_itemdesc.ensure(pq_scan_rot_ws(items * ngq, rot_log_cap, nwg));
                 return h->w_itemdesc.p;
             };
-            const int ngq = rot ? pq_scan_rot_ngq(h->M, true) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
+            const int ngq = rot ? pq_scan_rot_ngq(h->M, true, h->pq_rot8) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             // rotated layout: persistent workgroups draw items dynamically, so the tile is the whole (average) list — one table
             // staging per (list, query group) — as long as that leaves a few thousand items to balance over 256 CUs
@@ -1421,7 +1422,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                                  total_groups, item_off, total_items, nlist,
                                                  mi_main, vpl, tau_ptr, tau_stride,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rws1, rot_log_cap, h->pq_prune, (h->pq_pace & 0xffff) | ((h->scan_reserve_now >> 3) << 16), (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
+                                                 rws1, rot_log_cap, h->pq_prune, (h->pq_pace & 0xffff) | ((h->scan_reserve_now >> 3) << 16) | ((h->pq_rot8 ? 1 : 0) << 24), (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
                                                  use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
@@ -1732,7 +1733,7 @@ static rsx_index* refresh_view(rsx_index* h) {
     v->norms.borrow(h->norms); v->d_base.borrow(h->d_base); v->d_len.borrow(h->d_len); v->d_maxnorm.borrow(h->d_maxnorm);
     // knobs
     v->overlap = h->overlap; v->query_batch = h->query_batch; v->scan_chunk = h->scan_chunk; v->scan_kernel = h->scan_kernel;
-    v->pq_fast = h->pq_fast; v->pq_fast_kp = h->pq_fast_kp; v->pq_filter = h->pq_filter; v->pq_pace = h->pq_pace; v->pq_prune = h->pq_prune;
+    v->pq_fast = h->pq_fast; v->pq_fast_kp = h->pq_fast_kp; v->pq_filter = h->pq_filter; v->pq_pace = h->pq_pace; v->pq_prune = h->pq_prune; v->pq_rot8 = h->pq_rot8;
     v->lut_tiled = h->lut_tiled; v->pq_prepass_fused = h->pq_prepass_fused; v->ivf_wide2 = h->ivf_wide2; v->ivf_qtiles = h->ivf_qtiles;
     v->pq_prepass4 = h->pq_prepass4; v->pq_gather = h->pq_gather; v->pq_final_tab = h->pq_final_tab; v->pq_log_cap = h->pq_log_cap;
     v->pq_pre_mult = h->pq_pre_mult; v->pq_pre_max = h->pq_pre_max; v->pq_pre_rows = h->pq_pre_rows; v->flat_filter = h->flat_filter; v->flat_pre_mult = h->flat_pre_mult; v->flat_stages = h->flat_stages;
@@ -2788,6 +2789,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
         else if (s == "pq_filter") h->pq_filter = (int)value;
         else if (s == "pq_prune") h->pq_prune = (int)value;
+        else if (s == "pq_rot8") h->pq_rot8 = (int)value;
         else if (s == "pq_pace") h->pq_pace = std::max(0, (int)value);
         else if (s == "add_list_mod" || s == "add_list_rem") {
             if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_UNSUPPORTED, "%s: IVF indexes only", key);

@@ -305,7 +305,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
 // an 8-byte descriptor per (item, wave, slot) = {index of the run's first key in the log pool, keys stored | bit 31: keys were
 // dropped because the log was full} lets the gather / compaction kernels find an item's runs.
 int pq_scan_rot_max_wgs(int M);     // persistent workgroups of the scan on the current device
-int pq_scan_rot_ngq(int M, bool filtered);   // 4-query records per work item: 1, or 4 for the filtered M = 16 scan (group the pairs by 4 x this;
+int pq_scan_rot_ngq(int M, bool filtered, int wide8 = 0);   // 4-query records per work item: 1, or 4 for the filtered M = 16 scan (group the pairs by 4 x this;
                                              // size the workspace for max_items x this records and workgroups x this x 64 logs)
 inline size_t pq_scan_rot_ws(int64_t max_items, int log_cap, int nwg) {   // item records + run descriptors + logs + per-XCD counters + progress words
     return (size_t)(max_items + 8) * (176 + 512 + 4) + (size_t)nwg * 64 * (size_t)log_cap * 8 + 1024;

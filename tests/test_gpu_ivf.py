@@ -731,3 +731,35 @@ def test_large_k_prepass_histogram_form(gpu, M, d):
                 assert_same_results(D, I, De, Ie, f"M={M} k={k} pq_prepass4={pre4} sample={mult}x/{mx}")
                 assert ix.get_timing("fallback_queries") == 0, f"M={M} k={k} pq_prepass4={pre4} sample={mult}x/{mx}"
         ix.set_param("profile", 0); ix.set_param("pq_prepass4", 1); ix.set_param("pq_pre_mult", 160); ix.set_param("pq_pre_max", 16384)
+
+
+def test_m64_eight_queries_per_pass(gpu):
+    """pq_rot8 = 1: the filtered M = 64 scan with EIGHT queries per pass over a list tile (k_pq_scan_rot64x2: two 4-query records per
+    work item, one table plane each).  Ragged groups (a list probed by 1 .. 70 queries), lists of several tiles (scan_chunk), small
+    and large k, starved survivor logs (overflow -> exact re-run): always the exact kernel's ids and scores, and the same as the
+    4-query scan."""
+    d, M, n, nlist, nq = 256, 64, 120_000, 24, 203
+    x = gpu.synth_vectors(d, 24, 1234, 10000, 0.5, 0, n)
+    q = gpu.synth_queries(d, 24, 1234, 10000, 0.5, n, 999, 0.1, 0, nq)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    assert ix._get("pq_layout") == 1
+    ix.train(x[:30000]); ix.add(x); ix.nprobe = 8
+    for k in (10, 200, 1000):
+        ix.set_param("scan_kernel", 2)
+        De, Ie = ix.search(q, k)
+        ix.set_param("scan_kernel", 0)
+        for chunk, logcap in ((0, 0), (2048, 0), (0, 64)):
+            ix.set_param("scan_chunk", chunk); ix.set_param("pq_log_cap", logcap)
+            ix.set_param("pq_rot8", 0)
+            D4, I4 = ix.search(q, k)
+            ix.set_param("pq_rot8", 1); ix.set_param("profile", 1)
+            D8, I8 = ix.search(q, k)
+            fb = ix.get_timing("fallback_queries")
+            ix.set_param("profile", 0)
+            assert_same_results(D8, I8, De, Ie, f"k={k} scan_chunk={chunk} pq_log_cap={logcap}: 8 queries per pass vs the exact kernel")
+            assert_same_results(D8, I8, D4, I4, f"k={k} scan_chunk={chunk} pq_log_cap={logcap}: 8 vs 4 queries per pass")
+            if logcap == 0:
+                assert fb == 0, f"k={k} scan_chunk={chunk}: no exact re-run expected"
+        D1, I1 = ix.search(q[:5], k)            # a handful of queries: mostly one-query records
+        assert_same_results(D1, I1, De[:5], Ie[:5], f"k={k}: five queries")
+    ix.set_param("pq_rot8", 0); ix.set_param("scan_chunk", 0); ix.set_param("pq_log_cap", 0)

@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--ks", default="", help="ivfpq_ref / largek: comma-separated k values")
     ap.add_argument("--k", type=int, default=10, help="flat / ivfflat: results per query")
     ap.add_argument("--metric", default="ip", choices=["ip", "l2"])
+    ap.add_argument("--m", type=int, default=0, help="largek: sub-quantisers of the index (default 96)")
     a = ap.parse_args()
     params = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.param]
     if a.which == "latency":
@@ -235,7 +236,7 @@ def main():
         return
     if a.which == "largek":      # the headline index (M = 96, nlist 4096, nprobe 32) at the reference's n_docs
         ks = tuple(int(t) for t in a.ks.split(",")) if a.ks else (10, 100, 1000, 2000)
-        print(json.dumps(measure_ivfpq(a.n or 100_000_000, 96, 4096, 32, ks=ks, steps=a.steps, check=a.check, params=params)), flush=True)
+        print(json.dumps(measure_ivfpq(a.n or 100_000_000, a.m or 96, a.nlist, a.nprobe, ks=ks, steps=a.steps, check=a.check, params=params)), flush=True)
         return
     extra = tuple(int(t) for t in a.ks.split(",")) if a.ks else ()
     print(json.dumps(measure(a.which, a.n, a.steps, a.batch, a.nlist, a.nprobe, a.check, metric=a.metric, k=a.k, extra_ks=extra, params=params)), flush=True)
