@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the default) or gloo (the same collectives routed "
                          "through the host — what lets N ranks share one GPU in the dry-run test; RCCL refuses two ranks per device)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the SAME --n vectors cut over the N GPUs (default: BASELINE's metric is quoted on one 100M index at "
+                         "1/2/4/8 GPUs); weak = --n vectors PER GPU (N x --n in all; SURVEY 8(d) C5 asks for both curves)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="dry run: rank r uses device r %% (visible GPUs) instead of requiring one GPU per rank (tests/test_gpu_bench_ranks.py)")
     args = ap.parse_args()
@@ -114,7 +117,7 @@ def main():
         dist.all_gather_into_tensor(out, flat)
         return out.view((world,) + tuple(t.shape)).to(dev)
 
-    n_total, nq, k = args.n, args.batch, args.k
+    n_total, nq, k = (args.n * world if args.scaling == "weak" else args.n), args.batch, args.k
     lo, hi = shard_range(n_total, rank, world)
     n_local = hi - lo
     t_setup = time.time()
@@ -256,6 +259,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     index.set_param("profile", 1)      # HIP events on the library's stream around each stage
+    if searcher is not None:
+        searcher.profile = True        # ... and CUDA events around pack / collective / merge of the exchange
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, nsteps):
@@ -272,6 +277,11 @@ def main():
         elapsed = float(t.item())
     fallbacks = index.get_timing("fallback_queries") / max(1.0, index.get_timing("fast_queries"))
     index.set_param("profile", 0)
+    if searcher is not None:           # the exchange of this rank (rank 0's are printed): where a multi-GPU step's time goes beside the search
+        ex = searcher.stage_ms()
+        searcher.profile = False
+        for key in ("pack", "collective", "merge"):
+            stage_ms["exchange_" + key] = round(ex[key] / max(1, ex["calls"]), 4)
 
     # ---- the same loop with host-resident queries and results (H2D of Q, D2H of D, I inside the timed region)
     pcie = None
@@ -287,30 +297,22 @@ def main():
                 "note": "numpy fp16 queries in, numpy D/I out: 1.57 MB H2D + 0.12 MB D2H per step inside the timed loop"}
         del Qh
 
-    # ---- the reference's call shape (src/search.py:296: ALL queries in one index.search): four batches in one call, as the
-    # sequential loop over internal batches and through the batch pipeline (rsx_api.hip: search_impl).  A side key, never `value`.
+    # ---- the reference's call shape (src/search.py:296: ALL queries in one index.search): four batches in one call (the internal
+    # batches run back to back without the round trip through Python).  A side key, never `value`.
     one_call = None
     nb4 = min(4, args.steps)
     if world == 1 and nb4 >= 2 and not args.no_configs:      # (--no-configs: the profiled runs must hold the timed loop's kernels only)
         Q4 = Q[args.warmup * nq:(args.warmup + nb4) * nq]
-        one_call = {"queries": nb4 * nq, "k": k}
-        outs = {}
-        for name, pl in (("sequential", 0), ("pipelined", 1)):
-            index.set_param("pipeline", pl)
+        index.search(Q4, k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
             index.search(Q4, k)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                outs[name] = index.search(Q4, k)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t1) / 3 * 1e3
-            one_call[name] = {"ms": round(ms, 4), "queries_per_s": round(nb4 * nq / ms * 1e3, 1)}
-        index.set_param("pipeline", 0)      # the default: the pipeline does not pay on this hardware (profiles/r04_pipeline.md)
-        one_call["same_ids_and_scores"] = bool(torch.equal(outs["sequential"][0], outs["pipelined"][0]) and torch.equal(outs["sequential"][1], outs["pipelined"][1]))
-        one_call["note"] = ("one index.search call of %d queries (query_batch 1024): internal batches alternate between the handle and its "
-                            "pipeline view on two host threads, the scan grid leaves 16 CUs to the neighbouring batches' small kernels (engine parameter "
-                            "pipeline = 1; off by default: measured, no gain — profiles/r04_pipeline.md)" % (nb4 * nq))
-        del outs, Q4
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / 3 * 1e3
+        one_call = {"queries": nb4 * nq, "k": k, "ms": round(ms, 4), "queries_per_s": round(nb4 * nq / ms * 1e3, 1),
+                    "note": "one index.search call of %d queries (query_batch 1024)" % (nb4 * nq)}
+        del Q4
 
     ab = None
     if args.ab:
@@ -517,7 +519,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "u8 codes; i8-table integer scan (MFMA-i8 adder tree), exact f32-table re-rank (certified)",
             "data": "synthetic",
@@ -589,7 +591,7 @@ def kernel_source_hash():
     """sha256 over the sources that decide the scan kernel's HBM traffic (kernel, grouping, tile choice)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("k_pq_rot.hip", "k_pq.hip", "k_select.hip", "rsx_api.hip", "rsx_internal.h"):
+    for f in ("k_pq_rot.hip", "k_pq.hip", "k_select.hip", "api_search.hip", "rsx_internal.h"):
         h.update(open(os.path.join(REPO, "retrieval-scaling_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -170,7 +170,9 @@ int rsx_search_scan(rsx_index_t* h);
  *                                               api/serve_main_node.py:150-163 (rerank_elements)
  * D,I: [nshards, nq, k].  Output [nq, k]: best first; ties keep the earlier shard first, then the
  * original within-shard order (Python's stable sorted(..., reverse=True)).  ids < 0 are padding.
- * Pointers may be host or device (all four on the same side). */
+ * Pointers may be host or device (all four on the same side).  Any shard count for k <= 8192: up to 16384 keys per
+ * query merge in one launch, more (the reference backends' default k = 4096, src/indicies/flat.py:138, on 8 ranks) in
+ * rounds over groups of consecutive shards with the same result. */
 int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
                    float* D_out, int64_t* I_out, int device);
 

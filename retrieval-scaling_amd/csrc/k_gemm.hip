@@ -1061,13 +1061,12 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     if (a.max_groups <= 0 || a.max_chunks <= 0) return;
     dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
     const int base_rows = list_scan2_chunk_rows(a.x_f16, a.ld);
-    if (base_rows > 0 && (a.chunk_rows == base_rows || ((a.qtiles == 4 || a.qtiles == 2) && a.chunk_rows == 2 * base_rows))) {
+    if (base_rows > 0 && (a.chunk_rows == base_rows || (a.qtiles == 4 && a.chunk_rows == 2 * base_rows))) {
         if (a.item_off && !a.flat_mode && a.max_items > 0) grid = dim3((unsigned)((a.max_items + 7) & ~7), 1);   // XCD-aware item order
         // the grouping was made for 16 x qtiles queries per group: qtiles is binding (a smaller kernel would misread the groups)
         const int qt = (a.qtiles == 2 || a.qtiles == 4) && !a.flat_mode ? a.qtiles : 1;
         const bool wide = qt == 4 && a.chunk_rows == 2 * base_rows;        // 8 waves x 3 stages, 1024 rows per work item
-        const bool wide2 = qt == 2 && a.chunk_rows == 2 * base_rows;       // 32 queries, 8 waves x 6 stages (round 4: twice the rows in flight per CU)
-        const int nw = (wide || wide2) ? 8 : 4, dd = wide ? 3 : LS2_D;
+        const int nw = wide ? 8 : 4, dd = wide ? 3 : LS2_D;
         size_t shm2 = (size_t)16 * qt * (a.ld + 8) * 2 + 28 * 16 * qt + (size_t)nw * dd * 2048;
         static DevOnce once;
         once.once([&] {
@@ -1079,15 +1078,10 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 4, 4, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_list_scan2<false, 2, 8, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_list_scan2<true, 2, 8, LS2_D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
         if (wide) {
             if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 4, 8, 3>), grid, dim3(512), shm2, st, a);
             else hipLaunchKernelGGL((k_list_scan2<false, 4, 8, 3>), grid, dim3(512), shm2, st, a);
-        } else if (wide2) {
-            if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 2, 8, LS2_D>), grid, dim3(512), shm2, st, a);
-            else hipLaunchKernelGGL((k_list_scan2<false, 2, 8, LS2_D>), grid, dim3(512), shm2, st, a);
         } else if (qt == 4) {
             if (a.tau_key) hipLaunchKernelGGL((k_list_scan2<true, 4, 4, LS2_D>), grid, dim3(256), shm2, st, a);
             else hipLaunchKernelGGL((k_list_scan2<false, 4, 4, LS2_D>), grid, dim3(256), shm2, st, a);

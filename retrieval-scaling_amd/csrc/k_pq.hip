@@ -456,6 +456,18 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
 //   pass 0: per (query, m) min / max of the entries        -> mnmx [nq][Mpad][2]
 //   pass 1: entries again, quantised with the query's scale -> lut8, per (query, m) max error -> err [nq][Mpad]
 //   k_pq_qparam: per query, the sums over m in m order      -> {scale, bias, eps}
+#ifdef RSX_MEASURE
+// tools/ builds only (RSX_LUT_STEP, read once by launch_pq_lut8): table entries restricted to multiples of `step` (17 = 16 levels =
+// what a 4-bit table could hold) so that the survivor count of a coarser table can be MEASURED on the real index before a kernel
+// is written for it (profiles/r05_lut_bits_precheck.md).  eps follows by itself: it is the measured per-(query, m) maximum error.
+__device__ int g_lut_step = 1;
+__device__ __forceinline__ float lut_coarsen(float u) {
+    const int st = g_lut_step;
+    if (st <= 1) return u;
+    const float fs = (float)st;
+    return fs * fminf(rintf(u / fs), floorf(255.0f / fs));
+}
+#endif
 #define LT_MB 8
 #ifndef LT_QC
 #define LT_QC 8      // queries per tile: 32 -> 8 quadruples the workgroups (1536 at batch 1024), measured 0.135 -> 0.100 ms for the build
@@ -543,6 +555,9 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
                 for (int j = 0; j < 4; j++) {
                     float u = rintf((v[j] - mn) * inv);
                     u = fminf(fmaxf(u, 0.0f), 255.0f);
+#ifdef RSX_MEASURE
+                    u = lut_coarsen(u);
+#endif
                     o[ostep * j] = (uint8_t)u;
                     err = fmaxf(err, fabsf(v[j] - (mn + scale * u)));
                 }
@@ -586,7 +601,11 @@ __global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, c
     // quantised exactly as k_pq_lut_tiled<1> does (rint((mx - mn) / scale) clamped to 255) — the bound pair pruning uses
     const float inv_s = 1.0f / (mr > 0.0f ? mr / 255.0f : 1.0f);
     float smax = 0.0f;
+#ifdef RSX_MEASURE
+    for (int m = lane; m < Mpad; m += 64) smax += lut_coarsen(fminf(fmaxf(rintf((mm[2 * m + 1] - mm[2 * m]) * inv_s), 0.0f), 255.0f)) + (g_lut_step > 1 ? (float)g_lut_step : 0.0f);
+#else
     for (int m = lane; m < Mpad; m += 64) smax += fminf(fmaxf(rintf((mm[2 * m + 1] - mm[2 * m]) * inv_s), 0.0f), 255.0f);
+#endif
     for (int j = lane; j < nprobe; j += 64) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -620,6 +639,15 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
         return;
     }
     if (ws && dsub == 8) {   // tiled: codebook slices shared by 32 queries
+#ifdef RSX_MEASURE
+        static int lut_step = -1;
+        if (lut_step < 0) {
+            const char* e = getenv("RSX_LUT_STEP");
+            lut_step = e ? atoi(e) : 1;
+            if (lut_step < 1 || lut_step > 255) lut_step = 1;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lut_step), &lut_step, sizeof(int));
+        }
+#endif
         float* mnmx = reinterpret_cast<float*>(ws);
         float* errb = mnmx + (size_t)nq * Mpad * 2;
         const int64_t nmb = (Mpad + LT_MB - 1) / LT_MB, nqt8 = (((nq + LT_QC - 1) / LT_QC) + 7) / 8;

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         __builtin_amdgcn_s_setprio(0);
         if (FILTER && lane < 4) {
             const uint32_t c0 = qstart < (uint32_t)log_cap ? qstart : (uint32_t)log_cap, c1 = lcur < (uint32_t)log_cap ? lcur : (uint32_t)log_cap;
-            seg_desc[((size_t)item * 16 + w) * 4 + lane] = make_uint2((uint32_t)(mylog_i * (size_t)log_cap) + c0, (c1 - c0) | (lcur > (uint32_t)log_cap ? 0x80000000u : 0u));
+            seg_desc[((size_t)item * 16 + w) * 4 + lane] = make_uint2((uint32_t)(mylog_i * (size_t)log_cap) + c0, (c1 - c0) | ((lcur > (uint32_t)log_cap && lcur > qstart) ? 0x80000000u : 0u));   // only a run that itself lost keys is flagged
         }
 #ifdef RSX_MEASURE
         if (lane == 0 && item < 16384) g_rot_wave[16 * item + w] = (uint32_t)(wall_clock64() - t_scan0);
@@ -892,229 +892,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot16(PQScan8Args A, const PQR
             for (int x = 1; x < G; x++) if (gq == x) { l1 = lcur[x]; l0 = qstart[x]; }
             const uint32_t c0 = l0 < (uint32_t)log_cap ? l0 : (uint32_t)log_cap, c1 = l1 < (uint32_t)log_cap ? l1 : (uint32_t)log_cap;
             seg_desc[(((size_t)item * G + gq) * 16 + w) * 4 + (lane & 3)] =
-                make_uint2((uint32_t)((mylog_0 - nq4 + lane) * (size_t)log_cap) + c0, (c1 - c0) | (l1 > (uint32_t)log_cap ? 0x80000000u : 0u));
-        }
-        if (w == 0) {
-            if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[(buf ^ 1) * G])[lane] = pre;
-            if (lane == 0) islot[(buf ^ 1) * G].pad0 = i1;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// M = 64, filtered scan, EIGHT queries per pass over a list tile (round 4, opt-in: engine parameter pq_rot8) — what "more queries per
-// pass" is worth where the LDS allows it: a 4-query table image of M = 64 is ONE 64 KiB plane, so two records (groups) fit — group 0
-// in plane 0, group 1 in plane 1 — and every 16-vector code block is loaded once and looked up in both.  Structure of
-// k_pq_scan_rot16 (items of G records, static block columns, no circular join, items drawn one ahead), gathers / one-hot operand /
-// survivor path of k_pq_scan_rot<1, 0, true>.
-// ---------------------------------------------------------------------------------------
-constexpr int R64_G = 2;
-__global__ __launch_bounds__(1024) void k_pq_scan_rot64x2(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ log_keys,
-                                                          uint2* __restrict__ seg_desc, uint32_t* xcd_ctr, int log_cap, int bpw) {
-    constexpr int M = 64, BB = 16 * M, RD = 4, G = R64_G;
-    constexpr int TAB = 2 * 65536;
-    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) uint32_t rot64_s[];
-    uint8_t* sb = reinterpret_cast<uint8_t*>(rot64_s);
-    PQRotItem* islot = reinterpret_cast<PQRotItem*>(sb + TAB);                  // [2][G] current / next item's records
-    const PQScanArgs& a = A.b;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, i = lane & 15, n = lane & 15, nq4 = n & 3;
-    const int ti = *A.total_items;
-    const int per_xcd = (ti + 7) >> 3;
-    const int xcd = blockIdx.x & 7;
-    int xlo = xcd * per_xcd;
-    int xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
-    if (xlo >= xhi) return;
-    uint32_t* ctr = xcd_ctr + xcd * 32;
-    int cx = xcd, hops = 0;
-    unsigned drawn = 0;
-    auto resolve_draw = [&]() -> int {
-        for (;;) {
-            const int i2 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
-            if (i2 < xhi) return i2;
-            if (hops >= 7) return 0x7fffffff;
-            hops++;
-            cx = (cx + 1) & 7;
-            xlo = cx * per_xcd;
-            xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
-            ctr = xcd_ctr + cx * 32;
-            if (xlo >= xhi) { drawn = 0u; xlo = 0; xhi = 0; continue; }
-            if (lane == 0) drawn = atomicAdd(ctr, 1u);
-        }
-    };
-    // rotation bytes: lane (g, i) = vector i of the block reaches sub-quantiser 16 g + ((i + s) & 15) at step s; plane 0 packs four per
-    // register, plane 1 three + the plane byte (address bit 16)
-    uint32_t R0[4], R1[6];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int bb = 0; bb < 4; bb++) v |= (uint32_t)(64 * g + 4 * ((i + r * 4 + bb) & 15)) << (8 * bb);
-        R0[r] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-        uint32_t v = 0x01000000u;
-#pragma unroll
-        for (int bb = 0; bb < 3; bb++) { const int s2 = r * 3 + bb; if (s2 < 16) v |= (uint32_t)((64 * g + 4 * ((i + s2) & 15)) & 255) << (8 * bb); }
-        R1[r] = v;
-    }
-    const int bsel = n < 4 ? (1 << (8 * n)) : 0;          // column n picks byte n of every K group (the four lanes n < 4 own the queries)
-    const v4i Bm = {bsel, bsel, bsel, bsel};
-    const int vo16 = lane * 16;
-    const uint64_t QM = n < 4 ? (0x0001000100010001ull << n) : 0ull;
-    const size_t mylog_0 = ((size_t)blockIdx.x * 16 + (size_t)w) * (4 * G) + (size_t)nq4;      // + 4 gq: the log of (record gq, slot nq4) of this wave
-    uint32_t lcur[G];
-#pragma unroll
-    for (int gq = 0; gq < G; gq++) lcur[gq] = 0u;
-    const auto load_records = [&](int it_) -> uint4 {
-        uint4 r0 = make_uint4(0xffffffffu, 0, 0, 0);
-        if (lane < 11 * G && it_ != 0x7fffffff) r0 = reinterpret_cast<const uint4*>(&items[(size_t)it_ * G])[lane];
-        return r0;
-    };
-    int item = 0;
-    if (w == 0) {
-        if (lane == 0) drawn = atomicAdd(ctr, 1u);
-        item = resolve_draw();
-        const uint4 r0 = load_records(item);
-        if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
-        if (lane == 0) islot[0].pad0 = item;
-    }
-    int buf = 0;
-#pragma unroll 1
-    for (;; buf ^= 1) {
-        __syncthreads();    // #1
-        const PQRotItem* it0 = &islot[buf * G];
-        const int item_l = __builtin_amdgcn_readfirstlane(it0->l);
-        if (item_l == -1) break;
-        item = __builtin_amdgcn_readfirstlane(it0->pad0);
-        const int64_t len = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it0->len >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it0->len);
-        const int64_t base_row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it0->base_row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it0->base_row);
-        const int nblk = (int)(((len + 63) >> 6) << 2);           // 16-vector blocks, slab padding included
-        const int tb0 = __builtin_amdgcn_readfirstlane(it0->tile) * (16 * bpw);
-        int npg[G];
-#pragma unroll
-        for (int gq = 0; gq < G; gq++) npg[gq] = __builtin_amdgcn_readfirstlane(islot[buf * G + gq].np) & 15;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.codes + (base_row >> 4) * (int64_t)BB), 0, nblk * BB, 0x00020000);
-        const int so_oob = nblk * BB;
-        int bend = tb0 + 16 * bpw; if (bend > nblk) bend = nblk;
-        int nmine = (bend - (tb0 + w) + 15) >> 4; if (nmine < 0) nmine = 0;
-        v4u ca[RD];
-#pragma unroll
-        for (int dd = 0; dd < RD; dd++) {
-            ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, dd < nmine ? (tb0 + w + 16 * dd) * BB : so_oob, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (w == 0 && lane == 0) drawn = atomicAdd(ctr, 1u);
-        // ---- stage the two tables (k_pq_scan_rot's unit: (code, 4 consecutive m) -> 4 dwords, byte k = query k as int8), group gq -> plane gq
-#pragma unroll
-        for (int gq = 0; gq < G; gq++) {
-            const PQRotItem* itg = &islot[buf * G + gq];
-            const int npq = itg->np & 15;
-            const int64_t q0 = itg->q[0], q1 = itg->q[1], q2 = itg->q[2], q3 = itg->q[3];
-            constexpr int NU = 256 * (M / 4) / 1024;          // 4 units per thread
-            uint32_t in[NU][4];
-#pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const int e = tid + u * 1024;
-                const int c = e / (M / 4), m4 = e - c * (M / 4);
-                in[u][0] = npq > 0 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q0 * 256 + c) * M + m4 * 4) : 0u;
-                in[u][1] = npq > 1 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q1 * 256 + c) * M + m4 * 4) : 0u;
-                in[u][2] = npq > 2 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q2 * 256 + c) * M + m4 * 4) : 0u;
-                in[u][3] = npq > 3 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q3 * 256 + c) * M + m4 * 4) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const int e = tid + u * 1024;
-                const int c = e / (M / 4), m4 = e - c * (M / 4);
-                const uint32_t t0 = __builtin_amdgcn_perm(in[u][1], in[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[u][1], in[u][0], 0x07030602u);
-                const uint32_t u0 = __builtin_amdgcn_perm(in[u][3], in[u][2], 0x05010400u), u1 = __builtin_amdgcn_perm(in[u][3], in[u][2], 0x07030602u);
-                uint4 o;
-                o.x = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
-                o.y = __builtin_amdgcn_perm(u0, t0, 0x07060302u) ^ 0x80808080u;
-                o.z = __builtin_amdgcn_perm(u1, t1, 0x05040100u) ^ 0x80808080u;
-                o.w = __builtin_amdgcn_perm(u1, t1, 0x07060302u) ^ 0x80808080u;
-                *reinterpret_cast<uint4*>(sb + gq * 65536 + c * 256 + m4 * 16) = o;
-            }
-        }
-        uint4 pre = make_uint4(0xffffffffu, 0, 0, 0);
-        int i1 = 0x7fffffff;
-        if (w == 0) { i1 = resolve_draw(); pre = load_records(i1); }
-        int cin[G];
-        uint32_t qstart[G];
-#pragma unroll
-        for (int gq = 0; gq < G; gq++) { cin[gq] = n < 4 ? islot[buf * G + gq].cinit[nq4] : -(1 << 30); qstart[gq] = lcur[gq]; }
-        __syncthreads();    // #2: tables staged
-#pragma unroll 1
-        for (int j = 0; j < nmine; j += RD) {
-#pragma unroll
-            for (int dd = 0; dd < RD; dd++) {
-                const int b = tb0 + w + 16 * (j + dd);
-                const uint32_t cw[4] = {ca[dd].x, ca[dd].y, ca[dd].z, ca[dd].w};
-                __builtin_amdgcn_sched_barrier(0);
-                ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, j + dd + RD < nmine ? (b + 16 * RD) * BB : so_oob, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + dd >= nmine) continue;          // wave-uniform
-#pragma unroll
-                for (int gq = 0; gq < G; gq++) {
-                    if (npg[gq] == 0) continue;          // wave-uniform: no query in this record
-                    uint32_t gv[16];
-                    if (gq == 0) {
-#pragma unroll
-                        for (int s2 = 0; s2 < 16; s2++)
-                            gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], R0[s2 >> 2], 0x0c0c0000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 & 3));
-                    } else {
-#pragma unroll
-                        for (int s2 = 0; s2 < 16; s2++)
-                            gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], R1[s2 / 3], 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
-                    }
-#pragma unroll
-                    for (int s2 = 0; s2 < 16; s2++) gv[s2] = lds_rd32(gv[s2]);
-                    const int cinit = cin[gq];
-                    v4i C = {cinit, cinit, cinit, cinit};
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const v4i Av = {(int)gv[4 * t], (int)gv[4 * t + 1], (int)gv[4 * t + 2], (int)gv[4 * t + 3]};
-                        C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
-                    }
-                    // C[r] (lanes n < 4) = cinit + sum over m of (u8 - 128) for vector 4 g + r of the block and query n of record gq
-                    if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0)) {
-                        const PQRotItem* itg = &islot[buf * G + gq];
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const bool cnd = C[r] >= 0;
-                            if (__builtin_amdgcn_ballot_w64(cnd)) {
-                                const float p_dis0 = itg->dis0[nq4], p_scale = itg->scale[nq4], p_bias = itg->bias[nq4];
-                                const int64_t p_off = itg->off[nq4];
-                                const uint64_t p_tau = itg->tau[nq4];
-                                const int64_t pos = ((int64_t)b << 4) + 4 * g + r;
-                                const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(C[r] - cinit + 128 * M), p_bias);
-                                const uint64_t key = (cnd && pos < len) ? make_key(sc, (uint32_t)p_off + (uint32_t)pos) : 0ull;
-                                const bool pass = key > p_tau;
-                                const uint64_t mq = __builtin_amdgcn_ballot_w64(pass) & QM;
-                                if (pass) {
-                                    const uint32_t slot = lcur[gq] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
-                                    if (slot < (uint32_t)log_cap) log_keys[(mylog_0 + 4 * gq) * (size_t)log_cap + slot] = key;
-                                }
-                                lcur[gq] += (uint32_t)__builtin_popcountll(mq);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // item epilogue: lanes 0 .. 3 own the query slots (only lanes n < 4 count survivors here): each writes its slot's run descriptor
-        // for both records
-        if (lane < 4) {
-#pragma unroll
-            for (int gq = 0; gq < G; gq++) {
-                const uint32_t l1 = lcur[gq], l0 = qstart[gq];
-                const uint32_t c0 = l0 < (uint32_t)log_cap ? l0 : (uint32_t)log_cap, c1 = l1 < (uint32_t)log_cap ? l1 : (uint32_t)log_cap;
-                seg_desc[(((size_t)item * G + gq) * 16 + w) * 4 + lane] =
-                    make_uint2((uint32_t)((mylog_0 + 4 * gq) * (size_t)log_cap) + c0, (c1 - c0) | (l1 > (uint32_t)log_cap ? 0x80000000u : 0u));
-            }
+                make_uint2((uint32_t)((mylog_0 - nq4 + lane) * (size_t)log_cap) + c0, (c1 - c0) | ((l1 > (uint32_t)log_cap && l1 > l0) ? 0x80000000u : 0u));
         }
         if (w == 0) {
             if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[(buf ^ 1) * G])[lane] = pre;
@@ -1220,10 +998,8 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint32_t* prog = xcd_ctr + 256;
     hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, 1);
     static const int var = measure_env("RSX_ROT_VARIANT", 0);
-    // one persistent workgroup per CU; never more than the work items; a pipelined search (rsx_api.hip: search_impl) leaves
-    // 8 x (bits 16-19 of pace) CUs to the kernels of the neighbouring batches
-    int64_t grid = nwg - 8 * ((A.pace >> 16) & 15);
-    if (grid < 8) grid = 8;
+    // one persistent workgroup per CU; never more than the work items
+    int64_t grid = nwg;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
     hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER, NQ>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, prog,
                        log_cap, bpw, A.pace, var);
@@ -1234,33 +1010,7 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
 }
 
 // M = 16, filtered: sixteen queries per work item (k_pq_scan_rot16); A.max_items counts WORK ITEMS, the workspace holds R16_G records each
-int pq_scan_rot_ngq(int M, bool filtered, int wide8) { return (M == 16 && filtered) ? R16_G : (M == 64 && filtered && wide8) ? R64_G : 1; }
-static int launch_pq_scan_rot64x2(const PQScan8Args& A, int bpw, void* desc_ws, int log_cap, hipStream_t st) {
-    constexpr int G = R64_G;
-    const size_t shm = (size_t)2 * 65536 + (size_t)2 * G * 176 + 64;
-    static DevOnce once;
-    static std::atomic<int> failed{0};
-    once.once([&] {
-        if (hipFuncSetAttribute((const void*)k_pq_scan_rot64x2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) failed = 1;
-    });
-    if (failed) return -1;
-    const int nwg = pq_scan_rot_max_wgs(64);
-    const int64_t recs = (int64_t)A.max_items * G;
-    PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
-    uint2* seg_desc = pq_scan_rot_ws_desc(desc_ws, recs);
-    uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, recs);
-    uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
-    uint32_t* prog = xcd_ctr + 256;
-    hipLaunchKernelGGL((k_pq_rot_items<64, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
-    int64_t grid = nwg - 8 * ((A.pace >> 16) & 15);
-    if (grid < 8) grid = 8;
-    if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
-    hipLaunchKernelGGL(k_pq_scan_rot64x2, dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, bpw);
-    if (!A.qitems)
-        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((recs + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, G, log_keys, seg_desc,
-                           A.cand, A.cand_cnt, A.cand_cap);
-    return 0;
-}
+int pq_scan_rot_ngq(int M, bool filtered) { return (M == 16 && filtered) ? R16_G : 1; }
 static int launch_pq_scan_rot16(const PQScan8Args& A, int bpw, void* desc_ws, int log_cap, hipStream_t st) {
     constexpr int G = R16_G;
     const size_t shm = (size_t)2 * 65536 + (size_t)2 * G * 176 + 64;
@@ -1278,8 +1028,7 @@ static int launch_pq_scan_rot16(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
     uint32_t* prog = xcd_ctr + 256;
     hipLaunchKernelGGL((k_pq_rot_items<16, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
-    int64_t grid = nwg - 8 * ((A.pace >> 16) & 15);
-    if (grid < 8) grid = 8;
+    int64_t grid = nwg;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
     hipLaunchKernelGGL(k_pq_scan_rot16, dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, bpw);
     if (!A.qitems)
@@ -1308,8 +1057,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     switch (a.M) {
         case 16: return f ? launch_pq_scan_rot16(A, vpl, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, log_cap, st);   // 64-vector blocks
         case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, log_cap, st);
-        case 64: return (f && ((pace >> 24) & 1)) ? launch_pq_scan_rot64x2(A, bpw, item_ws, log_cap, st)      // bit 24 of pace: eight queries per pass (pq_rot8)
-                      : f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, log_cap, st);
+        case 64: return f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, log_cap, st);
         case 96: return f ? launch_pq_scan_rot_t<1, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 1, false>(A, bpw, item_ws, log_cap, st);
         case 128: return f ? launch_pq_scan_rot_t<2, 0, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<2, 0, false>(A, bpw, item_ws, log_cap, st);
         default: return -1;

@@ -733,37 +733,13 @@ __global__ void k_zero_i32(int32_t* p, int n) {
     if (i < n) p[i] = 0;
 }
 // jmin/jmax: only pairs whose probe rank j = i % nprobe lies in [jmin, jmax) take part
-// (jmax_q non-null: the query's own upper rank, jmax_q[q] <= jmax — the IVF-Flat threshold sample takes as many of a query's closest
-//  lists as it needs rows)
-__global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int nprobe, int jmin, int jmax, int32_t* cnt, const uint8_t* jmax_q) {
+__global__ void k_pair_hist(const int32_t* probe_list, int64_t npairs, int nprobe, int jmin, int jmax, int32_t* cnt) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npairs) {
         int j = (int)(i % nprobe);
         int32_t l = probe_list[i];
-        const int jm = jmax_q ? (int)jmax_q[i / nprobe] : jmax;
-        if (l >= 0 && j >= jmin && j < jm) atomicAdd(&cnt[l], 1);
+        if (l >= 0 && j >= jmin && j < jmax) atomicAdd(&cnt[l], 1);
     }
-}
-// per query: the number of its closest lists (min_lists .. max_lists) whose first `rows` vectors make a threshold sample of at least
-// min_lists x rows vectors, and the length of its sample row (lists x stride) for the selection
-__global__ void k_sample_ranks(const int32_t* probe_list, const int64_t* list_len, int64_t nq, int nprobe, int64_t rows, int min_lists, int max_lists,
-                               int64_t stride, uint8_t* jmax_q, int64_t* row_n) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    int64_t have = 0; int j = 0;
-    while (j < max_lists && j < nprobe && (j < min_lists || have < (int64_t)min_lists * rows)) {
-        const int32_t l = probe_list[q * nprobe + j];
-        if (l >= 0) { const int64_t len = list_len[l]; have += len < rows ? len : rows; }
-        j++;
-    }
-    jmax_q[q] = (uint8_t)j;
-    row_n[q] = (int64_t)j * stride;
-}
-void launch_sample_ranks(const int32_t* probe_list, const int64_t* list_len, int64_t nq, int nprobe, int64_t rows, int min_lists, int max_lists,
-                         int64_t stride, uint8_t* jmax_q, int64_t* row_n, hipStream_t st) {
-    if (nq <= 0) return;
-    hipLaunchKernelGGL(k_sample_ranks, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, probe_list, list_len, nq, nprobe, rows, min_lists,
-                       max_lists, stride, jmax_q, row_n);
 }
 // Exclusive scan of three per-thread values over a 1024-thread workgroup (wave shuffles + one LDS hop);
 // tot[0..2] receive the workgroup totals.  scratch: 3 * 16 ints of LDS.
@@ -855,13 +831,12 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t* cnt, int nlis
     }
 }
 __global__ void k_pair_scatter(const int32_t* probe_list, int64_t npairs, int nprobe, int jmin, int jmax,
-                               const int32_t* pair_off, int32_t* cursor, int32_t* pairs_sorted, const uint8_t* jmax_q) {
+                               const int32_t* pair_off, int32_t* cursor, int32_t* pairs_sorted) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npairs) {
         int j = (int)(i % nprobe);
         int32_t l = probe_list[i];
-        const int jm = jmax_q ? (int)jmax_q[i / nprobe] : jmax;
-        if (l >= 0 && j >= jmin && j < jm) { int s = atomicAdd(&cursor[l], 1); pairs_sorted[pair_off[l] + s] = (int32_t)i; }
+        if (l >= 0 && j >= jmin && j < jmax) { int s = atomicAdd(&cursor[l], 1); pairs_sorted[pair_off[l] + s] = (int32_t)i; }
     }
 }
 // The same grouping in ONE launch of one workgroup (histogram and cursors in LDS) for the sizes a search batch
@@ -871,7 +846,7 @@ __global__ __launch_bounds__(1024) void k_group_pairs_1wg(const int32_t* probe_l
                                                           int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                                                           int32_t* pairs_sorted, const int64_t* list_len, int tile_rows,
                                                           int32_t* item_off, int32_t* total_items, int nprobe, int jmin,
-                                                          int jmax, int tile_cap, const uint8_t* jmax_q) {
+                                                          int jmax, int tile_cap) {
     extern __shared__ int32_t gp_lds[];
     int32_t* cnt = gp_lds;                 // [nlist] histogram, then running cursor
     int32_t* sp = gp_lds + nlist;          // [48] scan scratch
@@ -886,8 +861,7 @@ __global__ __launch_bounds__(1024) void k_group_pairs_1wg(const int32_t* probe_l
     for (int i = t; i < npairs; i += 1024) {
         const int j = i % nprobe;
         const int32_t l = probe_list[i];
-        const int jm = jmax_q ? (int)jmax_q[i / nprobe] : jmax;
-        if (l >= 0 && j >= jmin && j < jm) atomicAdd(&cnt[l], 1);
+        if (l >= 0 && j >= jmin && j < jmax) atomicAdd(&cnt[l], 1);
     }
     __syncthreads();
     const int per = (nlist + 1023) / 1024;
@@ -916,21 +890,20 @@ __global__ __launch_bounds__(1024) void k_group_pairs_1wg(const int32_t* probe_l
     for (int i = t; i < npairs; i += 1024) {
         const int j = i % nprobe;
         const int32_t l = probe_list[i];
-        const int jm = jmax_q ? (int)jmax_q[i / nprobe] : jmax;
-        if (l >= 0 && j >= jmin && j < jm) pairs_sorted[atomicAdd(&cnt[l], 1)] = (int32_t)i;
+        if (l >= 0 && j >= jmin && j < jmax) pairs_sorted[atomicAdd(&cnt[l], 1)] = (int32_t)i;
     }
 }
 
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                         int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
-                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st, const uint8_t* jmax_q) {
+                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st) {
     if (nlist <= GP1_MAX_LISTS && npairs <= 8192) {   // larger batches: the multi-launch form is parallel and faster (32 k pairs: 45 vs 65 us)
         size_t shm = ((size_t)nlist + 64) * 4;
         if (shm > 48 * 1024) hipFuncSetAttribute((const void*)k_group_pairs_1wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         hipLaunchKernelGGL(k_group_pairs_1wg, dim3(1), dim3(1024), shm, st, probe_list, (int)npairs, nlist, group_size, pair_off,
                            group_off, total_groups, pairs_sorted, list_len, tile_rows, item_off, total_items, nprobe, jmin, jmax,
-                           tile_cap, jmax_q);
+                           tile_cap);
         return;
     }
     if (cursor == cnt + (nlist + 1)) {      // the callers lay the two arrays end to end: one launch
@@ -939,11 +912,11 @@ void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, in
         hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cnt, nlist);
         hipLaunchKernelGGL(k_zero_i32, dim3((nlist + 255) / 256), dim3(256), 0, st, cursor, nlist);
     }
-    hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, nprobe, jmin, jmax, cnt, jmax_q);
+    hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs, nprobe, jmin, jmax, cnt);
     hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, cnt, nlist, group_size, pair_off, group_off, total_groups,
                        list_len, tile_rows, tile_cap, item_off, total_items);
     hipLaunchKernelGGL(k_pair_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, probe_list, npairs,
-                       nprobe, jmin, jmax, pair_off, cursor, pairs_sorted, jmax_q);
+                       nprobe, jmin, jmax, pair_off, cursor, pairs_sorted);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1758,15 +1731,58 @@ static void launch_merge_strided(int nshards, int64_t nq, int k, int metric, con
     hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)nq), dim3(64), shm, st, nshards, nq, k, metric, D, d_sstride, d_estride, I,
                        i_sstride, Do, Io, NP);
 }
-void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do,
+// Any shard count x k (round 5; the reference backends' default is k = 4096, src/indicies/flat.py:138, and eight ranks of it are
+// 32768 keys per query): one launch while nshards * k <= 16384 keys fit the kernel's LDS sort, else ROUNDS over groups of
+// G = max(2, 8192 / k) consecutive blocks.  The rule (score, then earlier shard, then in-shard rank) survives the rounds: a group's
+// output is already in that order and the groups stay in shard order, so a tie between two groups resolves to the earlier shards
+// and a tie inside a group to the earlier position — the one-launch result, bit for bit (tests/test_gpu_merge_rounds.py).  The
+// round buffers are stream-ordered allocations on the caller's stream: no host synchronisation.  Returns false when k > 8192.
+static bool merge_any(int nshards, int64_t nq, int k, int metric, const float* D, int64_t d_sstride, int d_estride,
+                      const int64_t* I, int64_t i_sstride, float* Do, int64_t* Io, hipStream_t st) {
+    if (nq <= 0) return true;
+    if ((int64_t)nshards * k <= 16384) { launch_merge_strided(nshards, nq, k, metric, D, d_sstride, d_estride, I, i_sstride, Do, Io, st); return true; }
+    if (k > 8192) return false;
+    const int G = 8192 / k < 2 ? 2 : 8192 / k;
+    const size_t blk = (size_t)nq * k;
+    const int g0 = (nshards + G - 1) / G, g1 = (g0 + G - 1) / G;
+    float* tD[2] = {nullptr, nullptr}; int64_t* tI[2] = {nullptr, nullptr};
+    auto need = [&](int which, int groups) {
+        if (tD[which]) return true;
+        return hipMallocAsync((void**)&tD[which], (size_t)groups * blk * 4, st) == hipSuccess &&
+               hipMallocAsync((void**)&tI[which], (size_t)groups * blk * 8, st) == hipSuccess;
+    };
+    bool ok = need(0, g0);
+    if (ok) for (int g = 0; g < g0; g++) {          // round 1 reads the caller's (possibly packed) layout
+        const int n = nshards - g * G < G ? nshards - g * G : G;
+        launch_merge_strided(n, nq, k, metric, D + (int64_t)g * G * d_sstride, d_sstride, d_estride, I + (int64_t)g * G * i_sstride, i_sstride,
+                             tD[0] + (size_t)g * blk, tI[0] + (size_t)g * blk, st);
+    }
+    int cur = g0, src = 0;
+    while (ok && cur > G) {
+        const int groups = (cur + G - 1) / G;
+        ok = need(src ^ 1, src == 0 ? g1 : g0);
+        if (!ok) break;
+        for (int g = 0; g < groups; g++) {
+            const int n = cur - g * G < G ? cur - g * G : G;
+            launch_merge_strided(n, nq, k, metric, tD[src] + (size_t)g * G * blk, (int64_t)blk, 1, tI[src] + (size_t)g * G * blk, (int64_t)blk,
+                                 tD[src ^ 1] + (size_t)g * blk, tI[src ^ 1] + (size_t)g * blk, st);
+        }
+        cur = groups; src ^= 1;
+    }
+    if (ok) launch_merge_strided(cur, nq, k, metric, tD[src], (int64_t)blk, 1, tI[src], (int64_t)blk, Do, Io, st);
+    for (int w = 0; w < 2; w++) { if (tD[w]) (void)hipFreeAsync(tD[w], st); if (tI[w]) (void)hipFreeAsync(tI[w], st); }
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+bool launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do,
                        int64_t* Io, hipStream_t st) {
-    launch_merge_strided(nshards, nq, k, metric, D, nq * k, 1, I, nq * k, Do, Io, st);
+    return merge_any(nshards, nq, k, metric, D, nq * k, 1, I, nq * k, Do, Io, st);
 }
 // packed: [nshards, 2, nq, k] int64 — plane 0 = score bits (low word), plane 1 = ids
-void launch_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed, float* Do, int64_t* Io,
+bool launch_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed, float* Do, int64_t* Io,
                          hipStream_t st) {
-    launch_merge_strided(nshards, nq, k, metric, reinterpret_cast<const float*>(packed), 4 * nq * k, 2, packed + nq * k,
-                         2 * nq * k, Do, Io, st);
+    return merge_any(nshards, nq, k, metric, reinterpret_cast<const float*>(packed), 4 * nq * k, 2, packed + nq * k,
+                     2 * nq * k, Do, Io, st);
 }
 
 // Merge for the single-process multi-GPU handle (rsx_sharded_create): the shards are pieces of ONE logical index, so the

@@ -1,2391 +1,8 @@
-// rsx_api.hip — C-ABI implementation (include/rsx.h): index objects, HBM layout management,
-// add / train / search drivers, persistence.  Host control plane only; all search arithmetic
-// is in the k_*.hip kernels.  There is no CPU search path: every entry point needs a GPU.
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <condition_variable>
-#include <functional>
-#include <map>
-#include <memory>
-#include <stdexcept>
-#include <string>
-#include <thread>
-#include <tuple>
-#include <vector>
-
-#include "../../include/rsx.h"
-#include "rsx_internal.h"
-
-using namespace rsx;
-
-// ---------------------------------------------------------------------------------------
-// errors
-// ---------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-
-struct RsxError : std::runtime_error {
-    int code;
-    RsxError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
-};
-#define RSX_THROW(code, ...)                                  \
-    do {                                                      \
-        char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__);  \
-        throw RsxError(code, _b);                             \
-    } while (0)
-#define HIPCHECK(expr)                                                                              \
-    do {                                                                                            \
-        hipError_t _e = (expr);                                                                     \
-        if (_e != hipSuccess) {                                                                     \
-            int code = (_e == hipErrorOutOfMemory) ? RSX_ERR_OOM : RSX_ERR_HIP;                     \
-            RSX_THROW(code, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-        }                                                                                           \
-    } while (0)
-
-template <typename F>
-static int guarded(F&& f) {
-    try {
-        f();
-        return RSX_OK;
-    } catch (const RsxError& e) {
-        g_err = e.what();
-        return e.code;
-    } catch (const std::bad_alloc&) {
-        g_err = "host allocation failed";
-        return RSX_ERR_OOM;
-    } catch (const std::exception& e) {
-        g_err = e.what();
-        return RSX_ERR_INVALID;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// device buffers
-// ---------------------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    bool borrowed = false;      // a pipeline view's alias of its parent's buffer (refresh_view): never freed, never grown here
-    void ensure(size_t n) {
-        if (n <= bytes) return;
-        if (borrowed) throw std::logic_error("DevBuf: a borrowed buffer cannot grow");
-        release();
-        size_t want = n + n / 8;
-        if (hipMalloc(&p, want) != hipSuccess) {
-            (void)hipGetLastError();
-            p = nullptr;
-            HIPCHECK(hipMalloc(&p, n));
-            want = n;
-        }
-        bytes = want;
-    }
-    void release() {
-        if (p && !borrowed) (void)hipFree(p);
-        p = nullptr; bytes = 0; borrowed = false;
-    }
-    void borrow(const DevBuf& o) { release(); p = o.p; bytes = o.bytes; borrowed = o.p != nullptr; }
-    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-    ~DevBuf() { release(); }
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-};
-
-// Page-locked host staging for the small transfers of the latency path (a single query in, k results and the
-// certificate flags out): copies to and from pageable memory go through the runtime's own staging and block the host.
-struct PinBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    bool ensure(size_t n) {          // false: no pinned memory to be had — the caller keeps the pageable path
-        if (n <= bytes) return true;
-        release();
-        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
-        bytes = n;
-        return true;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
-    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-    ~PinBuf() { release(); }
-    PinBuf() = default;
-    PinBuf(const PinBuf&) = delete;
-    PinBuf& operator=(const PinBuf&) = delete;
-};
-
-static bool is_device_ptr(const void* p) {
-    if (!p) return false;
-    hipPointerAttribute_t at;
-    hipError_t e = hipPointerGetAttributes(&at, p);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
-}
-
-static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
-static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
-
-// ---------------------------------------------------------------------------------------
-// deterministic host RNG shared with the training spec (splitmix64 Fisher-Yates)
-// ---------------------------------------------------------------------------------------
-static inline uint64_t splitmix(uint64_t& s) {
-    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-static void rand_perm(int64_t n, uint64_t seed, std::vector<int64_t>& perm) {
-    perm.resize((size_t)n);
-    uint64_t s = seed;
-    for (int64_t i = 0; i < n; i++) perm[(size_t)i] = i;
-    for (int64_t i = 0; i + 1 < n; i++) {
-        int64_t j = i + (int64_t)(splitmix(s) % (uint64_t)(n - i));
-        std::swap(perm[(size_t)i], perm[(size_t)j]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// the index object
-// ---------------------------------------------------------------------------------------
-struct rsx_index {
-    int kind = 0, d = 0, metric = 0, device = 0;
-    int nlist = 1, M = 0, nbits = 8, Mpad = 0, CB = 16, dsub = 0;   // CB: code layout (rsx_internal.h), 0 = rotated
-    int CB_granule = 16;
-    int nprobe = 1;
-    bool trained = false;
-    int64_t ntotal = 0;
-    hipStream_t st = nullptr;
-    // side stream of a search batch (round 4): stages that do not depend on each other run beside the main chain — the table build
-    // beside the coarse quantiser + probe selection, the pair grouping beside the threshold pre-pass
-    hipStream_t st2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_probe = nullptr, ev_lut = nullptr, ev_group = nullptr;
-    int overlap = 1;          // 0 = everything on one stream
-    // Batch pipeline (round 4, VERDICT r3 task 4b; the reference hands ALL its queries to one index.search call, src/search.py:296):
-    // a search of several internal batches alternates them between this handle and a VIEW of it — a second handle that borrows
-    // the index payload (codes, ids, directory, trained parameters) and owns its own streams and workspaces — driven by a second
-    // host thread, so that the query-side stages of batch i+1 and the selection / re-rank of batch i-1 can run beside batch i's
-    // scan; the scan's persistent grid leaves `pipeline_reserve` CUs (a multiple of 8) free meanwhile.  Results are those of the
-    // sequential loop (every batch is still one search_batch call).  MEASURED AND OFF BY DEFAULT (profiles/r04_pipeline.md):
-    // 4096 queries take 11.4 ms sequentially and 11.4-11.8 ms pipelined for any reserve — a kernel of another queue makes no
-    // progress on the CUs a 240-workgroup scan leaves free unless EVERY shader engine of every XCD has room (32 CUs = 12.5 % of
-    // the scan's throughput, as much as the fixed cost it hides), and without a reserve the neighbouring batches' small kernels
-    // only meet between two scans, where they slow each other by what the overlap saves.
-    int pipeline = 0;         // 1 = IVF-PQ rotated fast scan, >= 2 internal batches, no profiling; 0 = never (default)
-    int pipeline_reserve = 16;
-    int scan_reserve_now = 0; // CUs the scan grid leaves free in the call under way (set by search_impl)
-    rsx_index* pipe_view = nullptr;
-    ~rsx_index() {
-        if (st2) { (void)hipSetDevice(device); (void)hipStreamDestroy(st2); }
-        for (hipEvent_t e : {ev_fork, ev_probe, ev_lut, ev_group}) if (e) (void)hipEventDestroy(e);
-    }
-    PinBuf pin_q, pin_out, pin_flags;     // latency path: pinned staging of queries / results / certificate flags
-
-    // trained parameters
-    std::vector<float> h_centroids, h_codebooks;
-    DevBuf d_centroids, d_codebooks;
-
-    // storage.  PQ: slab layout bytes.  Flat/IVFFlat: rows of ld elements (fp16 or fp32).
-    int ld = 0;               // row stride (elements) of flat rows: d rounded up to 64
-    int storage_f16 = 1;
-    bool storage_decided = false;
-    bool custom_ids = false;  // Flat: ids array only when the caller supplied ids
-    DevBuf data, ids, norms;
-    std::vector<int64_t> h_base, h_len, h_cap;
-    DevBuf d_base, d_len;
-    int64_t total_cap = 0;
-
-    // knobs
-    int query_batch = 1024;
-    int scan_chunk = 0;
-    int scan_kernel = 0;  // 0 = auto (list-major v2 when the layout allows), 1 = force the per-pair v1 kernel
-    int pq_fast = 1;      // IVFPQ: 8-bit-table fast scan + certified exact re-rank (results identical to exact)
-    int pq_fast_kp = 0;   // candidates kept by the fast scan (0 = auto); tests shrink it to force fallbacks
-    int pq_filter = 1;    // fast scan: filter candidates inside the scan kernel (0 = full score buffer + select)
-    int pq_pace = 128 | (4 << 12);   // rotated fast scan schedule (never changes a result): bit 7 = a query group that starts while a
-                          // sibling group of its list tile is under way JOINS it at its position and wraps around (L2 reuse of the code
-                          // lines), bits 8-11 = join offset in tile rows (0 = 2), bits 12-15 = the last n rows of a tile are handed to
-                          // the waves dynamically (default 4; 0 = static columns), bit 4 = every chunk dynamic, bit 6 = no issue-
-                          // priority rotation
-    int pq_rot8 = 0;      // rotated fast scan, M = 64: EIGHT queries per pass over a list tile (k_pq_scan_rot64x2: two 4-query records per work item, one table plane each); opt-in, measured in profiles/r04_rot8_m64.md
-    int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
-    int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
-    int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
-    int ivf_wide2 = 0;       // IVF-Flat LDS-DMA scan, 32-query groups: 8 waves x 6-stage rings (experiment)
-    int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scan: 1 = choose 16 / 32 / 64 queries per group from the queries per list, 2 / 4 = force, 0 = always 16
-    int pq_prepass4 = 1;     // rotated fast scan, full batches: threshold pre-pass with four queries per workgroup on the scan's table format (1 = small and large k, 2 = small k only, 0 = never)
-    int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
-    int pq_final_tab = 1;    // rotated fast scan: finalize from the complete candidate row with the fp32 table in LDS (1 = when K' >= 512 or dsub > 8 and as the second chance, 2 = always, 0 = never)
-    int pq_log_cap = 0;      // rotated fast scan: keys per survivor log (0 = from the pool budget); tests shrink it to force the overflow path
-    int pq_pre_mult = 160, pq_pre_max = 16384;   // ... and for larger k: pq_pre_mult x k rows, at most pq_pre_max (<= 32768: 64 KiB of 16-bit sums in LDS; 16384 measured best overall on the headline index at k = 100 / 1000 / 2000, profiles/r04u_pre_sweep.jsonl)
-    int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
-    int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
-    int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
-    int flat_filter = 1;  // Flat: filtered GEMM launches after the threshold phase (0 = score buffer per chunk)
-    int flat_pre_mult = 32;  // Flat: rows of the threshold phase per K' (through the score buffer), rounded up to 65536-row chunks
-    int flat_stages = 0;     // Flat: filtered stages behind the threshold phase (0 = from K' and the row count; see search_batch)
-    int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
-    int ivf_pre_lists = 0;   // IVF-Flat threshold sample at large K': closest lists sampled (0 = 2)
-    int ivf_pre_adaptive = 0;   // ... 1 = two, and up to two more per query when its closest lists are short
-    int ivf_pre_mult = 4;    // ... and rows of each per K'
-    int profile = 0;
-    int64_t temp_budget = (int64_t)16 << 30;
-
-    // workspace
-    DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
-        w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart, w_qitems, w_tiews, w_samp;
-    std::map<std::string, double> timing;
-
-    // Flat / IVF-Flat: largest |x|^2 ever added (certificate of the MFMA scan); device copy is the running atomic max
-    float max_norm2 = 0.0f;
-    DevBuf d_maxnorm;
-    int flat_cert = 1;        // 1 = certify the fp16-MFMA scan and re-run uncertified queries exactly (0 = round-1 behaviour)
-
-    // host-side bounds that only depend on the list lengths (top-nprobe sums of list / tile counts): computed once per
-    // directory generation instead of a partial_sort over nlist two to four times per search batch
-    uint64_t dir_gen = 0;
-    std::map<std::tuple<int, int, int>, std::pair<uint64_t, std::pair<int64_t, int64_t>>> bound_cache;
-
-    // two-call search (rsx_search_prepass / rsx_search_scan: the caller exchanges the per-query thresholds between the calls,
-    // e.g. an all-reduce(MAX) across the ranks of a LIST-sharded index).  The search runs on a worker thread that parks right
-    // after the threshold pre-pass (only the worker thread ever parks: TwoCall::worker); parked / go / done / tau are guarded by
-    // TwoCall::mu, and every other entry point refuses the handle while `active` (refuse_while_two_call).
-    struct TwoCall {
-        std::thread th;
-        std::thread::id worker;     // the thread running the parked search: the only one allowed to park
-        std::mutex mu;
-        std::condition_variable cv;
-        bool active = false, parked = false, go = false, done = false;
-        uint64_t* tau = nullptr; int64_t ntau = 0;
-        int status = 0; std::string err;
-    };
-    std::unique_ptr<TwoCall> tc;
-
-    // single-process multi-GPU handle (rsx_sharded_create): this object owns one child index per device and nothing else
-    std::vector<rsx_index*> shards;
-    DevBuf sh_D, sh_I, sh_q, sh_oD, sh_oI;      // parent-device gather / merge buffers
-    int64_t sh_next_id = 0;                      // next sequential id of the logical index
-
-    int row_align() const { return kind == KIND_IVFPQ ? 64 : (kind == KIND_FLAT ? 128 : 64); }
-    size_t row_bytes() const { return kind == KIND_IVFPQ ? (size_t)Mpad : (size_t)ld * (storage_f16 ? 2 : 4); }
-};
-
-static void use_device(rsx_index* h) { HIPCHECK(hipSetDevice(h->device)); }
-static void ensure_side_stream(rsx_index* h) {
-    if (h->st2) return;
-    HIPCHECK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&h->ev_fork, &h->ev_probe, &h->ev_lut, &h->ev_group}) HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-}
-// A two-call search that is parked between rsx_search_prepass and rsx_search_scan owns the handle's workspaces (thresholds,
-// candidate rows, state): every other entry point refuses to touch the handle until rsx_search_scan has finished it.
-static void refuse_while_two_call(const rsx_index* h, const char* what) {
-    if (h && h->tc && h->tc->active)
-        RSX_THROW(RSX_ERR_INVALID, "%s: a two-call search is open on this handle (finish it with rsx_search_scan first)", what);
-}
-
-// HBM held by the search / add workspaces of one (unsharded) handle — grows with the largest batch served so far, is never
-// part of the index payload (hbm_bytes) and is released with the handle.  The largest single item is the IVF-PQ fast scan's
-// per-item survivor segments (w_itemdesc: a few GB at the bench configuration, rsx_internal.h: pq_scan_rot_ws).
-static int64_t workspace_bytes(const rsx_index* h) {
-    const DevBuf* bufs[] = {&h->w_q32, &h->w_q16, &h->w_coarse, &h->w_keys1, &h->w_probekeys, &h->w_probelist, &h->w_dis0, &h->w_segstart,
-                            &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
-                            &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
-                            &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->w_qitems, &h->w_tiews, &h->w_samp, &h->sh_D, &h->sh_I, &h->sh_q,
-                            &h->sh_oD, &h->sh_oI};
-    int64_t t = 0;
-    for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
-    return t;
-}
-
-static void upload_dir(rsx_index* h) {
-    h->dir_gen++;       // list lengths changed: the memoised host-side bounds below are stale
-    size_t nb = (size_t)h->nlist * sizeof(int64_t);
-    h->d_base.ensure(nb);
-    h->d_len.ensure(nb);
-    HIPCHECK(hipMemcpyAsync(h->d_base.p, h->h_base.data(), nb, hipMemcpyHostToDevice, h->st));
-    HIPCHECK(hipMemcpyAsync(h->d_len.p, h->h_len.data(), nb, hipMemcpyHostToDevice, h->st));
-    HIPCHECK(hipStreamSynchronize(h->st));
-}
-
-// Make every list able to hold need[l] rows; re-lays-out HBM when a list overflows.
-static void ensure_capacity(rsx_index* h, const std::vector<int64_t>& need, bool exact) {
-    const int al = h->row_align();
-    bool grow = false;
-    for (int l = 0; l < h->nlist; l++)
-        if (need[(size_t)l] > h->h_cap[(size_t)l]) { grow = true; break; }
-    bool need_ids = (h->kind != KIND_FLAT) || h->custom_ids;
-    bool need_norms = (h->metric == RSX_METRIC_L2) && h->kind != KIND_IVFPQ;
-    if (!grow && h->data.p && (!need_ids || h->ids.p) && (!need_norms || h->norms.p)) return;
-
-    // Amortised growth: a re-layout moves the whole index, so when ANY list overflows EVERY list gets
-    // headroom proportional to its current need (2x for PQ codes, 1.5x for raw rows); the number of
-    // re-layouts is then logarithmic in the final size instead of one per add batch.
-    std::vector<int64_t> ncap(h->h_cap), nbase((size_t)h->nlist);
-    for (int l = 0; l < h->nlist; l++) {
-        int64_t nd = need[(size_t)l];
-        int64_t want = exact ? nd : (h->kind == KIND_IVFPQ ? 2 * nd + 64 : nd + nd / 2);
-        if (grow && round_up(want, al) > ncap[(size_t)l]) ncap[(size_t)l] = round_up(want, al);
-        if (nd > ncap[(size_t)l]) ncap[(size_t)l] = round_up(nd, al);
-        if (ncap[(size_t)l] == 0 && h->kind == KIND_FLAT) ncap[(size_t)l] = al;
-    }
-    int64_t tot = 0;
-    for (int l = 0; l < h->nlist; l++) { nbase[(size_t)l] = tot; tot += ncap[(size_t)l]; }
-    if (tot >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "more than 2^32 storage rows on one device");
-    size_t rb = h->row_bytes();
-    void* ndata = nullptr; void* nids = nullptr; void* nnorms = nullptr;
-    size_t dbytes = (size_t)std::max<int64_t>(tot, al) * rb;
-    HIPCHECK(hipMalloc(&ndata, dbytes));
-    HIPCHECK(hipMemsetAsync(ndata, 0, dbytes, h->st));
-    if (need_ids) { HIPCHECK(hipMalloc(&nids, (size_t)std::max<int64_t>(tot, 1) * 8)); }
-    if (need_norms) {
-        HIPCHECK(hipMalloc(&nnorms, (size_t)std::max<int64_t>(tot, 1) * 4));
-        HIPCHECK(hipMemsetAsync(nnorms, 0, (size_t)std::max<int64_t>(tot, 1) * 4, h->st));
-    }
-    if (h->data.p && h->ntotal > 0) {
-        DevBuf ob, nb2;
-        size_t nb = (size_t)h->nlist * 8;
-        ob.ensure(nb); nb2.ensure(nb);
-        HIPCHECK(hipMemcpyAsync(ob.p, h->h_base.data(), nb, hipMemcpyHostToDevice, h->st));
-        HIPCHECK(hipMemcpyAsync(nb2.p, nbase.data(), nb, hipMemcpyHostToDevice, h->st));
-        h->d_len.ensure(nb);
-        HIPCHECK(hipMemcpyAsync(h->d_len.p, h->h_len.data(), nb, hipMemcpyHostToDevice, h->st));
-        int64_t unit_rows = (h->kind == KIND_IVFPQ) ? 64 : 1;
-        int64_t unit_bytes = (int64_t)rb * unit_rows;
-        launch_copy_lists(h->nlist, ob.as<int64_t>(), nb2.as<int64_t>(), h->d_len.as<int64_t>(), h->data.as<uint8_t>(),
-                          (uint8_t*)ndata, unit_rows, unit_bytes, (need_ids && h->ids.p) ? h->ids.as<int64_t>() : nullptr,
-                          (int64_t*)nids, (need_norms && h->norms.p) ? h->norms.as<float>() : nullptr, (float*)nnorms,
-                          h->st);
-        HIPCHECK(hipStreamSynchronize(h->st));
-    }
-    h->data.release(); h->data.p = ndata; h->data.bytes = dbytes;
-    if (need_ids) { h->ids.release(); h->ids.p = nids; h->ids.bytes = (size_t)std::max<int64_t>(tot, 1) * 8; }
-    if (need_norms) { h->norms.release(); h->norms.p = nnorms; h->norms.bytes = (size_t)std::max<int64_t>(tot, 1) * 4; }
-    h->h_cap = ncap; h->h_base = nbase; h->total_cap = tot;
-    upload_dir(h);
-}
-
-// Flat / IVF-Flat keep fp16 rows while every value ever added is fp16-representable, else fp32.
-static void upgrade_storage_to_f32(rsx_index* h) {
-    if (!h->storage_f16) return;
-    if (h->data.p && h->total_cap > 0) {
-        void* nd = nullptr;
-        size_t nbytes = (size_t)std::max<int64_t>(h->total_cap, h->row_align()) * h->ld * 4;
-        HIPCHECK(hipMalloc(&nd, nbytes));
-        launch_widen_storage(h->data.as<__half>(), (float*)nd, (int64_t)std::max<int64_t>(h->total_cap, h->row_align()) * h->ld, h->st);
-        HIPCHECK(hipStreamSynchronize(h->st));
-        h->data.release(); h->data.p = nd; h->data.bytes = nbytes;
-    }
-    h->storage_f16 = 0;
-}
-
-// Stage `n` rows of caller data on the device; returns the device pointer (caller's own if it
-// already lives in HBM).
-static const void* stage_rows(rsx_index* h, DevBuf& buf, const void* x, int64_t n, int d, int dtype) {
-    size_t bytes = (size_t)n * d * (dtype == RSX_F16 ? 2 : 4);
-    if (is_device_ptr(x)) return x;
-    buf.ensure(bytes);
-    HIPCHECK(hipMemcpyAsync(buf.p, x, bytes, hipMemcpyHostToDevice, h->st));
-    return buf.p;
-}
-
-static void set_centroids(rsx_index* h, const float* c) {
-    size_t n = (size_t)h->nlist * h->d;
-    h->h_centroids.assign(c, c + n);
-    h->d_centroids.ensure(n * 4);
-    HIPCHECK(hipMemcpyAsync(h->d_centroids.p, h->h_centroids.data(), n * 4, hipMemcpyHostToDevice, h->st));
-    HIPCHECK(hipStreamSynchronize(h->st));
-}
-static void set_codebooks(rsx_index* h, const float* c) {
-    size_t n = (size_t)h->M * 256 * h->dsub;
-    h->h_codebooks.assign(c, c + n);
-    h->d_codebooks.ensure(n * 4);
-    HIPCHECK(hipMemcpyAsync(h->d_codebooks.p, h->h_codebooks.data(), n * 4, hipMemcpyHostToDevice, h->st));
-    HIPCHECK(hipStreamSynchronize(h->st));
-}
-static void update_trained(rsx_index* h) {
-    if (h->kind == KIND_FLAT) h->trained = true;
-    else if (h->kind == KIND_IVFFLAT) h->trained = !h->h_centroids.empty();
-    else h->trained = !h->h_centroids.empty() && !h->h_codebooks.empty();
-}
-
-// ---------------------------------------------------------------------------------------
-// creation
-// ---------------------------------------------------------------------------------------
-static rsx_index* create_common(int kind, int d, int nlist, int M, int nbits, int metric, int device) {
-    if (d <= 0) RSX_THROW(RSX_ERR_INVALID, "d must be positive (got %d)", d);
-    if (metric != RSX_METRIC_INNER_PRODUCT && metric != RSX_METRIC_L2) RSX_THROW(RSX_ERR_INVALID, "unknown metric %d", metric);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        (void)hipGetLastError();
-        RSX_THROW(RSX_ERR_HIP, "no HIP device available: librsx has no CPU path");
-    }
-    if (device < 0 || device >= ndev) RSX_THROW(RSX_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
-    std::unique_ptr<rsx_index> h(new rsx_index());
-    h->kind = kind; h->d = d; h->metric = metric; h->device = device;
-    h->nlist = (kind == KIND_FLAT) ? 1 : nlist;
-    if (kind != KIND_FLAT && nlist <= 0) RSX_THROW(RSX_ERR_INVALID, "nlist must be positive (got %d)", nlist);
-    h->ld = (int)round_up(d, 64);
-    if (kind == KIND_IVFPQ) {
-        if (nbits != 8) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: only nbits = 8 is implemented (got %d)", nbits);
-        if (M <= 0 || d % M != 0) RSX_THROW(RSX_ERR_INVALID, "IVFPQ: d (%d) must be a multiple of M (%d)", d, M);
-        if (metric != RSX_METRIC_INNER_PRODUCT)
-            RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: only METRIC_INNER_PRODUCT is implemented (the reference builds every index with it)");
-        h->M = M; h->nbits = nbits; h->dsub = d / M;
-        h->Mpad = (int)round_up(M, 4);
-        h->CB = (h->Mpad % 16 == 0) ? 16 : 4;
-        if (h->CB == 16) {
-            int nch = h->Mpad / 16;
-            if (!(nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8)) h->CB = 4;
-        }
-        // M in {16, 32, 64, 96, 128}: the rotated layout (conflict-free table gathers, k_pq_rot.hip) unless RSX_PQ_LAYOUT=0;
-        // rsx_set_param "pq_layout" switches an EMPTY index between the two.  (M = 16 — the reference's shipped IVF-PQ config,
-        // ric/conf/ivf_pq.yaml:64-78 — joined in round 4, once the survivors went to per-wave logs instead of fixed segments.)
-        h->CB_granule = h->CB;
-        const char* e = getenv("RSX_PQ_LAYOUT");
-        if (pq_rot_applies(M) && !(e && atoi(e) == 0)) h->CB = 0;
-        if ((size_t)h->Mpad * 1024 > 160 * 1024) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: M = %d needs more than 160 KiB of LDS for the look-up table", M);
-    }
-    HIPCHECK(hipSetDevice(device));
-    HIPCHECK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
-    h->h_base.assign((size_t)h->nlist, 0);
-    h->h_len.assign((size_t)h->nlist, 0);
-    h->h_cap.assign((size_t)h->nlist, 0);
-    update_trained(h.get());
-    return h.release();
-}
-
-// ---------------------------------------------------------------------------------------
-// add
-// ---------------------------------------------------------------------------------------
-static void decide_storage(rsx_index* h, const void* dx, int64_t n, int dtype) {
-    if (h->kind == KIND_IVFPQ) return;
-    if (dtype == RSX_F16) { h->storage_decided = true; return; }
-    if (h->storage_decided && !h->storage_f16) return;
-    h->w_flag.ensure(sizeof(int));
-    HIPCHECK(hipMemsetAsync(h->w_flag.p, 0, sizeof(int), h->st));
-    launch_check_f16((const float*)dx, n * h->d, h->w_flag.as<int>(), h->st);
-    int flag = 0;
-    HIPCHECK(hipMemcpyAsync(&flag, h->w_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
-    HIPCHECK(hipStreamSynchronize(h->st));
-    if (flag) upgrade_storage_to_f32(h);
-    h->storage_decided = true;
-}
-
-// fold the batch's largest |x|^2 into h->max_norm2 (read back here: every add path synchronises the stream anyway)
-static void track_max_norm(rsx_index* h, const void* dx, int64_t n, int dtype) {
-    if (!h->d_maxnorm.p) {
-        h->d_maxnorm.ensure(sizeof(unsigned int));
-        HIPCHECK(hipMemsetAsync(h->d_maxnorm.p, 0, sizeof(unsigned int), h->st));
-    }
-    launch_max_norm2(dx, dtype == RSX_F16, n, h->d, h->d_maxnorm.as<unsigned int>(), h->st);
-    HIPCHECK(hipMemcpyAsync(&h->max_norm2, h->d_maxnorm.p, sizeof(float), hipMemcpyDeviceToHost, h->st));
-    HIPCHECK(hipStreamSynchronize(h->st));
-}
-
-static void add_batch(rsx_index* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
-    const void* dx = stage_rows(h, h->w_x, x, n, h->d, dtype);
-    const int64_t* dids = nullptr;
-    if (ids) {
-        if (is_device_ptr(ids)) dids = ids;
-        else {
-            h->w_idsin.ensure((size_t)n * 8);
-            HIPCHECK(hipMemcpyAsync(h->w_idsin.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
-            dids = h->w_idsin.as<int64_t>();
-        }
-    }
-    decide_storage(h, dx, n, dtype);
-    if (h->kind != KIND_IVFPQ) track_max_norm(h, dx, n, dtype);
-
-    if (h->kind == KIND_FLAT) {
-        if (ids && !h->custom_ids) {
-            if (h->ntotal > 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "Flat: cannot switch to explicit ids after sequential adds");
-            h->custom_ids = true;
-        } else if (!ids && h->custom_ids) {
-            RSX_THROW(RSX_ERR_INVALID, "Flat: index was populated with explicit ids; ids required");
-        }
-        std::vector<int64_t> need(1, h->ntotal + n);
-        ensure_capacity(h, need, false);
-        size_t esz = h->storage_f16 ? 2 : 4;
-        launch_scatter_rows(dx, dtype == RSX_F16, n, h->d, nullptr, h->data.as<uint8_t>() + (size_t)h->ntotal * h->ld * esz,
-                            h->storage_f16, h->ld, h->norms.p ? h->norms.as<float>() + h->ntotal : nullptr, dids, 0,
-                            h->custom_ids ? h->ids.as<int64_t>() + h->ntotal : nullptr, h->st);
-        h->h_len[0] = h->ntotal + n;
-        h->ntotal += n;
-        upload_dir(h);
-        return;
-    }
-
-    // IVF: assignment on the matrix cores (exact fp32 chain), placement on the host
-    int ct = (h->nlist + 127) / 128;
-    h->w_partial.ensure((size_t)n * 2 * ct * 8);
-    h->w_assign.ensure((size_t)n * 4);
-    launch_gemm_exact_argmax(dx, dtype == RSX_F16, n, h->d, h->d_centroids.as<float>(), h->nlist, h->d,
-                             h->w_partial.as<uint64_t>(), h->w_assign.as<int32_t>(), nullptr, h->st);
-    // placement on the device (round 3): only the per-list totals of the batch visit the host (4 bytes per list — it has to
-    // grow the lists), not the assignments (4 bytes per vector out, 8 back): stable ranks = insertion order inside a list.
-    // List-sharded multi-GPU index: this handle keeps only the lists l with l % add_list_mod == add_list_rem; the other
-    // vectors of the stream are assigned (they advance the sequential ids) and dropped.
-    const int lmod = std::max(1, h->add_list_mod), lrem = h->add_list_rem;
-    const int64_t nseg = add_dest_segments(n);
-    std::vector<int64_t> need(h->h_len);
-    int64_t nkept = 0;
-    h->w_dest.ensure((size_t)n * 8);
-    if ((size_t)h->nlist * 4 > 60 * 1024) {
-        // more lists than the placement kernels' LDS table holds (15360): the round-2 host placement
-        std::vector<int32_t> assign((size_t)n);
-        HIPCHECK(hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
-        std::vector<int64_t> pos((size_t)n);
-        for (int64_t i = 0; i < n; i++) {
-            const int32_t l = assign[(size_t)i];
-            if (lmod > 1 && l % lmod != lrem) { pos[(size_t)i] = -1; continue; }
-            pos[(size_t)i] = need[(size_t)l]++;
-            nkept++;
-        }
-        ensure_capacity(h, need, false);
-        for (int64_t i = 0; i < n; i++) if (pos[(size_t)i] >= 0) pos[(size_t)i] += h->h_base[(size_t)assign[(size_t)i]];
-        HIPCHECK(hipMemcpyAsync(h->w_dest.p, pos.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));   // pos is a local
-    } else {
-    h->w_addcnt.ensure((size_t)(nseg + 1) * h->nlist * 4);
-    int32_t* seg_cnt = h->w_addcnt.as<int32_t>();
-    int32_t* d_total = seg_cnt + (size_t)nseg * h->nlist;
-    launch_add_destinations(h->w_assign.as<int32_t>(), n, h->nlist, lmod, lrem, seg_cnt, d_total, h->st);
-    std::vector<int32_t> total((size_t)h->nlist);
-    HIPCHECK(hipMemcpyAsync(total.data(), d_total, (size_t)h->nlist * 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHECK(hipStreamSynchronize(h->st));
-    for (int l = 0; l < h->nlist; l++) { need[(size_t)l] += total[(size_t)l]; nkept += total[(size_t)l]; }
-    ensure_capacity(h, need, false);
-    std::vector<int64_t> start((size_t)h->nlist);
-    for (int l = 0; l < h->nlist; l++) start[(size_t)l] = h->h_base[(size_t)l] + h->h_len[(size_t)l];
-    h->w_addstart.ensure((size_t)h->nlist * 8);
-    HIPCHECK(hipMemcpyAsync(h->w_addstart.p, start.data(), (size_t)h->nlist * 8, hipMemcpyHostToDevice, h->st));
-    launch_add_place(h->w_assign.as<int32_t>(), n, h->nlist, lmod, lrem, seg_cnt, h->w_addstart.as<int64_t>(), h->w_dest.as<int64_t>(), h->st);
-    }
-
-    if (h->kind == KIND_IVFPQ) {
-        launch_pq_encode(dx, dtype == RSX_F16, n, h->d, h->d, h->M, h->Mpad, h->CB, h->d_centroids.as<float>(),
-                         h->w_assign.as<int32_t>(), h->d_codebooks.as<float>(), h->w_dest.as<int64_t>(),
-                         h->data.as<uint8_t>(), nullptr, h->st);
-        launch_write_ids(h->w_dest.as<int64_t>(), dids, h->ntotal + h->ndropped, n, h->ids.as<int64_t>(), h->st);
-    } else {
-        launch_scatter_rows(dx, dtype == RSX_F16, n, h->d, h->w_dest.as<int64_t>(), h->data.p, h->storage_f16, h->ld,
-                            h->norms.p ? h->norms.as<float>() : nullptr, dids, h->ntotal + h->ndropped, h->ids.as<int64_t>(), h->st);
-    }
-    HIPCHECK(hipStreamSynchronize(h->st));  // pos / staging buffers are reused by the next batch
-    h->h_len = need;
-    h->ntotal += nkept;
-    h->ndropped += n - nkept;               // sequential ids count every vector of the add stream
-    upload_dir(h);
-}
-
-static void add_all(rsx_index* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
-    const int64_t B = 262144;  // rows per internal batch
-    size_t esz = dtype == RSX_F16 ? 2 : 4;
-    for (int64_t i0 = 0; i0 < n; i0 += B) {
-        int64_t nb = std::min(B, n - i0);
-        add_batch(h, nb, (const char*)x + (size_t)i0 * h->d * esz, dtype, ids ? ids + i0 : nullptr);
-    }
-    HIPCHECK(hipStreamSynchronize(h->st));
-}
-
-// ---------------------------------------------------------------------------------------
-// training (faiss::Clustering / ProductQuantizer::train restated; assignment on the GPU,
-// centroid update on the host in point order so that training is deterministic)
-// ---------------------------------------------------------------------------------------
-static void renorm_rows(int d, int k, float* c) {
-    for (int i = 0; i < k; i++) {
-        float nr = 0.0f;
-        float* r = c + (size_t)i * d;
-        for (int t = 0; t < d; t++) nr = fmaf(r[t], r[t], nr);
-        if (nr > 0.0f) {
-            float inv = 1.0f / sqrtf(nr);
-            for (int t = 0; t < d; t++) r[t] *= inv;
-        }
-    }
-}
-
-// One Lloyd update given assignments.  The accumulation (sum of the assigned points, point order, fp32) runs on the GPU
-// (k_kmeans_accumulate: one sequential chain per (centroid, dimension), all of them in flight); the host groups the points
-// by centroid (a stable counting sort of the assignment vector) and finishes the update on the k x d sums: division by the
-// counts, FAISS's empty-cluster split, both in the order the oracle uses.
-//   dx: training points on the device [n, ldx]; nsets sub-spaces at column offsets s * col_stride, each of width d, with its
-//   own assignment vector assign[s * astride_set + i * astride_pt]; cen: [nsets][k][d] on the host.
-struct KmeansWs { DevBuf order, off, sums; std::vector<int32_t> h_order, h_off; std::vector<float> h_sums; };
-
-static void kmeans_update_gpu(rsx_index* h, KmeansWs& ws, const float* dx, int64_t ldx, int col_stride, int d, int k, int nsets,
-                              int64_t n, const int32_t* assign, int64_t astride_set, int astride_pt, float* cen) {
-    ws.h_order.resize((size_t)nsets * n); ws.h_off.resize((size_t)nsets * (k + 1));
-    for (int s = 0; s < nsets; s++) {
-        int32_t* off = &ws.h_off[(size_t)s * (k + 1)];
-        std::fill(off, off + k + 1, 0);
-        const int32_t* as = assign + (size_t)s * astride_set;
-        for (int64_t i = 0; i < n; i++) off[as[(size_t)i * astride_pt] + 1]++;
-        for (int c = 0; c < k; c++) off[c + 1] += off[c];
-        std::vector<int32_t> cur(off, off + k);
-        int32_t* ord = &ws.h_order[(size_t)s * n];
-        for (int64_t i = 0; i < n; i++) ord[cur[(size_t)as[(size_t)i * astride_pt]]++] = (int32_t)i;   // stable: point order kept
-    }
-    ws.order.ensure(ws.h_order.size() * 4); ws.off.ensure(ws.h_off.size() * 4); ws.sums.ensure((size_t)nsets * k * d * 4);
-    HIPCHECK(hipMemcpyAsync(ws.order.p, ws.h_order.data(), ws.h_order.size() * 4, hipMemcpyHostToDevice, h->st));
-    HIPCHECK(hipMemcpyAsync(ws.off.p, ws.h_off.data(), ws.h_off.size() * 4, hipMemcpyHostToDevice, h->st));
-    launch_kmeans_accumulate(dx, ldx, col_stride, d, k, nsets, n, ws.order.as<int32_t>(), ws.off.as<int32_t>(), ws.sums.as<float>(), h->st);
-    HIPCHECK(hipMemcpyAsync(cen, ws.sums.p, (size_t)nsets * k * d * 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHECK(hipStreamSynchronize(h->st));
-    for (int s = 0; s < nsets; s++) {
-        const int32_t* off = &ws.h_off[(size_t)s * (k + 1)];
-        float* cs = cen + (size_t)s * k * d;
-        std::vector<int64_t> hassign((size_t)k);
-        for (int j = 0; j < k; j++) hassign[(size_t)j] = off[j + 1] - off[j];
-        for (int j = 0; j < k; j++) {
-            if (hassign[(size_t)j] == 0) continue;
-            const float norm = 1.0f / (float)hassign[(size_t)j];
-            float* cc = cs + (size_t)j * d;
-            for (int t = 0; t < d; t++) cc[t] *= norm;
-        }
-        uint64_t rs = 1234;
-        for (int ci = 0; ci < k; ci++) {
-            if (hassign[(size_t)ci] != 0) continue;
-            int cj = 0;
-            for (;;) {
-                double p = ((double)hassign[(size_t)cj] - 1.0) / (double)(n - k);
-                double r = (double)(splitmix(rs) >> 11) * (1.0 / 9007199254740992.0);
-                if (r < p) break;
-                cj = (cj + 1) % k;
-            }
-            float* a_ = cs + (size_t)ci * d; float* b_ = cs + (size_t)cj * d;
-            memcpy(a_, b_, sizeof(float) * (size_t)d);
-            for (int t = 0; t < d; t++) {
-                if (t % 2 == 0) { a_[t] *= 1.0f + 1.0f / 1024.0f; b_[t] *= 1.0f - 1.0f / 1024.0f; }
-                else { a_[t] *= 1.0f - 1.0f / 1024.0f; b_[t] *= 1.0f + 1.0f / 1024.0f; }
-            }
-            hassign[(size_t)ci] = hassign[(size_t)cj] / 2;
-            hassign[(size_t)cj] -= hassign[(size_t)ci];
-        }
-    }
-}
-
-static void train_impl(rsx_index* h, int64_t n, const void* x, int dtype) {
-    if (h->kind == KIND_FLAT) return;
-    if (n < h->nlist) RSX_THROW(RSX_ERR_INVALID, "train: %lld training points for %d centroids", (long long)n, h->nlist);
-    const int d = h->d;
-    // training set as fp32 on the host (the reference passes host numpy: ivf_flat.py:135)
-    std::vector<float> hx((size_t)n * d);
-    {
-        const void* dx = stage_rows(h, h->w_x, x, n, d, dtype);
-        DevBuf t32; t32.ensure((size_t)n * d * 4);
-        launch_convert_to_f32(dx, dtype == RSX_F16, d, n, d, t32.as<float>(), d, h->st);
-        HIPCHECK(hipMemcpyAsync(hx.data(), t32.p, (size_t)n * d * 4, hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
-    }
-    const uint64_t seed = 1234;
-    // ---- coarse quantiser: k-means, IP assignment, spherical centroids, niter 10, <=256 pts/centroid
-    {
-        const int k = h->nlist;
-        int64_t keep = (int64_t)k * 256;
-        std::vector<float> xs;
-        const float* xt = hx.data();
-        int64_t nt = n;
-        if (n > keep) {
-            std::vector<int64_t> perm; rand_perm(n, seed, perm);
-            xs.resize((size_t)keep * d);
-            for (int64_t i = 0; i < keep; i++) memcpy(&xs[(size_t)i * d], &hx[(size_t)perm[(size_t)i] * d], sizeof(float) * (size_t)d);
-            xt = xs.data(); nt = keep;
-        }
-        std::vector<float> cen((size_t)k * d);
-        std::vector<int64_t> perm; rand_perm(nt, seed + 1, perm);
-        for (int j = 0; j < k; j++) memcpy(&cen[(size_t)j * d], xt + (size_t)perm[(size_t)(j % nt)] * d, sizeof(float) * (size_t)d);
-        renorm_rows(d, k, cen.data());
-        DevBuf dxt; dxt.ensure((size_t)nt * d * 4);
-        HIPCHECK(hipMemcpyAsync(dxt.p, xt, (size_t)nt * d * 4, hipMemcpyHostToDevice, h->st));
-        DevBuf dcen; dcen.ensure((size_t)k * d * 4);
-        int ct = (k + 127) / 128;
-        h->w_partial.ensure((size_t)nt * 2 * ct * 8);
-        h->w_assign.ensure((size_t)nt * 4);
-        std::vector<int32_t> assign((size_t)nt);
-        KmeansWs kws;
-        for (int it = 0; it < 10; it++) {
-            HIPCHECK(hipMemcpyAsync(dcen.p, cen.data(), (size_t)k * d * 4, hipMemcpyHostToDevice, h->st));
-            launch_gemm_exact_argmax(dxt.p, 0, nt, d, dcen.as<float>(), k, d, h->w_partial.as<uint64_t>(),
-                                     h->w_assign.as<int32_t>(), nullptr, h->st);
-            HIPCHECK(hipMemcpyAsync(assign.data(), h->w_assign.p, (size_t)nt * 4, hipMemcpyDeviceToHost, h->st));
-            HIPCHECK(hipStreamSynchronize(h->st));
-            kmeans_update_gpu(h, kws, dxt.as<float>(), d, 0, d, k, 1, nt, assign.data(), 0, 1, cen.data());
-            renorm_rows(d, k, cen.data());
-        }
-        set_centroids(h, cen.data());
-    }
-    // ---- PQ codebooks on residuals: <=65536 points, per-subspace L2 k-means, niter 25
-    if (h->kind == KIND_IVFPQ) {
-        const int M = h->M, dsub = h->dsub, Mpad = h->Mpad;
-        int64_t keep = 256 * 256;
-        std::vector<float> xs;
-        const float* xt = hx.data();
-        int64_t nt = n;
-        if (n > keep) {
-            std::vector<int64_t> perm; rand_perm(n, seed, perm);
-            xs.resize((size_t)keep * d);
-            for (int64_t i = 0; i < keep; i++) memcpy(&xs[(size_t)i * d], &hx[(size_t)perm[(size_t)i] * d], sizeof(float) * (size_t)d);
-            xt = xs.data(); nt = keep;
-        }
-        if (nt < 256) RSX_THROW(RSX_ERR_INVALID, "train: %lld points cannot train 256 PQ codewords", (long long)nt);
-        DevBuf dxt, dres;
-        dxt.ensure((size_t)nt * d * 4); dres.ensure((size_t)nt * d * 4);
-        HIPCHECK(hipMemcpyAsync(dxt.p, xt, (size_t)nt * d * 4, hipMemcpyHostToDevice, h->st));
-        int ct = (h->nlist + 127) / 128;
-        h->w_partial.ensure((size_t)nt * 2 * ct * 8);
-        h->w_assign.ensure((size_t)nt * 4);
-        launch_gemm_exact_argmax(dxt.p, 0, nt, d, h->d_centroids.as<float>(), h->nlist, d, h->w_partial.as<uint64_t>(),
-                                 h->w_assign.as<int32_t>(), nullptr, h->st);
-        launch_residuals(dxt.as<float>(), nt, d, h->d_centroids.as<float>(), h->w_assign.as<int32_t>(), dres.as<float>(), h->st);
-        std::vector<float> res((size_t)nt * d);
-        HIPCHECK(hipMemcpyAsync(res.data(), dres.p, (size_t)nt * d * 4, hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
-
-        std::vector<float> cb((size_t)M * 256 * dsub);
-        for (int m = 0; m < M; m++) {
-            std::vector<int64_t> perm; rand_perm(nt, seed + (uint64_t)m + 1, perm);
-            for (int j = 0; j < 256; j++)
-                memcpy(&cb[((size_t)m * 256 + j) * dsub], &res[(size_t)perm[(size_t)(j % nt)] * d + (size_t)m * dsub], sizeof(float) * (size_t)dsub);
-        }
-        DevBuf dcb, dcodes;
-        dcb.ensure(cb.size() * 4); dcodes.ensure((size_t)nt * Mpad);
-        std::vector<uint8_t> codes((size_t)nt * Mpad);
-        std::vector<int32_t> a32((size_t)M * nt);
-        KmeansWs kws;
-        for (int it = 0; it < 25; it++) {
-            HIPCHECK(hipMemcpyAsync(dcb.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, h->st));
-            launch_pq_encode(dres.p, 0, nt, d, d, M, Mpad, h->CB, nullptr, nullptr, dcb.as<float>(), nullptr, nullptr,
-                             dcodes.as<uint8_t>(), h->st);
-            HIPCHECK(hipMemcpyAsync(codes.data(), dcodes.p, codes.size(), hipMemcpyDeviceToHost, h->st));
-            HIPCHECK(hipStreamSynchronize(h->st));
-            for (int m = 0; m < M; m++)
-                for (int64_t i = 0; i < nt; i++) a32[(size_t)m * nt + i] = codes[(size_t)i * Mpad + m];
-            // all M sub-spaces in one accumulation launch (M x 256 x dsub chains over the residuals on the device)
-            kmeans_update_gpu(h, kws, dres.as<float>(), d, dsub, dsub, 256, M, nt, a32.data(), nt, 1, cb.data());
-        }
-        set_codebooks(h, cb.data());
-    }
-    update_trained(h);
-}
-
-// ---------------------------------------------------------------------------------------
-// search
-// ---------------------------------------------------------------------------------------
-struct StageTimer {
-    rsx_index* h; bool on; std::string prefix;
-    hipEvent_t ev[64]; const char* name[64]; int n = 0;
-    StageTimer(rsx_index* hh, const char* pre = "") : h(hh), on(hh->profile != 0), prefix(pre) {}
-    void mark(const char* nm) {
-        if (!on || n >= 64) return;
-        (void)hipEventCreate(&ev[n]);
-        (void)hipEventRecord(ev[n], h->st);
-        name[n] = nm; n++;
-    }
-    void finish() {
-        if (!on || n == 0) return;
-        (void)hipEventSynchronize(ev[n - 1]);
-        for (int i = 1; i < n; i++) {
-            float ms = 0; (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
-            h->timing[prefix + name[i]] += ms;
-        }
-        float tot = 0; (void)hipEventElapsedTime(&tot, ev[0], ev[n - 1]);
-        h->timing[prefix + "total"] += tot;
-        for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]);
-        n = 0;
-    }
-};
-
-static void kp_for(const rsx_index* h, int k, bool fast, int& KP, int& BUF) {
-    int want;
-    // fast IVF-PQ scan: K' = the candidates re-scored exactly per query.  With the round-3 threshold (k_pq_prepass: the sample's
-    // k-th best approximate score minus 2 eps) the scan admits what the data needs — measured on the bench mixture ~130 keys
-    // for k = 10, ~500 for k = 100, ~2300 for k = 1000, ~3400 for k = 2000 — and K' only has to hold them: 3k, at least
-    // k + 118, at most 4096 (k_finalize sorts K' candidates in LDS).  A query with more candidates keeps its best K' by
-    // approximate score and is still certified against the K'-th one (k_finalize) or re-run exactly.
-    if (h->kind == KIND_IVFPQ && fast) want = h->pq_fast_kp > 0 ? std::max(k, h->pq_fast_kp) : std::min(4096, std::max(k + 118, 3 * k));
-    else if (h->kind == KIND_IVFPQ) want = (k >= 512) ? k : k + 4;
-    else want = k + std::max(8, k / 16);
-    KP = std::max(16, pow2ceil(want));
-    BUF = std::max(2 * KP, (h->kind == KIND_IVFPQ && fast) ? 512 : 256);
-}
-
-// top-k of `nrows` rows of fp32 scores (row r valid length: row_n or n_uniform) into state [nrows, KP]
-static void select_rows(rsx_index* h, const float* scores, int64_t row_stride, const int64_t* row_n, int64_t row_n_stride,
-                        int64_t n_max, uint32_t idx_base, int64_t nrows, int KP, int BUF, int k, uint64_t* state,
-                        bool merge_state, unsigned long long* threshold_only_cnt = nullptr) {
-    int64_t seg_len = std::max<int64_t>(4096, (int64_t)8 * BUF);
-    seg_len = round_up(seg_len, 256);
-    if (KP >= 1024 && n_max <= 131072) seg_len = round_up(n_max, 256);     // one segment: the radix selection (launch_select)
-    int nseg = (int)std::max<int64_t>(1, (n_max + seg_len - 1) / seg_len);
-    SelectArgs a{};
-    a.in = scores; a.in_is_keys = 0; a.row_stride = row_stride;
-    a.row_n = row_n; a.row_n_stride = row_n_stride; a.n_uniform = n_max;
-    a.seg_len = seg_len; a.nseg = nseg; a.idx_base = idx_base;
-    a.nrows = nrows; a.KP = KP; a.BUF = BUF; a.k = k;
-    if (nseg == 1) {
-        a.init = merge_state ? state : nullptr;
-        a.out = state; a.out_row_stride = KP;
-        if (threshold_only_cnt) { a.keep_last = 1; a.zero_cnt = threshold_only_cnt; }
-        launch_select(a, h->st);
-        return;
-    }
-    h->w_keys1.ensure((size_t)nrows * nseg * KP * 8);
-    a.init = nullptr; a.out = h->w_keys1.as<uint64_t>(); a.out_row_stride = (int64_t)nseg * KP;
-    if (nseg >= 4 && !merge_state) {
-        // Phase A: segment 0 of every row (for IVF: the head of the closest list) alone; its k-th key is a
-        // lower bound of the row's final k-th best, so (phase B) the other segments start from that
-        // threshold and append almost nothing — no LDS sorts on the bulk of the row.
-        SelectArgs a0 = a; a0.nseg = 1; a0.seg_base = 0;
-        launch_select(a0, h->st);
-        a.seg_base = 1;
-        a.tau_ptr = h->w_keys1.as<uint64_t>() + (k - 1); a.tau_stride = (int64_t)nseg * KP;
-        launch_select(a, h->st);
-    } else {
-        launch_select(a, h->st);
-    }
-    SelectArgs b{};
-    b.in = h->w_keys1.p; b.in_is_keys = 1; b.row_stride = (int64_t)nseg * KP;
-    b.row_n = nullptr; b.n_uniform = (int64_t)nseg * KP;
-    b.seg_len = round_up((int64_t)nseg * KP, 256); b.nseg = 1; b.idx_base = 0;
-    b.init = merge_state ? state : nullptr;
-    b.out = state; b.out_row_stride = KP;
-    b.nrows = nrows; b.KP = KP; b.BUF = BUF; b.k = k;
-    if (threshold_only_cnt) { b.keep_last = 1; b.zero_cnt = threshold_only_cnt; }
-    launch_select(b, h->st);
-}
-
-// Upper bound on the number of (list, tile, group) work items of a list-major scan without a host round
-// trip: sum_l ceil(cnt_l/G)*tiles_l <= (nq * TQ)/G + sum_l tiles_l, TQ = tiles of the nprobe longest lists.
-// (sum, max) of the nprobe largest values of ceil(len / unit) * scale over the lists (unit > 0), memoised per directory
-// generation.  tag distinguishes the callers' (unit, scale) families.
-static std::pair<int64_t, int64_t> top_probe_sum(rsx_index* h, int nprobe, int unit, int scale) {
-    const auto key = std::make_tuple(nprobe, unit, scale);
-    auto it = h->bound_cache.find(key);
-    if (it != h->bound_cache.end() && it->second.first == h->dir_gen) return it->second.second;
-    std::vector<int64_t> t((size_t)h->nlist);
-    for (int l = 0; l < h->nlist; l++) t[(size_t)l] = (h->h_len[(size_t)l] + unit - 1) / unit * scale;
-    const int np = std::min(nprobe, h->nlist);
-    std::partial_sort(t.begin(), t.begin() + np, t.end(), std::greater<int64_t>());
-    int64_t s = 0;
-    for (int j = 0; j < np; j++) s += t[(size_t)j];
-    const std::pair<int64_t, int64_t> r(s, np > 0 ? t[0] : 0);
-    h->bound_cache[key] = std::make_pair(h->dir_gen, r);
-    return r;
-}
-static int64_t max_scan_items(rsx_index* h, int64_t nq, int nprobe, int G, int tile_rows) {
-    const auto key = std::make_tuple(-1, tile_rows, 0);       // all tiles of all lists
-    int64_t all;
-    auto it = h->bound_cache.find(key);
-    if (it != h->bound_cache.end() && it->second.first == h->dir_gen) all = it->second.second.first;
-    else {
-        all = 0;
-        for (int l = 0; l < h->nlist; l++) all += (h->h_len[(size_t)l] + tile_rows - 1) / tile_rows;
-        h->bound_cache[key] = std::make_pair(h->dir_gen, std::make_pair(all, (int64_t)0));
-    }
-    const int64_t tq = top_probe_sum(h, nprobe, tile_rows, 1).first;
-    return (nq * tq + G - 1) / G + all + 8;
-}
-
-static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI, bool allow_fast = true);
-
-// The IVF-PQ fast scan with in-kernel filtering and the one-launch threshold pre-pass never writes a score row (search_batch):
-// such a search needs no [nq, sum of the nprobe longest lists] score buffer, and its internal batch is not bounded by one.
-static bool pq_search_needs_score_rows(const rsx_index* h, int nprobe) {
-    const bool fast = h->pq_fast != 0 && h->scan_kernel == 0 && (h->CB == 16 || h->CB == 0) && h->M * 255 < 65536;
-    return !(h->kind == KIND_IVFPQ && fast && nprobe > 1 && h->pq_filter != 0 && h->pq_prepass_fused != 0);
-}
-
-// Keys a query's candidate row can hold (filtered IVF-PQ fast scan).  The threshold is valid by construction, so the
-// row must hold every vector within 2 eps of the query's k-th best: ~700 keys at M = 96 / k = 10, but eps grows as the tables get
-// coarser — at M = 16 (48 dimensions per 8-bit table entry) the measured mean is 1800 and the maximum 23 000 at k = 10.  An
-// overflowing row sends its query to the exact re-run, so small M gets four times the room (8 B x nq x cap of HBM).
-static int64_t pq_cand_cap(int k, int M) {
-    int64_t cap = k > 512 ? 131072 : (k > 64 ? 65536 : 16384);
-    if (M <= 32) cap = std::min<int64_t>(cap * 4, 262144);
-    return cap;
-}
-
-// Queries whose certificate failed (h->w_uncertain, written by k_finalize) are re-run through the exact path of their index
-// kind and their result rows replaced — rare, and what makes the fast paths EXACT rather than "almost always right".
-// temp_bytes_per_query > 0 bounds the exact path's score buffer (Flat / IVF-Flat): the re-run proceeds in chunks.
-static void rerun_uncertified(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI,
-                              size_t temp_bytes_per_query, const std::function<void()>& second_chance = nullptr) {
-    std::vector<int32_t> bad_v;
-    const int32_t* bad;
-    auto read_flags = [&]() {
-        if (nq <= 4096 && h->pin_flags.ensure(4096 * 4)) {
-            HIPCHECK(hipMemcpyAsync(h->pin_flags.p, h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
-            bad = h->pin_flags.as<int32_t>();
-        } else {
-            bad_v.resize((size_t)nq);
-            HIPCHECK(hipMemcpyAsync(bad_v.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
-            bad = bad_v.data();
-        }
-        HIPCHECK(hipStreamSynchronize(h->st));
-    };
-    read_flags();
-    if (second_chance) {
-        // flag 1 = the certificate could not clear the query although none of its candidates was dropped: every vector that
-        // can matter is still in its candidate row — re-rank from a larger K' there before paying for an exact scan
-        int64_t n1 = 0;
-        for (int64_t q = 0; q < nq; q++) n1 += bad[(size_t)q] == 1;
-        if (n1 > 0) {
-            h->timing["second_chance_queries"] += (double)n1;
-            second_chance();
-            read_flags();
-        }
-    }
-    const int d = h->d;
-    const size_t esz = dtype == RSX_F16 ? 2 : 4;
-    std::vector<int64_t> badq;
-    int64_t n_over = 0;
-    for (int64_t q = 0; q < nq; q++) if (bad[(size_t)q]) {
-        badq.push_back(q); n_over += (bad[(size_t)q] & 2) != 0;
-        if (bad[(size_t)q] & 4) { h->timing["fallback_tie_queries"] += 1.0; h->timing["fallback_tie_max"] = std::max(h->timing["fallback_tie_max"], (double)(bad[(size_t)q] >> 8)); }
-    }
-    h->timing["fallback_overflow_queries"] += (double)n_over;     // of the fallbacks: candidate buffer / survivor segment overflows
-    const int64_t nbad = (int64_t)badq.size();
-    h->timing["fallback_queries"] += (double)nbad;
-    h->timing["fast_queries"] += (double)nq;
-    if (nbad == 0) return;
-    int64_t chunk = nbad;
-    if (temp_bytes_per_query > 0) chunk = std::max<int64_t>(1, std::min<int64_t>(nbad, (int64_t)(((size_t)2 << 30) / temp_bytes_per_query)));
-    const size_t qrow = (size_t)d * esz;
-    h->w_fbq.ensure((size_t)chunk * qrow);
-    h->w_fbD.ensure((size_t)chunk * k * 4);
-    h->w_fbI.ensure((size_t)chunk * k * 8);
-    for (int64_t c0 = 0; c0 < nbad; c0 += chunk) {
-        const int64_t nb = std::min(chunk, nbad - c0);
-        // gather the uncertified queries into one contiguous batch, search it exactly, scatter the rows back
-        for (int64_t i = 0; i < nb; i++)
-            HIPCHECK(hipMemcpyAsync((char*)h->w_fbq.p + (size_t)i * qrow, (const char*)dq + (size_t)badq[(size_t)(c0 + i)] * qrow, qrow,
-                                    hipMemcpyDeviceToDevice, h->st));
-        search_batch(h, nb, h->w_fbq.p, dtype, k, h->w_fbD.as<float>(), h->w_fbI.as<int64_t>(), false);
-        for (int64_t i = 0; i < nb; i++) {
-            HIPCHECK(hipMemcpyAsync(dD + badq[(size_t)(c0 + i)] * k, h->w_fbD.as<float>() + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, h->st));
-            HIPCHECK(hipMemcpyAsync(dI + badq[(size_t)(c0 + i)] * k, h->w_fbI.as<int64_t>() + i * k, (size_t)k * 8, hipMemcpyDeviceToDevice, h->st));
-        }
-    }
-}
-
-static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI, bool allow_fast) {
-    StageTimer tm(h, allow_fast ? "" : "fb_");
-    const int d = h->d, ld = h->ld;
-    // IVFPQ fast path: needs the 16-byte-granule layout, 16-bit integer sums, and K' <= 4096
-    const bool rot = h->kind == KIND_IVFPQ && h->CB == 0;
-    bool fast = allow_fast && h->kind == KIND_IVFPQ && h->pq_fast != 0 && h->scan_kernel == 0 && (h->CB == 16 || rot) &&
-                h->M * 255 < 65536;
-    int KP, BUF;
-    kp_for(h, k, fast, KP, BUF);
-    if (fast && KP > 4096) { fast = false; kp_for(h, k, false, KP, BUF); }
-    tm.mark("start");
-    // queries: fp32 copy (exact re-rank, coarse quantiser, LUT) [nq, ld]; fp16 copy for the scans
-    h->w_q32.ensure((size_t)nq * ld * 4);
-    launch_convert_to_f32(dq, dtype == RSX_F16, d, nq, d, h->w_q32.as<float>(), ld, h->st);
-    int64_t nq_pad = nq > 128 ? round_up(nq, 256) : 128;   // query tiles: 128 (k_flat_gemm) or 256 (k_flat_gemm2)
-    const bool certify = h->kind != KIND_IVFPQ && allow_fast && h->flat_cert != 0;
-    if (h->kind != KIND_IVFPQ) {
-        h->w_q16.ensure((size_t)nq_pad * ld * 2);
-        h->w_flag.ensure(sizeof(int));
-        HIPCHECK(hipMemsetAsync(h->w_flag.p, 0, sizeof(int), h->st));
-        launch_convert_to_f16(dq, dtype == RSX_F16, nq, d, h->w_q16.as<__half>(), ld, nq_pad, h->w_flag.as<int>(), h->st);
-    }
-    h->w_state.ensure((size_t)nq * KP * 8);
-    uint64_t* state = h->w_state.as<uint64_t>();
-    tm.mark("convert");
-    // Round 4: the 8-bit tables depend on the queries only — their build (k_pq_lut_tiled<0/1>, ~80 us per 1024 queries) starts here
-    // on the side stream and runs beside the coarse quantiser and the probe selection (~115 us); the per-query parameters
-    // (k_pq_qparam: they need the coarse scores) follow on the main stream once both have finished.
-    const bool pq_fused_lut = h->kind == KIND_IVFPQ && fast && pq_lut8_fused_lds(h->M, h->Mpad, h->dsub) <= 160 * 1024 - 64;
-    const bool side_lut = pq_fused_lut && h->overlap != 0 && h->dsub == 8 && h->lut_tiled != 0 && nq >= 64;
-    // the finalize-from-the-row kernel (k_pq_final_tab) will serve this batch: let the table builder store the fp32 tables for it
-    // (M KiB per query, 100 MB at M = 96 / batch 1024) instead of every query's workgroup re-deriving its table from the 786 KB codebook
-    const bool tab_expected = pq_fused_lut && rot && h->pq_final_tab != 0 && (h->pq_final_tab == 2 || KP >= 512 || h->dsub > 8) &&
-                              std::min(h->nprobe, h->nlist) > 1 && h->pq_filter != 0 && h->pq_prepass_fused != 0 &&
-                              pq_final_tab_capacity(h->M, h->CB, k) > 0;
-    float* lut32_out = nullptr;
-    if (tab_expected) { h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4); lut32_out = h->w_lut.as<float>(); }
-    if (side_lut) {
-        ensure_side_stream(h);
-        h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
-        h->w_qparam.ensure((size_t)nq * 16);
-        h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad));
-        HIPCHECK(hipEventRecord(h->ev_fork, h->st));
-        HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-        launch_pq_lut8(nullptr, h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad, nullptr, 0,
-                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, rot ? 1 : 0, h->st2, 1, lut32_out);
-        HIPCHECK(hipEventRecord(h->ev_lut, h->st2));
-    }
-
-    FinalizeArgs fa{};
-    fa.kind = h->kind; fa.metric = h->metric; fa.state = state; fa.KP = KP; fa.k = k; fa.nq = nq;
-    fa.list_base = h->d_base.as<int64_t>();
-    fa.ids = (h->kind == KIND_FLAT && !h->custom_ids) ? nullptr : h->ids.as<int64_t>();
-    fa.Q32 = h->w_q32.as<float>(); fa.ldq = ld; fa.d = d;
-    fa.X = h->data.p; fa.x_f16 = h->storage_f16; fa.ld = ld;
-    fa.D = dD; fa.I = dI;
-    if (certify) {
-        // |approx - exact| of the fp16-MFMA scan for ANY stored vector (Cauchy-Schwarz on the per-element errors):
-        //   fp32 accumulation of d exact products       (d + 2) 2^-24 |q| |x|
-        //   fp32 rows rounded to fp16 inside the scan   2^-11 |q| |x|        (fp16 storage is lossless)
-        //   fp32 queries rounded to fp16                2^-11 |q| |x|        (only when the batch held such a value: device flag)
-        //   L2: the ranking score adds -|x|^2/2 (fp32)  (d + 4) 2^-24 |x|^2  (folded into the absolute term)
-        const float u24 = 5.9604645e-8f, u11 = 4.8828125e-4f;
-        const float xmax = sqrtf(h->max_norm2) * 1.0000002f;
-        h->w_uncertain.ensure((size_t)nq * 4);
-        fa.uncertain = h->w_uncertain.as<int32_t>();
-        fa.cert_xmax = xmax;
-        fa.cert_rel = ((float)d + 2.0f) * u24 * 1.01f + (h->storage_f16 ? 0.0f : u11 * 1.002f);
-        fa.cert_rel_qlossy = u11 * 1.002f + u11 * u11;
-        fa.cert_qflag = h->w_flag.as<int>();
-        fa.cert_abs = sqrtf((float)d) * u24 + (h->metric == RSX_METRIC_L2 ? ((float)d + 4.0f) * u24 * xmax : 0.0f);
-    }
-
-    if (h->kind == KIND_FLAT) {
-        const float* bias = nullptr;
-        if (h->metric == RSX_METRIC_L2) {
-            // ranking score = <q,x> - |x|^2/2 ; bias buffer holds -|x|^2/2 (derived from norms)
-            h->w_misc.ensure((size_t)h->ntotal * 4);
-            bias = h->w_misc.as<float>();
-        }
-        const int64_t N = h->ntotal;
-        if (N == 0) {
-            launch_fill_u64(state, nq * KP, 0, h->st);
-        } else if (!allow_fast) {
-            // exact mode (queries the certificate could not clear): fp64 scores of every row, rounded once = the canonical
-            // scores themselves, then the ordinary selection
-            const int64_t tstride = round_up(N, 16);
-            h->w_temp.ensure((size_t)nq * tstride * 4);
-            ExactScoreArgs ea{};
-            ea.kind = KIND_FLAT; ea.metric = h->metric; ea.nq = nq; ea.Q32 = h->w_q32.as<float>(); ea.ldq = ld; ea.d = d;
-            ea.X = h->data.p; ea.x_f16 = h->storage_f16; ea.ld = ld; ea.flat_n = N;
-            ea.temp = h->w_temp.as<float>(); ea.tstride = tstride;
-            launch_exact_scores(ea, h->st);
-            tm.mark("scan");
-            select_rows(h, h->w_temp.as<float>(), tstride, nullptr, 0, N, 0, nq, KP, BUF, KP, state, false);
-            tm.mark("select");
-        } else if (nq <= 32) {
-            // small batch: stream the database once per group of 16 queries (list-scan kernel)
-            int64_t tstride = round_up(N, 16);
-            h->w_temp.ensure((size_t)nq * tstride * 4);
-            ListScanArgs a{};
-            a.Q16 = h->w_q16.as<__half>(); a.ld = ld; a.X = h->data.p; a.x_f16 = h->storage_f16; a.bias = bias;
-            a.list_base = h->d_base.as<int64_t>(); a.list_len = h->d_len.as<int64_t>();
-            a.flat_mode = 1; a.flat_n = N; a.nq = (int)nq; a.nprobe = 1; a.nlist = 1;
-            a.temp = h->w_temp.as<float>(); a.tstride = tstride;
-            a.chunk_rows = 1024;
-            if (list_scan2_chunk_rows(h->storage_f16, ld) > 0 && round_up(N, 16) / list_scan2_chunk_rows(h->storage_f16, ld) < 65535)
-                a.chunk_rows = list_scan2_chunk_rows(h->storage_f16, ld);     // LDS-DMA streaming kernel
-            a.max_groups = (int)((nq + 15) / 16);
-            a.max_chunks = (int)((round_up(N, 16) + a.chunk_rows - 1) / a.chunk_rows);
-            if (a.max_chunks > 65535) { a.chunk_rows = (int)round_up((round_up(N, 16) + 65534) / 65535, 64); a.max_chunks = (int)((round_up(N, 16) + a.chunk_rows - 1) / a.chunk_rows); }
-            launch_list_scan(a, h->st);
-            tm.mark("scan");
-            // threshold = the KP-th approximate key (not the k-th): the exact re-rank needs the true top-KP
-            select_rows(h, h->w_temp.as<float>(), tstride, nullptr, 0, N, 0, nq, KP, BUF, KP, state, false);
-            tm.mark("select");
-        } else {
-            const int64_t CH = 65536;
-            h->w_temp.ensure((size_t)nq_pad * CH * 4);
-            launch_fill_u64(state, nq * KP, 0, h->st);
-            // chunk 0 through the score buffer: its top-K' gives every query a running threshold
-            int64_t done_rows = 0;
-            auto chunk_pass = [&](int64_t v0, int64_t vend) {
-                int64_t nv = std::min<int64_t>(CH, vend - v0);
-                launch_flat_gemm(h->w_q16.as<__half>(), (int)nq_pad, h->data.p, h->storage_f16, v0, nv, ld, bias,
-                                 h->w_temp.as<float>(), CH, h->st);
-                select_rows(h, h->w_temp.as<float>(), CH, nullptr, 0, nv, (uint32_t)v0, nq, KP, BUF, KP, state, true);
-            };
-            // Threshold phase: the K'-th key of the first rows is a threshold for everything behind them, so a filtered pass over
-            // the rows [a, b) keeps ~K' (b - a) / a keys per query.  One 65536-row chunk is right for k = 10 (K' = 32: 5 k keys at
-            // 10M rows).  For the reference's n_docs = 1000 (K' = 2048) one chunk let 310 k keys through, overflowed every candidate row
-            // and fell back to 153 chunk passes (550 ms per batch, round 4); 160 K' rows and ONE filtered launch over the rest still
-            // emitted 62 k keys per query — 64 M atomically placed keys, the filtered GEMM 27.8 instead of 17.4 ms — behind five
-            // chunk selections of 0.93 ms.  Now: flat_pre_mult x K' rows through the score buffer (default 32: one chunk), then the rest
-            // in STAGES of geometrically growing row ranges, each one filtered launch + one selection that tightens the threshold for
-            // the next: S stages of ratio r = (N / first)^(1/S) emit ~S K' (r - 1) keys.  Measured at 10M x 768, batch 1024
-            // (profiles/r04_flat_staged_filter.md): k = 1000 36.5 -> 23.3 ms (S = 5), k = 10 18.9 -> 17.2 ms (S = 2: even 5 k keys
-            // per query cost the single filtered launch 1.6 ms), k = 100 17.8 ms.
-            const int64_t nchunks = (N + CH - 1) / CH;
-            const int64_t n0 = std::min<int64_t>(nchunks, std::max<int64_t>(1, ((int64_t)KP * std::max(1, h->flat_pre_mult) + CH - 1) / CH));
-            for (int64_t c = 0; c < n0; c++) chunk_pass(c * CH, N);
-            done_rows = std::min<int64_t>(n0 * CH, N);
-            tm.mark("scan0");
-            if (done_rows < N && h->flat_filter != 0) {
-                int S = h->flat_stages;
-                if (S <= 0) S = KP <= 64 ? 2 : std::min(6, std::max(1, (int)lround(log((double)nchunks / (double)n0) / log(3.0))));
-                const double r = pow((double)nchunks / (double)n0, 1.0 / S);
-                const int cap = KP <= 64 ? 32768 : 131072;
-                h->w_cand.ensure((size_t)nq * cap * 8);
-                h->w_candcnt.ensure((size_t)nq * 8 * CCS);
-                std::vector<unsigned long long> cnts((size_t)nq * CCS);
-                for (int st_ = 0; st_ < S && done_rows < N; st_++) {
-                    // stage boundaries on chunk multiples (the database tiles of the GEMM stay aligned)
-                    int64_t endc = st_ == S - 1 ? nchunks : std::min<int64_t>(nchunks, std::max<int64_t>(done_rows / CH + 1, (int64_t)llround((double)n0 * pow(r, st_ + 1))));
-                    const int64_t end = std::min<int64_t>(N, endc * CH);
-                    // ONE GEMM launch over the stage's rows whose epilogue keeps only keys beating the running K'-th key
-                    HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8 * CCS, h->st));
-                    launch_flat_gemm_filter(h->w_q16.as<__half>(), (int)nq_pad, (int)nq, h->data.p, h->storage_f16, done_rows,
-                                            end - done_rows, ld, bias, state + (KP - 1), KP, h->w_cand.as<uint64_t>(),
-                                            h->w_candcnt.as<unsigned long long>(), cap, h->st);
-                    tm.mark("scan");
-                    HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
-                    HIPCHECK(hipStreamSynchronize(h->st));
-                    bool filtered_ok = true;
-                    for (int64_t qi = 0; qi < nq; qi++) if (cnts[(size_t)qi * CCS] > (unsigned long long)cap) { filtered_ok = false; break; }
-                    if (filtered_ok) {
-                        SelectArgs b{};
-                        b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cap;
-                        b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cap;
-                        b.seg_len = cap; b.nseg = 1; b.idx_base = 0;
-                        b.init = state; b.out = state; b.out_row_stride = KP;
-                        b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;
-                        launch_select(b, h->st);
-                        tm.mark("select");
-                    } else {
-                        h->timing["flat_filter_overflows"] += 1;   // adversarial order: redo this stage's rows chunk by chunk
-                        for (int64_t v0 = done_rows; v0 < end; v0 += CH) chunk_pass(v0, end);
-                        tm.mark("scan");
-                    }
-                    done_rows = end;
-                }
-            }
-            if (done_rows < N) {       // flat_filter = 0
-                for (int64_t v0 = done_rows; v0 < N; v0 += CH) chunk_pass(v0, N);
-                tm.mark("scan");
-            }
-        }
-        launch_finalize(fa, h->st);
-        tm.mark("finalize");
-        tm.finish();
-        if (certify && N > 0) rerun_uncertified(h, nq, dq, dtype, k, dD, dI, (size_t)round_up(N, 16) * 4);
-        return;
-    }
-
-    // ---------------- IVF ----------------
-    const int nlist = h->nlist;
-    const int nprobe = std::min(h->nprobe, nlist);
-    if (nprobe > 4096) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: %d probed lists per query exceed this build's maximum of 4096", nprobe);
-    // 1. coarse quantiser (exact fp32) + top-nprobe
-    const int nlp = (int)round_up(nlist, 4);   // row stride of the coarse scores: 16-byte aligned rows for k_select
-    h->w_coarse.ensure((size_t)nq * nlp * 4);
-    launch_gemm_exact_scores(h->w_q32.p, 0, nq, ld, h->d_centroids.as<float>(), nlist, d, h->w_coarse.as<float>(), nlp, h->st);
-    tm.mark("coarse");
-    int KPp = std::max(16, pow2ceil(nprobe));
-    int BUFp = std::max(2 * KPp, 256);
-    h->w_probekeys.ensure((size_t)nq * KPp * 8);
-    select_rows(h, h->w_coarse.as<float>(), nlp, nullptr, 0, nlist, 0, nq, KPp, BUFp, nprobe, h->w_probekeys.as<uint64_t>(), false);
-    // 2. probe set-up
-    const int pad_to = (h->kind == KIND_IVFPQ) ? 64 : 16;
-    h->w_probelist.ensure((size_t)nq * nprobe * 4);
-    h->w_dis0.ensure((size_t)nq * nprobe * 4);
-    h->w_segstart.ensure((size_t)nq * (nprobe + 1) * 8);
-    launch_probe_setup(h->w_probekeys.as<uint64_t>(), KPp, nq, nprobe, h->d_len.as<int64_t>(), pad_to,
-                       h->w_probelist.as<int32_t>(), h->w_dis0.as<float>(), h->w_segstart.as<int64_t>(), h->st);
-    if (side_lut) HIPCHECK(hipEventRecord(h->ev_probe, h->st));
-    tm.mark("select_probe");
-    if (h->profile >= 2) {
-        std::vector<int32_t> pl((size_t)nq * nprobe);
-        HIPCHECK(hipMemcpyAsync(pl.data(), h->w_probelist.p, pl.size() * 4, hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
-        double tot = 0;
-        std::vector<int32_t> pc((size_t)nlist, 0);
-        for (int32_t l : pl) if (l >= 0) { tot += (double)h->h_len[(size_t)l]; pc[(size_t)l]++; }
-        h->timing["scanned_vectors"] += tot;
-        // the same batch seen list-major: vectors of every list probed at least once (what HBM must deliver), and vectors x
-        // groups of 4 probing queries (what the IVF-PQ fast scan gathers)
-        double uniq = 0, grp = 0;
-        for (int l = 0; l < nlist; l++)
-            if (pc[(size_t)l]) { uniq += (double)h->h_len[(size_t)l]; grp += (double)h->h_len[(size_t)l] * ((pc[(size_t)l] + 3) / 4); }
-        h->timing["scanned_unique_vectors"] += uniq; h->timing["scanned_group_vectors"] += grp;
-        tm.mark("count");
-    }
-    // host-side bound on a query's row of the score buffer: the nprobe longest (padded) lists
-    const auto padded = top_probe_sum(h, nprobe, pad_to, pad_to);    // the nprobe longest lists, padded: sum and maximum
-    int64_t tmax = padded.first, maxlen = padded.second;
-    tmax = std::max<int64_t>(round_up(tmax, 256), 256);
-    if (tmax >= ((int64_t)1 << 32)) RSX_THROW(RSX_ERR_UNSUPPORTED, "probed lists exceed 2^32 vectors per query");
-    // score rows [nq, tmax]: every path but the filtered IVF-PQ fast scan with the one-launch pre-pass fills (part of) them.  At the
-    // reference's nprobe 512 a row is 35 MB: allocating it unconditionally used to cut a 1024-query batch into four internal
-    // batches (round 4: 4x the fixed stages, a quarter of the queries per list group)
-    if (allow_fast ? pq_search_needs_score_rows(h, nprobe) : true) h->w_temp.ensure((size_t)nq * tmax * 4);
-    bool filtered = false;   // fast path with in-kernel candidate filtering (no full score buffer)
-    bool use_gather = false; int gs_tmax = 0; PQGatherArgs gs{};   // ... whose candidates are gathered and selected in one launch
-    bool fused_pre_used = false;   // ... whose threshold came from the one-launch pre-pass (complete candidate rows: second chance)
-    int cand_cap = 0;
-    // the exact kernels gather fp32 table entries; the fast path builds the table in LDS (when it fits)
-    const bool fused_lut = pq_fused_lut;
-
-    if (h->kind == KIND_IVFPQ) {
-        if (!fused_lut) {
-            h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4);
-            launch_pq_lut(h->w_q32.as<float>(), ld, nq, d, h->M, h->Mpad, h->d_codebooks.as<float>(), h->w_lut.as<float>(), h->st);
-            tm.mark("lut");
-        }
-        PQScanArgs a{};
-        a.codes = h->data.as<uint8_t>(); a.M = h->M; a.Mpad = h->Mpad; a.CB = h->CB;
-        a.list_base = h->d_base.as<int64_t>(); a.list_len = h->d_len.as<int64_t>();
-        a.lut = h->w_lut.as<float>(); a.probe_list = h->w_probelist.as<int32_t>(); a.probe_dis0 = h->w_dis0.as<float>();
-        a.seg_start = h->w_segstart.as<int64_t>(); a.nq = nq; a.nprobe = nprobe;
-        a.temp = h->w_temp.as<float>(); a.tstride = tmax;
-        int64_t max_slabs = std::max<int64_t>(1, maxlen / 64);
-        int64_t pairs = nq * nprobe;
-        bool done = false;
-        if (fast) {
-            // 8-bit tables, 4 queries per LDS read; approximate scores, certified in k_finalize
-            h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
-            h->w_qparam.ensure((size_t)nq * 16);
-            h->w_uncertain.ensure((size_t)nq * 4);
-            void* lut_ws = nullptr;
-            if (fused_lut && h->dsub == 8 && h->lut_tiled != 0) { h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad)); lut_ws = h->w_lutws.p; }
-            if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_lut, 0));     // the tables were built beside the probe selection
-            launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
-                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st, side_lut ? 2 : 0,
-                           fused_lut ? lut32_out : nullptr);
-            tm.mark("lut8");
-            int rot_log_cap = 64;
-            auto rot_desc = [&](int64_t items, int ngq) -> void* {   // work-item records + run descriptors + survivor logs of the rotated-layout scan
-                // the log pool = (persistent workgroups x 64 logs x log_cap keys): 1 / 2 / 4 GiB by k, never more than a quarter of the
-                // temp budget.  A log that fills up only sends the queries of its later runs to the exact re-run (counted); the pool is
-                // touched where survivors land, so its size costs nothing per batch; reported by rsx_get "workspace_bytes"
-                const int nwg = pq_scan_rot_max_wgs(h->M) * ngq;
-                int64_t pool = (int64_t)(k <= 64 ? 1 : k <= 512 ? 2 : 4) << 30;
-                pool = std::min(pool, std::max<int64_t>(h->temp_budget / 4, (int64_t)64 << 20));
-                int64_t cap = pool / 8 / ((int64_t)nwg * 64);
-                cap = std::max<int64_t>(64, cap / 16 * 16);
-                if (h->pq_log_cap > 0) cap = h->pq_log_cap;            // tests starve the logs to force the overflow path
-                rot_log_cap = (int)std::min<int64_t>(cap, (int64_t)1 << 24);
-                h->w_itemdesc.ensure(pq_scan_rot_ws(items * ngq, rot_log_cap, nwg));
-                return h->w_itemdesc.p;
-            };
-            const int ngq = rot ? pq_scan_rot_ngq(h->M, true, h->pq_rot8) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
-            int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
-            // rotated layout: persistent workgroups draw items dynamically, so the tile is the whole (average) list — one table
-            // staging per (list, query group) — as long as that leaves a few thousand items to balance over 256 CUs
-            int vpl = 8;
-            if (rot) { vpl = 32; while (vpl > 8 && 16 * (vpl / 2) >= avg_slabs) vpl /= 2; }
-            if (h->scan_chunk > 0) vpl = std::max(1, std::min(rot ? 64 : 16, h->scan_chunk / 1024));
-            else {
-                // enough items to balance the chip: a few thousand for a full batch; for a handful of queries every (query, list)
-                // pair is its own group and each item stages a whole table, so one item per CU is the better trade
-                const int64_t groups_est = pairs <= nlist / 4 ? pairs : pairs / 4 + 1;
-                const int64_t want_items = pairs <= nlist / 4 ? 256 : 2048;
-                while (vpl > 1 && groups_est * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < want_items) vpl /= 2;
-            }
-            if (vpl != 64 && vpl != 32 && vpl != 16 && vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
-            const int tile_rows = 64 * 16 * vpl;
-            h->w_pairs.ensure((size_t)(pairs + 5 * (size_t)(nlist + 1) + 8) * 4);
-            int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
-            int32_t* cnt = pairs_sorted + pairs;
-            int32_t* cursor = cnt + (nlist + 1);
-            int32_t* pair_off = cursor + (nlist + 1);
-            int32_t* group_off = pair_off + (nlist + 1);
-            int32_t* item_off = group_off + (nlist + 1);
-            int32_t* total_groups = item_off + (nlist + 1);
-            int32_t* total_items = total_groups + 1;
-            // Two stages, so that only a sliver of the scores ever leaves the scan kernel:
-            //  stage 1: score ONLY the first tile of each query's closest list (probe rank 0) into the score
-            //           buffer and take its top-K' -> state0; its K'-th key is a lower bound of the query's final
-            //           K'-th best key;
-            //  stage 2: scan everything else (all probes, all tiles, minus that piece) in the multi-query groups,
-            //           appending to a small per-query candidate buffer only the keys that beat the bound
-            //           (wave-aggregated atomics); a final select merges them with state0.
-            // A full candidate buffer marks the query uncertain (-> exact fallback), so this is always exact.
-            filtered = (nprobe > 1) && (h->pq_filter != 0);
-            // the pre-pass only has to produce a threshold: it scores a (smaller) prefix of the closest list
-            int pre_vpl = vpl;
-            if (filtered && h->pq_pre_rows > 0) {
-                while (pre_vpl > 1 && 64 * 16 * pre_vpl > h->pq_pre_rows) pre_vpl /= 2;
-                while (pre_vpl > 1 && 64 * 16 * pre_vpl < KP * 4) pre_vpl *= 2;   // ... but well above K' candidates
-                if (pre_vpl > vpl) pre_vpl = vpl;
-            }
-            int pre_rows = filtered ? 64 * 16 * pre_vpl : tile_rows;
-            // one-launch pre-pass (k_pq_prepass: score a prefix of the closest list with byte gathers on the query's own table,
-            // 16-bit integer sums in LDS, k-th largest by a radix walk -> threshold a_k - 2 eps) when its LDS footprint allows;
-            // else grouping + scan of the prefix + selection (K'-th key of the prefix as the threshold)
-            bool fused_pre = filtered && h->pq_prepass_fused != 0;
-            bool pre4 = false;
-            bool grouped_early = false;
-            if (fused_pre) {
-                // the sample's k-th best score is the threshold: the sample must be a large part of the closest list once k is large
-                // (measured at 24k-vector lists: a 2048-vector prefix gives ~1000 candidates per query for k = 10 but ~20000 for
-                // k = 100) — 160 k vectors, at least pq_pre_rows, at most 32768 (64 KiB of 16-bit sums in LDS)
-                // (round 3, measured on the bench index at k = 10: 2048 / 4096 / 8192 / 16384 sample rows leave 1046 / 633 / 372 / 217
-                // candidates per query; the pre-pass costs 85 / 131 / 239 / 446 us and the scan 2.50 / 2.41 / 2.43 / 2.42 ms: 4096 is
-                // the best total for a full batch, a few queries keep the cheaper 2048)
-                int64_t base_rows = h->pq_pre_rows > 0 ? h->pq_pre_rows : 2048;
-                if (nq <= 64) base_rows = std::min<int64_t>(base_rows, 2048);
-                int64_t want_rows = std::max<int64_t>(base_rows, std::min<int64_t>(h->pq_pre_max, (int64_t)h->pq_pre_mult * k));
-                want_rows = std::min<int64_t>(round_up(want_rows, 64), round_up(std::max<int64_t>(maxlen, 64), 64));
-                // small k, full batch, rotated layout: the 4-queries-per-workgroup form (k_pq_prepass4) — its sample is what fits the LDS
-                // beside the four-query table image (3520 rows at M = 96)
-                pre4 = rot && h->pq_prepass4 != 0 && nq >= 64 && (int64_t)160 * k <= base_rows && pq_prepass4_max_rows(h->Mpad) >= 1024;
-                if (pre4) want_rows = std::min<int64_t>(want_rows, pq_prepass4_max_rows(h->Mpad));
-                pre_rows = (int)want_rows;
-                fused_pre = (size_t)pre_rows * 2 + (size_t)h->Mpad * 256 + 2048 <= 150 * 1024;
-                if (!fused_pre) pre_rows = 64 * 16 * pre_vpl;
-            }
-            if (fused_pre) {
-                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), pq_cand_cap(k, h->M));
-                h->w_cand.ensure((size_t)nq * cand_cap * 8);
-                h->w_candcnt.ensure((size_t)nq * 8 * CCS);
-                PQPrepassArgs pa{};
-                pa.codes = h->data.as<uint8_t>(); pa.list_base = h->d_base.as<int64_t>(); pa.list_len = h->d_len.as<int64_t>();
-                pa.probe_list = h->w_probelist.as<int32_t>(); pa.probe_dis0 = h->w_dis0.as<float>();
-                pa.seg_start = h->w_segstart.as<int64_t>();
-                pa.lut8 = h->w_lut8.as<uint8_t>(); pa.qparam = h->w_qparam.as<float>();
-                pa.nprobe = nprobe; pa.Mpad = h->Mpad; pa.pre_rows = pre_rows; pa.KP = KP; pa.CB = h->CB;
-                pa.k = k;
-                pa.state = state; pa.cand_cnt = h->w_candcnt.as<unsigned long long>();
-                h->w_tau.ensure((size_t)nq * 8);
-                pa.tau = h->w_tau.as<uint64_t>();
-                if (rot) {       // the sample's own candidates leave from the pre-pass; the scan drops that (query, list, tile 0)
-                    h->w_excl.ensure((size_t)nq * 2);
-                    pa.cand = h->w_cand.as<uint64_t>(); pa.cand_cap = cand_cap; pa.tile_rows = tile_rows; pa.excl = h->w_excl.as<uint16_t>();
-                }
-                if (side_lut) {       // the (list, tile, group) work items of the scan: built beside the pre-pass (they need the probes only)
-                    HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_probe, 0));
-                    launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4 * ngq, cnt, cursor, pair_off, group_off, total_groups,
-                                       pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
-                                       h->st2);
-                    HIPCHECK(hipEventRecord(h->ev_group, h->st2));
-                    grouped_early = true;
-                }
-                // large k: the histogram form of the four-query pre-pass (any sample size, several lists; pq_prepass4 = 2 keeps k_pq_prepass)
-                const bool pre4big = rot && !pre4 && h->pq_prepass4 == 1 && nq >= 64 && h->Mpad >= 32 && pre_rows <= 32768;
-                if (!(pre4 && launch_pq_prepass4(pa, nq, h->st) == 0) && !(pre4big && launch_pq_prepass4_big(pa, nq, h->st) == 0))
-                    launch_pq_prepass(pa, nq, h->st);
-                fused_pre_used = true;
-                done = true;
-                if (h->tc && h->tc->active && allow_fast && std::this_thread::get_id() == h->tc->worker) {
-                    // two-call search: the thresholds are final on the device; hand them to the caller and wait for rsx_search_scan
-                    HIPCHECK(hipStreamSynchronize(h->st));
-                    rsx_index::TwoCall& t = *h->tc;
-                    std::unique_lock<std::mutex> lk(t.mu);
-                    t.tau = h->w_tau.as<uint64_t>(); t.ntau = nq; t.parked = true;
-                    t.cv.notify_all();
-                    t.cv.wait(lk, [&] { return t.go; });
-                    t.parked = false; t.tau = nullptr; t.ntau = 0;
-                }
-            } else {
-                h->w_temp.ensure((size_t)nq * tmax * 4);       // this form scores a prefix / everything into the score rows
-                a.temp = h->w_temp.as<float>();
-                launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
-                                   pairs_sorted, h->d_len.as<int64_t>(), pre_rows, item_off, total_items, nprobe, 0,
-                                   filtered ? 1 : nprobe, filtered ? 1 : 0, h->st);
-                tm.mark("group");
-                const int64_t mi = filtered ? (nq + nlist + 8) : max_scan_items(h, nq, nprobe, 4, tile_rows);
-                void* rws0 = rot ? rot_desc(mi, 1) : nullptr;
-                done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                                 total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl,
-                                                 nullptr, 0, nullptr, nullptr, 0, rws0, rot_log_cap, 0, 0, nullptr, nullptr, 0, h->st)
-                            : launch_pq_scan8(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                              total_groups, item_off, total_items, nlist, mi, filtered ? pre_vpl : vpl, h->st)) == 0;
-            }
-            if (done && filtered) {
-                tm.mark("scan0");
-                cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), pq_cand_cap(k, h->M));
-                h->w_cand.ensure((size_t)nq * cand_cap * 8);
-                h->w_candcnt.ensure((size_t)nq * 8 * CCS);
-                // multi-launch form: top-K' of the scored prefix of the closest list, row prefix
-                // [0, min(seg_start[q][1], pre_rows)), written as the threshold key + counter reset
-                if (!fused_pre)
-                    select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
-                                std::min<int64_t>(maxlen, pre_rows), 0, nq, KP, BUF, KP, state, false,
-                                h->w_candcnt.as<unsigned long long>());
-                // The pre-pass is only a threshold: keep its K'-th key and let the main scan score EVERYTHING (the
-                // prefix included), so the scan kernel carries no per-slab "already scored" test and no key can
-                // arrive twice (the prefix keys above the threshold come back through the candidate buffer).
-                // (the selection wrote only the K'-th key of each query and reset the query's candidate counter)
-                tm.mark("select0");
-                if (grouped_early) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_group, 0));
-                else launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4 * ngq, cnt, cursor, pair_off, group_off, total_groups,
-                                        pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
-                                        h->st);
-                tm.mark("group");
-                const int64_t mi_main = max_scan_items(h, nq, nprobe, 4 * ngq, tile_rows);
-                void* rws1 = rot ? rot_desc(mi_main, ngq) : nullptr;
-                // threshold keys: one per query from the one-launch pre-pass, else the K'-th key the selection left in the state rows
-                const uint64_t* tau_ptr = fused_pre ? h->w_tau.as<uint64_t>() : state + (KP - 1);
-                const int64_t tau_stride = fused_pre ? 1 : KP;
-                // candidate gather + selection in one launch when the (probe rank, tile) table of a query is small (rsx_internal.h)
-                gs_tmax = (int)((maxlen + tile_rows - 1) / tile_rows);
-                use_gather = rot && h->pq_gather != 0 && pq_gather_select_applies(nprobe, gs_tmax, KP);
-                if (use_gather) {
-                    h->w_qitems.ensure((size_t)nq * nprobe * gs_tmax * 4);
-                    gs.probe_list = h->w_probelist.as<int32_t>(); gs.list_len = h->d_len.as<int64_t>(); gs.nprobe = nprobe;
-                    gs.tile_rows = tile_rows; gs.tmax = gs_tmax; gs.qitems = h->w_qitems.as<int32_t>();
-                    gs.seg_desc = pq_scan_rot_ws_desc(rws1, mi_main * ngq); gs.log_keys = pq_scan_rot_ws_keys(rws1, mi_main * ngq);
-                    gs.cand = h->w_cand.as<uint64_t>(); gs.cand_cnt = h->w_candcnt.as<unsigned long long>(); gs.cand_cap = cand_cap;
-                    gs.state = state; gs.KP = KP;
-                }
-                done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                                 total_groups, item_off, total_items, nlist,
-                                                 mi_main, vpl, tau_ptr, tau_stride,
-                                                 h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                 rws1, rot_log_cap, h->pq_prune, (h->pq_pace & 0xffff) | ((h->scan_reserve_now >> 3) << 16) | ((h->pq_rot8 ? 1 : 0) << 24), (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
-                                                 use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st)
-                            : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
-                                                     total_groups, item_off, total_items, nlist,
-                                                     max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,
-                                                     h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
-                                                     h->st)) == 0;
-            }
-            if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
-        }
-        if (!done && h->scan_kernel != 1 && h->CB == 16) {
-            // v2: list-major, two queries per LDS read
-            int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
-            int vpl = 8;
-            if (h->scan_chunk > 0) vpl = std::max(1, std::min(8, h->scan_chunk / 1024));
-            else while (vpl > 1 && (pairs / 2 + 1) * ((avg_slabs + 16 * vpl - 1) / (16 * vpl)) < 2048) vpl /= 2;
-            if (vpl != 8 && vpl != 4 && vpl != 2) vpl = 1;
-            const int tile_rows = 64 * 16 * vpl;
-            h->w_pairs.ensure((size_t)(pairs + 5 * (size_t)(nlist + 1) + 8) * 4);
-            int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
-            int32_t* cnt = pairs_sorted + pairs;
-            int32_t* cursor = cnt + (nlist + 1);
-            int32_t* pair_off = cursor + (nlist + 1);
-            int32_t* group_off = pair_off + (nlist + 1);
-            int32_t* item_off = group_off + (nlist + 1);
-            int32_t* total_groups = item_off + (nlist + 1);
-            int32_t* total_items = total_groups + 1;
-            launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 2, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0, h->st);
-            tm.mark("group");
-            done = launch_pq_scan2(a, pairs_sorted, pair_off, group_off, total_groups, item_off, total_items, nlist,
-                                   max_scan_items(h, nq, nprobe, 2, tile_rows), vpl, h->st) == 0;
-        }
-        if (!done) {
-            int64_t spc;
-            if (h->scan_chunk > 0) spc = std::max<int64_t>(16, h->scan_chunk / 64);
-            else {
-                // enough work items to fill 256 CUs several times over, but no smaller than 32 slabs
-                int64_t want_items = 4096;
-                int64_t chunks = std::max<int64_t>(1, (want_items + pairs - 1) / pairs);
-                spc = std::max<int64_t>(32, (max_slabs + chunks - 1) / chunks);
-            }
-            a.slabs_per_chunk = (int)spc;
-            a.max_chunks = (int)((max_slabs + spc - 1) / spc);
-            if ((rot ? launch_pq_scan_rot_exact(a, h->st) : launch_pq_scan(a, h->st)) != 0)
-                RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ scan: no kernel for M=%d", h->M);
-        }
-        h->timing[allow_fast ? "scan_launches" : "fb_scan_launches"] += 1;
-        tm.mark("scan");
-    } else if (!allow_fast) {
-        // exact mode (see the Flat branch): fp64 scores of every row of the probed lists into the score rows
-        ExactScoreArgs ea{};
-        ea.kind = KIND_IVFFLAT; ea.metric = h->metric; ea.nq = nq; ea.Q32 = h->w_q32.as<float>(); ea.ldq = ld; ea.d = d;
-        ea.X = h->data.p; ea.x_f16 = h->storage_f16; ea.ld = ld;
-        ea.probe_list = h->w_probelist.as<int32_t>(); ea.seg_start = h->w_segstart.as<int64_t>(); ea.nprobe = nprobe;
-        ea.list_base = h->d_base.as<int64_t>(); ea.list_len = h->d_len.as<int64_t>();
-        ea.temp = h->w_temp.as<float>(); ea.tstride = tmax;
-        launch_exact_scores(ea, h->st);
-        tm.mark("scan");
-    } else {
-        // group (query, probe) pairs by list, then list-major MFMA scan
-        int64_t npairs = nq * nprobe;
-        h->w_pairs.ensure((size_t)(npairs + 5 * (size_t)(nlist + 1) + 8) * 4);
-        int32_t* pairs_sorted = h->w_pairs.as<int32_t>();
-        int32_t* cnt = pairs_sorted + npairs;
-        int32_t* cursor = cnt + (nlist + 1);
-        int32_t* pair_off = cursor + (nlist + 1);
-        int32_t* group_off = pair_off + (nlist + 1);
-        int32_t* item_off = group_off + (nlist + 1);
-        int32_t* total_groups = item_off + (nlist + 1);
-        int32_t* total_items = total_groups + 1;
-        // query tiles per group of the LDS-DMA list scan: with ~64 probing queries per list (nlist 2048 / nprobe 128) groups of 16 read
-        // every list four times; 32 / 64 queries per group read it twice / once (k_list_scan2<_, QT>)
-        int ls_qt = 1;
-        if (h->scan_chunk <= 0 && h->ivf_qtiles != 0 && list_scan2_chunk_rows(h->storage_f16, ld) > 0) {
-            const int64_t qpl = npairs / std::max(1, nlist);
-            ls_qt = h->ivf_qtiles > 1 ? h->ivf_qtiles : (qpl >= 40 ? 4 : qpl >= 20 ? 2 : 1);
-            ls_qt = std::min(ls_qt == 3 ? 2 : ls_qt, list_scan2_max_qtiles(ld));
-            if (ls_qt != 2 && ls_qt != 4) ls_qt = 1;
-        }
-        // (list, chunk, group) work items in list-major order for the LDS-DMA scan's XCD-aware 1-D grid (round 4): the groups of a
-        // list chunk run on one XCD at the same moment and its rows cross HBM once — at nlist 2048 / nprobe 128 half of the lists
-        // are probed by more than 64 queries, i.e. by two groups, which used to land on different XCDs (two fetches)
-        const int ls2_rows = list_scan2_chunk_rows(h->storage_f16, ld);
-        const bool ls_wide = ls_qt == 4 || (ls_qt == 2 && h->ivf_wide2 != 0);     // 8-wave forms: 1024 rows per work item
-        const int item_rows = (h->scan_chunk <= 0 && ls2_rows > 0) ? (ls_wide ? 2 * ls2_rows : ls2_rows) : 0;
-        launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,
-                           pairs_sorted, item_rows ? h->d_len.as<int64_t>() : nullptr, item_rows, item_rows ? item_off : nullptr,
-                           item_rows ? total_items : nullptr, nprobe, 0, nprobe, 0, h->st);
-        tm.mark("group");
-        const float* bias = nullptr;
-        if (h->metric == RSX_METRIC_L2) { bias = h->w_misc.as<float>(); }
-        ListScanArgs a{};
-        a.Q16 = h->w_q16.as<__half>(); a.ld = ld; a.X = h->data.p; a.x_f16 = h->storage_f16; a.bias = bias;
-        a.list_base = h->d_base.as<int64_t>(); a.list_len = h->d_len.as<int64_t>();
-        a.pairs_sorted = pairs_sorted; a.pair_off = pair_off; a.group_off = group_off; a.total_groups = total_groups;
-        a.probe_list = h->w_probelist.as<int32_t>(); a.seg_start = h->w_segstart.as<int64_t>();
-        a.nlist = nlist; a.nprobe = nprobe; a.flat_mode = 0; a.nq = (int)nq;
-        a.temp = h->w_temp.as<float>(); a.tstride = tmax;
-        a.max_groups = (int)std::min<int64_t>(npairs, npairs / 16 + std::min<int64_t>(nlist, npairs));
-        int64_t chunk_rows = h->scan_chunk > 0 ? round_up(h->scan_chunk, 64) : 2048;
-        int64_t want = 2048;  // work items
-        while (chunk_rows > 256 && (int64_t)a.max_groups * ((maxlen + chunk_rows - 1) / chunk_rows) < want) chunk_rows /= 2;
-        if (h->scan_chunk <= 0 && list_scan2_chunk_rows(h->storage_f16, ld) > 0) chunk_rows = list_scan2_chunk_rows(h->storage_f16, ld);
-        a.chunk_rows = (int)chunk_rows;
-        a.qtiles = ls_qt;
-        a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
-        // Same two-stage shape as the IVF-PQ fast path when the LDS-DMA kernel applies: score a prefix of every
-        // query's closest list, take its K'-th key as the query's threshold, then scan everything with the keys
-        // above it going to a small per-query candidate buffer instead of a full score row.  A full buffer
-        // (never seen at the bench sizes) falls back to the score-buffer path, so the result is always exact.
-        // (ivf_filter: 1 = when the score rows would exceed ~2 GB — below that the second grouping pass and the
-        //  count read-back cost more than the row traffic they save; 2 = always; 0 = never)
-        // (round 4: for large k the pre-pass scores the first 4 K' rows of the closest list — up to 32 chunks — instead of giving up
-        //  the filter when K' no longer fits one chunk: k = 1000 at nlist 2048 / nprobe 128 wrote and re-read 10 GB of score rows)
-        const int64_t pre_chunks = std::max<int64_t>(1, ((int64_t)KP * std::max(1, h->ivf_pre_mult) + chunk_rows - 1) / chunk_rows);
-        bool want_filter = h->ivf_filter != 0 && nprobe > 1 && chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld) &&
-                           pre_chunks <= 32 && (h->ivf_filter > 1 || nq * tmax >= (int64_t)500000000);
-        if (want_filter) {
-            // ... of the closest list — of the EIGHT closest lists when K' is large: a query whose closest list holds fewer than K'
-            // rows would get no threshold, keep every row of its 128 lists and overflow (the prefix of its score row then runs on
-            // into the next lists' first rows)
-            // (round 4: two lists, not eight — with 64 probing queries per list nearly every list is among some query's eight closest,
-            //  and the 'sample' read 26 of the 31 GB: 3.4 + 0.8 ms of a 13.2 ms batch at nlist 2048 / nprobe 128 / k 1000; two lists
-            //  leave 11.3 ms and as few candidates; ONE list overflows the queries whose closest list is short: profiles/r04_n_docs_1000.md)
-            // ivf_pre_lists = 0 (default): the query's TWO closest lists.  ONE list is not enough even when it is long: at nlist 2048 /
-            // nprobe 128 its K'-th key lets > 131072 keys of some queries through (the score-row pass follows: 27 instead of 11.7 ms); at
-            // 100M / nprobe 32 it would do (28.7 against 29.8 ms) — two is the setting that is safe at both (profiles/r04_n_docs_1000.md).
-            // ivf_pre_adaptive = 1: two lists, and up to two more for the queries whose two closest lists are short (a batch with ONE
-            // query that has no threshold takes the score-row pass as a whole); costs 1-2 % on the bench configs, off by default.
-            const int pre_want = h->ivf_pre_lists > 0 ? h->ivf_pre_lists : (h->ivf_pre_adaptive ? 4 : 2);
-            const int pre_lists = (KP >= 256 && (int64_t)pre_want * pre_chunks * chunk_rows <= tmax) ? std::min(pre_want, nprobe) : 1;
-            a.max_chunks = (int)pre_chunks;                        // the first chunk(s) of ...
-            a.qtiles = 1;                                          // (groups of 16 there: most lists are the closest of at most a few queries)
-            const int64_t pre_stride = pre_lists > 1 ? pre_chunks * chunk_rows : 0;    // several lists: one slice of the sample buffer each
-            const bool pre_adaptive = pre_stride && h->ivf_pre_lists == 0 && h->ivf_pre_adaptive != 0;
-            if (pre_stride) {
-                a.pre_stride = pre_stride; a.tstride = pre_lists * pre_stride;
-                launch_fill_f32(h->w_temp.as<float>(), nq * a.tstride, -INFINITY, h->st);
-            }
-            const uint8_t* jmax_q = nullptr;
-            if (pre_adaptive) {
-                h->w_samp.ensure((size_t)nq * 8 + (size_t)round_up(nq, 8));
-                launch_sample_ranks(h->w_probelist.as<int32_t>(), h->d_len.as<int64_t>(), nq, nprobe, pre_stride, std::min(2, pre_lists), pre_lists, pre_stride,
-                                    reinterpret_cast<uint8_t*>(h->w_samp.as<int64_t>() + nq), h->w_samp.as<int64_t>(), h->st);
-                jmax_q = reinterpret_cast<const uint8_t*>(h->w_samp.as<int64_t>() + nq);
-            }
-            launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, nullptr, 0, nullptr, nullptr, nprobe, 0, pre_lists, 0, h->st, jmax_q);   // ... the closest list(s) only
-            launch_list_scan(a, h->st);
-            tm.mark("scan0");
-            cand_cap = (int)std::min<int64_t>(std::max<int64_t>(tmax, 1024), k > 512 ? 131072 : (k > 64 ? 65536 : 16384));
-            h->w_cand.ensure((size_t)nq * cand_cap * 8);
-            h->w_candcnt.ensure((size_t)nq * 8 * CCS);
-            // the pre-pass is only a threshold (see the IVF-PQ path): the K'-th key, candidate counters reset
-            if (pre_stride) {
-                select_rows(h, h->w_temp.as<float>(), a.tstride, pre_adaptive ? h->w_samp.as<int64_t>() : nullptr, pre_adaptive ? 1 : 0, a.tstride, 0,
-                            nq, KP, BUF, KP, state, false, h->w_candcnt.as<unsigned long long>());
-                a.pre_stride = 0; a.tstride = tmax;
-            } else
-            select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + 1, nprobe + 1,
-                        std::min<int64_t>(maxlen, pre_chunks * chunk_rows), 0, nq, KP, BUF, KP, state, false,
-                        h->w_candcnt.as<unsigned long long>());
-            tm.mark("select0");
-            launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,
-                               pairs_sorted, item_rows ? h->d_len.as<int64_t>() : nullptr, item_rows, item_rows ? item_off : nullptr,
-                               item_rows ? total_items : nullptr, nprobe, 0, nprobe, 0, h->st);
-            tm.mark("group");
-            a.qtiles = ls_qt;
-            if (ls_wide) { chunk_rows *= 2; a.chunk_rows = (int)chunk_rows; }      // 8 waves, 1024 rows per work item
-            a.max_chunks = (int)std::max<int64_t>(1, (maxlen + chunk_rows - 1) / chunk_rows);
-            if (item_rows == (int)chunk_rows) { a.item_off = item_off; a.total_items = total_items; a.max_items = (int)max_scan_items(h, nq, nprobe, 16 * ls_qt, item_rows); }
-            a.tau_key = state + (KP - 1); a.tau_stride = KP;
-            a.cand = h->w_cand.as<uint64_t>(); a.cand_cnt = h->w_candcnt.as<unsigned long long>(); a.cand_cap = cand_cap;
-            launch_list_scan(a, h->st);
-            tm.mark("scan");
-            std::vector<unsigned long long> cnts((size_t)nq * CCS);
-            HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
-            HIPCHECK(hipStreamSynchronize(h->st));
-            filtered = true;
-            for (int64_t qi = 0; qi < nq; qi++) if (cnts[(size_t)qi * CCS] > (unsigned long long)cand_cap) { filtered = false; break; }
-            a.tau_key = nullptr; a.cand = nullptr; a.cand_cnt = nullptr; a.cand_cap = 0;
-        }
-        if (!filtered) {
-            if (ls_wide && a.chunk_rows == list_scan2_chunk_rows(h->storage_f16, ld)) {     // 8 waves, 1024 rows per work item
-                a.chunk_rows *= 2;
-                a.max_chunks = (int)std::max<int64_t>(1, (maxlen + a.chunk_rows - 1) / a.chunk_rows);
-            }
-            if (!want_filter && item_rows > 0 && item_rows == a.chunk_rows) {     // (after a filtered attempt the grouping in place is the filtered scan's: same items)
-                a.item_off = item_off; a.total_items = total_items; a.max_items = (int)max_scan_items(h, nq, nprobe, 16 * ls_qt, item_rows);
-            }
-            launch_list_scan(a, h->st);
-            tm.mark("scan");
-        }
-    }
-    // IVF-PQ, rotated layout, threshold by construction: finalize straight from the complete candidate row (k_pq_final_tab) when K'
-    // is large or a table entry is a long chain (M = 16: dsub 48) — the K' cut, its certificate and the second chance disappear
-    const int tabP = (fast && filtered && fused_pre_used && rot && h->pq_final_tab != 0) ? pq_final_tab_capacity(h->M, h->CB, k) : 0;
-    const bool use_tab = tabP > 0 && (h->pq_final_tab == 2 || KP >= 512 || h->dsub > 8);
-    // 3. per-query k-selection over the score rows
-    if (filtered && use_gather) {
-        if (use_tab) gs.KP = 0;        // gather only
-        launch_pq_gather_select(gs, nq, h->st);
-    } else if (filtered && use_tab) {
-        // the compaction has laid the survivors end to end in the candidate rows already
-    } else if (filtered) {
-        // merge the filtered candidates (keys) into state0: one wave per query, the whole buffer in one segment
-        SelectArgs b{};
-        b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cand_cap;
-        b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cand_cap;
-        b.seg_len = round_up(cand_cap, 256); b.nseg = 1; b.idx_base = 0;
-        b.init = state; b.out = state; b.out_row_stride = KP;
-        b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;
-        launch_select(b, h->st);
-    } else {
-        // fast scan: the certificate needs the TRUE top-K' by approximate score, so the selection threshold
-        // is the K'-th key, not the k-th
-        select_rows(h, h->w_temp.as<float>(), tmax, h->w_segstart.as<int64_t>() + nprobe, nprobe + 1, tmax, 0, nq, KP, BUF,
-                    (fast || h->kind == KIND_IVFFLAT) ? KP : k, state, false);
-    }
-    tm.mark("select");
-    if (filtered && h->profile >= 2) {   // diagnostics: keys that passed the in-kernel filter
-        std::vector<unsigned long long> cnts((size_t)nq * CCS);
-        HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
-        double tot = 0, mx = 0;
-        for (int64_t qi = 0; qi < nq; qi++) { const double c = (double)cnts[(size_t)qi * CCS]; tot += c; mx = std::max(mx, c); }
-        h->timing["cand_keys"] += tot; h->timing["cand_keys_max"] = std::max(h->timing["cand_keys_max"], mx);
-    }
-    fa.probe_list = h->w_probelist.as<int32_t>(); fa.seg_start = h->w_segstart.as<int64_t>(); fa.nprobe = nprobe;
-    if (fast) {
-        fa.pq_rescore = 1; fa.codes = h->data.as<uint8_t>(); fa.M = h->M; fa.Mpad = h->Mpad; fa.CB = h->CB;
-        fa.lut32 = fused_lut ? nullptr : h->w_lut.as<float>(); fa.codebooks = h->d_codebooks.as<float>(); fa.dsub = h->dsub;
-        fa.probe_dis0 = h->w_dis0.as<float>(); fa.qparam = h->w_qparam.p;
-        fa.uncertain = h->w_uncertain.as<int32_t>();
-        if (filtered) { fa.cand_cnt = h->w_candcnt.as<unsigned long long>(); fa.cand_cap = cand_cap; }
-    }
-    if (tabP > 0) h->w_tiews.ensure((size_t)nq * cand_cap * 8);
-    if (use_tab) { FinalizeArgs ft = fa; if (lut32_out) ft.lut32 = lut32_out; launch_pq_final_tab(ft, h->w_cand.as<uint64_t>(), cand_cap, h->w_tiews.as<uint64_t>(), h->st); }
-    else launch_finalize(fa, h->st);
-    tm.mark("finalize");
-    tm.finish();
-    std::function<void()> second;
-    if (fast && filtered && fused_pre_used && !use_tab && tabP > 0) {
-        second = [&]() {       // the flagged queries' candidate rows are complete: settle them from there (k_pq_final_tab)
-            h->timing["rescore_all_launches"] += 1;
-            FinalizeArgs fr = fa;
-            fr.row_filter = h->w_uncertain.as<int32_t>();
-            launch_pq_final_tab(fr, h->w_cand.as<uint64_t>(), cand_cap, h->w_tiews.as<uint64_t>(), h->st);
-        };
-    } else if (fast && filtered && fused_pre_used && !use_tab) {
-        second = [&]() {
-            // the flagged queries' candidate rows are complete (threshold by construction) and did not overflow: score every
-            // candidate exactly in place, then the best K2 >= k + 64 of them by (exact score, index) go through k_finalize for
-            // the (score, id) order — no certificate needed, no exact scan
-            h->timing["rescore_all_launches"] += 1;
-            FinalizeArgs fr = fa;
-            fr.row_filter = h->w_uncertain.as<int32_t>();
-            launch_pq_rescore_all(fr, h->w_cand.as<uint64_t>(), cand_cap, h->st);
-            const int KP2 = std::min(4096, std::max(128, pow2ceil(k + 64)));
-            h->w_state2.ensure((size_t)nq * KP2 * 8);
-            SelectArgs b{};
-            b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cand_cap;
-            b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cand_cap;
-            b.seg_len = round_up(cand_cap, 256); b.nseg = 1; b.idx_base = 0;
-            b.init = nullptr; b.out = h->w_state2.as<uint64_t>(); b.out_row_stride = KP2;
-            b.nrows = nq; b.KP = KP2; b.BUF = 2 * KP2; b.k = KP2;
-            b.row_filter = h->w_uncertain.as<int32_t>();
-            launch_select(b, h->st);
-            FinalizeArgs f2 = fa;
-            f2.state = h->w_state2.as<uint64_t>(); f2.KP = KP2; f2.row_filter = h->w_uncertain.as<int32_t>(); f2.no_cert = 1;
-            launch_finalize(f2, h->st);
-        };
-    }
-    if (fast || certify) rerun_uncertified(h, nq, dq, dtype, k, dD, dI, (size_t)tmax * 4, second);     // the re-run fills score rows: chunked by the budget
-}
-
-// L2 ranking bias  -|x|^2/2  from the stored squared norms
-__global__ void k_bias_from_norms(const float* norms, float* bias, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) bias[i] = -0.5f * norms[i];
-}
-
-// The pipeline view of an (unsharded) index: same configuration and knobs, the parent's payload BORROWED (refreshed at the start
-// of every pipelined search: an add may have re-laid the lists out since the last one), its own streams and workspaces.
-static void free_view(rsx_index* h) {
-    rsx_index* v = h->pipe_view;
-    if (!v) return;
-    (void)hipSetDevice(v->device);
-    if (v->st) { (void)hipStreamSynchronize(v->st); (void)hipStreamDestroy(v->st); }
-    delete v;
-    h->pipe_view = nullptr;
-}
-static rsx_index* refresh_view(rsx_index* h) {
-    if (!h->pipe_view) {
-        std::unique_ptr<rsx_index> v(new rsx_index());
-        v->device = h->device;
-        HIPCHECK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
-        h->pipe_view = v.release();
-    }
-    rsx_index* v = h->pipe_view;
-    v->kind = h->kind; v->d = h->d; v->metric = h->metric; v->nlist = h->nlist; v->M = h->M; v->nbits = h->nbits; v->Mpad = h->Mpad;
-    v->CB = h->CB; v->dsub = h->dsub; v->CB_granule = h->CB_granule; v->nprobe = h->nprobe; v->trained = h->trained; v->ntotal = h->ntotal;
-    v->ld = h->ld; v->storage_f16 = h->storage_f16; v->storage_decided = h->storage_decided; v->custom_ids = h->custom_ids;
-    v->total_cap = h->total_cap; v->max_norm2 = h->max_norm2; v->flat_cert = h->flat_cert;
-    v->h_base = h->h_base; v->h_len = h->h_len; v->h_cap = h->h_cap;          // nlist x 8 bytes each
-    v->dir_gen = h->dir_gen;                                                   // its memoised bounds carry the generation they were made for
-    v->d_centroids.borrow(h->d_centroids); v->d_codebooks.borrow(h->d_codebooks); v->data.borrow(h->data); v->ids.borrow(h->ids);
-    v->norms.borrow(h->norms); v->d_base.borrow(h->d_base); v->d_len.borrow(h->d_len); v->d_maxnorm.borrow(h->d_maxnorm);
-    // knobs
-    v->overlap = h->overlap; v->query_batch = h->query_batch; v->scan_chunk = h->scan_chunk; v->scan_kernel = h->scan_kernel;
-    v->pq_fast = h->pq_fast; v->pq_fast_kp = h->pq_fast_kp; v->pq_filter = h->pq_filter; v->pq_pace = h->pq_pace; v->pq_prune = h->pq_prune; v->pq_rot8 = h->pq_rot8;
-    v->lut_tiled = h->lut_tiled; v->pq_prepass_fused = h->pq_prepass_fused; v->ivf_wide2 = h->ivf_wide2; v->ivf_qtiles = h->ivf_qtiles;
-    v->pq_prepass4 = h->pq_prepass4; v->pq_gather = h->pq_gather; v->pq_final_tab = h->pq_final_tab; v->pq_log_cap = h->pq_log_cap;
-    v->pq_pre_mult = h->pq_pre_mult; v->pq_pre_max = h->pq_pre_max; v->pq_pre_rows = h->pq_pre_rows; v->flat_filter = h->flat_filter; v->flat_pre_mult = h->flat_pre_mult; v->flat_stages = h->flat_stages;
-    v->ivf_filter = h->ivf_filter; v->ivf_pre_lists = h->ivf_pre_lists; v->ivf_pre_adaptive = h->ivf_pre_adaptive; v->ivf_pre_mult = h->ivf_pre_mult; v->profile = 0; v->temp_budget = h->temp_budget; v->pipeline = 0;
-    return v;
-}
-
-static void search_impl(rsx_index* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
-    if (nq < 0 || k <= 0) RSX_THROW(RSX_ERR_INVALID, "search: nq=%lld k=%d", (long long)nq, k);
-    if (k > 4096) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: k = %d exceeds this build's maximum of 4096 (the reference backends' default k)", k);
-    if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "search before train");
-    if (nq == 0) return;
-    if (!q || !D || !I) RSX_THROW(RSX_ERR_INVALID, "search: null pointer");
-    bool q_dev = is_device_ptr(q), o_dev = is_device_ptr(D);
-    if (o_dev != is_device_ptr(I)) RSX_THROW(RSX_ERR_INVALID, "search: D and I must both be host or both device pointers");
-    size_t esz = dtype == RSX_F16 ? 2 : 4;
-
-    if (h->ntotal == 0) {  // FAISS returns -1 / -inf for an empty index
-        std::vector<float> hd((size_t)nq * k, h->metric == 0 ? -INFINITY : INFINITY);
-        std::vector<int64_t> hi((size_t)nq * k, -1);
-        HIPCHECK(hipMemcpy(D, hd.data(), hd.size() * 4, o_dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
-        HIPCHECK(hipMemcpy(I, hi.data(), hi.size() * 8, o_dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
-        return;
-    }
-    if (h->metric == RSX_METRIC_L2 && h->kind != KIND_IVFPQ) {
-        int64_t rows = h->total_cap;
-        h->w_misc.ensure((size_t)rows * 4);
-        hipLaunchKernelGGL(k_bias_from_norms, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->st, h->norms.as<float>(),
-                           h->w_misc.as<float>(), rows);
-    }
-    // batch size: bounded by the knob and by the score-buffer budget
-    int64_t qb = std::max(1, h->query_batch);
-    if (h->kind != KIND_FLAT) {
-        const int nprobe = std::min(h->nprobe, h->nlist);
-        const int pad_to = (h->kind == KIND_IVFPQ) ? 64 : 16;
-        int64_t tmax = top_probe_sum(h, nprobe, pad_to, pad_to).first;
-        tmax = std::max<int64_t>(round_up(tmax, 256), 256);
-        if (pq_search_needs_score_rows(h, nprobe)) qb = std::max<int64_t>(1, std::min<int64_t>(qb, h->temp_budget / (tmax * 4)));
-    } else if (nq <= 32) {
-        qb = 32;
-    }
-    // e: the handle that executes (h itself, or its pipeline view); batches first, first + stride, ...
-    auto run_batches = [&](rsx_index* e, int64_t first, int64_t stride) {
-    rsx_index* const h = e;
-    for (int64_t q0 = first * qb; q0 < nq; q0 += stride * qb) {
-        int64_t nb = std::min(qb, nq - q0);
-        const void* dq;
-        const bool small = nb <= 64;      // latency path: stage through pinned memory (see PinBuf)
-        if (q_dev) dq = (const char*)q + (size_t)q0 * h->d * esz;
-        else {
-            const size_t qbytes = (size_t)nb * h->d * esz;
-            const char* src = (const char*)q + (size_t)q0 * h->d * esz;
-            h->w_qin.ensure(qbytes);
-            if (small && h->pin_q.ensure(qbytes)) { memcpy(h->pin_q.p, src, qbytes); src = h->pin_q.as<char>(); }
-            HIPCHECK(hipMemcpyAsync(h->w_qin.p, src, qbytes, hipMemcpyHostToDevice, h->st));
-            dq = h->w_qin.p;
-        }
-        float* dD; int64_t* dI;
-        if (o_dev) { dD = D + q0 * k; dI = I + q0 * k; }
-        else {
-            h->w_D.ensure((size_t)nb * k * 4); h->w_I.ensure((size_t)nb * k * 8);
-            dD = h->w_D.as<float>(); dI = h->w_I.as<int64_t>();
-        }
-        search_batch(h, nb, dq, dtype, k, dD, dI);
-        const size_t dbytes = (size_t)nb * k * 4, ibytes = (size_t)nb * k * 8;
-        const bool pin_out = !o_dev && small && h->pin_out.ensure(round_up(dbytes, 16) + ibytes);
-        if (pin_out) {
-            HIPCHECK(hipMemcpyAsync(h->pin_out.p, dD, dbytes, hipMemcpyDeviceToHost, h->st));
-            HIPCHECK(hipMemcpyAsync(h->pin_out.as<char>() + round_up(dbytes, 16), dI, ibytes, hipMemcpyDeviceToHost, h->st));
-        } else if (!o_dev) {
-            HIPCHECK(hipMemcpyAsync(D + q0 * k, dD, dbytes, hipMemcpyDeviceToHost, h->st));
-            HIPCHECK(hipMemcpyAsync(I + q0 * k, dI, ibytes, hipMemcpyDeviceToHost, h->st));
-        }
-        HIPCHECK(hipStreamSynchronize(h->st));
-        if (pin_out) {
-            memcpy(D + q0 * k, h->pin_out.p, dbytes);
-            memcpy(I + q0 * k, h->pin_out.as<char>() + round_up(dbytes, 16), ibytes);
-        }
-    }
-    };
-    const bool piped = h->pipeline == 1 && nq > qb && h->kind == KIND_IVFPQ && h->CB == 0 && h->pq_fast && h->pq_filter && h->scan_kernel == 0 &&
-                       h->profile == 0 && !(h->tc && h->tc->active);
-    if (!piped) {
-        run_batches(h, 0, 1);
-    } else {
-        rsx_index* v = refresh_view(h);
-        const int res = std::max(0, std::min(120, h->pipeline_reserve)) & ~7;
-        h->scan_reserve_now = res; v->scan_reserve_now = res;
-        std::exception_ptr verr;
-        std::thread th([&] {
-            try {
-                HIPCHECK(hipSetDevice(v->device));
-                run_batches(v, 1, 2);
-            } catch (...) { verr = std::current_exception(); }
-        });
-        std::exception_ptr herr;
-        try { run_batches(h, 0, 2); } catch (...) { herr = std::current_exception(); }
-        th.join();
-        h->scan_reserve_now = 0; v->scan_reserve_now = 0;
-        if (herr) std::rethrow_exception(herr);
-        if (verr) std::rethrow_exception(verr);
-    }
-    HIPCHECK(hipGetLastError());
-}
-
-// ---------------------------------------------------------------------------------------
-// list export / import, persistence
-// ---------------------------------------------------------------------------------------
-static void get_list_impl(rsx_index* h, int64_t l, int64_t* n_out, void* codes_out, int64_t* ids_out) {
-    if (h->kind == KIND_FLAT) l = 0;
-    if (l < 0 || l >= h->nlist) RSX_THROW(RSX_ERR_INVALID, "list %lld out of range", (long long)l);
-    int64_t n = h->h_len[(size_t)l], base = h->h_base[(size_t)l];
-    if (n_out) *n_out = n;
-    if (n == 0) return;
-    if (codes_out) {
-        DevBuf t;
-        size_t bytes;
-        if (h->kind == KIND_IVFPQ) {
-            bytes = (size_t)n * h->M;
-            t.ensure(bytes);
-            launch_pq_export_list(h->data.as<uint8_t>(), base, n, h->M, h->Mpad, h->CB, t.as<uint8_t>(), h->st);
-        } else {
-            bytes = (size_t)n * h->d * 4;
-            t.ensure(bytes);
-            size_t esz = h->storage_f16 ? 2 : 4;
-            launch_convert_to_f32(h->data.as<uint8_t>() + (size_t)base * h->ld * esz, h->storage_f16, h->ld, n, h->d, t.as<float>(), h->d, h->st);
-        }
-        HIPCHECK(hipMemcpyAsync(codes_out, t.p, bytes, is_device_ptr(codes_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
-    }
-    if (ids_out) {
-        if (h->kind == KIND_FLAT && !h->custom_ids) {
-            std::vector<int64_t> v((size_t)n);
-            for (int64_t i = 0; i < n; i++) v[(size_t)i] = i;
-            HIPCHECK(hipMemcpy(ids_out, v.data(), (size_t)n * 8, is_device_ptr(ids_out) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
-        } else {
-            HIPCHECK(hipMemcpy(ids_out, h->ids.as<int64_t>() + base, (size_t)n * 8,
-                               is_device_ptr(ids_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
-        }
-    }
-}
-
-static void add_list_impl(rsx_index* h, int64_t l, int64_t n, const void* codes, int dtype, const int64_t* ids) {
-    if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "add_list: use rsx_add for Flat");
-    if (!h->trained) RSX_THROW(RSX_ERR_NOT_TRAINED, "add_list before train");
-    if (l < 0 || l >= h->nlist) RSX_THROW(RSX_ERR_INVALID, "list %lld out of range", (long long)l);
-    if (n <= 0) return;
-    if (!ids) RSX_THROW(RSX_ERR_INVALID, "add_list: ids required");
-    std::vector<int64_t> need(h->h_len);
-    int64_t pos0 = need[(size_t)l];
-    need[(size_t)l] += n;
-    std::vector<int64_t> dest((size_t)n);
-    if (h->kind == KIND_IVFPQ) {
-        ensure_capacity(h, need, true);
-        DevBuf t;
-        const void* dc = codes;
-        if (!is_device_ptr(codes)) {
-            t.ensure((size_t)n * h->M);
-            HIPCHECK(hipMemcpyAsync(t.p, codes, (size_t)n * h->M, hipMemcpyHostToDevice, h->st));
-            dc = t.p;
-        }
-        launch_pq_import_list((const uint8_t*)dc, h->h_base[(size_t)l], pos0, n, h->M, h->Mpad, h->CB, h->data.as<uint8_t>(), h->st);
-        for (int64_t i = 0; i < n; i++) dest[(size_t)i] = h->h_base[(size_t)l] + pos0 + i;
-        h->w_dest.ensure((size_t)n * 8);
-        HIPCHECK(hipMemcpyAsync(h->w_dest.p, dest.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
-        const int64_t* dids = ids;
-        DevBuf ti;
-        if (!is_device_ptr(ids)) {
-            ti.ensure((size_t)n * 8);
-            HIPCHECK(hipMemcpyAsync(ti.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
-            dids = ti.as<int64_t>();
-        }
-        launch_write_ids(h->w_dest.as<int64_t>(), dids, 0, n, h->ids.as<int64_t>(), h->st);
-        HIPCHECK(hipStreamSynchronize(h->st));
-    } else {
-        const void* dx = stage_rows(h, h->w_x, codes, n, h->d, dtype);
-        decide_storage(h, dx, n, dtype);
-        track_max_norm(h, dx, n, dtype);
-        ensure_capacity(h, need, true);
-        for (int64_t i = 0; i < n; i++) dest[(size_t)i] = h->h_base[(size_t)l] + pos0 + i;
-        h->w_dest.ensure((size_t)n * 8);
-        HIPCHECK(hipMemcpyAsync(h->w_dest.p, dest.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
-        const int64_t* dids = ids;
-        DevBuf ti;
-        if (!is_device_ptr(ids)) {
-            ti.ensure((size_t)n * 8);
-            HIPCHECK(hipMemcpyAsync(ti.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
-            dids = ti.as<int64_t>();
-        }
-        launch_scatter_rows(dx, dtype == RSX_F16, n, h->d, h->w_dest.as<int64_t>(), h->data.p, h->storage_f16, h->ld,
-                            h->norms.p ? h->norms.as<float>() : nullptr, dids, 0, h->ids.as<int64_t>(), h->st);
-        HIPCHECK(hipStreamSynchronize(h->st));
-    }
-    h->h_len = need;
-    h->ntotal += n;
-    upload_dir(h);
-}
-
-struct FileHeader {
-    char magic[4];
-    int32_t version, kind, d, metric, nlist, M, nbits, trained, storage_f16, custom_ids, nprobe;
-    int64_t ntotal;
-};
-// version >= 2 appends: what a LIST shard (rsx_set_param "add_list_mod") needs to keep assigning the logical index's
-// sequential ids after a reload — the vectors it saw but did not keep, and its (mod, rem)
-struct FileHeaderV2 { int64_t ndropped; int32_t add_list_mod, add_list_rem; };
-
-static void wr(FILE* f, const void* p, size_t n) {
-    if (n && fwrite(p, 1, n, f) != n) RSX_THROW(RSX_ERR_IO, "short write");
-}
-static void rd(FILE* f, void* p, size_t n) {
-    if (n && fread(p, 1, n, f) != n) RSX_THROW(RSX_ERR_IO, "short read (truncated index file)");
-}
-
-static void save_impl(rsx_index* h, const char* path) {
-    FILE* f = fopen(path, "wb");
-    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s for writing", path);
-    try {
-        FileHeader hd{};
-        memcpy(hd.magic, "RSX1", 4);
-        hd.version = 2; hd.kind = h->kind; hd.d = h->d; hd.metric = h->metric; hd.nlist = h->nlist; hd.M = h->M;
-        hd.nbits = h->nbits; hd.trained = h->trained; hd.storage_f16 = h->storage_f16; hd.custom_ids = h->custom_ids;
-        hd.nprobe = h->nprobe; hd.ntotal = h->ntotal;
-        wr(f, &hd, sizeof(hd));
-        FileHeaderV2 h2{h->ndropped, h->add_list_mod, h->add_list_rem};
-        wr(f, &h2, sizeof(h2));
-        int64_t nc = (int64_t)h->h_centroids.size(), ncb = (int64_t)h->h_codebooks.size();
-        wr(f, &nc, 8); wr(f, h->h_centroids.data(), (size_t)nc * 4);
-        wr(f, &ncb, 8); wr(f, h->h_codebooks.data(), (size_t)ncb * 4);
-        std::vector<uint8_t> buf; std::vector<int64_t> ib;
-        if (h->kind == KIND_FLAT) {
-            // one list of ntotal rows, streamed in bounded chunks (a 10M x 768 index is 30 GB as fp32: no whole-index temporaries)
-            const int64_t n = h->h_len[0], CH = 262144;
-            wr(f, &n, 8);
-            DevBuf t; t.ensure((size_t)std::min(CH, std::max<int64_t>(n, 1)) * h->d * 4);
-            buf.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)) * h->d * 4);
-            const size_t esz = h->storage_f16 ? 2 : 4;
-            for (int64_t r0 = 0; r0 < n; r0 += CH) {
-                const int64_t nb = std::min(CH, n - r0);
-                launch_convert_to_f32(h->data.as<uint8_t>() + (size_t)r0 * h->ld * esz, h->storage_f16, h->ld, nb, h->d, t.as<float>(), h->d, h->st);
-                HIPCHECK(hipMemcpyAsync(buf.data(), t.p, (size_t)nb * h->d * 4, hipMemcpyDeviceToHost, h->st));
-                HIPCHECK(hipStreamSynchronize(h->st));
-                wr(f, buf.data(), (size_t)nb * h->d * 4);
-            }
-            ib.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)));
-            for (int64_t r0 = 0; r0 < n; r0 += CH) {
-                const int64_t nb = std::min(CH, n - r0);
-                if (h->custom_ids) HIPCHECK(hipMemcpy(ib.data(), h->ids.as<int64_t>() + r0, (size_t)nb * 8, hipMemcpyDeviceToHost));
-                else for (int64_t i = 0; i < nb; i++) ib[(size_t)i] = r0 + i;
-                wr(f, ib.data(), (size_t)nb * 8);
-            }
-        } else
-        for (int l = 0; l < h->nlist; l++) {
-            int64_t n = h->h_len[(size_t)l];
-            wr(f, &n, 8);
-            if (n == 0) continue;
-            size_t pb = (h->kind == KIND_IVFPQ) ? (size_t)n * h->M : (size_t)n * h->d * 4;
-            buf.resize(pb); ib.resize((size_t)n);
-            get_list_impl(h, l, nullptr, buf.data(), ib.data());
-            wr(f, buf.data(), pb);
-            wr(f, ib.data(), (size_t)n * 8);
-        }
-    } catch (...) { fclose(f); throw; }
-    if (fclose(f) != 0) RSX_THROW(RSX_ERR_IO, "close failed for %s", path);
-}
-
-static rsx_index* load_impl(const char* path, int device) {
-    FILE* f = fopen(path, "rb");
-    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s", path);
-    rsx_index* h = nullptr;
-    try {
-        FileHeader hd{};
-        rd(f, &hd, sizeof(hd));
-        if (memcmp(hd.magic, "RSX1", 4) != 0) RSX_THROW(RSX_ERR_IO, "%s is not an RSX1 index file", path);
-        h = create_common(hd.kind, hd.d, hd.nlist, hd.M, hd.nbits, hd.metric, device);
-        h->nprobe = hd.nprobe;
-        FileHeaderV2 h2{0, 1, 0};
-        if (hd.version >= 2) rd(f, &h2, sizeof(h2));
-        int64_t nc = 0, ncb = 0;
-        rd(f, &nc, 8);
-        std::vector<float> c((size_t)nc); rd(f, c.data(), (size_t)nc * 4);
-        rd(f, &ncb, 8);
-        std::vector<float> cb((size_t)ncb); rd(f, cb.data(), (size_t)ncb * 4);
-        if (nc) { if (nc != (int64_t)h->nlist * h->d) RSX_THROW(RSX_ERR_IO, "bad centroid block"); set_centroids(h, c.data()); }
-        if (ncb) { if (ncb != (int64_t)h->M * 256 * h->dsub) RSX_THROW(RSX_ERR_IO, "bad codebook block"); set_codebooks(h, cb.data()); }
-        update_trained(h);
-        std::vector<int64_t> lens((size_t)h->nlist);
-        long dir_pos = ftell(f);
-        // first pass: list sizes (to reserve exactly)
-        for (int l = 0; l < h->nlist; l++) {
-            int64_t n = 0; rd(f, &n, 8); lens[(size_t)l] = n;
-            size_t pb = (h->kind == KIND_IVFPQ) ? (size_t)n * h->M : (size_t)n * h->d * 4;
-            if (n && fseek(f, (long)(pb + (size_t)n * 8), SEEK_CUR) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
-        }
-        fseek(f, dir_pos, SEEK_SET);
-        if (!hd.storage_f16 && h->kind != KIND_IVFPQ) { h->storage_f16 = 0; h->storage_decided = true; }
-        if (h->kind == KIND_FLAT && hd.custom_ids) h->custom_ids = true;
-        ensure_capacity(h, lens, true);      // exact reservation: the load never re-lays-out HBM
-        std::vector<uint8_t> buf; std::vector<int64_t> ib;
-        if (h->kind == KIND_FLAT) {
-            // rows then ids, both streamed in bounded chunks (the ids sit behind the rows: two file cursors)
-            int64_t n = 0; rd(f, &n, 8);
-            const int64_t CH = 262144;
-            const long rows_pos = ftell(f);
-            const long ids_pos = rows_pos + (long)((size_t)n * h->d * 4);
-            buf.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)) * h->d * 4); ib.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)));
-            for (int64_t r0 = 0; r0 < n; r0 += CH) {
-                const int64_t nb = std::min(CH, n - r0);
-                if (fseek(f, rows_pos + (long)((size_t)r0 * h->d * 4), SEEK_SET) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
-                rd(f, buf.data(), (size_t)nb * h->d * 4);
-                if (hd.custom_ids) {
-                    if (fseek(f, ids_pos + (long)((size_t)r0 * 8), SEEK_SET) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
-                    rd(f, ib.data(), (size_t)nb * 8);
-                }
-                add_all(h, nb, buf.data(), RSX_F32, hd.custom_ids ? ib.data() : nullptr);
-            }
-        } else
-        for (int l = 0; l < h->nlist; l++) {
-            int64_t n = 0; rd(f, &n, 8);
-            if (n == 0) continue;
-            size_t pb = (h->kind == KIND_IVFPQ) ? (size_t)n * h->M : (size_t)n * h->d * 4;
-            buf.resize(pb); ib.resize((size_t)n);
-            rd(f, buf.data(), pb); rd(f, ib.data(), (size_t)n * 8);
-            add_list_impl(h, l, n, buf.data(), RSX_F32, ib.data());
-        }
-        h->ndropped = h2.ndropped; h->add_list_mod = h2.add_list_mod; h->add_list_rem = h2.add_list_rem;
-    } catch (...) {
-        fclose(f);
-        if (h) { if (h->st) (void)hipStreamDestroy(h->st); delete h; }
-        throw;
-    }
-    fclose(f);
-    return h;
-}
-
-// ---------------------------------------------------------------------------------------
-// Single-process multi-GPU handle: N child indexes (one per device) behind one rsx_index_t.  The reference's driver makes
-// ONE index.search(all_queries, k) call (src/search.py:296) and its serving tier fans the query out to shard workers over
-// HTTP and re-sorts (api/serve_main_node.py:281-323); here the fan-out is N host threads driving N GPUs and the fan-in is
-// a device-to-device copy of each shard's [nq, k] block plus one merge kernel on the first device.
-//   * add: every call's rows are cut into N contiguous pieces, piece r -> shard r, ids = the logical index's sequential
-//     ids, so the union of the shards' lists IS the single index's lists and the merged result (score desc, id asc) is
-//     bit-identical to one index holding everything.
-//   * trained parameters are identical on every shard (trained once on the first, copied).
-// ---------------------------------------------------------------------------------------
-static bool is_sharded(const rsx_index* h) { return !h->shards.empty(); }
-
-template <typename F>
-static void for_each_shard_parallel(rsx_index* h, F&& f) {
-    const size_t n = h->shards.size();
-    std::vector<std::string> errs(n);
-    std::vector<int> codes(n, 0);
-    std::vector<std::thread> th;
-    for (size_t r = 0; r < n; r++)
-        th.emplace_back([&, r] {
-            try { (void)hipSetDevice(h->shards[r]->device); f((int)r, h->shards[r]); }
-            catch (const RsxError& e) { errs[r] = e.what(); codes[r] = e.code; }
-            catch (const std::exception& e) { errs[r] = e.what(); codes[r] = RSX_ERR_INVALID; }
-        });
-    for (auto& t : th) t.join();
-    for (size_t r = 0; r < n; r++)
-        if (codes[r]) RSX_THROW(codes[r], "shard %zu (device %d): %s", r, h->shards[r]->device, errs[r].c_str());
-}
-
-static rsx_index* sharded_create(int kind, int d, int nlist, int M, int nbits, int metric, int ndev, const int* devices) {
-    if (ndev <= 0 || !devices) RSX_THROW(RSX_ERR_INVALID, "sharded_create: need at least one device");
-    if (ndev > 64) RSX_THROW(RSX_ERR_INVALID, "sharded_create: %d shards", ndev);
-    std::unique_ptr<rsx_index> p(new rsx_index());
-    try {
-        for (int r = 0; r < ndev; r++) p->shards.push_back(create_common(kind, d, nlist, M, nbits, metric, devices[r]));
-    } catch (...) {
-        for (auto* c : p->shards) { if (c->st) { (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->st); } delete c; }
-        throw;
-    }
-    rsx_index* c0 = p->shards[0];
-    p->kind = kind; p->d = d; p->metric = metric; p->device = devices[0];
-    p->nlist = c0->nlist; p->M = c0->M; p->nbits = c0->nbits; p->Mpad = c0->Mpad; p->CB = c0->CB; p->dsub = c0->dsub; p->ld = c0->ld;
-    p->trained = c0->trained;
-    HIPCHECK(hipSetDevice(p->device));
-    HIPCHECK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
-    return p.release();
-}
-
-static void sharded_sync_trained(rsx_index* h) {
-    rsx_index* c0 = h->shards[0];
-    for (size_t r = 1; r < h->shards.size(); r++) {
-        rsx_index* c = h->shards[r];
-        HIPCHECK(hipSetDevice(c->device));
-        if (!c0->h_centroids.empty()) set_centroids(c, c0->h_centroids.data());
-        if (!c0->h_codebooks.empty()) set_codebooks(c, c0->h_codebooks.data());
-        update_trained(c);
-    }
-    h->trained = c0->trained;
-}
-
-static int ptr_device(const void* p) {   // device ordinal of a device pointer, -1 for host memory
-    hipPointerAttribute_t at;
-    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    return (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) ? at.device : -1;
-}
-
-static void sharded_add(rsx_index* h, int64_t n, const void* x, int dtype, const int64_t* ids) {
-    const int N = (int)h->shards.size();
-    const size_t esz = dtype == RSX_F16 ? 2 : 4;
-    const int xdev = ptr_device(x);
-    std::vector<int64_t> seq;
-    if (!ids) { seq.resize((size_t)n); for (int64_t i = 0; i < n; i++) seq[(size_t)i] = h->sh_next_id + i; }
-    std::vector<int64_t> hids;
-    if (ids && ptr_device(ids) >= 0) {   // device ids: bring them to the host once (children stage host ids themselves)
-        hids.resize((size_t)n);
-        HIPCHECK(hipMemcpy(hids.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost));
-    }
-    const int64_t* hid = ids ? (hids.empty() ? ids : hids.data()) : seq.data();
-    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
-        const int64_t lo = n * r / N, hi = n * (r + 1) / N;
-        if (hi <= lo) return;
-        const char* xp = (const char*)x + (size_t)lo * h->d * esz;
-        DevBuf tmp;
-        if (xdev >= 0 && xdev != c->device) {     // rows live on another GPU: one peer copy into this shard's staging buffer
-            // (on the child's own stream + a stream synchronise: a plain device-to-device hipMemcpy is not guaranteed to block
-            //  the host, and the child's kernels run on a non-blocking stream that is not ordered after the null stream)
-            tmp.ensure((size_t)(hi - lo) * h->d * esz);
-            HIPCHECK(hipMemcpyAsync(tmp.p, xp, (size_t)(hi - lo) * h->d * esz, hipMemcpyDefault, c->st));
-            HIPCHECK(hipStreamSynchronize(c->st));
-            xp = (const char*)tmp.p;
-        }
-        add_all(c, hi - lo, xp, dtype, hid + lo);
-    });
-    h->ntotal += n;
-    if (!ids) h->sh_next_id += n;
-}
-
-static void sharded_search(rsx_index* h, int64_t nq, const void* q, int dtype, int k, float* D, int64_t* I) {
-    const int N = (int)h->shards.size();
-    if (nq < 0 || k <= 0) RSX_THROW(RSX_ERR_INVALID, "search: nq=%lld k=%d", (long long)nq, k);
-    if (k > 4096) RSX_THROW(RSX_ERR_UNSUPPORTED, "search: k = %d exceeds this build's maximum of 4096 (the reference backends' default k)", k);
-    if (nq == 0) return;
-    if (!q || !D || !I) RSX_THROW(RSX_ERR_INVALID, "search: null pointer");
-    const bool o_dev = is_device_ptr(D);
-    if (o_dev != is_device_ptr(I)) RSX_THROW(RSX_ERR_INVALID, "search: D and I must both be host or both device pointers");
-    const size_t esz = dtype == RSX_F16 ? 2 : 4;
-    const int qdev = ptr_device(q);
-    const size_t blk = (size_t)nq * k;
-    HIPCHECK(hipSetDevice(h->device));
-    h->sh_D.ensure((size_t)N * blk * 4); h->sh_I.ensure((size_t)N * blk * 8);
-    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
-        const void* qp = q;
-        if (qdev >= 0 && qdev != c->device) {     // the caller's queries sit on another GPU: peer copy on this shard's stream
-            c->sh_q.ensure((size_t)nq * h->d * esz);
-            HIPCHECK(hipMemcpyAsync(c->sh_q.p, q, (size_t)nq * h->d * esz, hipMemcpyDefault, c->st));
-            HIPCHECK(hipStreamSynchronize(c->st));
-            qp = c->sh_q.p;
-        }
-        c->sh_oD.ensure(blk * 4); c->sh_oI.ensure(blk * 8);
-        search_impl(c, nq, qp, dtype, k, c->sh_oD.as<float>(), c->sh_oI.as<int64_t>());   // synchronises c->st
-        // fan-in: this shard's [nq, k] block -> the parent device's gather buffers, asynchronously on the shard's stream (all
-        // shards copy concurrently); the stream is synchronised before the thread joins, so the merge below sees every block
-        HIPCHECK(hipMemcpyAsync(h->sh_D.as<float>() + (size_t)r * blk, c->sh_oD.p, blk * 4, hipMemcpyDefault, c->st));
-        HIPCHECK(hipMemcpyAsync(h->sh_I.as<int64_t>() + (size_t)r * blk, c->sh_oI.p, blk * 8, hipMemcpyDefault, c->st));
-        HIPCHECK(hipStreamSynchronize(c->st));
-    });
-    HIPCHECK(hipSetDevice(h->device));
-    float* dD = D; int64_t* dI = I;
-    if (!o_dev || ptr_device(D) != h->device) {
-        h->sh_oD.ensure(blk * 4); h->sh_oI.ensure(blk * 8);
-        dD = h->sh_oD.as<float>(); dI = h->sh_oI.as<int64_t>();
-    }
-    // merge by (score, id) — associative, so any k works for any shard count: rounds of groups of G blocks with G * k <= 8192
-    // (one launch for the usual k; k = 4096 on 8 shards takes three rounds of pairs)
-    float* srcD = h->sh_D.as<float>(); int64_t* srcI = h->sh_I.as<int64_t>();
-    int cur = N;
-    const int G = std::max(2, 8192 / k);
-    DevBuf tD[2], tI[2];
-    int flip = 0;
-    while (cur > G) {
-        const int groups = (cur + G - 1) / G;
-        tD[flip].ensure((size_t)groups * blk * 4); tI[flip].ensure((size_t)groups * blk * 8);
-        for (int g = 0; g < groups; g++) {
-            const int n = std::min(G, cur - g * G);
-            launch_merge_topk_byid(n, nq, k, h->metric, srcD + (size_t)g * G * blk, srcI + (size_t)g * G * blk,
-                                   tD[flip].as<float>() + (size_t)g * blk, tI[flip].as<int64_t>() + (size_t)g * blk, h->st);
-        }
-        srcD = tD[flip].as<float>(); srcI = tI[flip].as<int64_t>();
-        cur = groups; flip ^= 1;
-    }
-    launch_merge_topk_byid(cur, nq, k, h->metric, srcD, srcI, dD, dI, h->st);
-    if (dD != D) {
-        HIPCHECK(hipMemcpyAsync(D, dD, blk * 4, hipMemcpyDefault, h->st));
-        HIPCHECK(hipMemcpyAsync(I, dI, blk * 8, hipMemcpyDefault, h->st));
-    }
-    HIPCHECK(hipStreamSynchronize(h->st));     // also keeps the round buffers alive until the merges have run
-    HIPCHECK(hipGetLastError());
-}
-
-// Bulk import of one inverted list into a sharded handle: the rows are cut into N contiguous pieces like every add call
-// (piece r -> shard r, ids kept), so a FAISS / RSX1 file written from ONE index can be spread over the node while loading.
-static void sharded_add_list(rsx_index* h, int64_t l, int64_t n, const void* codes, int dtype, const int64_t* ids) {
-    if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_INVALID, "add_list: use rsx_add for Flat");
-    if (!ids) RSX_THROW(RSX_ERR_INVALID, "add_list: ids required");
-    if (ptr_device(codes) >= 0 || ptr_device(ids) >= 0) RSX_THROW(RSX_ERR_UNSUPPORTED, "add_list on a sharded handle takes host pointers");
-    if (n <= 0) return;
-    const int N = (int)h->shards.size();
-    const size_t rowb = h->kind == KIND_IVFPQ ? (size_t)h->M : (size_t)h->d * (dtype == RSX_F16 ? 2 : 4);
-    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
-        const int64_t lo = n * r / N, hi = n * (r + 1) / N;
-        if (hi > lo) add_list_impl(c, l, hi - lo, (const char*)codes + (size_t)lo * rowb, dtype, ids + lo);
-    });
-    h->ntotal += n;
-    // a later rsx_add without ids continues the sequence where the unsharded handle (and FAISS) would: at ntotal — a `.faiss`
-    // file re-sharded through rsx_add_list used to leave the counter at 0 and hand out ids 0..n-1 again
-    h->sh_next_id = std::max(h->sh_next_id, h->ntotal);
-}
-static void sharded_reserve(rsx_index* h, const int64_t* counts) {      // exact when every list arrives in ONE add_list call
-    const int N = (int)h->shards.size();
-    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
-        std::vector<int64_t> need((size_t)c->nlist);
-        for (int l = 0; l < c->nlist; l++)
-            need[(size_t)l] = std::max(counts[l] * (r + 1) / N - counts[l] * r / N, c->h_len[(size_t)l]);
-        ensure_capacity(c, need, true);
-    });
-}
-
-static void sharded_save(rsx_index* h, const char* path) {
-    FILE* f = fopen(path, "wb");
-    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s for writing", path);
-    int32_t hdr[4] = {0, 1, (int32_t)h->shards.size(), 0};
-    memcpy(hdr, "RSXS", 4);
-    int64_t next = h->sh_next_id;
-    bool ok = fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr) && fwrite(&next, 1, 8, f) == 8;
-    if (fclose(f) != 0 || !ok) RSX_THROW(RSX_ERR_IO, "write failed for %s", path);
-    for_each_shard_parallel(h, [&](int r, rsx_index* c) {
-        save_impl(c, (std::string(path) + ".shard" + std::to_string(r)).c_str());
-    });
-}
-
-static void destroy_handle(rsx_index* h) {
-    if (!h) return;
-    for (auto* c : h->shards) { free_view(c); if (c->st) { (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->st); } delete c; }
-    free_view(h);
-    if (h->st) { (void)hipSetDevice(h->device); (void)hipStreamDestroy(h->st); }
-    delete h;
-}
-
-// An RSX1 file written from ONE (unsharded) index, loaded onto several devices: the lists / rows are spread over the
-// shards as they stream in (nothing is staged on one GPU first), ids are kept, so the handle answers exactly like the
-// index the file was written from.
-static rsx_index* sharded_load_plain(const char* path, int ndev, const int* devices) {
-    FILE* f = fopen(path, "rb");
-    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s", path);
-    rsx_index* p = nullptr;
-    try {
-        FileHeader hd{};
-        rd(f, &hd, sizeof(hd));
-        if (memcmp(hd.magic, "RSX1", 4) != 0) RSX_THROW(RSX_ERR_IO, "%s is not an RSX1 index file", path);
-        FileHeaderV2 h2{0, 1, 0};
-        if (hd.version >= 2) rd(f, &h2, sizeof(h2));
-        if (h2.add_list_mod > 1) RSX_THROW(RSX_ERR_UNSUPPORTED, "%s is a list shard (add_list_mod = %d): it cannot be re-sharded", path, h2.add_list_mod);
-        p = sharded_create(hd.kind, hd.d, hd.nlist, hd.M, hd.nbits, hd.metric, ndev, devices);
-        p->nprobe = hd.nprobe;
-        for (auto* c : p->shards) c->nprobe = hd.nprobe;
-        int64_t nc = 0, ncb = 0;
-        rd(f, &nc, 8);
-        std::vector<float> cen((size_t)nc); rd(f, cen.data(), (size_t)nc * 4);
-        rd(f, &ncb, 8);
-        std::vector<float> cb((size_t)ncb); rd(f, cb.data(), (size_t)ncb * 4);
-        if (nc && nc != (int64_t)p->nlist * p->d) RSX_THROW(RSX_ERR_IO, "bad centroid block");
-        if (ncb && ncb != (int64_t)p->M * 256 * p->dsub) RSX_THROW(RSX_ERR_IO, "bad codebook block");
-        for (auto* c : p->shards) {
-            HIPCHECK(hipSetDevice(c->device));
-            if (nc) set_centroids(c, cen.data());
-            if (ncb) set_codebooks(c, cb.data());
-            update_trained(c);
-            if (!hd.storage_f16 && c->kind != KIND_IVFPQ) { c->storage_f16 = 0; c->storage_decided = true; }
-        }
-        p->trained = p->shards[0]->trained;
-        std::vector<uint8_t> buf; std::vector<int64_t> ib;
-        if (p->kind == KIND_FLAT) {
-            int64_t n = 0; rd(f, &n, 8);
-            const int64_t CH = 262144;
-            const long rows_pos = ftell(f);
-            const long ids_pos = rows_pos + (long)((size_t)n * p->d * 4);
-            buf.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)) * p->d * 4); ib.resize((size_t)std::min(CH, std::max<int64_t>(n, 1)));
-            for (int64_t r0 = 0; r0 < n; r0 += CH) {
-                const int64_t nb = std::min(CH, n - r0);
-                if (fseek(f, rows_pos + (long)((size_t)r0 * p->d * 4), SEEK_SET) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
-                rd(f, buf.data(), (size_t)nb * p->d * 4);
-                if (hd.custom_ids) {
-                    if (fseek(f, ids_pos + (long)((size_t)r0 * 8), SEEK_SET) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
-                    rd(f, ib.data(), (size_t)nb * 8);
-                }
-                sharded_add(p, nb, buf.data(), RSX_F32, hd.custom_ids ? ib.data() : nullptr);
-            }
-        } else {
-            std::vector<int64_t> lens((size_t)p->nlist);
-            const long dir_pos = ftell(f);
-            for (int l = 0; l < p->nlist; l++) {
-                int64_t n = 0; rd(f, &n, 8); lens[(size_t)l] = n;
-                const size_t pb = (p->kind == KIND_IVFPQ) ? (size_t)n * p->M : (size_t)n * p->d * 4;
-                if (n && fseek(f, (long)(pb + (size_t)n * 8), SEEK_CUR) != 0) RSX_THROW(RSX_ERR_IO, "seek failed");
-            }
-            fseek(f, dir_pos, SEEK_SET);
-            sharded_reserve(p, lens.data());
-            for (int l = 0; l < p->nlist; l++) {
-                int64_t n = 0; rd(f, &n, 8);
-                if (n == 0) continue;
-                const size_t pb = (p->kind == KIND_IVFPQ) ? (size_t)n * p->M : (size_t)n * p->d * 4;
-                buf.resize(pb); ib.resize((size_t)n);
-                rd(f, buf.data(), pb); rd(f, ib.data(), (size_t)n * 8);
-                sharded_add_list(p, l, n, buf.data(), RSX_F32, ib.data());
-            }
-        }
-        p->sh_next_id = hd.ntotal + h2.ndropped;
-    } catch (...) {
-        fclose(f);
-        destroy_handle(p);
-        throw;
-    }
-    fclose(f);
-    return p;
-}
-
-static rsx_index* sharded_load(const char* path, int ndev, const int* devices) {
-    FILE* f = fopen(path, "rb");
-    if (!f) RSX_THROW(RSX_ERR_IO, "cannot open %s", path);
-    int32_t hdr[4] = {0, 0, 0, 0}; int64_t next = 0;
-    bool ok = fread(hdr, 1, sizeof(hdr), f) == sizeof(hdr) && fread(&next, 1, 8, f) == 8;
-    fclose(f);
-    if (ok && memcmp(hdr, "RSX1", 4) == 0) {      // a plain single-index file: re-shard it over the devices while loading
-        if (ndev <= 0 || !devices) RSX_THROW(RSX_ERR_INVALID, "load_sharded: need at least one device");
-        return sharded_load_plain(path, ndev, devices);
-    }
-    if (!ok || memcmp(hdr, "RSXS", 4) != 0) RSX_THROW(RSX_ERR_IO, "%s is not a sharded (RSXS) index manifest", path);
-    const int ns = hdr[2];
-    if (ns <= 0 || ns > 64) RSX_THROW(RSX_ERR_IO, "bad shard count in %s", path);
-    if (ndev <= 0 || !devices) RSX_THROW(RSX_ERR_INVALID, "load_sharded: need at least one device");
-    std::unique_ptr<rsx_index> p(new rsx_index());
-    try {
-        for (int r = 0; r < ns; r++)   // more shards than devices: several shards share a device
-            p->shards.push_back(load_impl((std::string(path) + ".shard" + std::to_string(r)).c_str(), devices[r % ndev]));
-    } catch (...) {
-        for (auto* c : p->shards) { if (c->st) { (void)hipSetDevice(c->device); (void)hipStreamDestroy(c->st); } delete c; }
-        throw;
-    }
-    rsx_index* c0 = p->shards[0];
-    p->kind = c0->kind; p->d = c0->d; p->metric = c0->metric; p->device = c0->device;
-    p->nlist = c0->nlist; p->M = c0->M; p->nbits = c0->nbits; p->Mpad = c0->Mpad; p->CB = c0->CB; p->dsub = c0->dsub; p->ld = c0->ld;
-    p->trained = c0->trained; p->nprobe = c0->nprobe; p->sh_next_id = next;
-    for (auto* c : p->shards) p->ntotal += c->ntotal;
-    HIPCHECK(hipSetDevice(p->device));
-    HIPCHECK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
-    return p.release();
-}
+// rsx_api.hip — the C ABI of include/rsx.h: argument checks, error codes (rsx_last_error), dispatch to the host functions of
+// api_build.hip / api_search.hip / api_sharded.hip (rsx_host.h).  Every entry point needs a GPU: there is no CPU search path.
+#include "rsx_host.h"
+
+thread_local std::string g_err;
 
 // ---------------------------------------------------------------------------------------
 // C ABI
@@ -2437,14 +54,12 @@ int rsx_destroy(rsx_index_t* h) {
         }
         for (auto* c : h->shards) {
             (void)hipSetDevice(c->device);
-            free_view(c);
             if (c->st) { (void)hipStreamSynchronize(c->st); (void)hipStreamDestroy(c->st); }
             delete c;
         }
         h->shards.clear();
         (void)hipSetDevice(h->device);
-        free_view(h);
-        if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+            if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
         delete h;
     });
 }
@@ -2687,7 +302,7 @@ int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, c
                    int device) {
     return guarded([&] {
         if (nshards <= 0 || nq < 0 || k <= 0 || !D || !I || !Do || !Io) RSX_THROW(RSX_ERR_INVALID, "merge_topk: bad arguments");
-        if ((int64_t)nshards * k > 16384) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_topk: nshards*k = %lld exceeds 16384", (long long)nshards * k);
+        if (k > 8192) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_topk: k = %d exceeds 8192", k);
         if (nq == 0) return;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); RSX_THROW(RSX_ERR_HIP, "no HIP device available: librsx has no CPU path"); }
@@ -2695,14 +310,15 @@ int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, c
         bool dev = is_device_ptr(D);
         size_t nin = (size_t)nshards * nq * k, nout = (size_t)nq * k;
         if (dev) {
-            launch_merge_topk(nshards, nq, k, metric, D, I, Do, Io, nullptr);
+            if (!launch_merge_topk(nshards, nq, k, metric, D, I, Do, Io, nullptr)) RSX_THROW(RSX_ERR_OOM, "merge_topk: no memory for the round buffers");
             HIPCHECK(hipStreamSynchronize(nullptr));
         } else {
             DevBuf a, b, c, e;
             a.ensure(nin * 4); b.ensure(nin * 8); c.ensure(nout * 4); e.ensure(nout * 8);
             HIPCHECK(hipMemcpy(a.p, D, nin * 4, hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(b.p, I, nin * 8, hipMemcpyHostToDevice));
-            launch_merge_topk(nshards, nq, k, metric, a.as<float>(), b.as<int64_t>(), c.as<float>(), e.as<int64_t>(), nullptr);
+            if (!launch_merge_topk(nshards, nq, k, metric, a.as<float>(), b.as<int64_t>(), c.as<float>(), e.as<int64_t>(), nullptr))
+                RSX_THROW(RSX_ERR_OOM, "merge_topk: no memory for the round buffers");
             HIPCHECK(hipMemcpy(Do, c.p, nout * 4, hipMemcpyDeviceToHost));
             HIPCHECK(hipMemcpy(Io, e.p, nout * 8, hipMemcpyDeviceToHost));
         }
@@ -2726,11 +342,11 @@ int rsx_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* 
                      void* stream) {
     return guarded([&] {
         if (nshards <= 0 || nq < 0 || k <= 0 || !packed || !Do || !Io) RSX_THROW(RSX_ERR_INVALID, "merge_packed: bad arguments");
-        if ((int64_t)nshards * k > 16384) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_packed: nshards*k = %lld exceeds 16384", (long long)nshards * k);
+        if (k > 8192) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_packed: k = %d exceeds 8192", k);
         if (nq == 0) return;
         if (!is_device_ptr(packed) || !is_device_ptr(Do) || !is_device_ptr(Io)) RSX_THROW(RSX_ERR_INVALID, "merge_packed: device pointers only");
         HIPCHECK(hipSetDevice(device));
-        launch_merge_packed(nshards, nq, k, metric, packed, Do, Io, (hipStream_t)stream);
+        if (!launch_merge_packed(nshards, nq, k, metric, packed, Do, Io, (hipStream_t)stream)) RSX_THROW(RSX_ERR_OOM, "merge_packed: no memory for the round buffers");
         HIPCHECK(hipGetLastError());
     });
 }
@@ -2769,7 +385,7 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
         else if (s == "query_batch") *out = h->query_batch;
         else if (s == "pq_layout") *out = (h->kind == KIND_IVFPQ && h->CB == 0) ? 1 : 0;
         else if (s == "hbm_bytes") *out = (int64_t)(h->data.bytes + h->ids.bytes + h->norms.bytes);
-        else if (s == "workspace_bytes") *out = workspace_bytes(h) + (h->pipe_view ? workspace_bytes(h->pipe_view) : 0);
+        else if (s == "workspace_bytes") *out = workspace_bytes(h);
         else RSX_THROW(RSX_ERR_INVALID, "unknown property '%s'", key);
     });
 }
@@ -2786,10 +402,9 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "scan_chunk") h->scan_chunk = std::max(0, (int)value);
         else if (s == "scan_kernel") h->scan_kernel = (int)value;
         else if (s == "pq_fast") h->pq_fast = (int)value;
-        else if (s == "pq_fast_kp") h->pq_fast_kp = std::max(0, (int)value);
+        else if (s == "pq_fast_kp") h->pq_fast_kp = std::min(4096, std::max(0, (int)value));     // k_finalize sorts K' <= 4096 candidates in LDS
         else if (s == "pq_filter") h->pq_filter = (int)value;
         else if (s == "pq_prune") h->pq_prune = (int)value;
-        else if (s == "pq_rot8") h->pq_rot8 = (int)value;
         else if (s == "pq_pace") h->pq_pace = std::max(0, (int)value);
         else if (s == "add_list_mod" || s == "add_list_rem") {
             if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_UNSUPPORTED, "%s: IVF indexes only", key);
@@ -2805,7 +420,6 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "ivf_pre_lists") h->ivf_pre_lists = std::max(0, (int)value);
-        else if (s == "ivf_pre_adaptive") h->ivf_pre_adaptive = (int)value;
         else if (s == "ivf_pre_mult") h->ivf_pre_mult = std::max(1, (int)value);
         else if (s == "pq_pre_rows") h->pq_pre_rows = (int)value;
         else if (s == "pq_log_cap") h->pq_log_cap = std::max(0, (int)value);
@@ -2813,12 +427,9 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_pre_max") h->pq_pre_max = std::min(32768, std::max(64, (int)value));
         else if (s == "pq_final_tab") h->pq_final_tab = (int)value;
         else if (s == "overlap") h->overlap = (int)value;
-        else if (s == "pipeline") h->pipeline = (int)value;
-        else if (s == "pipeline_reserve") h->pipeline_reserve = std::max(0, (int)value);
         else if (s == "pq_gather") h->pq_gather = (int)value;
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;
-        else if (s == "ivf_wide2") h->ivf_wide2 = (int)value;
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;
         else if (s == "lut_tiled") h->lut_tiled = (int)value;
         else if (s == "flat_filter") h->flat_filter = (int)value;
@@ -2895,3 +506,4 @@ int rsx_synth_queries(int device, int d, int ncentres, uint32_t seed_c, uint32_t
 }
 
 }  // extern "C"
+

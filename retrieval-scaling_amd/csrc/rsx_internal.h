@@ -305,7 +305,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
 // an 8-byte descriptor per (item, wave, slot) = {index of the run's first key in the log pool, keys stored | bit 31: keys were
 // dropped because the log was full} lets the gather / compaction kernels find an item's runs.
 int pq_scan_rot_max_wgs(int M);     // persistent workgroups of the scan on the current device
-int pq_scan_rot_ngq(int M, bool filtered, int wide8 = 0);   // 4-query records per work item: 1, or 4 for the filtered M = 16 scan (group the pairs by 4 x this;
+int pq_scan_rot_ngq(int M, bool filtered);   // 4-query records per work item: 1, or 4 for the filtered M = 16 scan (group the pairs by 4 x this;
                                              // size the workspace for max_items x this records and workgroups x this x 64 logs)
 inline size_t pq_scan_rot_ws(int64_t max_items, int log_cap, int nwg) {   // item records + run descriptors + logs + per-XCD counters + progress words
     return (size_t)(max_items + 8) * (176 + 512 + 4) + (size_t)nwg * 64 * (size_t)log_cap * 8 + 1024;
@@ -379,12 +379,7 @@ void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int npr
 void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, int group_size, int32_t* cnt,
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                         int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
-                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st,
-                        const uint8_t* jmax_q = nullptr /* per-query upper probe rank (<= jmax) instead of jmax */);
-// per query: how many of its closest lists (min_lists .. max_lists) give a threshold sample of min_lists x rows vectors from their first
-// `rows` each; row_n[q] = that count x stride (the length of the query's sample row)
-void launch_sample_ranks(const int32_t* probe_list, const int64_t* list_len, int64_t nq, int nprobe, int64_t rows, int min_lists, int max_lists,
-                         int64_t stride, uint8_t* jmax_q, int64_t* row_n, hipStream_t st);
+                        int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st);
 struct FinalizeArgs {
     int kind; int metric;
     const uint64_t* state; int KP; int k; int64_t nq;
@@ -432,12 +427,14 @@ struct ExactScoreArgs {
     float* temp; int64_t tstride;
 };
 void launch_exact_scores(const ExactScoreArgs& a, hipStream_t st);
-void launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
+// any nshards x k with k <= 8192 (rounds of groups when nshards * k > 16384; stream-ordered round buffers); false: k too large or
+// no memory for the round buffers
+bool launch_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I,
                        float* Do, int64_t* Io, hipStream_t st);
 // single-index order (score desc, id asc) for the shards of ONE logical index (rsx_sharded_create); nshards * k <= 8192
 void launch_merge_topk_byid(int nshards, int64_t nq, int k, int metric, const float* D, const int64_t* I, float* Do,
                             int64_t* Io, hipStream_t st);
-void launch_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed /* [nshards,2,nq,k] */, float* Do,
+bool launch_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* packed /* [nshards,2,nq,k] */, float* Do,
                          int64_t* Io, hipStream_t st);
 void launch_pack_topk(int64_t n, const float* D, const int64_t* I, int64_t id_offset, int64_t* out /* [2,n] */, hipStream_t st);
 

@@ -74,6 +74,32 @@ class ShardedSearcher:
         self.exchange_thresholds = exchange_thresholds
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # profile = True: CUDA events around the three device steps of the exchange (pack, collective, merge) on the caller's stream;
+        # stage_ms() sums them per key (bench.py reports them beside the library's own stage times when world > 1)
+        self.profile = False
+        self._events = []
+
+    def _mark(self, name, dev):
+        if self.profile:
+            import torch
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(dev))
+            self._events.append((name, e))
+
+    def stage_ms(self, reset=True):
+        """{"pack": ms, "collective": ms, "merge": ms, "calls": n} accumulated since the last reset (synchronises the device)."""
+        import torch
+        out = {"pack": 0.0, "collective": 0.0, "merge": 0.0, "calls": 0}
+        if self._events:
+            torch.cuda.synchronize()
+            for (n0, e0), (n1, e1) in zip(self._events[:-1], self._events[1:]):
+                if n1 == "start":
+                    continue
+                out[n1] += e0.elapsed_time(e1)
+            out["calls"] = sum(1 for n, _ in self._events if n == "start")
+        if reset:
+            self._events = []
+        return out
 
     def _search_two_call(self, q, k):
         """One all-reduce(MAX) of the per-query threshold keys between rsx_search_prepass and rsx_search_scan.  The library runs
@@ -125,7 +151,9 @@ class ShardedSearcher:
             # all on the current stream
             import rsx
             nq = D.shape[0]
+            self._mark("start", D.device)
             packed = rsx.pack_topk(D, I, self.id_offset)
+            self._mark("pack", D.device)
             gathered = torch.empty((self.world_size, 2, nq, k), dtype=torch.int64, device=D.device)
             if dist.get_backend(self.group) == "nccl":
                 dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
@@ -133,7 +161,10 @@ class ShardedSearcher:
                 hg = torch.empty((self.world_size, 2, nq, k), dtype=torch.int64)
                 dist.all_gather_into_tensor(hg.view(-1), packed.cpu().view(-1), group=self.group)
                 gathered.copy_(hg)
-            return rsx.merge_packed(gathered, metric=self.metric)
+            self._mark("collective", D.device)
+            out = rsx.merge_packed(gathered, metric=self.metric)      # any world_size x k <= 8192: rounds inside the library
+            self._mark("merge", D.device)
+            return out
         I = torch.where(I >= 0, I + self.id_offset, I)
         if self.world_size == 1 and not self.force_collective:
             return (D.numpy(), I.numpy()) if as_numpy else (D, I)

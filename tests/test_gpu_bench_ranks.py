@@ -53,3 +53,25 @@ def test_bench_py_with_n_ranks_on_one_gpu(gpu, single, ngpu, shard):
         assert "inverted lists" in r["config"]["parallelism"]
     else:
         assert r["config"]["vectors_per_gpu"] == 1600000 // ngpu
+    st = r["stage_ms_per_step"]      # round 5: the exchange is reported beside the library's stages when world > 1
+    assert all(k_ in st for k_ in ("exchange_pack", "exchange_collective", "exchange_merge")), st
+    assert st["exchange_collective"] > 0
+
+
+def test_bench_py_weak_scaling_switch(gpu):
+    """--scaling weak: --n is the shard of EVERY rank (fixed N/GPU), the line says so, and the merged result is
+    that of a single index of N x n vectors."""
+    r2 = _run(["--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--scaling", "weak", "--n", "800000"])
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "weak"
+    assert r2["config"]["vectors_per_gpu"] == 800000 and r2["config"]["workload"].startswith("1600000x")
+    r1 = _run([])                                     # the 1.6M-vector single index of COMMON
+    assert r2["first_timed_batch_sha256"] == r1["first_timed_batch_sha256"]
+
+
+def test_eight_ranks_at_the_reference_default_k(gpu):
+    """k = 4096 (the reference backends' default, src/indicies/flat.py:138) on 8 ranks: 32768 keys per query reach the merge, which
+    now runs in rounds (round 4 refused nshards * k > 16384).  Same ids and scores as the single index."""
+    extra = ["--k", "4096", "--batch", "64", "--no-recall"]
+    r1 = _run(extra)
+    r8 = _run(extra + ["--gpus", "8", "--share-gpu", "--dist-backend", "gloo"])
+    assert r8["n_gpus"] == 8 and r8["first_timed_batch_sha256"] == r1["first_timed_batch_sha256"]

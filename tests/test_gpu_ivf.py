@@ -664,41 +664,33 @@ def test_round4_engine_knobs_never_change_a_result(gpu, orc, M, d):
 
 
 @pytest.mark.parametrize("M", [96, 16])
-def test_pipelined_batches_equal_the_sequential_loop(gpu, M):
-    """One index.search call with several internal batches (the reference hands ALL its queries to one call, src/search.py:296)
-    alternates the batches between the handle and its pipeline view on two host threads (rsx_api.hip: search_impl).  The results
-    must be those of the sequential loop (pipeline = 0) — CUDA-tensor and host queries, ragged last batch, any reserve — also
-    after the index grew between two calls (the view borrows the payload and must pick up the re-laid-out lists), and the
-    exact kernel's."""
+def test_one_call_of_many_batches_equals_batch_by_batch(gpu, M):
+    """One index.search call with several internal batches (the reference hands ALL its queries to one call, src/search.py:296;
+    api_search.hip: search_impl walks them in query_batch pieces).  The results must be those of one call per batch — CUDA-tensor and
+    host queries, ragged last batch — also after the index grew between two calls (the lists are re-laid out), and the exact
+    kernel's."""
     import torch
     d, n, nlist, nq = 768, 80000, 32, 64 * 7 + 19
     x = gpu.synth_vectors(d, 64, 1234, 10000, 0.5, 0, n + 40000)
     q = gpu.synth_queries(d, 64, 1234, 10000, 0.5, n, 999, 0.1, 0, nq)
     ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
     ix.train(x[:20000]); ix.add(x[:n]); ix.nprobe = 8
-    ix.set_param("query_batch", 64)
     qd = torch.from_numpy(q).cuda()
     for round_ in range(2):
         for k in (10, 200):
-            ix.set_param("pipeline", 0)
-            Ds, Is = ix.search(q, k)
-            ws0 = ix._get("workspace_bytes")
-            ix.set_param("pipeline", 1)
-            for reserve in (16, 0, 64):
-                ix.set_param("pipeline_reserve", reserve)
-                D, I = ix.search(q, k)
-                assert_same_results(D, I, Ds, Is, f"M={M} k={k} reserve={reserve} host queries, round {round_}")
-                Dd, Id = ix.search(qd, k)
-                assert_same_results(Dd.cpu().numpy(), Id.cpu().numpy(), Ds, Is, f"M={M} k={k} reserve={reserve} device queries, round {round_}")
-            if round_ == 0 and k == 10:
-                assert ix._get("workspace_bytes") > ws0, "the pipeline view's workspaces are reported"
-            D1, I1 = ix.search(q[:64], k)          # a single batch never takes the pipeline
-            assert_same_results(D1, I1, Ds[:64], Is[:64], f"M={M} k={k} one batch")
-        ix.set_param("scan_kernel", 2); ix.set_param("pipeline", 1)
+            ix.set_param("query_batch", 1024)
+            parts = [ix.search(q[b:b + 64], k) for b in range(0, nq, 64)]
+            Ds, Is = np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts])
+            ix.set_param("query_batch", 64)
+            D, I = ix.search(q, k)
+            assert_same_results(D, I, Ds, Is, f"M={M} k={k} host queries, round {round_}")
+            Dd, Id = ix.search(qd, k)
+            assert_same_results(Dd.cpu().numpy(), Id.cpu().numpy(), Ds, Is, f"M={M} k={k} device queries, round {round_}")
+        ix.set_param("scan_kernel", 2)
         De, Ie = ix.search(q, 10)
         ix.set_param("scan_kernel", 0)
         D, I = ix.search(q, 10)
-        assert_same_results(D, I, De, Ie, f"M={M} pipelined vs the exact kernel, round {round_}")
+        assert_same_results(D, I, De, Ie, f"M={M} internal batches vs the exact kernel, round {round_}")
         ix.add(x[n:])                              # lists overflow: the payload moves
 
 
@@ -733,11 +725,11 @@ def test_large_k_prepass_histogram_form(gpu, M, d):
         ix.set_param("profile", 0); ix.set_param("pq_prepass4", 1); ix.set_param("pq_pre_mult", 160); ix.set_param("pq_pre_max", 16384)
 
 
-def test_m64_eight_queries_per_pass(gpu):
-    """pq_rot8 = 1: the filtered M = 64 scan with EIGHT queries per pass over a list tile (k_pq_scan_rot64x2: two 4-query records per
-    work item, one table plane each).  Ragged groups (a list probed by 1 .. 70 queries), lists of several tiles (scan_chunk), small
-    and large k, starved survivor logs (overflow -> exact re-run): always the exact kernel's ids and scores, and the same as the
-    4-query scan."""
+def test_m64_ragged_groups_tiles_and_starved_logs(gpu):
+    """The filtered M = 64 scan (k_pq_scan_rot<1, 0, true>: ONE 64 KiB table plane).  Ragged groups (a list probed by 1 .. 70
+    queries), lists of several tiles (scan_chunk), small and large k, starved survivor logs (overflow -> exact re-run): always the
+    exact kernel's ids and scores.  (Round 4's eight-queries-per-pass variant of this kernel was measured 7-10 % slower and
+    removed in round 5: profiles/r04_rot8_m64.md.)"""
     d, M, n, nlist, nq = 256, 64, 120_000, 24, 203
     x = gpu.synth_vectors(d, 24, 1234, 10000, 0.5, 0, n)
     q = gpu.synth_queries(d, 24, 1234, 10000, 0.5, n, 999, 0.1, 0, nq)
@@ -749,17 +741,13 @@ def test_m64_eight_queries_per_pass(gpu):
         De, Ie = ix.search(q, k)
         ix.set_param("scan_kernel", 0)
         for chunk, logcap in ((0, 0), (2048, 0), (0, 64)):
-            ix.set_param("scan_chunk", chunk); ix.set_param("pq_log_cap", logcap)
-            ix.set_param("pq_rot8", 0)
+            ix.set_param("scan_chunk", chunk); ix.set_param("pq_log_cap", logcap); ix.set_param("profile", 1)
             D4, I4 = ix.search(q, k)
-            ix.set_param("pq_rot8", 1); ix.set_param("profile", 1)
-            D8, I8 = ix.search(q, k)
             fb = ix.get_timing("fallback_queries")
             ix.set_param("profile", 0)
-            assert_same_results(D8, I8, De, Ie, f"k={k} scan_chunk={chunk} pq_log_cap={logcap}: 8 queries per pass vs the exact kernel")
-            assert_same_results(D8, I8, D4, I4, f"k={k} scan_chunk={chunk} pq_log_cap={logcap}: 8 vs 4 queries per pass")
+            assert_same_results(D4, I4, De, Ie, f"k={k} scan_chunk={chunk} pq_log_cap={logcap}: fast scan vs the exact kernel")
             if logcap == 0:
                 assert fb == 0, f"k={k} scan_chunk={chunk}: no exact re-run expected"
         D1, I1 = ix.search(q[:5], k)            # a handful of queries: mostly one-query records
         assert_same_results(D1, I1, De[:5], Ie[:5], f"k={k}: five queries")
-    ix.set_param("pq_rot8", 0); ix.set_param("scan_chunk", 0); ix.set_param("pq_log_cap", 0)
+    ix.set_param("scan_chunk", 0); ix.set_param("pq_log_cap", 0)

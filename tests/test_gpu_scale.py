@@ -259,7 +259,7 @@ def test_m16_reference_shape_mid_scale(gpu, orc):
 def test_flat_staged_filter_at_the_reference_n_docs(gpu, orc, metric):
     """Flat at the reference's n_docs (ric/conf/default.yaml:70,84: Flat, n_docs 1000) behind the staged threshold: the rows
     behind the threshold phase are scanned in stages of growing row ranges, each filtered by the running K'-th key and followed
-    by a selection that tightens it (rsx_api.hip: search_batch).  Any number of stages and any threshold-phase size must
+    by a selection that tightens it (api_search.hip: search_batch).  Any number of stages and any threshold-phase size must
     return the oracle's ids and scores; the default must take more than one stage here."""
     import torch
     d, n, nq = 128, 1_000_000, 160
@@ -312,9 +312,9 @@ def test_ivfflat_filter_at_the_reference_n_docs(gpu, orc, metric):
         assert np.array_equal(Iu[:6], Ir), f"metric={metric} k={k} unfiltered vs oracle"
         assert np.allclose(Du[:6], Dr, rtol=0, atol=max(1e-30, np.abs(Dr[np.isfinite(Dr)]).max() * 2 ** -22))
         ix.set_param("ivf_filter", 2)
-        for pre_lists, adaptive in ((0, 0), (1, 0), (2, 0), (4, 0), (0, 1)):
-            ix.set_param("ivf_pre_lists", pre_lists); ix.set_param("ivf_pre_adaptive", adaptive); ix.set_param("profile", 1)
+        for pre_lists in (0, 1, 2, 4):
+            ix.set_param("ivf_pre_lists", pre_lists); ix.set_param("profile", 1)
             D, I = ix.search(qf, k)
             assert ix.get_timing("fallback_queries") == 0
-            assert np.array_equal(Iu, I) and np.array_equal(Du, D), f"metric={metric} k={k} ivf_pre_lists={pre_lists} adaptive={adaptive}: the filter must be invisible"
-        ix.set_param("profile", 0); ix.set_param("ivf_pre_lists", 0); ix.set_param("ivf_pre_adaptive", 0)
+            assert np.array_equal(Iu, I) and np.array_equal(Du, D), f"metric={metric} k={k} ivf_pre_lists={pre_lists}: the filter must be invisible"
+        ix.set_param("profile", 0); ix.set_param("ivf_pre_lists", 0)
