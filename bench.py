@@ -470,6 +470,23 @@ def main():
             log(f"headline index at k={kk}: {r}")
     lm = None
 
+    # ---------------- the same operating point on other data distributions (tools/bench_dist.py; side keys, never `value`):
+    # a hot-list batch on THIS index now, the informative and the norm-skewed mixtures on their own 100M indexes below
+    dist_legs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import bench_dist
+        dist_legs = {}
+        try:
+            dist_legs["hot_lists"] = bench_dist.hot_list_leg(index, n_total, M=args.m, nlist=args.nlist, nprobe=args.nprobe, k=k,
+                                                             steps=min(5, args.steps), batch=nq, check=8 if cpu is not None else 0)
+            dist_legs["hot_probe_sets"] = bench_dist.hot_list_leg(index, n_total, M=args.m, nlist=args.nlist, nprobe=args.nprobe, k=k,
+                                                                  steps=min(5, args.steps), batch=nq, check=8 if cpu is not None else 0,
+                                                                  shared_probe_sets=True)
+        except Exception as e:
+            dist_legs["hot_lists"] = {"error": repr(e)}
+        log(f"hot-list batches: {json.dumps(dist_legs)[:600]}")
+
     # ---------------- opportunistic FAISS leg: the real reference engine on the same index and queries, when the
     # box has it (tools/faiss_leg.py; never required, {"available": false} otherwise)
     faiss_res = None
@@ -485,8 +502,19 @@ def main():
         index = Q = Qgt = out = D1 = I1 = gtD = gtI = None   # the 100M index leaves HBM before the next ones are built
         import gc
         gc.collect(); torch.cuda.synchronize()
-        recall2 = recall_informative(args, log)
-        sys.path.insert(0, os.path.join(REPO, "tools"))
+        for leg in ("informative", "norm_skew"):
+            t0 = time.time()
+            try:
+                dist_legs[leg] = bench_dist.mixture_leg(leg, n=n_total, M=args.m, nlist=args.nlist, nprobe=args.nprobe, k=k,
+                                                        steps=min(5, args.steps), batch=nq, check=8 if cpu is not None else 0)
+            except Exception as e:
+                dist_legs[leg] = {"error": repr(e)}
+            log(f"distribution leg {leg}: {time.time() - t0:.1f}s -> {json.dumps(dist_legs[leg])[:400]}")
+            gc.collect()
+        inf = dist_legs.get("informative", {})
+        if "recall_at_10" in inf:      # (rounds 1-4 reported this figure from a 10M index of the same mixture)
+            recall2 = {"recall_at_10": inf["recall_at_10"], "by_nprobe": {k_: v_["recall_at_10"] for k_, v_ in inf["recall_by_nprobe"].items()},
+                       "data": inf["data"]}
         import bench_configs
         configs = {}
         # every index also at k = 1000, the reference's default n_docs (ric/conf/default.yaml:84)
@@ -511,7 +539,7 @@ def main():
             gc.collect()
 
     if rank == 0:
-        traffic, traffic_note = load_pmc_traffic(n_total, world, kernel)
+        traffic, traffic_note, mfma_busy = load_pmc_traffic(n_total, world, kernel)
         res = {
             "metric": "queries/sec + recall@10, 100M x 768 IVF-PQ nprobe=32 batch=1024",
             "value": round(args.steps * nq / elapsed, 2),
@@ -540,6 +568,7 @@ def main():
                          "traffic_gbs": (round(traffic / sec / 1e9, 2) if traffic and sec > 0 else None),
                          "traffic_over_algorithmic": (round(traffic / alg_bytes, 3) if traffic and alg_bytes > 0 else None),
                          "traffic_note": traffic_note,
+                         "mfma_busy": (round(mfma_busy, 4) if mfma_busy else None),      # north_star's MFMA-busy counter: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), same stamped PMC session
                          "lds": {"achieved": round(lds_bytes / sec / 1e9, 1) if sec > 0 else None, "peak": round(lds_peak, 1), "unit": "GB/s",
                                  "frac": round(lds_bytes / sec / 1e9 / lds_peak, 4) if sec > 0 else None,
                                  "note": "4-byte ds_read_b32 table gathers: one per lane per (vector, sub-quantiser, group of <= 4 "
@@ -560,6 +589,7 @@ def main():
             "filter_survivors_per_query": {"mean": round(cand_keys / max(1, nq), 1), "max": cand_keys_max},
             "ab_exact_kernels_same_process": ab,
             "reference_n_docs_on_this_index": ops,
+            "other_distributions": dist_legs,
             "configs": configs,
             "cpu_baseline": cpu,
             "cpu_parity_ids_and_scores_bit_exact": parity,
@@ -603,57 +633,14 @@ def load_pmc_traffic(n_total, world, kernel):
     try:
         t = json.load(open(tpath))
     except Exception:
-        return None, "profiles/pmc_traffic.json missing"
+        return None, "profiles/pmc_traffic.json missing", None
     if t.get("n") != n_total or t.get("n_gpus") != world:
-        return None, "pmc_traffic.json describes another workload"
+        return None, "pmc_traffic.json describes another workload", None
     if t.get("kernel") != kernel:
-        return None, f"pmc_traffic.json was measured on {t.get('kernel')}, this run used {kernel}"
+        return None, f"pmc_traffic.json was measured on {t.get('kernel')}, this run used {kernel}", None
     if t.get("source_sha256") != kernel_source_hash():
-        return None, "pmc_traffic.json is stale: the kernel sources changed since the PMC pass"
-    return t.get("hbm_bytes_per_launch"), f"PMC pass of {t.get('date', '?')}, FETCH_SIZE x 2 (gfx950 correction), same sources"
-
-
-def recall_informative(args, log):
-    """recall@10 on a mixture whose neighbours a 96-byte PQ can resolve: N/8 centres (about 8 vectors each), sigma 0.1, so a
-    query's exact top-10 is its centre's handful of vectors plus the nearest strangers; 10M x 768, same index parameters."""
-    import torch, rsx
-    dev = torch.device("cuda", 0)
-    n, nq, k = 10_000_000, args.batch, args.k
-    nc, sig, sigq = n // 8, 0.1, 0.02
-    t0 = time.time()
-    ix = rsx.IndexIVFPQ(rsx.IndexFlatIP(D), D, args.nlist, args.m, 8, rsx.METRIC_INNER_PRODUCT, device=0)
-    nt = 256 * args.nlist
-    xt = torch.empty((nt, D), dtype=torch.float16, device=dev)
-    blk, stride = 4096, n // nt
-    for b in range(0, nt, blk):
-        nb = min(blk, nt - b)
-        rsx.synth_vectors(D, nc, SEED_C, SEED_X, sig, (b * stride) % (n - nb), nb, out=xt[b:b + nb])
-    ix.train(xt); del xt
-    ix.nprobe = args.nprobe
-    Q = torch.empty((nq, D), dtype=torch.float16, device=dev)
-    rsx.synth_queries(D, nc, SEED_C, SEED_X, sig, n, SEED_Q, sigq, 0, nq, out=Q)
-    buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
-    flat = rsx.IndexFlatIP(D, device=0)
-    gD = gI = None
-    for c0 in range(0, n, buf.shape[0]):
-        nb = min(buf.shape[0], n - c0)
-        rsx.synth_vectors(D, nc, SEED_C, SEED_X, sig, c0, nb, out=buf[:nb])
-        ix.add(buf[:nb])
-        flat.reset(); flat.add(buf[:nb])
-        Dc, Ic = flat.search(Q, k); Ic = Ic + c0
-        gD, gI = (Dc, Ic) if gD is None else rsx.merge_topk(torch.stack([gD, Dc]), torch.stack([gI, Ic]))
-    out = {}
-    for npb in sorted({1, 8, args.nprobe}):
-        ix.nprobe = npb
-        _, I = ix.search(Q, k)
-        a, b = I.cpu().numpy(), gI.cpu().numpy()
-        out[f"nprobe{npb}"] = round(float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(a, b)])), 4)
-    res = {"recall_at_10": out[f"nprobe{args.nprobe}"], "by_nprobe": out,
-           "data": f"{n}x{D} mixture of {nc} centres (sigma {sig}), queries = base vector + {sigq} noise; IVF-PQ M={args.m} nlist={args.nlist}",
-           "build_and_gt_s": round(time.time() - t0, 1)}
-    log(f"recall on the informative mixture: {res}")
-    del ix, flat, buf, Q
-    return res
+        return None, "pmc_traffic.json is stale: the kernel sources changed since the PMC pass", None
+    return t.get("hbm_bytes_per_launch"), f"PMC pass of {t.get('date', '?')}, FETCH_SIZE x 2 (gfx950 correction), same sources", t.get("mfma_busy_frac")
 
 
 if __name__ == "__main__":

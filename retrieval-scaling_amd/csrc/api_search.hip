@@ -271,6 +271,9 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
 
     FinalizeArgs fa{};
     fa.kind = h->kind; fa.metric = h->metric; fa.state = state; fa.KP = KP; fa.k = k; fa.nq = nq;
+    // Flat / IVF-Flat re-score rows of 2 d bytes that sit anywhere in HBM: only the k + max(8, k / 16) best approximate candidates the
+    // certificate needs, not the power of two the selection and the sort round them up to (round 5: k = 1000 re-read 2048 rows per query)
+    if (h->kind != KIND_IVFPQ && allow_fast) fa.KPv = std::min(KP, k + std::max(8, k / 16));
     fa.list_base = h->d_base.as<int64_t>();
     fa.ids = (h->kind == KIND_FLAT && !h->custom_ids) ? nullptr : h->ids.as<int64_t>();
     fa.Q32 = h->w_q32.as<float>(); fa.ldq = ld; fa.d = d;
@@ -904,7 +907,21 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     }
     // (the tie scratch is allocated where k_pq_final_tab actually runs, not whenever it is a possible second chance)
     if (use_tab) h->w_tiews.ensure((size_t)nq * cand_cap * 8);
-    if (use_tab) { FinalizeArgs ft = fa; if (lut32_out) ft.lut32 = lut32_out; launch_pq_final_tab(ft, h->w_cand.as<uint64_t>(), cand_cap, h->w_tiews.as<uint64_t>(), h->st); }
+    if (use_tab) {
+        FinalizeArgs ft = fa; if (lut32_out) ft.lut32 = lut32_out;
+        if (h->profile >= 2) {      // diagnostics: how many candidates the 2 eps cut of k_pq_final_tab leaves to the exact re-score
+            h->w_flag.ensure(16);
+            HIPCHECK(hipMemsetAsync(h->w_flag.p, 0, 16, h->st));
+            ft.stat = reinterpret_cast<unsigned long long*>(h->w_flag.p);
+        }
+        launch_pq_final_tab(ft, h->w_cand.as<uint64_t>(), cand_cap, h->w_tiews.as<uint64_t>(), h->st);
+        if (h->profile >= 2) {
+            unsigned long long v = 0;
+            HIPCHECK(hipMemcpyAsync(&v, h->w_flag.p, 8, hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipStreamSynchronize(h->st));
+            h->timing["final_tab_rescored"] += (double)v;
+        }
+    }
     else launch_finalize(fa, h->st);
     tm.mark("finalize");
     tm.finish();

@@ -223,8 +223,19 @@ void launch_gemm_exact_scores(const void* X, int x_f16, int64_t n, int ldx, cons
     dim3 grid((nc + 127) / 128, (unsigned)((n + 127) / 128));
     int xv = aligned16(X) && (ldx % 8 == 0);
     int cv = aligned16(C) && (d % 4 == 0);
-    if (x_f16) hipLaunchKernelGGL((k_gemm_exact<true, false>), grid, dim3(256), 0, st, X, n, ldx, xv, C, nc, d, cv, S, lds_, (uint64_t*)nullptr, 0);
-    else hipLaunchKernelGGL((k_gemm_exact<false, false>), grid, dim3(256), 0, st, X, n, ldx, xv, C, nc, d, cv, S, lds_, (uint64_t*)nullptr, 0);
+    // measurement builds: RSX_COARSE_SPREAD = dynamic LDS (KiB) requested on top of the kernel's 34 KB of tiles, so that only one
+    // workgroup fits a CU and the dispatcher has to spread a grid of ~#CUs workgroups over all CUs (profiles/r05_coarse_gemm.md)
+    static const int spread_kib = measure_env("RSX_COARSE_SPREAD", 0);
+    const size_t dyn = (size_t)spread_kib * 1024;
+    if (dyn > 0) {
+        static DevOnce once;
+        once.once([&] {
+            (void)hipFuncSetAttribute((const void*)k_gemm_exact<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            (void)hipFuncSetAttribute((const void*)k_gemm_exact<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        });
+    }
+    if (x_f16) hipLaunchKernelGGL((k_gemm_exact<true, false>), grid, dim3(256), dyn, st, X, n, ldx, xv, C, nc, d, cv, S, lds_, (uint64_t*)nullptr, 0);
+    else hipLaunchKernelGGL((k_gemm_exact<false, false>), grid, dim3(256), dyn, st, X, n, ldx, xv, C, nc, d, cv, S, lds_, (uint64_t*)nullptr, 0);
 }
 
 void launch_gemm_exact_argmax(const void* X, int x_f16, int64_t n, int ldx, const float* C, int nc, int d,

@@ -365,10 +365,12 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 const int e = tid + (g0 + u) * 1024;
                 const int ee = e < nunits ? e : 0;
                 const int c = ee / (M / 4), m4 = ee - c * (M / 4);
-                in[u][0] = *reinterpret_cast<const uint32_t*>(A.lut8 + (q0 * 256 + c) * M + m4 * 4);
-                in[u][1] = np > 1 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q1 * 256 + c) * M + m4 * 4) : 0u;
-                in[u][2] = np > 2 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q2 * 256 + c) * M + m4 * 4) : 0u;
-                in[u][3] = np > 3 ? *reinterpret_cast<const uint32_t*>(A.lut8 + (q3 * 256 + c) * M + m4 * 4) : 0u;
+                // non-temporal: a table row is read once per item (out of the Infinity Cache) — it should not displace the code lines the
+                // sibling groups are about to re-read from this L2 (round 5, interleaved A/B on one box: scan 2.515 -> 2.467 ms)
+                in[u][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (q0 * 256 + c) * M + m4 * 4));
+                in[u][1] = np > 1 ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (q1 * 256 + c) * M + m4 * 4)) : 0u;
+                in[u][2] = np > 2 ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (q2 * 256 + c) * M + m4 * 4)) : 0u;
+                in[u][3] = np > 3 ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (q3 * 256 + c) * M + m4 * 4)) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < GB; u++) {

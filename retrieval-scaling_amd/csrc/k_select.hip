@@ -302,6 +302,13 @@ __global__ __launch_bounds__(256) void k_select_radix(SelectArgs a) {
 // largest from LDS.  Key order inside the row is free (keys are distinct; every consumer sorts or re-scores).
 // ---------------------------------------------------------------------------------------
 constexpr int GS_LCAP = 2048;      // row lengths up to this are selected from LDS; longer rows are read back from the candidate row
+#ifdef RSX_MEASURE
+__device__ uint64_t g_gs_trace[256 * 8];          // tools/ builds only: [workgroup < 256][mark] wall clock (10 ns ticks) of k_pq_gather_select's phases
+extern "C" int rsx_debug_gs_trace(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gs_trace), sizeof(uint64_t) * 256 * 8) == hipSuccess ? 0 : -1; }
+#define GS_MARK(i) do { if (blockIdx.x < 256 && threadIdx.x == 0) g_gs_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define GS_MARK(i)
+#endif
 __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t gs_smem[];
     const int KP = a.KP, NP = a.nprobe * a.tmax, NS = NP * 16;
@@ -311,10 +318,13 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
     int32_t* ctl = hist + 256;                                     // [8]
     int32_t* misc = ctl + 8;                                       // [8]: 0 overflow flag, 1..4 wave totals
     int32_t* slots = misc + 8;                                     // [NP]: item * 4 + slot, -1 = no such tile
-    uint16_t* cnts = reinterpret_cast<uint16_t*>(slots + NP);      // [NS]
+    uint32_t* sfirst = reinterpret_cast<uint32_t*>(slots + NP);    // [NS]: first key of the run in the log pool
+    uint32_t* spre = sfirst + NS;                                  // [NS]: keys in the runs before this one (exclusive prefix)
+    uint16_t* cnts = reinterpret_cast<uint16_t*>(spre + NS);       // [NS]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t q = blockIdx.x;
     if (tid < 8) misc[tid] = 0;
+    GS_MARK(0);
     __syncthreads();
     // 1. the query's segments and their counts: three short phases, every load of a phase independent of the others
     //    (a) tiles per probed list, (b) the work item + slot of every (probe rank, tile), (c) the 16 wave counters of each
@@ -332,29 +342,31 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
     {
         bool over = false;
         for (int s0 = tid; s0 < NS; s0 += 256 * 8) {
-            uint32_t c[8];
+            uint32_t c[8], f[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int s2 = s0 + u * 256;
                 const int32_t slot = s2 < NS ? slots[s2 >> 4] : -1;
-                c[u] = slot >= 0 ? a.seg_desc[(size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)].y : 0u;
+                const uint2 dsc = slot >= 0 ? a.seg_desc[(size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)] : make_uint2(0u, 0u);
+                f[u] = dsc.x; c[u] = dsc.y;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int s2 = s0 + u * 256;
                 if (s2 >= NS) break;
                 if (c[u] >> 31) { over = true; c[u] &= 0x7fffffffu; }         // the wave's log was full: keys were dropped
-                cnts[s2] = (uint16_t)c[u];
+                cnts[s2] = (uint16_t)c[u]; sfirst[s2] = f[u];
             }
         }
         if (over) misc[0] = 1;
     }
     const unsigned long long e0 = a.cand_cnt[q * CCS];             // keys the pre-pass emitted (row prefix)
     __syncthreads();
-    // 2. thread t owns the segments s = t, t + 256, ... (the closest list's segments, where most survivors sit, spread over the
-    //    threads); exclusive scan of the threads' totals
+    GS_MARK(1);
+    // 2. exclusive prefix of the run lengths (thread t owns the runs [t spt, (t + 1) spt); wave scan + one LDS hop)
+    const int spt = (NS + 255) >> 8;
     int mine = 0;
-    for (int s2 = tid; s2 < NS; s2 += 256) mine += cnts[s2];
+    for (int u = 0; u < spt; u++) { const int s2 = tid * spt + u; if (s2 < NS) mine += cnts[s2]; }
     int incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off); if (lane >= off) incl += y; }
@@ -363,6 +375,10 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
     int wbase = 0, total = 0;
 #pragma unroll
     for (int ww = 0; ww < 4; ww++) { const int v = misc[1 + ww]; if (ww < w) wbase += v; total += v; }
+    {
+        uint32_t run = (uint32_t)(wbase + incl - mine);
+        for (int u = 0; u < spt; u++) { const int s2 = tid * spt + u; if (s2 < NS) { spre[s2] = run; run += cnts[s2]; } }
+    }
     const bool over = misc[0] != 0;
     const unsigned long long e0c = e0 < (unsigned long long)a.cand_cap ? e0 : (unsigned long long)a.cand_cap;
     // the row's count: past the capacity when a segment dropped keys (k_finalize then flags the query), exactly like the compaction's
@@ -370,31 +386,35 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
     const unsigned long long nrow_ = e0c + (unsigned long long)total;
     const int nrow = (int)(nrow_ < (unsigned long long)a.cand_cap ? nrow_ : (unsigned long long)a.cand_cap);   // keys that fit the row
     const bool in_lds = KP > 0 && nrow_ <= (unsigned long long)GS_LCAP;
-    // 3. copy: segment keys -> candidate row (and LDS when the whole row fits)
+    __syncthreads();        // spre is complete
+    GS_MARK(2);
+    // 3. copy, one KEY per thread and step (round 5): key p of the concatenated runs sits in the run found by bisection of the prefix
+    // array — every load is independent of every other, where a thread used to walk its own runs one after the other (descriptor,
+    // then keys: two dependent round trips per run, 20 of the kernel's 42 us per query in the phase trace)
     uint64_t* row = a.cand + q * a.cand_cap;
     if (in_lds) for (int i2 = tid; i2 < (int)e0c; i2 += 256) lkeys[i2] = row[i2];
-    int pos = (int)e0c + wbase + incl - mine;
-    for (int s2 = tid; s2 < NS; s2 += 256) {
-        const int c = cnts[s2];
-        if (c == 0) continue;
-        const int32_t slot = slots[s2 >> 4];
-        const uint64_t* src = a.log_keys + a.seg_desc[(size_t)(slot >> 2) * 64 + (size_t)(s2 & 15) * 4 + (slot & 3)].x;
-        for (int e = 0; e < c; e += 4) {
-            uint64_t kk[4];
+    for (int p0 = tid; p0 < total; p0 += 256 * 4) {
+        uint64_t kk[4]; int pp[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) kk[u] = e + u < c ? src[e + u] : 0ull;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (e + u >= c) break;
-                const int pp = pos + e + u;
-                if (pp < a.cand_cap) row[pp] = kk[u];
-                if (in_lds) lkeys[pp] = kk[u];
-            }
+        for (int u = 0; u < 4; u++) {
+            const int pk = p0 + u * 256;
+            pp[u] = -1; kk[u] = 0ull;
+            if (pk >= total) continue;
+            int lo = 0, hi = NS;         // largest run index with spre <= pk among the non-empty ones: spre is non-decreasing
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (spre[mid] <= (uint32_t)pk) lo = mid; else hi = mid; }
+            kk[u] = a.log_keys[(size_t)sfirst[lo] + (size_t)((uint32_t)pk - spre[lo])];
+            pp[u] = (int)e0c + pk;
         }
-        pos += c;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (pp[u] < 0) continue;
+            if (pp[u] < a.cand_cap) row[pp[u]] = kk[u];
+            if (in_lds) lkeys[pp[u]] = kk[u];
+        }
     }
     if (KP == 0) return;    // gather only: k_pq_final_tab works on the whole row
     __syncthreads();        // workgroup-scope release / acquire: the row (and lkeys) written above are visible to every thread
+    GS_MARK(3);
     // 4. the K' largest keys, sorted, to the state row
     if (in_lds) {
         auto key_at = [&](int i2) -> uint64_t { return lkeys[i2]; };
@@ -403,12 +423,14 @@ __global__ __launch_bounds__(256) void k_pq_gather_select(PQGatherArgs a) {
         auto key_at = [&](int i2) -> uint64_t { return row[i2]; };
         radix_topk_wg<256>(key_at, nrow, KP, obuf, hist, ctl);
     }
+    GS_MARK(4);
     uint64_t* o = a.state + q * KP;
     for (int i2 = tid; i2 < KP; i2 += 256) o[i2] = obuf[i2];
+    GS_MARK(5);
 }
 
 static size_t gather_select_lds(int nprobe, int tmax, int KP) {
-    return (size_t)KP * 8 + (size_t)GS_LCAP * 8 + (256 + 8 + 8) * 4 + (size_t)nprobe * tmax * 4 + (size_t)nprobe * tmax * 16 * 2 + 64;
+    return (size_t)KP * 8 + (size_t)GS_LCAP * 8 + (256 + 8 + 8) * 4 + (size_t)nprobe * tmax * 4 + (size_t)nprobe * tmax * 16 * (2 + 8) + 64;
 }
 bool pq_gather_select_applies(int nprobe, int tmax, int KP) {
     return tmax >= 1 && tmax <= 16 && nprobe <= 256 && (int64_t)nprobe * tmax * 16 <= 16384 && KP <= 4096 && gather_select_lds(nprobe, tmax, KP) <= 96 * 1024;
@@ -1093,8 +1115,11 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     }
     const int64_t* ssq = plds ? s_ss : a.seg_start + q * (a.nprobe + 1);
 
-    for (int c = tid; c < KP; c += nt) {
-        uint64_t key = a.state[q * KP + c];
+    const int KPv = (a.KPv > 0 && a.KPv < KP) ? a.KPv : KP;
+    // candidates [c_lo, c_hi) of the state row -> (id, storage row, approximate order word) in slot c; the others of [c_lo, c_end) become sinks
+    auto resolve = [&](int c_lo, int c_hi, int c_end) {
+    for (int c = c_lo + tid; c < c_end; c += nt) {
+        uint64_t key = c < c_hi ? a.state[q * KP + c] : 0ull;
         int64_t row = -1, id = INT64_MAX;
         uint32_t ord = 0;
         if (key) {
@@ -1113,19 +1138,44 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         sid[c] = id; srow[c] = row; sord[c] = ord;
     }
     __syncthreads();
+    };
+    resolve(0, KPv, KP);
 
     if (a.kind == KIND_IVFPQ && a.pq_rescore && a.par_entries) {
-        // few queries in flight (latency path, launch_finalize): the K' x M table entries of the candidates' codes are
-        // independent — all threads compute them (code byte -> codeword -> 8 fmaf, the table builder's chain) into LDS, then
-        // one thread per candidate adds its row in m order: the same canonical sum, without M dependent loads per thread
+        // The K' x M table entries of the candidates' codes are independent — all threads compute them (code byte -> codeword -> 8 fmaf,
+        // the table builder's chain) into LDS, then one thread per candidate adds its row in m order: the same canonical sum, without M
+        // dependent loads per thread.  Round 3: the latency path (few queries in flight).  Round 5: every batch with K' <= 128 — one thread
+        // per candidate walked 6 runs x (code piece -> 16 codewords) of dependent round trips, ~60 us per 1024 queries at k = 10 whatever
+        // the chip had free; the code bytes now arrive as 8-byte PIECES (a thread per (candidate, 16-sub-quantiser run): 2 x 8 bytes,
+        // rotated back into m order, 16 bytes to LDS) instead of one byte load per entry.
         float* ent = reinterpret_cast<float*>(fin_buf) + (((size_t)KP * 20 + 15) / 16) * 4;      // [KP][M + 1]
         const int M = a.M, es = M + 1;
+        uint8_t* cbytes = reinterpret_cast<uint8_t*>(ent + (size_t)KP * es);                      // [KP][M] (M >= 32: staged by pieces)
+        const bool pieces = M >= 32 && (M & 15) == 0;
+        if (pieces) {
+            const int NF = M >> 6, nrun = M >> 4;
+            for (int u = tid; u < KP * nrun; u += nt) {
+                const int c = u / nrun, run = u - c * nrun;
+                const int64_t row = srow[c];
+                if (row < 0) continue;
+                const int i = (int)(row & 15);
+                const uint8_t* base = a.codes + (row >> 4) * (int64_t)(16 * M);
+                const uint8_t* p0; const uint8_t* p1;
+                if (run < 4 * NF) { p0 = base + (run >> 2) * 1024 + ((run & 3) * 16 + i) * 16; p1 = p0 + 8; }
+                else { const int h = run & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
+                const uint2 lo2 = *reinterpret_cast<const uint2*>(p0), hi2 = *reinterpret_cast<const uint2*>(p1);
+                uint32_t w[4] = {lo2.x, lo2.y, hi2.x, hi2.y};
+                rot16_bytes(w, i);
+                *reinterpret_cast<uint4*>(cbytes + (size_t)c * M + run * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            __syncthreads();
+        }
         const float* qv = a.Q32 + q * a.ldq;
         for (int e = tid; e < KP * M; e += nt) {
             const int c = e / M, m = e - c * M;
             const int64_t row = srow[c];
             if (row < 0) continue;
-            const uint32_t code = a.codes[pq_code_addr(row, m, M, 0)];
+            const uint32_t code = pieces ? (uint32_t)cbytes[(size_t)c * M + m] : (uint32_t)a.codes[pq_code_addr(row, m, M, 0)];
             const float* qs = qv + m * 8;
             const float* cw = a.codebooks + ((int64_t)m * 256 + code) * 8;
             const float4 x = ((const float4*)cw)[0], y = ((const float4*)cw)[1];
@@ -1169,14 +1219,14 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         }
         __syncthreads();
     }
-    if (a.kind != KIND_IVFPQ) {
+    auto rescore_rows = [&](int c_lo, int c_hi) {
         // one wave per candidate, lanes over the dimensions; FOUR candidates per wave in flight (round 4: at the reference's n_docs =
         // 1000 a query re-scores 2048 rows of 1.5 KB that sit anywhere in HBM — one row at a time per wave was 3.2 ms per 1024 queries)
         const float* qv = a.Q32 + q * a.ldq;
-        for (int c0 = 4 * wv; c0 < KP; c0 += 4 * nwv) {
+        for (int c0 = c_lo + 4 * wv; c0 < c_hi; c0 += 4 * nwv) {
             int64_t rows[4]; double acc[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { rows[u] = c0 + u < KP ? srow[c0 + u] : -1; acc[u] = 0.0; }   // wave-uniform (LDS values)
+            for (int u = 0; u < 4; u++) { rows[u] = c0 + u < c_hi ? srow[c0 + u] : -1; acc[u] = 0.0; }   // wave-uniform (LDS values)
             if (a.x_f16 && (a.ldq & 7) == 0 && a.ldq >= a.ld) {
                 // fp16 rows: 16 bytes (8 values) per lane and load — a 1536-byte row is 1.5 wave loads instead of 12 two-byte ones (the
                 // rows' zero padding up to ld contributes exact zeros; fp64 sums of products of fp16-valued numbers do not depend on the order)
@@ -1220,11 +1270,13 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             }
         }
         __syncthreads();
-    }
+    };
+    if (a.kind != KIND_IVFPQ) rescore_rows(0, KPv);
 
     // order by (ord desc, id asc); invalid entries (ord 0, id INT64_MAX) sink to the end.  Up to FIN_RANK_MAX candidates by
     // counting: a candidate's position is the number of candidates that beat it (every thread walks the same LDS words —
     // broadcasts — and there are two barriers instead of the 28 of a 128-key bitonic network); larger sets by the network.
+    auto sort_all = [&]() {
     if (a.rank_sort) {
         uint32_t* sord2 = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(fin_buf) + (((size_t)KP * 20 + 15) / 16) * 16);
         int64_t* sid2 = reinterpret_cast<int64_t*>(sord2 + KP + (KP & 1));
@@ -1259,12 +1311,14 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             __syncthreads();
         }
     }
+    };
+    sort_all();
     if (a.kind == KIND_IVFPQ && a.pq_rescore && tid == 0) {
         // certificate: every vector outside the candidate set has approximate score <= the K'-th
         // candidate's, hence exact score <= that + eps; if this is below the exact k-th best
         // candidate, the top k (ties included) lies inside the candidate set.
         const float eps = reinterpret_cast<const float*>(a.qparam)[q * 4 + 2];
-        uint64_t last = a.state[q * KP + (KP - 1)];
+        uint64_t last = a.state[q * KP + (KPv - 1)];
         int bad = 0;
         if (last != 0 && !a.no_cert) {  // the candidate buffer is full: vectors were excluded
             float a_last = key_score(last);
@@ -1279,16 +1333,18 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         if (a.no_cert && last != 0 && sord[a.k - 1] != 0 && sord[KP - 1] == sord[a.k - 1]) bad |= 2;
         a.uncertain[q] = bad;
     }
-    if (a.kind != KIND_IVFPQ && a.uncertain) {
-        // certificate of the MFMA scan (see FinalizeArgs): wave 0 sums |q|^2, thread 0 decides
+    // certificate of the MFMA scan (see FinalizeArgs) against the `considered`-th approximate candidate.  EVERY wave evaluates it (|q|^2 is a
+    // wave sum, the rest reads LDS and the state row): the verdict is the same in all of them and needs no LDS word to travel — the sort
+    // buffers fill the whole 160 KiB at K' = 8192
+    auto certify_rows = [&](int considered) -> int {
         const float* qv = a.Q32 + q * a.ldq;
-        if (wv == 0) {
+        int bad = 0;
+        {
             double q2 = 0.0;
             for (int t = lane; t < a.d; t += 64) q2 += (double)qv[t] * (double)qv[t];
             q2 = wave_sum_f64(q2);
             if (lane == 0) {
-                const uint64_t last = a.state[q * KP + (KP - 1)];
-                int bad = 0;
+                const uint64_t last = a.state[q * KP + (considered - 1)];
                 if (last != 0) {     // K' candidates were kept: vectors were excluded on their approximate score
                     const float qn = (float)sqrt(q2) * 1.0000002f;
                     const float rel = a.cert_rel + ((a.cert_qflag && *a.cert_qflag) ? a.cert_rel_qlossy : 0.0f);
@@ -1310,9 +1366,23 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
                     }
                 }
                 if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad = 1;
-                a.uncertain[q] = bad;
             }
         }
+        return __shfl(bad, 0);
+    };
+    if (a.kind != KIND_IVFPQ && a.uncertain) {
+        // Round 5: the first pass re-scores only the KPv = k + max(8, k / 16) best approximate candidates (rows of 2 d bytes anywhere in
+        // HBM) and certifies against the KPv-th.  A query it cannot clear is not sent to the exact re-run yet: the remaining candidates
+        // of its state row (up to K', the power of two the selection kept) are resolved, re-scored and sorted in, and the certificate
+        // runs again against the K'-th — what every query paid in round 4 (k = 1000: 2048 rows; finalize 1.05 -> 0.6 ms per 1024 queries).
+        int bad = certify_rows(KPv);
+        if (bad && KPv < KP) {
+            resolve(KPv, KP, KP);         // slots [KPv, KP) held sinks after the first sort
+            rescore_rows(KPv, KP);
+            sort_all();
+            bad = certify_rows(KP);
+        }
+        if (tid == 0) a.uncertain[q] = bad;
     }
     for (int j = tid; j < a.k; j += nt) {
         bool valid = (j < KP) && sord[j] != 0 && sid[j] != INT64_MAX;
@@ -1420,6 +1490,14 @@ void launch_pq_rescore_all(const FinalizeArgs& a, uint64_t* cand, int cand_cap, 
 // the k-th score send the query to the exact re-run).  row_filter != null: only the queries flagged 1 (second chance of the
 // K' path) are processed.
 // ---------------------------------------------------------------------------------------
+#ifdef RSX_MEASURE
+__device__ uint64_t g_ft_trace[256 * 8];          // tools/ builds only: [workgroup < 256][mark] wall clock (10 ns ticks) of k_pq_final_tab's phases
+extern "C" int rsx_debug_ft_trace(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ft_trace), sizeof(uint64_t) * 256 * 8) == hipSuccess ? 0 : -1; }
+#define FT_MARK(i) do { if (blockIdx.x < 256 && threadIdx.x == 0) g_ft_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define FT_MARK(i)
+#endif
+template <int NRUN>      // M / 16: the 16-sub-quantiser runs of a code vector (1, 2, 4, 6, 8)
 __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t* cand, int cand_cap, int P, uint64_t* tie_ws, int stage_probes) {
     extern __shared__ __attribute__((aligned(16))) float ft_T[];
     const int M = a.M, dsub = a.dsub;
@@ -1445,6 +1523,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     const int n = (int)n_raw;
     uint64_t* row = cand + q * (int64_t)cand_cap;
     const float* qv = a.Q32 + q * a.ldq;
+    FT_MARK(0);
     // 1. the table: copied when the table builder stored it (lut32: the same fmaf chains), else built here from the codebooks
     if (a.lut32) {
         const float4* src = reinterpret_cast<const float4*>(a.lut32 + q * (int64_t)a.Mpad * 256);
@@ -1476,6 +1555,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         }
     }
     __syncthreads();
+    FT_MARK(1);
     // candidate index -> storage row (the probed list that holds it, by bisection of the query's row offsets)
     const int64_t* ss = stage_probes ? s_ss : ss_g;
     auto locate = [&](uint32_t idx, int& lo) -> int64_t {
@@ -1483,52 +1563,13 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ss[mid] <= (int64_t)idx) lo = mid; else hi = mid; }
         return (stage_probes ? s_lb[lo] : a.list_base[a.probe_list[q * a.nprobe + lo]]) + ((int64_t)idx - ss[lo]);
     };
-    // 2. exact scores of the whole row, in place
-    const int NF = M >> 6, nrun = M >> 4;
-    int myvalid = 0;
-    for (int c = tid; c < n; c += 1024) {
-        const uint64_t key = row[c];
-        if (!key) continue;
-        const uint32_t idx = key_idx(key);
-        int lo;
-        const int64_t r = locate(idx, lo);
-        const float dis0 = stage_probes ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
-        float sum = 0.0f;
-        if (M == 16) {       // 64-vector blocks of 1 KiB: vector v's 16 bytes at v * 16, byte s = sub-quantiser (v + s) & 15
-            const uint4 cw4 = *reinterpret_cast<const uint4*>(a.codes + (r >> 6) * 1024 + (r & 63) * 16);
-            uint32_t w[4] = {cw4.x, cw4.y, cw4.z, cw4.w};
-            rot16_bytes(w, (int)(r & 15));
-#pragma unroll
-            for (int j = 0; j < 16; j++) sum += ft_T[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 255u)];
-        } else {             // 16-vector blocks (pq_exact_sum_rot_wide's pieces), 16 sub-quantisers per run in m order
-            const int i = (int)(r & 15);
-            const uint8_t* base = a.codes + (r >> 4) * (int64_t)(16 * M);
-            for (int run = 0; run < nrun; run++) {
-                const uint8_t* p0; const uint8_t* p1;
-                if (run < 4 * NF) { p0 = base + (run >> 2) * 1024 + ((run & 3) * 16 + i) * 16; p1 = p0 + 8; }
-                else { const int h = run & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
-                const uint2 lo2 = *reinterpret_cast<const uint2*>(p0), hi2 = *reinterpret_cast<const uint2*>(p1);
-                uint32_t w[4] = {lo2.x, lo2.y, hi2.x, hi2.y};
-                rot16_bytes(w, i);
-                const float* Tr = ft_T + run * 16 * 256;
-#pragma unroll
-                for (int j = 0; j < 16; j++) sum += Tr[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 255u)];
-            }
-        }
-        const uint64_t nk = make_key(dis0 + sum, idx);
-        row[c] = nk;
-        myvalid += nk != 0ull;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) myvalid += __shfl_xor(myvalid, off);
-    if (lane == 0 && myvalid) atomicAdd(&ctl[2], myvalid);
-    __syncthreads();        // workgroup-scope release / acquire: every thread sees the re-scored row
-    // 3. threshold = the k-th largest 32-bit score word (ties counted with multiplicity)
-    const int V = ctl[2];
-    uint32_t thr = 1u;      // fewer than k valid keys: take every valid one
-    if (V > a.k) {
+    // the kk-th largest 32-bit score word of the row's non-zero keys (ties counted with multiplicity) by an MSB-first radix walk — or,
+    // when every key under a prefix is selected, that prefix with zero low bits: a lower bound of it that selects the same keys.
+    // ctl[1] / ctl[4] / ctl[6] describe the last digit's bin afterwards (wanted, present, ties straddle rank kk).  Needs > kk - 1 valid keys.
+    auto kth_word = [&](int kk) -> uint32_t {
         uint32_t prefix = 0;
-        if (tid == 0) ctl[1] = a.k;
+        if (tid == 0) { ctl[1] = kk; ctl[4] = 0; ctl[6] = 0; }
+        __syncthreads();
         for (int shift = 24; shift >= 0; shift -= 8) {
             for (int i2 = tid; i2 < 256; i2 += 1024) hist[i2] = 0;
             __syncthreads();
@@ -1565,8 +1606,113 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
             __syncthreads();
             if (all_in) break;
         }
-        thr = prefix;
+        return prefix;
+    };
+    // 1b. (round 5) which candidates are worth an exact score.  The row holds EVERY vector that can matter (threshold by construction:
+    // tau = the SAMPLE's a_k - 2 eps), but the sample's k-th best is a weak quantile of the probed lists: at k = 1000 the row holds ~5200
+    // keys.  The row's own k-th largest approximate score a_(k) is a much better bound: k candidates have a >= a_(k), hence exact score
+    // >= a_(k) - eps, so a candidate with a < a_(k) - 2 eps (exact score < a_(k) - eps) cannot be among the top k, ties included.  Its
+    // code bytes — 12 pieces of 8 bytes in 12 different 64-byte sectors of the rotated layout at M = 96: the phase trace put the re-score
+    // at 106 of the kernel's 160 us per query, HBM-bound on ~770 fetched bytes per candidate — are never read.
+    uint32_t cut = 0u;
+    {
+        int cntv = 0;
+        for (int c = tid; c < n; c += 1024) cntv += row[c] != 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cntv += __shfl_xor(cntv, off);
+        if (lane == 0 && cntv) atomicAdd(&ctl[7], cntv);
+        __syncthreads();
+        if (ctl[7] > a.k) {
+            const uint32_t ak = kth_word(a.k);               // a lower bound of the k-th largest approximate score word
+            const float eps = reinterpret_cast<const float*>(a.qparam)[q * 4 + 2];
+            float cf = ord2f(ak) - 2.0f * eps;
+            cf -= fabsf(cf) * 4.8e-7f + 1e-37f;              // the subtraction's own rounding, and then some
+            cut = f2ord(cf + 0.0f);
+            __syncthreads();
+            if (tid == 0) { ctl[1] = 0; ctl[4] = 0; ctl[6] = 0; }
+        }
     }
+    // 2. exact scores of the whole row, in place.  Round 5: a candidate's code bytes are 2 (M = 16: 1) x M / 16 loads of 8 bytes anywhere in
+    // HBM; the loop used to walk the runs one after the other — six dependent round trips per candidate at M = 96, ~2 us each — and a
+    // thread took its ~5 candidates (k = 1000) in turn: 106 of the kernel's 160 us per query (phase trace, profiles/r05e_*).  Now all of a candidate's
+    // loads are in flight before the first table look-up, and two candidates per thread and pass where the registers allow (M <= 64).
+    const int NF = M >> 6;
+    constexpr int nrun = NRUN, FT_RUNS = NRUN;
+    int myvalid = 0;
+    struct Cand { uint64_t key; uint32_t idx; int64_t r; float dis0; uint2 lo2[FT_RUNS], hi2[FT_RUNS]; uint4 w16; };
+    auto fetch = [&](int c, Cand& x) {
+        x.key = c < n ? row[c] : 0ull;
+        if (!x.key) return;
+        if ((uint32_t)(x.key >> 32) < cut) { row[c] = 0ull; x.key = 0ull; return; }      // cannot reach the top k: never re-scored
+        x.idx = key_idx(x.key);
+        int lo;
+        x.r = locate(x.idx, lo);
+        x.dis0 = stage_probes ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
+        if (NRUN == 1) {     // M = 16: 64-vector blocks of 1 KiB: vector v's 16 bytes at v * 16, byte s = sub-quantiser (v + s) & 15
+            x.w16 = *reinterpret_cast<const uint4*>(a.codes + (x.r >> 6) * 1024 + (x.r & 63) * 16);
+        } else {             // 16-vector blocks (pq_exact_sum_rot_wide's pieces), 16 sub-quantisers per run in m order
+            const int i = (int)(x.r & 15);
+            const uint8_t* base = a.codes + (x.r >> 4) * (int64_t)(16 * M);
+#pragma unroll
+            for (int run = 0; run < FT_RUNS; run++) {
+                if (run >= nrun) break;
+                const uint8_t* p0; const uint8_t* p1;
+                if (run < 4 * NF) { p0 = base + (run >> 2) * 1024 + ((run & 3) * 16 + i) * 16; p1 = p0 + 8; }
+                else { const int h = run & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
+                x.lo2[run] = *reinterpret_cast<const uint2*>(p0); x.hi2[run] = *reinterpret_cast<const uint2*>(p1);
+            }
+        }
+    };
+    auto score = [&](int c, Cand& x) {
+        if (!x.key) return;
+        float sum = 0.0f;
+        if (NRUN == 1) {
+            uint32_t w[4] = {x.w16.x, x.w16.y, x.w16.z, x.w16.w};
+            rot16_bytes(w, (int)(x.r & 15));
+#pragma unroll
+            for (int j = 0; j < 16; j++) sum += ft_T[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 255u)];
+        } else {
+            const int i = (int)(x.r & 15);
+#pragma unroll
+            for (int run = 0; run < FT_RUNS; run++) {
+                if (run >= nrun) break;
+                uint32_t w[4] = {x.lo2[run].x, x.lo2[run].y, x.hi2[run].x, x.hi2[run].y};
+                rot16_bytes(w, i);
+                const float* Tr = ft_T + run * 16 * 256;
+#pragma unroll
+                for (int j = 0; j < 16; j++) sum += Tr[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 255u)];
+            }
+        }
+        const uint64_t nk = make_key(x.dis0 + sum, x.idx);
+        row[c] = nk;
+        myvalid += nk != 0ull;
+    };
+    if (NRUN <= 4) {
+        for (int c = tid; c < n; c += 2048) {
+            Cand xa, xb;
+            fetch(c, xa);
+            fetch(c + 1024, xb);
+            score(c, xa);
+            score(c + 1024, xb);
+        }
+    } else {             // M >= 96: two candidates' pieces do not fit the 128 registers of a 1024-thread workgroup
+        for (int c = tid; c < n; c += 1024) {
+            Cand xa;
+            fetch(c, xa);
+            score(c, xa);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) myvalid += __shfl_xor(myvalid, off);
+    if (lane == 0 && myvalid) atomicAdd(&ctl[2], myvalid);
+    __syncthreads();        // workgroup-scope release / acquire: every thread sees the re-scored row
+    FT_MARK(2);
+    // 3. threshold = the k-th largest 32-bit score word (ties counted with multiplicity)
+    const int V = ctl[2];
+    if (a.stat && tid == 0) atomicAdd(a.stat, (unsigned long long)V);
+    uint32_t thr = 1u;      // fewer than k valid keys: take every valid one
+    if (V > a.k) thr = kth_word(a.k);
+    FT_MARK(3);
     // 4. collect.  Usually the keys at or above the threshold are just k (+ a few ties) and all of them go to the sort.  PQ codes
     // are coarse, though: vectors with IDENTICAL codes in one list have bit-equal scores (at M = 16 on the bench mixture whole
     // data clusters do: 40 % of adjacent results tie, up to 16 000 vectors at one score), and the order among them is id
@@ -1609,6 +1755,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         if (tid == 0) a.uncertain[q] = 2 | 4 | (int)((unsigned)(ctl[3] > 0xfffff ? 0xfffff : ctl[3]) << 8);    // bit 2 + the count: diagnostics
         return;
     }
+    FT_MARK(4);
     int ns = 2;              // sort only the power of two that holds the keys
     while (ns < ctl[3]) ns <<= 1;
     for (int size = 2; size <= ns; size <<= 1) {
@@ -1625,12 +1772,14 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
             __syncthreads();
         }
     }
+    FT_MARK(5);
     for (int j = tid; j < a.k; j += 1024) {
         const bool valid = j < ns && sord[j] != 0u && sid[j] != INT64_MAX;
         a.D[q * a.k + j] = valid ? ord2f(sord[j]) : -__builtin_inff();
         a.I[q * a.k + j] = valid ? sid[j] : -1;
     }
     if (tid == 0) a.uncertain[q] = 0;
+    FT_MARK(6);
 }
 // sort capacity of k_pq_final_tab for this (M, k), 0 when the kernel does not apply (layout, or the table + sort do not fit the LDS)
 int pq_final_tab_capacity(int M, int CB, int k) {
@@ -1649,8 +1798,15 @@ void launch_pq_final_tab(const FinalizeArgs& a, uint64_t* cand, int cand_cap, ui
     const int stage_probes = shm + probes <= (size_t)160 * 1024 ? 1 : 0;
     if (stage_probes) shm += probes;
     static DevSize attr;
-    attr.grow(shm, [&] { (void)hipFuncSetAttribute((const void*)k_pq_final_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
-    hipLaunchKernelGGL(k_pq_final_tab, dim3((unsigned)a.nq), dim3(1024), shm, st, a, cand, cand_cap, P, tie_ws, stage_probes);
+    auto kern = a.M == 16 ? k_pq_final_tab<1> : a.M == 32 ? k_pq_final_tab<2> : a.M == 64 ? k_pq_final_tab<4> : a.M == 96 ? k_pq_final_tab<6> : k_pq_final_tab<8>;
+    attr.grow(shm, [&] {
+        (void)hipFuncSetAttribute((const void*)k_pq_final_tab<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_pq_final_tab<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_pq_final_tab<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_pq_final_tab<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_pq_final_tab<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.nq), dim3(1024), shm, st, a, cand, cand_cap, P, tie_ws, stage_probes);
 }
 
 void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
@@ -1660,8 +1816,8 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
     int waves = std::min(4, std::max(1, (a.KP + 63) / 64));
     // a handful of queries leave the chip idle: 16 waves per query and the parallel table-entry form of the IVF-PQ re-score
     const size_t base20 = (((size_t)a.KP * 20 + 15) / 16) * 16;
-    const size_t par_shm = base20 + (size_t)a.KP * (a.M + 1) * 4;
-    a.par_entries = (a.kind == KIND_IVFPQ && a.pq_rescore && a.CB == 0 && !a.lut32 && a.dsub == 8 && a.nq <= 64 && par_shm <= 64 * 1024) ? 1 : 0;
+    const size_t par_shm = ((base20 + (size_t)a.KP * (a.M + 1) * 4 + 15) / 16) * 16 + (size_t)a.KP * a.M;      // entries + the staged code bytes
+    a.par_entries = (a.kind == KIND_IVFPQ && a.pq_rescore && a.CB == 0 && !a.lut32 && a.dsub == 8 && (a.nq <= 64 || a.KP <= 128) && par_shm <= 64 * 1024) ? 1 : 0;
     a.rank_sort = (a.KP <= FIN_RANK_MAX && a.nq <= 64) ? 1 : 0;     // fewer barriers, more instructions: a latency trade, not a throughput one
     if (a.rank_sort) shm = base20 + (size_t)a.KP * 12 + 16;       // the second copy shares the table-entry region (used earlier)
     if (a.par_entries) { shm = std::max(shm, par_shm); waves = 16; }

@@ -383,6 +383,9 @@ void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, in
 struct FinalizeArgs {
     int kind; int metric;
     const uint64_t* state; int KP; int k; int64_t nq;
+    int KPv;                                // candidates CONSIDERED (0 = KP): the state rows are sorted by approximate key, so the first KPv are the
+                                            // KPv best; the rest is ignored and the certificate runs against the KPv-th.  Flat / IVF-Flat pass
+                                            // k + max(8, k / 16) instead of its power of two (k = 1000: 1062 rows of 1.5 KB re-read, not 2048)
     // location resolution
     const int32_t* probe_list; const int64_t* seg_start; int nprobe;
     const int64_t* list_base;
@@ -404,6 +407,7 @@ struct FinalizeArgs {
     float* D; int64_t* I;
     const int32_t* row_filter;     // optional: only queries with row_filter[q] == 1 are processed (second-chance pass)
     int no_cert;                   // the state keys are the best of a COMPLETE, exactly scored candidate row: nothing to certify
+    unsigned long long* stat;      // profile >= 2 (else null): [0] += candidates k_pq_final_tab re-scored exactly (after its 2 eps cut)
     int probe_lds_off;             // set by launch_finalize: byte offset of the query's probe table in the dynamic LDS (0 = keep it in global memory)
     int par_entries;               // set by launch_finalize: parallel table-entry form of the IVF-PQ re-score (small batches)
     int rank_sort;                 // set by launch_finalize: order the candidates by counting (K' <= 1024) instead of a bitonic network

@@ -1,0 +1,84 @@
+"""GPU: the certified fast IVF-PQ scan on data distributions other than the bench mixture (task 4; the reference hands a
+real evaluation set to one index.search call, src/search.py:296): a HOT-LIST batch (every query from a handful of inverted lists:
+dozens of query groups per list tile — the sibling join, the work stealing and the survivor logs under load) and NORM-SKEWED data
+(1 % of the rows scaled x3: heavy rows win every inner-product top-k, their residuals are long, the 8-bit tables coarse).  1.5M x 768,
+M = 96: the whole batch against the exact kernel (itself pinned to the oracle by the golden / shape tests) and a sample against the
+oracle on the exported lists; the hot batch must not need a single exact re-run."""
+import numpy as np
+import pytest
+
+from util import assert_same_results
+
+pytestmark = pytest.mark.gpu
+
+D, N, NLIST, M, NPROBE, NQ = 768, 1_500_000, 256, 96, 16, 1024
+
+
+def _oracle_lists(orc, ix, need, nlist, M_):
+    ls = ix.list_sizes()
+    lens = np.zeros(nlist, np.int64); lens[need] = ls[need]
+    off = np.zeros(nlist + 1, np.int64); np.cumsum(lens, out=off[1:])
+
+    class LM: pass
+    lm = LM(); lm.list_off = off
+    lm.payload = np.empty((int(off[-1]), M_), np.uint8); lm.ids = np.empty(int(off[-1]), np.int64)
+    for l in need:
+        c, i = ix.get_list(int(l)); lm.payload[off[l]:off[l + 1]] = c; lm.ids[off[l]:off[l + 1]] = i
+    return lm
+
+
+def _check(gpu, orc, ix, q, ks, label, expect_no_rerun):
+    import torch
+    for k in ks:
+        ix.set_param("scan_kernel", 2)
+        De, Ie = ix.search(q, k)
+        ix.set_param("scan_kernel", 0); ix.set_param("profile", 1)
+        D, I = ix.search(q, k)
+        fb = ix.get_timing("fallback_queries")
+        ix.set_param("profile", 0)
+        assert torch.equal(D, De) and torch.equal(I, Ie), f"{label} k={k}: fast scan vs the exact kernel"
+        if expect_no_rerun:
+            assert fb == 0, f"{label} k={k}: {fb} exact re-runs"
+        sample = [0, 17, 500, NQ - 1]
+        qs = q[sample].cpu().numpy().astype(np.float32)
+        cen = ix.get_centroids()
+        pid, _ = orc.coarse_probe(cen, qs, NPROBE)
+        lm = _oracle_lists(orc, ix, np.unique(pid), NLIST, M)
+        Dr, Ir = orc.ivfpq_search(cen, ix.get_codebooks(), lm, qs, NPROBE, k)
+        assert_same_results(D[sample].cpu().numpy(), I[sample].cpu().numpy(), Dr, Ir, f"{label} k={k} vs oracle")
+
+
+def test_hot_list_batch(gpu, orc):
+    import torch
+    x = torch.empty((N, D), dtype=torch.float16, device="cuda")
+    gpu.synth_vectors(D, NLIST, 1234, 10000, 0.5, 0, N, out=x)
+    ix = gpu.IndexIVFPQ(None, D, NLIST, M, 8, 0)
+    ix.train(x[:65536]); ix.add(x); ix.nprobe = NPROBE
+    a = torch.from_numpy(np.asarray(ix.assign(x[:200_000]))).cuda()
+    hot = torch.argsort(torch.bincount(a, minlength=NLIST), descending=True)[:4]
+    rows = torch.cat([torch.nonzero(a == l).flatten()[:NQ // 4] for l in hot.tolist()])
+    assert rows.numel() == NQ
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    q = (x[rows].float() + 0.1 * torch.randn((NQ, D), generator=g, device="cuda")).half()
+    # 256 lists, 16 probes per query, 1024 queries from 4 clusters: a probed list is scanned by well over a dozen query groups
+    ix.set_param("profile", 2); ix.search(q, 10)
+    groups_per_list = ix.get_timing("scanned_group_vectors") / max(1.0, ix.get_timing("scanned_unique_vectors"))
+    ix.set_param("profile", 0)
+    assert groups_per_list > 12, groups_per_list
+    _check(gpu, orc, ix, q, (10, 100, 1000), "hot lists", expect_no_rerun=True)
+
+
+def test_norm_skewed_rows(gpu, orc):
+    import torch
+    x = torch.empty((N, D), dtype=torch.float16, device="cuda")
+    gpu.synth_vectors(D, NLIST, 1234, 10000, 0.5, 0, N, out=x)
+    heavy = (torch.arange(N, device="cuda") % 100) == 37
+    x[heavy] = (x[heavy].float() * 3.0).half()
+    q = torch.empty((NQ, D), dtype=torch.float16, device="cuda")
+    gpu.synth_queries(D, NLIST, 1234, 10000, 0.5, N, 999, 0.1, 0, NQ, out=q)
+    ix = gpu.IndexIVFPQ(None, D, NLIST, M, 8, 0)
+    ix.train(x[:65536]); ix.add(x); ix.nprobe = NPROBE
+    _, I = ix.search(q, 10)
+    frac_heavy = float((I.cpu().numpy() % 100 == 37).mean())
+    assert frac_heavy > 0.9, f"the heavy rows should own the top-10 ({frac_heavy})"
+    _check(gpu, orc, ix, q, (10, 100, 1000), "norm skew", expect_no_rerun=False)

@@ -19,7 +19,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 O=$PWD/gpurun_out
 FAST="--cpu-queries 0 --no-recall --no-configs"
 for s in "$@"; do
@@ -44,11 +44,13 @@ for s in "$@"; do
       python tools/rocprof_summary.py $O/prof/${TAG}_results.db $O/${TAG}_rocprof_stats_ivfpq100M.md "IVF-PQ 100M x 768, M=96, nlist=4096, nprobe=32, batch=1024 (python bench.py --steps 5 --warmup 2 $FAST ${BENCH_ARGS:-})"
       rm -rf $O/prof ;;
     pmc_fetch)
-      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc.log ); echo "exit $?" >> $O/${TAG}_pmc.log
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc.log ); echo "exit $?" >> $O/${TAG}_pmc.log
+      ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc_mfma.log ); echo "exit $?" >> $O/${TAG}_pmc_mfma.log
       rm -f $O/${TAG}_pmc_fetch_size.md
-      python tools/pmc_summary.py $O/pmc_fetch/${TAG}_results.db $O/${TAG}_pmc_fetch_size.md '%k_pq_scan%' '%k_pq_prepass%' '%k_pq_rot%'
-      python tools/update_pmc_traffic.py $O/pmc_fetch/${TAG}_results.db $O/pmc_traffic.json
-      rm -rf $O/pmc_fetch ;;
+      python tools/pmc_summary.py /tmp/pmc_fetch/${TAG}_results.db $O/${TAG}_pmc_fetch_size.md '%k_pq_scan%' '%k_pq_prepass%' '%k_pq_rot%'
+      python tools/pmc_summary.py /tmp/pmc_mfma/${TAG}_results.db $O/${TAG}_pmc_fetch_size.md '%k_pq_scan%'
+      python tools/update_pmc_traffic.py /tmp/pmc_fetch/${TAG}_results.db $O/pmc_traffic.json 100000000 1 /tmp/pmc_mfma/${TAG}_results.db
+      rm -rf /tmp/pmc_fetch /tmp/pmc_mfma ;;
     pmc_sq)
       ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $O/pmc_sq -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc_sq.log ); echo "exit $?" >> $O/${TAG}_pmc_sq.log
       rm -f $O/${TAG}_pmc_sq_counters.md

@@ -4,7 +4,10 @@ HBM bytes per launch of the IVF-PQ scan kernel, stamped with the hash of the sou
 refuses the file when the hash no longer matches).  FETCH_SIZE is reported in KiB and, on gfx950, counts exactly half
 of the bytes of 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM) -> bytes = value * 1024 * 2.
 
-usage: update_pmc_traffic.py <results.db> <out.json> [n_vectors] [n_gpus]"""
+A second db — an SQ pass of the same command (`--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`) — adds the matrix-core busy fraction
+of the same kernel: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE cycles x 1024).
+
+usage: update_pmc_traffic.py <results.db> <out.json> [n_vectors] [n_gpus] [sq_results.db]"""
 import datetime, json, os, sqlite3, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -25,5 +28,13 @@ res = {"kernel": kernel, "kernel_name": name.split("(")[0].replace("void ", ""),
        "source_sha256": kernel_source_hash(), "date": datetime.date.today().isoformat(),
        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --steps 2 --warmup 1 --cpu-queries 0 --no-recall --no-configs; "
                  "bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 halves 16-B/lane streaming reads)"}
+if len(sys.argv) > 5:
+    c2 = sqlite3.connect(sys.argv[5]).cursor()
+    q = "select avg(value) from counters_collection where counter_name = ? and kernel_name = ?"
+    busy = c2.execute(q, ("SQ_VALU_MFMA_BUSY_CYCLES", name)).fetchone()[0]
+    act = c2.execute(q, ("GRBM_GUI_ACTIVE", name)).fetchone()[0]
+    if busy and act:
+        res["mfma_busy_cycles"] = busy; res["gui_active_cycles"] = act
+        res["mfma_busy_frac"] = busy / (act * 1024.0)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
