@@ -366,7 +366,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 const int ee = e < nunits ? e : 0;
                 const int c = ee / (M / 4), m4 = ee - c * (M / 4);
                 // non-temporal: a table row is read once per item (out of the Infinity Cache) — it should not displace the code lines the
-                // sibling groups are about to re-read from this L2 (round 5, interleaved A/B on one box: scan 2.515 -> 2.467 ms)
+                // sibling groups are about to re-read from this L2 (round 5, interleaved A/Bs: scan -1 to -2 % at every shard size from 12.5M to 100M vectors)
                 in[u][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (q0 * 256 + c) * M + m4 * 4));
                 in[u][1] = np > 1 ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (q1 * 256 + c) * M + m4 * 4)) : 0u;
                 in[u][2] = np > 2 ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (q2 * 256 + c) * M + m4 * 4)) : 0u;

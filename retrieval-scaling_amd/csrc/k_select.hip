@@ -204,20 +204,34 @@ template <int NT, bool ONLY_KTH = false, class KeyAt>
 __device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf, int32_t* hist, int32_t* ctl) {
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 8) ctl[tid] = 0;          // [0] digit, [1] remaining, [2] valid count, [3] output cursor, [4] keys in the digit's bin
+    if (tid == 0) { hist[0] = -1; hist[1] = 0; }      // min / max of the keys' high words (unsigned), gathered with the valid count
     if (!ONLY_KTH) for (int i = tid; i < KP; i += NT) obuf[i] = 0;
     __syncthreads();
     int myvalid = 0;
-    for (int i = tid; i < N; i += NT) myvalid += key_at(i) != 0ull;
+    uint32_t lmin = 0xffffffffu, lmax = 0u;
+    for (int i = tid; i < N; i += NT) {
+        const uint64_t key = key_at(i);
+        if (key != 0ull) { myvalid++; const uint32_t o = (uint32_t)(key >> 32); lmin = o < lmin ? o : lmin; lmax = o > lmax ? o : lmax; }
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) myvalid += __shfl_xor(myvalid, off);
-    if (lane == 0 && myvalid) atomicAdd(&ctl[2], myvalid);
+    for (int off = 32; off > 0; off >>= 1) {
+        myvalid += __shfl_xor(myvalid, off);
+        const uint32_t a0 = __shfl_xor(lmin, off), a1 = __shfl_xor(lmax, off);
+        lmin = a0 < lmin ? a0 : lmin; lmax = a1 > lmax ? a1 : lmax;
+    }
+    if (lane == 0 && myvalid) { atomicAdd(&ctl[2], myvalid); atomicMin(reinterpret_cast<uint32_t*>(&hist[0]), lmin); atomicMax(reinterpret_cast<uint32_t*>(&hist[1]), lmax); }
     __syncthreads();
     const int V = ctl[2];
     uint64_t kth = 1;                   // fewer than KP valid keys: take every valid one
     if (V > KP) {
-        uint64_t prefix = 0;
+        // Round 5: the walk starts at the first byte in which the keys differ.  Keys are (order word of the score) || ~index, and the scores
+        // of one query's candidates share their top one or two bytes: a round over such a byte is N LDS atomics on one counter and tells nothing.
+        const uint32_t gd = (uint32_t)hist[0] ^ (uint32_t)hist[1];
+        const int nb = (gd >> 24) ? 0 : (gd >> 16) ? 1 : (gd >> 8) ? 2 : gd ? 3 : 4;      // common top bytes of the high words
+        uint64_t prefix = nb ? ((uint64_t)((uint32_t)hist[1] & (nb == 4 ? 0xffffffffu : ~((1u << (32 - 8 * nb)) - 1u)))) << 32 : 0ull;
         if (tid == 0) ctl[1] = KP;
-        for (int shift = 56; shift >= 0; shift -= 8) {
+        __syncthreads();                // hist is zeroed by the first round: every thread has read the min / max
+        for (int shift = 56 - 8 * nb; shift >= 0; shift -= 8) {
             for (int i = tid; i < 256; i += NT) hist[i] = 0;
             __syncthreads();
             for (int i = tid; i < N; i += NT) {
@@ -1144,10 +1158,10 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     if (a.kind == KIND_IVFPQ && a.pq_rescore && a.par_entries) {
         // The K' x M table entries of the candidates' codes are independent — all threads compute them (code byte -> codeword -> 8 fmaf,
         // the table builder's chain) into LDS, then one thread per candidate adds its row in m order: the same canonical sum, without M
-        // dependent loads per thread.  Round 3: the latency path (few queries in flight).  Round 5: every batch with K' <= 128 — one thread
-        // per candidate walked 6 runs x (code piece -> 16 codewords) of dependent round trips, ~60 us per 1024 queries at k = 10 whatever
-        // the chip had free; the code bytes now arrive as 8-byte PIECES (a thread per (candidate, 16-sub-quantiser run): 2 x 8 bytes,
-        // rotated back into m order, 16 bytes to LDS) instead of one byte load per entry.
+        // dependent loads per thread.  The latency path (few queries in flight: launch_finalize).  Round 5: the code bytes arrive as 8-byte
+        // PIECES (a thread per (candidate, 16-sub-quantiser run): 2 x 8 bytes, rotated back into m order, 16 bytes to LDS) instead of one
+        // byte load per entry.  (Measured for full batches at K' = 128 as well: 16 waves x 52 KiB per query leave two queries per CU, and
+        // finalize went 0.060 -> 0.14 ms per 1024 queries — one thread per candidate stays the form for batches.)
         float* ent = reinterpret_cast<float*>(fin_buf) + (((size_t)KP * 20 + 15) / 16) * 4;      // [KP][M + 1]
         const int M = a.M, es = M + 1;
         uint8_t* cbytes = reinterpret_cast<uint8_t*>(ent + (size_t)KP * es);                      // [KP][M] (M >= 32: staged by pieces)
@@ -1494,11 +1508,15 @@ void launch_pq_rescore_all(const FinalizeArgs& a, uint64_t* cand, int cand_cap, 
 __device__ uint64_t g_ft_trace[256 * 8];          // tools/ builds only: [workgroup < 256][mark] wall clock (10 ns ticks) of k_pq_final_tab's phases
 extern "C" int rsx_debug_ft_trace(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ft_trace), sizeof(uint64_t) * 256 * 8) == hipSuccess ? 0 : -1; }
 #define FT_MARK(i) do { if (blockIdx.x < 256 && threadIdx.x == 0) g_ft_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+__device__ uint64_t g_ft_trace2[256 * 8];         // ... and of the re-score phase's parts: count, k-th approximate, stage 1, k-th exact of stage 1, stage 2
+extern "C" int rsx_debug_ft_trace2(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ft_trace2), sizeof(uint64_t) * 256 * 8) == hipSuccess ? 0 : -1; }
+#define FT_MARK2(i) do { if (blockIdx.x < 256 && threadIdx.x == 0) g_ft_trace2[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define FT_MARK(i)
+#define FT_MARK2(i)
 #endif
 template <int NRUN>      // M / 16: the 16-sub-quantiser runs of a code vector (1, 2, 4, 6, 8)
-__global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t* cand, int cand_cap, int P, uint64_t* tie_ws, int stage_probes) {
+__global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t* cand, int cand_cap, int P, uint64_t* tie_ws, int stage_probes, int bm_off, int wq_off, int wq_cap) {
     extern __shared__ __attribute__((aligned(16))) float ft_T[];
     const int M = a.M, dsub = a.dsub;
     int64_t* sid = reinterpret_cast<int64_t*>(ft_T + (size_t)M * 256);     // [P]
@@ -1566,17 +1584,40 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     // the kk-th largest 32-bit score word of the row's non-zero keys (ties counted with multiplicity) by an MSB-first radix walk — or,
     // when every key under a prefix is selected, that prefix with zero low bits: a lower bound of it that selects the same keys.
     // ctl[1] / ctl[4] / ctl[6] describe the last digit's bin afterwards (wanted, present, ties straddle rank kk).  Needs > kk - 1 valid keys.
-    auto kth_word = [&](int kk) -> uint32_t {
+    auto kth_word = [&](int kk, const uint32_t* only = nullptr) -> uint32_t {      // only: bitmap of the row entries that take part (null: all)
         uint32_t prefix = 0;
-        if (tid == 0) { ctl[1] = kk; ctl[4] = 0; ctl[6] = 0; }
+        // Round 5: the walk starts at the first byte in which the keys DIFFER.  The scores of a query's candidates sit in a narrow band —
+        // their order words share the top one or two bytes — and a round over a byte all keys share is n LDS atomics on ONE counter
+        // (10-16 us per round at n = 6000: the phase trace), for no information.
+        if (tid == 0) { ctl[1] = kk; ctl[4] = 0; ctl[6] = 0; ctl2[0] = -1; ctl2[1] = 0; }     // ctl2[0] / [1]: min / max word (as unsigned)
         __syncthreads();
-        for (int shift = 24; shift >= 0; shift -= 8) {
+        {
+            uint32_t lmin = 0xffffffffu, lmax = 0u;
+            for (int c = tid; c < n; c += 1024) {
+                const uint64_t key = row[c];
+                if (key != 0ull && (!only || ((only[c >> 5] >> (c & 31)) & 1u))) { const uint32_t o = (uint32_t)(key >> 32); lmin = o < lmin ? o : lmin; lmax = o > lmax ? o : lmax; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t a0 = __shfl_xor(lmin, off), a1 = __shfl_xor(lmax, off);
+                lmin = a0 < lmin ? a0 : lmin; lmax = a1 > lmax ? a1 : lmax;
+            }
+            if (lane == 0) { atomicMin(reinterpret_cast<uint32_t*>(&ctl2[0]), lmin); atomicMax(reinterpret_cast<uint32_t*>(&ctl2[1]), lmax); }
+            __syncthreads();
+        }
+        const uint32_t gmin = (uint32_t)ctl2[0], gmax = (uint32_t)ctl2[1];
+        const uint32_t gdiff = gmin ^ gmax;
+        const int shift0 = (gdiff >> 24) ? 24 : (gdiff >> 16) ? 16 : (gdiff >> 8) ? 8 : 0;
+        if (shift0 < 24) prefix = gmax & ~((1u << (shift0 + 8)) - 1u);       // the bytes above the first differing one are common to all keys
+        __syncthreads();
+        for (int shift = shift0; shift >= 0; shift -= 8) {
             for (int i2 = tid; i2 < 256; i2 += 1024) hist[i2] = 0;
             __syncthreads();
             for (int c = tid; c < n; c += 1024) {
                 const uint64_t key = row[c];
                 const uint32_t o = (uint32_t)(key >> 32);
-                if (key != 0ull && (shift == 24 || (o >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&hist[(o >> shift) & 255u], 1);
+                if (key != 0ull && (!only || ((only[c >> 5] >> (c & 31)) & 1u)) && (shift == 24 || (o >> (shift + 8)) == (prefix >> (shift + 8))))
+                    atomicAdd(&hist[(o >> shift) & 255u], 1);      // (at shift0 < 24 every key matches the common prefix)
             }
             __syncthreads();
             if (tid < 64) {
@@ -1614,7 +1655,9 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     // >= a_(k) - eps, so a candidate with a < a_(k) - 2 eps (exact score < a_(k) - eps) cannot be among the top k, ties included.  Its
     // code bytes — 12 pieces of 8 bytes in 12 different 64-byte sectors of the rotated layout at M = 96: the phase trace put the re-score
     // at 106 of the kernel's 160 us per query, HBM-bound on ~770 fetched bytes per candidate — are never read.
-    uint32_t cut = 0u;
+    uint32_t cut = 0u, ak_word = 0u;
+    float eps_q = 0.0f;
+    uint32_t* bm = bm_off ? reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(ft_T) + bm_off) : nullptr;      // [ceil(cand_cap / 32)]
     {
         int cntv = 0;
         for (int c = tid; c < n; c += 1024) cntv += row[c] != 0ull;
@@ -1622,12 +1665,14 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         for (int off = 32; off > 0; off >>= 1) cntv += __shfl_xor(cntv, off);
         if (lane == 0 && cntv) atomicAdd(&ctl[7], cntv);
         __syncthreads();
+        FT_MARK2(0);
         if (ctl[7] > a.k) {
             const uint32_t ak = kth_word(a.k);               // a lower bound of the k-th largest approximate score word
             const float eps = reinterpret_cast<const float*>(a.qparam)[q * 4 + 2];
             float cf = ord2f(ak) - 2.0f * eps;
             cf -= fabsf(cf) * 4.8e-7f + 1e-37f;              // the subtraction's own rounding, and then some
             cut = f2ord(cf + 0.0f);
+            ak_word = ak; eps_q = eps;
             __syncthreads();
             if (tid == 0) { ctl[1] = 0; ctl[4] = 0; ctl[6] = 0; }
         }
@@ -1640,11 +1685,24 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     constexpr int nrun = NRUN, FT_RUNS = NRUN;
     int myvalid = 0;
     struct Cand { uint64_t key; uint32_t idx; int64_t r; float dis0; uint2 lo2[FT_RUNS], hi2[FT_RUNS]; uint4 w16; };
-    auto fetch = [&](int c, Cand& x) {
-        x.key = c < n ? row[c] : 0ull;
+    int stage = 0;
+    // does row entry c (key) get an exact score in this stage?  (side effects: the first stage marks it in the bitmap, the last drops what is cut)
+    auto admit = [&](int c, uint64_t key) -> bool {
+        if (!key) return false;
+        const uint32_t aw = (uint32_t)(key >> 32);
+        if (stage == 1) {                 // first stage: only the candidates at or above the row's k-th approximate score
+            if (aw < ak_word) return false;
+            atomicOr(&bm[c >> 5], 1u << (c & 31));
+            return true;
+        }
+        if (stage == 2 && ((bm[c >> 5] >> (c & 31)) & 1u)) return false;      // re-scored in the first stage: row[c] is exact already
+        if (aw < cut) { row[c] = 0ull; return false; }      // cannot reach the top k: never re-scored
+        return true;
+    };
+    auto fetch = [&](int c, uint32_t idx, Cand& x) {       // c < 0: nothing
+        x.key = c >= 0 ? 1ull : 0ull;
         if (!x.key) return;
-        if ((uint32_t)(x.key >> 32) < cut) { row[c] = 0ull; x.key = 0ull; return; }      // cannot reach the top k: never re-scored
-        x.idx = key_idx(x.key);
+        x.idx = idx;
         int lo;
         x.r = locate(x.idx, lo);
         x.dis0 = stage_probes ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
@@ -1687,20 +1745,72 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         row[c] = nk;
         myvalid += nk != 0ull;
     };
-    if (NRUN <= 4) {
-        for (int c = tid; c < n; c += 2048) {
-            Cand xa, xb;
-            fetch(c, xa);
-            fetch(c + 1024, xb);
-            score(c, xa);
-            score(c + 1024, xb);
+    // One pass over the row = an ADMISSION scan (four keys per thread and step, their loads independent) that queues the row indices
+    // to re-score in LDS, then the re-score itself over the queue: every thread gets the same number of candidates, and none of its steps
+    // waits for a key that turns out to be cut.  (The first form walked the row entry by entry per thread — key load, decision, piece
+    // loads, table look-ups in turn: ~16 us per step whatever the decision, 113 us at k = 1000 with 2300 or with 5200 candidates to score.)
+    uint2* wq = wq_off ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(ft_T) + wq_off) : nullptr;       // [wq_cap] {row index, candidate index}
+    int32_t* wq_n = reinterpret_cast<int32_t*>(wq + wq_cap);
+    auto rescore_one = [&](int c, uint32_t idx) { Cand xa; fetch(c, idx, xa); score(c, xa); };
+    auto rescore_pass = [&]() {
+        if (wq && tid == 0) *wq_n = 0;
+        if (wq) __syncthreads();
+        for (int c0 = tid; c0 < n; c0 += 4096) {
+            uint64_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int c = c0 + u * 1024; kk[u] = c < n ? row[c] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int c = c0 + u * 1024;
+                if (!admit(c, kk[u])) continue;
+                int pos = wq ? atomicAdd(wq_n, 1) : wq_cap;
+                if (pos < wq_cap) wq[pos] = make_uint2((uint32_t)c, key_idx(kk[u]));
+                else rescore_one(c, key_idx(kk[u]));          // no queue, or full: in place
+            }
         }
-    } else {             // M >= 96: two candidates' pieces do not fit the 128 registers of a 1024-thread workgroup
-        for (int c = tid; c < n; c += 1024) {
-            Cand xa;
-            fetch(c, xa);
-            score(c, xa);
+        if (!wq) return;
+        __syncthreads();
+        const int qn = *wq_n < wq_cap ? *wq_n : wq_cap;
+        if (NRUN <= 4) {
+            for (int i2 = tid; i2 < qn; i2 += 2048) {
+                Cand xa, xb;
+                const uint2 ea = wq[i2], eb = i2 + 1024 < qn ? wq[i2 + 1024] : make_uint2(0u, 0u);
+                fetch((int)ea.x, ea.y, xa);
+                fetch(i2 + 1024 < qn ? (int)eb.x : -1, eb.y, xb);
+                score((int)ea.x, xa);
+                score((int)eb.x, xb);
+            }
+        } else {             // M >= 96: two candidates' pieces do not fit the 128 registers of a 1024-thread workgroup
+            for (int i2 = tid; i2 < qn; i2 += 1024) { const uint2 e = wq[i2]; rescore_one((int)e.x, e.y); }
         }
+        __syncthreads();     // the queue is free again
+    };
+    if (bm && cut != 0u) {
+        // Two stages (round 5): the candidates at or above a_(k) first — at least k of them; the k-th largest of THEIR exact scores, s_lo,
+        // is a lower bound of the query's exact k-th best, and it sits near a_(k) where the one-stage bound had to assume a_(k) - eps.  A
+        // remaining candidate with a < s_lo - eps has exact score < s_lo and is out (strictly: ties stay in): the window of the second
+        // stage is ~eps wide instead of 2 eps (k = 1000 on the bench index: 6400 keys in the row, 4150 above the one-stage cut,
+        // ~2600 re-scored this way).  The bitmap says which row entries hold exact keys already.
+        for (int i2 = tid; i2 < ((n + 31) >> 5); i2 += 1024) bm[i2] = 0u;
+        __syncthreads();
+        FT_MARK2(1);
+        stage = 1;
+        rescore_pass();
+        __syncthreads();
+        FT_MARK2(2);
+        const uint32_t slo = kth_word(a.k, bm);           // (a lower bound of) the k-th largest exact score word among the first stage's
+        float cf = ord2f(slo) - eps_q;
+        cf -= fabsf(cf) * 4.8e-7f + 1e-37f;
+        const uint32_t cut2 = f2ord(cf + 0.0f);
+        if (cut2 > cut) cut = cut2;
+        __syncthreads();
+        if (tid == 0) { ctl[1] = 0; ctl[4] = 0; ctl[6] = 0; }
+        FT_MARK2(3);
+        stage = 2;
+        rescore_pass();
+        FT_MARK2(4);
+    } else {
+        rescore_pass();
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) myvalid += __shfl_xor(myvalid, off);
@@ -1797,6 +1907,20 @@ void launch_pq_final_tab(const FinalizeArgs& a, uint64_t* cand, int cand_cap, ui
     const size_t probes = (size_t)(a.nprobe + 1) * 8 + (size_t)a.nprobe * 12 + 16;
     const int stage_probes = shm + probes <= (size_t)160 * 1024 ? 1 : 0;
     if (stage_probes) shm += probes;
+    // bitmap of the row entries the first re-score stage has settled (two-stage cut): one bit per candidate slot, behind everything else
+    int bm_off = 0;
+    {
+        const size_t off = (shm + 15) / 16 * 16, need = ((size_t)cand_cap + 31) / 32 * 4;
+        if (a.qparam && off + need <= (size_t)160 * 1024) { bm_off = (int)off; shm = off + need; }
+    }
+    // work queue of the re-score (row index + candidate index per entry, then the counter): as many entries as the LDS has left, 512 .. 4096
+    int wq_off = 0, wq_cap = 0;
+    {
+        const size_t off = (shm + 15) / 16 * 16;
+        size_t room = off + 64 < (size_t)160 * 1024 ? ((size_t)160 * 1024 - off - 64) / 8 : 0;
+        if (room > 4096) room = 4096;
+        if (room >= 512) { wq_off = (int)off; wq_cap = (int)room; shm = off + room * 8 + 16; }
+    }
     static DevSize attr;
     auto kern = a.M == 16 ? k_pq_final_tab<1> : a.M == 32 ? k_pq_final_tab<2> : a.M == 64 ? k_pq_final_tab<4> : a.M == 96 ? k_pq_final_tab<6> : k_pq_final_tab<8>;
     attr.grow(shm, [&] {
@@ -1806,7 +1930,7 @@ void launch_pq_final_tab(const FinalizeArgs& a, uint64_t* cand, int cand_cap, ui
         (void)hipFuncSetAttribute((const void*)k_pq_final_tab<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_pq_final_tab<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.nq), dim3(1024), shm, st, a, cand, cand_cap, P, tie_ws, stage_probes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.nq), dim3(1024), shm, st, a, cand, cand_cap, P, tie_ws, stage_probes, bm_off, wq_off, wq_cap);
 }
 
 void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
@@ -1817,7 +1941,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
     // a handful of queries leave the chip idle: 16 waves per query and the parallel table-entry form of the IVF-PQ re-score
     const size_t base20 = (((size_t)a.KP * 20 + 15) / 16) * 16;
     const size_t par_shm = ((base20 + (size_t)a.KP * (a.M + 1) * 4 + 15) / 16) * 16 + (size_t)a.KP * a.M;      // entries + the staged code bytes
-    a.par_entries = (a.kind == KIND_IVFPQ && a.pq_rescore && a.CB == 0 && !a.lut32 && a.dsub == 8 && (a.nq <= 64 || a.KP <= 128) && par_shm <= 64 * 1024) ? 1 : 0;
+    a.par_entries = (a.kind == KIND_IVFPQ && a.pq_rescore && a.CB == 0 && !a.lut32 && a.dsub == 8 && a.nq <= 64 && par_shm <= 64 * 1024) ? 1 : 0;
     a.rank_sort = (a.KP <= FIN_RANK_MAX && a.nq <= 64) ? 1 : 0;     // fewer barriers, more instructions: a latency trade, not a throughput one
     if (a.rank_sort) shm = base20 + (size_t)a.KP * 12 + 16;       // the second copy shares the table-entry region (used earlier)
     if (a.par_entries) { shm = std::max(shm, par_shm); waves = 16; }

@@ -32,6 +32,13 @@ for k in ks:
         d = [(t[:, i + 1] - t[:, i]).mean() / 100.0 for i in range(5)]
         print(f"k={k}: select stage {ix.get_timing('select'):.3f} ms; k_pq_gather_select per workgroup (us): " + "  ".join(f"{nm} {v:.1f}" for nm, v in zip(gn, d)) +
               f"  | total {(t[:, 5] - t[:, 0]).mean() / 100.0:.1f} us; span of the 256 {(t[:, 5].max() - t[:, 0].min()) / 100.0:.1f} us")
+    if k > 25:
+        tr2 = np.zeros((256, 8), dtype=np.uint64)
+        assert rsx.lib().rsx_debug_ft_trace2(tr2.ctypes.data_as(ctypes.c_void_p)) == 0
+        t2 = tr2.astype(np.int64)
+        parts = [("count", t2[:, 0] - t[:, 1]), ("k-th approximate + bitmap", t2[:, 1] - t2[:, 0]), ("stage 1", t2[:, 2] - t2[:, 1]),
+                 ("k-th exact of stage 1", t2[:, 3] - t2[:, 2]), ("stage 2", t2[:, 4] - t2[:, 3]), ("to the end of the phase", t[:, 2] - t2[:, 4])]
+        print(f"k={k}: the re-score phase in parts (us): " + "  ".join(f"{nm} {v.mean() / 100.0:.1f}" for nm, v in parts))
     ix.set_param("profile", 2)
     ix.search(Q[3 * 1024:], k)
     print(f"k={k}: candidate keys per query {ix.get_timing('cand_keys') / 1024:.0f} (max {ix.get_timing('cand_keys_max'):.0f}); re-scored exactly by k_pq_final_tab per query {ix.get_timing('final_tab_rescored') / 1024:.0f}")
