@@ -83,6 +83,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
+    # idle OpenMP workers SLEEP between parallel regions instead of spinning (read when libgomp initialises, i.e. at `import torch`): with the
+    # default policy the 128 threads of the CPU-baseline leg kept the host cores busy into the next GPU leg, whose launches then took 14 ms
+    # per batch instead of 3.7 (round 5; the CPU leg itself is one ~2 s parallel region per repeat and does not notice)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import torch
     import rsx
     from sharded import ShardedSearcher, shard_range
