@@ -49,3 +49,12 @@ def test_committed_bench_line_keeps_the_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    # round 5: the MFMA-busy counter rides with the traffic stamp, and the same operating point is reported on four other distributions
+    assert "mfma_busy" in r and "lds" in r
+    od = j.get("other_distributions")
+    assert od and set(od) >= {"hot_lists", "hot_probe_sets", "informative", "norm_skew"}, od and list(od)
+    for name, leg in od.items():
+        assert "error" not in leg, (name, leg.get("error"))
+        assert leg["exact_fallback_queries_per_step"] == 0 and leg["oracle_parity_ids_and_scores"] is True, name
+        assert leg["ms_per_step"] < 2 * j["ms_per_step"], (name, leg["ms_per_step"])       # no distribution slower than 2x the headline
+    assert od["informative"]["recall_by_nprobe"]["nprobe32"]["recall_at_10"] > od["informative"]["recall_by_nprobe"]["nprobe1"]["recall_at_10"]
