@@ -747,20 +747,27 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int32_t* item_off = group_off + (nlist + 1);
         int32_t* total_groups = item_off + (nlist + 1);
         int32_t* total_items = total_groups + 1;
-        // query tiles per group of the LDS-DMA list scan: with ~64 probing queries per list (nlist 2048 / nprobe 128) groups of 16 read
-        // every list four times; 32 / 64 queries per group read it twice / once (k_list_scan2<_, QT>)
+        // probing queries per group of the LDS-DMA list scans.  A group passes over its list's rows once, so the larger the group the fewer
+        // passes: 16 (k_list_scan2<_, 1>: two workgroups per CU), 64 (the 8-wave form, queries in LDS) or 128 (k_list_scan3, queries in
+        // registers, inner product at d = 768).  Round 5, 20M x 768, batch 1024 (profiles/r05_ivfflat_wide.md): at 8 probing queries per
+        // list on average 16 wins (5.47 ms against 5.59 with 64), at 16 already 64 does (nlist 2048 / nprobe 32: 5.08 against 5.95;
+        // nlist 4096 / nprobe 64: 6.93 against 8.53), at 32 64 beats 128 (5.20 against 5.61: no list needs a second pass yet, and the
+        // 8-wave form has no barrier), at 64 and more 128 wins (6.04 against 7.23; nlist 1024 / nprobe 128: 10.6 against 11.4).  The
+        // 32-query form lost everywhere and is only reachable through the parameter.
         int ls_qt = 1;
         if (h->scan_chunk <= 0 && h->ivf_qtiles != 0 && list_scan2_chunk_rows(h->storage_f16, ld) > 0) {
             const int64_t qpl = npairs / std::max(1, nlist);
-            ls_qt = h->ivf_qtiles > 1 ? h->ivf_qtiles : (qpl >= 40 ? 4 : qpl >= 20 ? 2 : 1);
-            ls_qt = std::min(ls_qt == 3 ? 2 : ls_qt, list_scan2_max_qtiles(ld));
-            if (ls_qt != 2 && ls_qt != 4) ls_qt = 1;
+            const bool ls3 = list_scan3_applies(h->storage_f16, ld, h->metric == RSX_METRIC_L2) != 0;      // 128 queries per group, held in registers (k_list_scan3)
+            ls_qt = h->ivf_qtiles > 1 ? h->ivf_qtiles : (qpl >= 48 && ls3 ? 8 : qpl >= 12 ? 4 : 1);
+            if (ls_qt == 8 && !ls3) ls_qt = 4;
+            if (ls_qt != 8) ls_qt = std::min(ls_qt == 3 ? 2 : ls_qt, list_scan2_max_qtiles(ld));
+            if (ls_qt != 2 && ls_qt != 4 && ls_qt != 8) ls_qt = 1;
         }
         // (list, chunk, group) work items in list-major order for the LDS-DMA scan's XCD-aware 1-D grid (round 4): the groups of a
         // list chunk run on one XCD at the same moment and its rows cross HBM once — at nlist 2048 / nprobe 128 half of the lists
         // are probed by more than 64 queries, i.e. by two groups, which used to land on different XCDs (two fetches)
         const int ls2_rows = list_scan2_chunk_rows(h->storage_f16, ld);
-        const bool ls_wide = ls_qt == 4;     // the 8-wave form: 1024 rows per work item
+        const bool ls_wide = ls_qt >= 4;     // the 8-wave forms: 1024 rows per work item
         const int item_rows = (h->scan_chunk <= 0 && ls2_rows > 0) ? (ls_wide ? 2 * ls2_rows : ls2_rows) : 0;
         launch_group_pairs(h->w_probelist.as<int32_t>(), npairs, nlist, 16 * ls_qt, cnt, cursor, pair_off, group_off, total_groups,
                            pairs_sorted, item_rows ? h->d_len.as<int64_t>() : nullptr, item_rows, item_rows ? item_off : nullptr,

@@ -1061,6 +1061,199 @@ int list_scan2_chunk_rows(int x_f16, int ld) {
     return (!off && x_f16 && ld % 64 == 0) ? 64 * LS2_NB : 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// k_list_scan3 (round 5): the QUERY-STATIONARY form for lists probed by many queries (nprobe >= 64 at the bench's nlist).
+// k_list_scan2 keeps a group's queries in LDS (97 KiB for 64) and gives every wave a private ring of rows: a list probed by 65-128
+// queries is streamed twice through the CU, and the passes, not HBM latency, are what the 64-query form pays for
+// (profiles/r05_ivfflat_wide.md: a prefetch wave and a ring twice as deep both LOSE; time = 3.8 ms of unique bytes + 2.2 ms per
+// pass over the 31 GB at nlist 2048 / nprobe 128).  Here a wave keeps ITS 16 queries in registers as MFMA A fragments (2 KT
+// x 4 VGPRs = 96 at d = 768), the eight waves of a workgroup share ONE ring of D stages of 128 rows x 128 B (one K step),
+// filled by LDS-DMA (wave w fetches rows 16 w .. 16 w + 15 of every stage, the swizzled 1 KiB pieces of k_list_scan2) and read
+// by every wave: 128 queries per pass, the LDS holds nothing but the rows in flight (4 stages = 64 KiB).  One s_barrier per K step (stage s
+// has landed for everybody / everybody is done with stage s - 1, whose slot takes stage s + D - 1).  Same MFMA, same operand
+// order, same K order per (query, row) as k_list_scan2 -> the same bits.
+// Inner product only (no per-row bias: a load whose result a later instruction needs would put a full vmcnt wait into the counted stream).
+// The scores of a 128-row block leave after its last K step while the DMA stream runs on: vmcnt(2 (D - 2)) stays a SUFFICIENT
+// wait with stores in flight (loads retire in order among themselves; outstanding stores can only make it wait for more).
+// ---------------------------------------------------------------------------------------
+// Ring depth: 4 stages beat 6, 8 and 9 (6.04 / 6.14 / 6.25 / 6.29 ms at nlist 2048 / nprobe 128) and 3 (6.35): the fewer bytes in flight the
+// better, down to what covers one barrier.  Requesting the next stage before the barrier instead of after it: +-0.  Stages of 16 WHOLE rows
+// (24 KiB contiguous, a wave's 24 MFMAs chained on one accumulator) instead of one K step of 128 rows: 6.27-6.36 against 6.12-6.15 —
+// the row stream is not short of DRAM page hits (profiles/r05_ivfflat_wide.md).
+#define LS3_D 4
+template <bool FILTER, int KT, int D = LS3_D>
+__global__ __launch_bounds__(512) void k_list_scan3(ListScanArgs a) {
+    constexpr int NQG = 128, BR = 128, NB = 8;
+    constexpr int STAGE = 16384;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
+    unsigned char* ring = ls_smem;                                               // [D][8 waves][2 KiB]
+    int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + D * STAGE);          // [NQG] score-buffer offset | (FILTER) row column
+    int64_t* sq = segoff + NQG;                                                  // [NQG] query            (FILTER)
+    uint64_t* stau = reinterpret_cast<uint64_t*>(sq + NQG);                      // [NQG] threshold key    (FILTER)
+    int32_t* sqn = reinterpret_cast<int32_t*>(stau + NQG);                       // [NQG] query numbers, -1 = padding
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int g = blockIdx.x;
+    int chunk = blockIdx.y;
+    int l, gi;
+    if (a.item_off) {
+        if (!pq_decode_item(a.item_off, a.group_off, *a.total_items, a.nlist, l, gi, chunk)) return;
+    } else {
+        if (g >= *a.total_groups) return;
+        int lo = 0, hi = a.nlist;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.group_off[mid] <= g) lo = mid; else hi = mid; }
+        l = lo;
+        gi = g - a.group_off[l];
+    }
+    const int cnt = a.pair_off[l + 1] - a.pair_off[l];
+    int np = cnt - NQG * gi; if (np > NQG) np = NQG;
+    const int pair0 = a.pair_off[l] + NQG * gi;
+    const int64_t base = a.list_base[l], len = a.list_len[l];
+    const int64_t len_pad = (len + 15) & ~15ll;
+    const int64_t c0 = (int64_t)chunk * (BR * NB);
+    if (c0 >= len_pad) return;
+    int64_t c1 = c0 + BR * NB; if (c1 > len_pad) c1 = len_pad;
+
+    if (tid < NQG) {
+        int64_t q = -1, off = 0; uint64_t t = ~0ull;      // padding slot: nothing passes
+        if (tid < np) {
+            const int pidx = a.pairs_sorted[pair0 + tid];
+            q = pidx / a.nprobe; const int j = pidx % a.nprobe;
+            off = q * a.tstride + ((!FILTER && a.pre_stride) ? (int64_t)j * a.pre_stride : a.seg_start[q * (a.nprobe + 1) + j]);
+            if (FILTER) { t = a.tau_key[q * a.tau_stride]; off -= q * a.tstride; }      // the column inside the query's row = the candidate's index
+        }
+        sqn[tid] = (int32_t)q; segoff[tid] = off;
+        if (FILTER) { sq[tid] = q < 0 ? 0 : q; stau[tid] = t; }
+    }
+    __syncthreads();
+
+    const int lr = lane & 15, kg = lane >> 4;
+    const bool active = 16 * w < np;           // waves without queries still fetch their rows of every stage
+    half8 qa[2 * KT];
+    {
+        const int q = sqn[16 * w + lr];
+        const __half* qp = a.Q16 + (int64_t)(q < 0 ? 0 : q) * a.ld + 8 * kg;
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+            qa[2 * kt] = q >= 0 ? *reinterpret_cast<const half8*>(qp + kt * 64) : z;
+            qa[2 * kt + 1] = q >= 0 ? *reinterpret_cast<const half8*>(qp + kt * 64 + 32) : z;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * KT; i++) asm volatile("" : "+v"(qa[i]));      // landed before the counted waits below start counting
+    }
+
+    const int64_t nrows = c1 - c0;             // a multiple of 16
+    const int nblk = (int)((nrows + BR - 1) / BR);
+    const int T = nblk * KT;
+    const char* xc = reinterpret_cast<const char*>(reinterpret_cast<const __half*>(a.X) + (base + c0) * a.ld);
+    const int64_t row_bytes = (int64_t)a.ld * 2;
+    uint32_t off0, off1;
+    {
+        const int r8 = lane >> 3, p = lane & 7;
+        const int R0 = r8, R1 = 8 + r8;
+        off0 = (uint32_t)R0 * (uint32_t)(a.ld * 2) + ((p ^ ((R0 >> 1) & 7)) << 4);
+        off1 = (uint32_t)R1 * (uint32_t)(a.ld * 2) + ((p ^ ((R1 >> 1) & 7)) << 4);
+    }
+    // my 16 rows of block b; past the end of a short last block: its last 16 rows again (nobody reads that copy)
+    auto row0 = [&](int b) { int64_t r = (int64_t)BR * b + 16 * w; return r > nrows - 16 ? nrows - 16 : r; };
+    int i_kt = 0, i_blk = 0, i_slot = 0, i_left = T;
+    int64_t i_boff = row0(0) * row_bytes;
+    auto issue = [&]() {
+        const char* gsrc = xc + i_boff + (int64_t)i_kt * 128;
+        unsigned char* dst = ring + i_slot * STAGE + w * 2048;
+        fg2_dma16<RSX_NT_LIST>(gsrc + off0, dst);
+        fg2_dma16<RSX_NT_LIST>(gsrc + off1, dst + 1024);
+        const bool adv = i_left > 1;           // past the last step: the last piece again, into the slot of a finished stage
+        i_left -= adv ? 1 : 0;
+        i_kt += adv ? 1 : 0;
+        if (i_kt == KT) { i_kt = 0; i_blk++; i_boff = row0(i_blk) * row_bytes; }
+        i_slot = (i_slot + 1 == D) ? 0 : i_slot + 1;
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; d++) issue();
+
+    const int swz = (lr >> 1) & 7;
+    const int boff0 = lr * 128 + (((0 + kg) ^ swz) << 4), boff1 = lr * 128 + (((4 + kg) ^ swz) << 4);
+    int slot = 0;
+    for (int b = 0; b < nblk; b++) {
+        floatx4 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int64_t rb = (int64_t)BR * b;
+        const int jn = nrows - rb >= BR ? 8 : (int)((nrows - rb) >> 4);
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+            static_assert(D == 8 || D == 6 || D == 4 || D == 3, "the vmcnt literals below are 2 (D - 2)");
+            if (D == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // my two pieces of this stage are in LDS ...
+            else if (D == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // ... and so are everybody's; everybody has left the previous stage
+            issue();                                                // -> into the previous stage's slot
+            if (active) {
+                const unsigned char* bs = ring + slot * STAGE;
+                // all eight 16-row pieces, also of a short last block (what the slot holds beyond its rows is never stored); the sixteen
+                // fragment reads go out first, the MFMAs follow them in with counted waits
+                half8 xs[16];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    xs[2 * j] = *reinterpret_cast<const half8*>(bs + j * 2048 + boff0);
+                    xs[2 * j + 1] = *reinterpret_cast<const half8*>(bs + j * 2048 + boff1);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[2 * kt], xs[2 * j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[2 * kt + 1], xs[2 * j + 1], acc[j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // eight reads ahead, then two MFMAs per two reads
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            slot = (slot + 1 == D) ? 0 : slot + 1;
+        }
+        if (!active) continue;
+        // C/D layout of the 16x16 MFMA: reg r of lane l holds (row i = 4 (l >> 4) + r = query, col j = l & 15 = db row)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j >= jn) break;
+            const int64_t rloc = c0 + rb + 16 * j + lr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int qi = 16 * w + kg * 4 + r;
+                if (!FILTER) {
+                    if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[j][r] : -__builtin_inff();
+                } else {
+                    const uint64_t key = (rloc < len && qi < np) ? make_key(acc[j][r], (uint32_t)(segoff[qi] + rloc)) : 0ull;
+                    const bool pass = key > stau[qi];
+                    const uint64_t mask = __ballot(pass);
+                    const uint64_t mine = (mask >> (16 * kg)) & 0xffffull;
+                    if (mine) {   // one atomic per query per 16 rows
+                        const int64_t q = sq[qi];
+                        unsigned long long slot0 = 0;
+                        const int leader = (__ffsll((unsigned long long)mine) - 1) + 16 * kg;
+                        if (lane == leader) slot0 = atomicAdd(&a.cand_cnt[(int64_t)q * CCS], (unsigned long long)__popcll(mine));
+                        slot0 = __shfl(slot0, leader);
+                        const unsigned long long sl = slot0 + __popcll(mine & ((1ull << lr) - 1ull));
+                        if (pass && sl < (unsigned long long)a.cand_cap) a.cand[q * a.cand_cap + sl] = key;
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// the query-stationary form applies to fp16 rows of d = 768 (KT = 12: the fragments are register arrays); 0 otherwise
+int list_scan3_applies(int x_f16, int ld, int has_bias) {
+    static const int off = measure_env("RSX_LIST_SCAN3_OFF", 0);
+    return !off && !has_bias && list_scan2_chunk_rows(x_f16, ld) > 0 && ld == 768;
+}
+
 // 16-query tiles per group the LDS holds beside the four DMA rings (queries 16 qt x (ld + 8) halfs)
 int list_scan2_max_qtiles(int ld) {
     for (int qt = 4; qt > 1; qt >>= 1)
@@ -1072,8 +1265,32 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     if (a.max_groups <= 0 || a.max_chunks <= 0) return;
     dim3 grid((unsigned)a.max_groups, (unsigned)a.max_chunks);
     const int base_rows = list_scan2_chunk_rows(a.x_f16, a.ld);
-    if (base_rows > 0 && (a.chunk_rows == base_rows || (a.qtiles == 4 && a.chunk_rows == 2 * base_rows))) {
+    if (base_rows > 0 && (a.chunk_rows == base_rows || ((a.qtiles == 4 || a.qtiles == 8) && a.chunk_rows == 2 * base_rows))) {
         if (a.item_off && !a.flat_mode && a.max_items > 0) grid = dim3((unsigned)((a.max_items + 7) & ~7), 1);   // XCD-aware item order
+        if (a.qtiles == 8) {            // 128 queries per group: the query-stationary form (the caller asked list_scan3_applies)
+            if (a.bias || a.ld != 768) { fprintf(stderr, "rsx: k_list_scan3 asked for a biased metric or d != 768 (internal error)\n"); abort(); }
+            static DevOnce once3;
+            once3.once([&] {
+                (void)hipFuncSetAttribute((const void*)k_list_scan3<false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_list_scan3<true, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            });
+#ifdef RSX_MEASURE
+            static const int d_env = measure_env("RSX_LS3_D", 0);
+#define LS3_VARIANT(DD) if (d_env == DD) { \
+                (void)hipFuncSetAttribute((const void*)k_list_scan3<false, 12, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                (void)hipFuncSetAttribute((const void*)k_list_scan3<true, 12, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                const size_t shm = (size_t)DD * 16384 + 28 * 128; \
+                if (a.tau_key) hipLaunchKernelGGL((k_list_scan3<true, 12, DD>), grid, dim3(512), shm, st, a); \
+                else hipLaunchKernelGGL((k_list_scan3<false, 12, DD>), grid, dim3(512), shm, st, a); \
+                return; }
+            LS3_VARIANT(3) LS3_VARIANT(6) LS3_VARIANT(8)
+#undef LS3_VARIANT
+#endif
+            const size_t shm3 = (size_t)LS3_D * 16384 + 28 * 128;
+            if (a.tau_key) hipLaunchKernelGGL((k_list_scan3<true, 12>), grid, dim3(512), shm3, st, a);
+            else hipLaunchKernelGGL((k_list_scan3<false, 12>), grid, dim3(512), shm3, st, a);
+            return;
+        }
         // the grouping was made for 16 x qtiles queries per group: qtiles is binding (a smaller kernel would misread the groups)
         const int qt = (a.qtiles == 2 || a.qtiles == 4) && !a.flat_mode ? a.qtiles : 1;
         const bool wide = qt == 4 && a.chunk_rows == 2 * base_rows;        // 8 waves x 3 stages, 1024 rows per work item

@@ -196,7 +196,7 @@ struct rsx_index {
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
-    int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scan: 1 = choose 16 / 32 / 64 queries per group from the queries per list, 2 / 4 = force, 0 = always 16
+    int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scans: 1 = choose 16 / 64 / 128 probing queries per group from the queries per list, 2 / 4 / 8 = force 32 / 64 / 128, 0 = always 16
     int pq_prepass4 = 1;     // rotated fast scan, full batches: threshold pre-pass with four queries per workgroup on the scan's table format (1 = small and large k, 2 = small k only, 0 = never)
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
     int pq_final_tab = 1;    // rotated fast scan: finalize from the complete candidate row with the fp32 table in LDS (1 = when K' >= 512 or dsub > 8 and as the second chance, 2 = always, 0 = never)

@@ -196,7 +196,7 @@ struct ListScanArgs {
     int flat_mode; int64_t flat_n; int nq;  // flat_mode: single list, groups = blocks of 16 queries
     float* temp; int64_t tstride;
     int chunk_rows;                         // rows per work item (multiple of 64)
-    int qtiles;                             // k_list_scan2: 16-query tiles per group (1, 2, 4): the grouping must have used 16 x qtiles
+    int qtiles;                             // k_list_scan2: 16-query tiles per group (1, 2, 4; 8 = k_list_scan3): the grouping must have used 16 x qtiles
     int max_groups; int max_chunks;
     // filtered output (k_list_scan2 only; tau_key != null): keys > tau_key[q * tau_stride] are appended to
     // cand[q][0..cand_cap) (count in cand_cnt[q]) instead of storing every score
@@ -212,6 +212,7 @@ struct ListScanArgs {
 };
 int list_scan2_chunk_rows(int x_f16, int ld);   // work-item rows of the LDS-DMA list scan, 0 if it does not apply
 int list_scan2_max_qtiles(int ld);              // ... and the 16-query tiles per group its LDS holds
+int list_scan3_applies(int x_f16, int ld, int has_bias);          // the query-stationary form (qtiles = 8: 128 queries per group, 1024 rows per work item) applies
 void launch_list_scan(const ListScanArgs& a, hipStream_t st);
 
 // k_pq.hip
