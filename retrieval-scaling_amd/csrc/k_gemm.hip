@@ -1003,6 +1003,8 @@ __global__ __launch_bounds__(64 * NW) void k_list_scan2(ListScanArgs a) {
             for (int kt = 0; kt < KT; kt++) {
                 issue();
                 // all but the newest LS2_D - 1 stages (2 pieces each) have landed -> this stage is in LDS
+                // (ring depth, round 5: 4 or 3 stages instead of 6 in the 16-query form — three workgroups per CU — change nothing, 2 instead of
+                //  3 in the 64-query form costs 5 %: profiles/r05_ivfflat_wide.md)
                 static_assert(D == 6 || D == 3, "the vmcnt literals below are 2 (D - 1)");
                 if (D == 6) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
