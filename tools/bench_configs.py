@@ -75,13 +75,16 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
         else:
             rows = ix.get_timing("scanned_vectors") / steps
             uniq = ix.get_timing("scanned_unique_vectors") / steps
-            res["roofline"] = {"bound": "hbm", "kernel": "k_list_scan2", "achieved": round(uniq * D * 2 / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+            qpl = nq * nprobe / max(1, nlist)      # the library's choice of the scan form (api_search.hip): probing queries per list
+            kern = ("k_list_scan3 (128 probing queries per group)" if qpl >= 48 and D == 768 and not mcode else
+                    "k_list_scan2, 8-wave form (64 per group)" if qpl >= 12 else "k_list_scan2 (16 per group)")
+            res["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": round(uniq * D * 2 / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                                "unit": "GB/s", "frac": round(uniq * D * 2 / (scan_ms * 1e-3) / 8e12, 4),
                                "algorithmic_bytes_per_step": uniq * D * 2, "logical_bytes_per_step": rows * D * 2,
                                "effective_GBs": round(rows * D * 2 / (scan_ms * 1e-3) / 1e9, 1),
                                "note": "achieved = rows of every list probed at least once x d x 2 B (each must cross HBM once per batch) / scan "
                                        "stage; logical = sum over (query, probed list) of len*d*2 B (SURVEY 8d), served from one HBM read per "
-                                       "group of <=16 probing queries"}
+                                       "group of 16 / 64 / 128 probing queries"}
         ix.set_param("profile", 0)
         # parity spot check against the oracle (exact arithmetic) on a few queries of the last batch
         if check:
