@@ -1081,7 +1081,7 @@ int list_scan2_chunk_rows(int x_f16, int ld) {
 // Ring depth: 4 stages beat 6, 8 and 9 (6.04 / 6.14 / 6.25 / 6.29 ms at nlist 2048 / nprobe 128) and 3 (6.35): the fewer bytes in flight the
 // better, down to what covers one barrier.  Requesting the next stage before the barrier instead of after it: +-0.  Stages of 16 WHOLE rows
 // (24 KiB contiguous, a wave's 24 MFMAs chained on one accumulator) instead of one K step of 128 rows: 6.27-6.36 against 6.12-6.15 —
-// the row stream is not short of DRAM page hits (profiles/r05_ivfflat_wide.md).
+// the row stream is not short of DRAM page hits.  2 / 3 / 4 K steps per stage and barrier: 6.16-6.36 against 5.99-6.07 (profiles/r05_ivfflat_wide.md).
 #define LS3_D 4
 template <bool FILTER, int KT, int D = LS3_D>
 __global__ __launch_bounds__(512) void k_list_scan3(ListScanArgs a) {
