@@ -749,7 +749,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         int32_t* total_items = total_groups + 1;
         // probing queries per group of the LDS-DMA list scans.  A group passes over its list's rows once, so the larger the group the fewer
         // passes: 16 (k_list_scan2<_, 1>: two workgroups per CU), 64 (the 8-wave form, queries in LDS) or 128 (k_list_scan3, queries in
-        // registers, inner product at d = 768).  Round 5, 20M x 768, batch 1024 (profiles/r05_ivfflat_wide.md): at 8 probing queries per
+        // registers: d = 384 / 512 / 768 / 1024).  Round 5, 20M x 768, inner product, batch 1024 (profiles/r05_ivfflat_wide.md): at 8 probing queries per
         // list on average 16 wins (5.47 ms against 5.59 with 64), at 16 already 64 does (nlist 2048 / nprobe 32: 5.08 against 5.95;
         // nlist 4096 / nprobe 64: 6.93 against 8.53), at 32 64 beats 128 (5.20 against 5.61: no list needs a second pass yet, and the
         // 8-wave form has no barrier), at 64 and more 128 wins (6.04 against 7.23; nlist 1024 / nprobe 128: 10.6 against 11.4).  The

@@ -1074,7 +1074,6 @@ int list_scan2_chunk_rows(int x_f16, int ld) {
 // by every wave: 128 queries per pass, the LDS holds nothing but the rows in flight (4 stages = 64 KiB).  One s_barrier per K step (stage s
 // has landed for everybody / everybody is done with stage s - 1, whose slot takes stage s + D - 1).  Same MFMA, same operand
 // order, same K order per (query, row) as k_list_scan2 -> the same bits.
-// Inner product only (no per-row bias: a load whose result a later instruction needs would put a full vmcnt wait into the counted stream).
 // The scores of a 128-row block leave after its last K step while the DMA stream runs on: vmcnt(2 (D - 2)) stays a SUFFICIENT
 // wait with stores in flight (loads retire in order among themselves; outstanding stores can only make it wait for more).
 // ---------------------------------------------------------------------------------------
@@ -1083,16 +1082,18 @@ int list_scan2_chunk_rows(int x_f16, int ld) {
 // (24 KiB contiguous, a wave's 24 MFMAs chained on one accumulator) instead of one K step of 128 rows: 6.27-6.36 against 6.12-6.15 —
 // the row stream is not short of DRAM page hits.  2 / 3 / 4 K steps per stage and barrier: 6.16-6.36 against 5.99-6.07 (profiles/r05_ivfflat_wide.md).
 #define LS3_D 4
-template <bool FILTER, int KT, int D = LS3_D>
+template <bool FILTER, int KT, bool BIAS, int D = LS3_D>
 __global__ __launch_bounds__(512) void k_list_scan3(ListScanArgs a) {
     constexpr int NQG = 128, BR = 128, NB = 8;
     constexpr int STAGE = 16384;
+    static_assert(KT >= D, "a block's bias slot is rewritten two blocks later: the ring must not reach that far");
     extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
     unsigned char* ring = ls_smem;                                               // [D][8 waves][2 KiB]
     int64_t* segoff = reinterpret_cast<int64_t*>(ls_smem + D * STAGE);          // [NQG] score-buffer offset | (FILTER) row column
     int64_t* sq = segoff + NQG;                                                  // [NQG] query            (FILTER)
     uint64_t* stau = reinterpret_cast<uint64_t*>(sq + NQG);                      // [NQG] threshold key    (FILTER)
     int32_t* sqn = reinterpret_cast<int32_t*>(stau + NQG);                       // [NQG] query numbers, -1 = padding
+    float* sbias = reinterpret_cast<float*>(sqn + NQG);                          // [2][BR] the rows' bias of the even / odd blocks (BIAS)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int g = blockIdx.x;
@@ -1161,9 +1162,23 @@ __global__ __launch_bounds__(512) void k_list_scan3(ListScanArgs a) {
     auto row0 = [&](int b) { int64_t r = (int64_t)BR * b + 16 * w; return r > nrows - 16 ? nrows - 16 : r; };
     int i_kt = 0, i_blk = 0, i_slot = 0, i_left = T;
     int64_t i_boff = row0(0) * row_bytes;
+    // BIAS (squared distances: score = q.x - |x|^2 / 2): the FIRST stage of a block carries a third piece, ahead of its two row pieces — the
+    // 16 bias values of the wave's rows, into the block's slot of sbias.  Loads retire in order, so the piece is in LDS when the stage's
+    // rows are, for everybody after that step's barrier, long before the block's epilogue reads it.  The counted waits see it as one
+    // more newer piece while a NEXT block's first stage is among the D - 2 stages in flight behind the awaited one: the block's last
+    // D - 2 steps, unless it is the chunk's last block (a piece per STAGE keeps the literal single and was measured first: 6.67-6.72 ms
+    // against 6.53-6.56 at nlist 2048 / nprobe 128, squared distances; the 64-query form: 7.1-7.5).
+    const float* bias_l = BIAS ? a.bias + base : nullptr;
     auto issue = [&]() {
         const char* gsrc = xc + i_boff + (int64_t)i_kt * 128;
         unsigned char* dst = ring + i_slot * STAGE + w * 2048;
+        if (BIAS && i_kt == 0) {
+            if (lane < 16) {
+                int64_t r = c0 + row0(i_blk) + lane; r = r > len - 1 ? len - 1 : r;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias_l + r),
+                                                 (__attribute__((address_space(3))) void*)(sbias + (i_blk & 1) * BR + 16 * w), 4, 0, 0);
+            }
+        }
         fg2_dma16<RSX_NT_LIST>(gsrc + off0, dst);
         fg2_dma16<RSX_NT_LIST>(gsrc + off1, dst + 1024);
         const bool adv = i_left > 1;           // past the last step: the last piece again, into the slot of a finished stage
@@ -1186,11 +1201,9 @@ __global__ __launch_bounds__(512) void k_list_scan3(ListScanArgs a) {
         const int jn = nrows - rb >= BR ? 8 : (int)((nrows - rb) >> 4);
 #pragma unroll
         for (int kt = 0; kt < KT; kt++) {
-            static_assert(D == 8 || D == 6 || D == 4 || D == 3, "the vmcnt literals below are 2 (D - 2)");
-            if (D == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // my two pieces of this stage are in LDS ...
-            else if (D == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // my pieces of this stage are in LDS ...
+            if (BIAS && kt >= KT - (D - 2) && b + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (D - 2) + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (D - 2)) : "memory");
             __builtin_amdgcn_s_barrier();                           // ... and so are everybody's; everybody has left the previous stage
             issue();                                                // -> into the previous stage's slot
             if (active) {
@@ -1224,13 +1237,14 @@ __global__ __launch_bounds__(512) void k_list_scan3(ListScanArgs a) {
         for (int j = 0; j < 8; j++) {
             if (j >= jn) break;
             const int64_t rloc = c0 + rb + 16 * j + lr;
+            const float bv = BIAS ? sbias[(b & 1) * BR + 16 * j + lr] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int qi = 16 * w + kg * 4 + r;
                 if (!FILTER) {
-                    if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[j][r] : -__builtin_inff();
+                    if (qi < np) a.temp[segoff[qi] + rloc] = (rloc < len) ? acc[j][r] + bv : -__builtin_inff();
                 } else {
-                    const uint64_t key = (rloc < len && qi < np) ? make_key(acc[j][r], (uint32_t)(segoff[qi] + rloc)) : 0ull;
+                    const uint64_t key = (rloc < len && qi < np) ? make_key(acc[j][r] + bv, (uint32_t)(segoff[qi] + rloc)) : 0ull;
                     const bool pass = key > stau[qi];
                     const uint64_t mask = __ballot(pass);
                     const uint64_t mine = (mask >> (16 * kg)) & 0xffffull;
@@ -1250,10 +1264,11 @@ __global__ __launch_bounds__(512) void k_list_scan3(ListScanArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// the query-stationary form applies to fp16 rows of d = 768 (KT = 12: the fragments are register arrays); 0 otherwise
+// the query-stationary form applies to fp16 rows of d = 384 / 512 / 768 / 1024 (KT = 6 / 8 / 12 / 16: the fragments are register arrays); 0 otherwise
 int list_scan3_applies(int x_f16, int ld, int has_bias) {
     static const int off = measure_env("RSX_LIST_SCAN3_OFF", 0);
-    return !off && !has_bias && list_scan2_chunk_rows(x_f16, ld) > 0 && ld == 768;
+    (void)has_bias;                              // (round 5, second half: the bias rides in the stages)
+    return !off && list_scan2_chunk_rows(x_f16, ld) > 0 && (ld == 384 || ld == 512 || ld == 768 || ld == 1024);
 }
 
 // 16-query tiles per group the LDS holds beside the four DMA rings (queries 16 qt x (ld + 8) halfs)
@@ -1270,28 +1285,38 @@ void launch_list_scan(const ListScanArgs& a, hipStream_t st) {
     if (base_rows > 0 && (a.chunk_rows == base_rows || ((a.qtiles == 4 || a.qtiles == 8) && a.chunk_rows == 2 * base_rows))) {
         if (a.item_off && !a.flat_mode && a.max_items > 0) grid = dim3((unsigned)((a.max_items + 7) & ~7), 1);   // XCD-aware item order
         if (a.qtiles == 8) {            // 128 queries per group: the query-stationary form (the caller asked list_scan3_applies)
-            if (a.bias || a.ld != 768) { fprintf(stderr, "rsx: k_list_scan3 asked for a biased metric or d != 768 (internal error)\n"); abort(); }
-            static DevOnce once3;
-            once3.once([&] {
-                (void)hipFuncSetAttribute((const void*)k_list_scan3<false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)k_list_scan3<true, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            });
+            const size_t shm3 = (size_t)LS3_D * 16384 + 28 * 128 + 2 * 128 * 4;
 #ifdef RSX_MEASURE
             static const int d_env = measure_env("RSX_LS3_D", 0);
-#define LS3_VARIANT(DD) if (d_env == DD) { \
-                (void)hipFuncSetAttribute((const void*)k_list_scan3<false, 12, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                (void)hipFuncSetAttribute((const void*)k_list_scan3<true, 12, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                const size_t shm = (size_t)DD * 16384 + 28 * 128; \
-                if (a.tau_key) hipLaunchKernelGGL((k_list_scan3<true, 12, DD>), grid, dim3(512), shm, st, a); \
-                else hipLaunchKernelGGL((k_list_scan3<false, 12, DD>), grid, dim3(512), shm, st, a); \
+#define LS3_VARIANT(DD) if (d_env == DD && a.ld == 768 && !a.bias) { \
+                (void)hipFuncSetAttribute((const void*)k_list_scan3<false, 12, false, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                (void)hipFuncSetAttribute((const void*)k_list_scan3<true, 12, false, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                const size_t shm = (size_t)DD * 16384 + 28 * 128 + 2 * 128 * 4; \
+                if (a.tau_key) hipLaunchKernelGGL((k_list_scan3<true, 12, false, DD>), grid, dim3(512), shm, st, a); \
+                else hipLaunchKernelGGL((k_list_scan3<false, 12, false, DD>), grid, dim3(512), shm, st, a); \
                 return; }
             LS3_VARIANT(3) LS3_VARIANT(6) LS3_VARIANT(8)
 #undef LS3_VARIANT
 #endif
-            const size_t shm3 = (size_t)LS3_D * 16384 + 28 * 128;
-            if (a.tau_key) hipLaunchKernelGGL((k_list_scan3<true, 12>), grid, dim3(512), shm3, st, a);
-            else hipLaunchKernelGGL((k_list_scan3<false, 12>), grid, dim3(512), shm3, st, a);
-            return;
+#define LS3_LAUNCH(KT_, B_) { \
+                static DevOnce once3; \
+                once3.once([&] { \
+                    (void)hipFuncSetAttribute((const void*)k_list_scan3<false, KT_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    (void)hipFuncSetAttribute((const void*)k_list_scan3<true, KT_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                }); \
+                if (a.tau_key) hipLaunchKernelGGL((k_list_scan3<true, KT_, B_>), grid, dim3(512), shm3, st, a); \
+                else hipLaunchKernelGGL((k_list_scan3<false, KT_, B_>), grid, dim3(512), shm3, st, a); \
+                return; }
+#define LS3_BY_BIAS(KT_) { if (a.bias) LS3_LAUNCH(KT_, true) else LS3_LAUNCH(KT_, false) }
+            switch (a.ld) {
+                case 384: LS3_BY_BIAS(6)
+                case 512: LS3_BY_BIAS(8)
+                case 768: LS3_BY_BIAS(12)
+                case 1024: LS3_BY_BIAS(16)
+                default: fprintf(stderr, "rsx: k_list_scan3 asked for d = %d (internal error)\n", a.ld); abort();
+            }
+#undef LS3_BY_BIAS
+#undef LS3_LAUNCH
         }
         // the grouping was made for 16 x qtiles queries per group: qtiles is binding (a smaller kernel would misread the groups)
         const int qt = (a.qtiles == 2 || a.qtiles == 4) && !a.flat_mode ? a.qtiles : 1;

@@ -212,7 +212,7 @@ struct ListScanArgs {
 };
 int list_scan2_chunk_rows(int x_f16, int ld);   // work-item rows of the LDS-DMA list scan, 0 if it does not apply
 int list_scan2_max_qtiles(int ld);              // ... and the 16-query tiles per group its LDS holds
-int list_scan3_applies(int x_f16, int ld, int has_bias);          // the query-stationary form (qtiles = 8: 128 queries per group, 1024 rows per work item) applies
+int list_scan3_applies(int x_f16, int ld, int has_bias);          // the query-stationary form (qtiles = 8: 128 queries per group, 1024 rows per work item) applies: fp16 rows, d = 384 / 512 / 768 / 1024
 void launch_list_scan(const ListScanArgs& a, hipStream_t st);
 
 // k_pq.hip

@@ -326,40 +326,36 @@ def test_round3_engine_knobs_never_change_a_result(gpu, orc):
 
 def test_ivfflat_query_stationary_scan_equals_the_oracle(gpu, orc):
     """k_list_scan3 (ivf_qtiles = 8: 128 probing queries per group held in registers, the rows of a list streamed once per group
-    through a ring all eight waves read): inner product at d = 768.  Ragged groups (150 probing queries per list = 128 + 22), lists
-    whose length is no multiple of the 128-row stage or of the 1024-row work item, a list shorter than one 16-row piece, filtered
-    and score-row forms, k = 10 and k = 100: the ids of the oracle and the bits of the 16-query kernel."""
-    rng = np.random.RandomState(5)
-    d, nlist, n, nq = 768, 8, 20000, 300
-    cen = rng.randn(nlist, d).astype(np.float32)
-    lab = rng.randint(0, nlist - 1, n); lab[:5] = nlist - 1                 # list 7: five rows
-    x = (cen[lab] + 0.4 * rng.randn(n, d)).astype(np.float16)
-    qf = (x[rng.randint(0, n, nq)].astype(np.float32) + 0.05 * rng.randn(nq, d)).astype(np.float32)
-    xf = x.astype(np.float32)
-    a, _ = orc.assign_ip(cen, xf)
-    lm = orc.ListMajor(a, np.arange(n), xf, nlist)
-    ixf = gpu.IndexIVFFlat(None, d, nlist, 0)
-    ixf.set_centroids(cen); ixf.add(x)
-    assert ixf.storage_dtype == "float16"
-    for nprobe in (4, nlist):
-        ixf.nprobe = nprobe
-        for k in (10, 100):
-            Dr, Ir = orc.ivfflat_search(0, cen, lm, qf, nprobe, k)
-            ixf.set_param("ivf_qtiles", 0); ixf.set_param("ivf_filter", 0)
-            D1, I1 = ixf.search(qf, k)
-            assert np.array_equal(I1, Ir)
-            for filt in (0, 2):
-                ixf.set_param("ivf_qtiles", 8); ixf.set_param("ivf_filter", filt)
-                D, I = ixf.search(qf, k)
-                assert np.array_equal(I, Ir), f"nprobe={nprobe} k={k} ivf_filter={filt}"
-                assert np.array_equal(D.view(np.uint32), D1.view(np.uint32)), f"nprobe={nprobe} k={k} ivf_filter={filt}: score bits"
-    # the squared-distance metric has a per-row bias: the 64-query kernel takes the groups the parameter asked 128 for
-    ixl = gpu.IndexIVFFlat(None, d, nlist, 1)
-    ixl.set_centroids(cen); ixl.add(x); ixl.nprobe = 4
-    Dr, Ir = orc.ivfflat_search(1, cen, lm, qf, 4, 10)
-    ixl.set_param("ivf_qtiles", 8)
-    D, I = ixl.search(qf, 10)
-    assert np.array_equal(I, Ir)
+    through a ring all eight waves read), d = 768 / 384 / 1024, inner product and squared distance (the rows' bias rides in the stages).
+    Ragged groups (150 probing queries per list = 128 + 22), lists whose length is no multiple of the 128-row stage or of the 1024-row
+    work item, a list shorter than one 16-row piece, filtered and score-row forms, k = 10 and k = 100: the ids of the oracle and the
+    score bits of the 16-query kernel."""
+    for d, n, nq, ks in ((768, 20000, 300, (10, 100)), (384, 12000, 200, (10,)), (1024, 9000, 200, (10,))):
+        rng = np.random.RandomState(5 + d)
+        nlist = 8
+        cen = rng.randn(nlist, d).astype(np.float32)
+        lab = rng.randint(0, nlist - 1, n); lab[:5] = nlist - 1                 # list 7: five rows
+        x = (cen[lab] + 0.4 * rng.randn(n, d)).astype(np.float16)
+        qf = (x[rng.randint(0, n, nq)].astype(np.float32) + 0.05 * rng.randn(nq, d)).astype(np.float32)
+        xf = x.astype(np.float32)
+        a, _ = orc.assign_ip(cen, xf)
+        lm = orc.ListMajor(a, np.arange(n), xf, nlist)
+        for metric in (0, 1):
+            ixf = gpu.IndexIVFFlat(None, d, nlist, metric)
+            ixf.set_centroids(cen); ixf.add(x)
+            assert ixf.storage_dtype == "float16"
+            for nprobe in (4, nlist):
+                ixf.nprobe = nprobe
+                for k in ks:
+                    Dr, Ir = orc.ivfflat_search(metric, cen, lm, qf, nprobe, k)
+                    ixf.set_param("ivf_qtiles", 0); ixf.set_param("ivf_filter", 0)
+                    D1, I1 = ixf.search(qf, k)
+                    assert np.array_equal(I1, Ir), f"d={d} metric={metric} nprobe={nprobe} k={k}: 16-query kernel"
+                    for filt in (0, 2):
+                        ixf.set_param("ivf_qtiles", 8); ixf.set_param("ivf_filter", filt)
+                        D, I = ixf.search(qf, k)
+                        assert np.array_equal(I, Ir), f"d={d} metric={metric} nprobe={nprobe} k={k} ivf_filter={filt}"
+                        assert np.array_equal(D.view(np.uint32), D1.view(np.uint32)), f"d={d} metric={metric} nprobe={nprobe} k={k} ivf_filter={filt}: score bits"
 
 
 def test_train_matches_oracle(gpu, orc):

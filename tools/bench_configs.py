@@ -29,7 +29,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
     if which == "flat":
         ix = rsx.IndexFlat(D, rsx.METRIC_L2 if mcode else rsx.METRIC_INNER_PRODUCT)
     else:
-        ix = rsx.IndexIVFFlat(None, D, nlist, rsx.METRIC_INNER_PRODUCT)
+        ix = rsx.IndexIVFFlat(None, D, nlist, rsx.METRIC_L2 if mcode else rsx.METRIC_INNER_PRODUCT)
         nt = min(n, 256 * nlist)
         xt = torch.empty((nt, D), dtype=torch.float16, device=dev)
         rsx.synth_vectors(D, NC, SC, SX, 0.5, 0, nt, out=xt)
@@ -61,7 +61,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
             Dq, Iq = ix.search(Q[s * nq:(s + 1) * nq], k)
         torch.cuda.synchronize(); el = time.perf_counter() - t0
         scan_ms = ix.get_timing("scan") / steps
-        res = {"config": f"{which} {n}x{D} batch={nq} k={k}" + (f" nlist={nlist} nprobe={nprobe}" if which == "ivfflat" else f" metric={'L2' if mcode else 'IP'}"),
+        res = {"config": f"{which} {n}x{D} batch={nq} k={k}" + (f" nlist={nlist} nprobe={nprobe}" + (" metric=L2" if mcode else "") if which == "ivfflat" else f" metric={'L2' if mcode else 'IP'}"),
                "queries_per_s": round(steps * nq / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
                "scan_ms": round(scan_ms, 3), "select_ms": round(ix.get_timing("select") / steps, 3),
                "finalize_ms": round(ix.get_timing("finalize") / steps, 3), "build_s": round(build_s, 1),
@@ -76,7 +76,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
             rows = ix.get_timing("scanned_vectors") / steps
             uniq = ix.get_timing("scanned_unique_vectors") / steps
             qpl = nq * nprobe / max(1, nlist)      # the library's choice of the scan form (api_search.hip): probing queries per list
-            kern = ("k_list_scan3 (128 probing queries per group)" if qpl >= 48 and D == 768 and not mcode else
+            kern = ("k_list_scan3 (128 probing queries per group)" if qpl >= 48 and D in (384, 512, 768, 1024) else
                     "k_list_scan2, 8-wave form (64 per group)" if qpl >= 12 else "k_list_scan2 (16 per group)")
             res["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": round(uniq * D * 2 / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                                "unit": "GB/s", "frac": round(uniq * D * 2 / (scan_ms * 1e-3) / 8e12, 4),
@@ -111,7 +111,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
                     class LM: pass
                     lm = LM(); lm.list_off = off; lm.payload = np.concatenate(pay); lm.ids = np.concatenate(ids)
                     lm_cache["lm"] = lm
-                Dr, Ir = orc.ivfflat_search(0, cen, lm_cache["lm"], qs, nprobe, k)
+                Dr, Ir = orc.ivfflat_search(mcode, cen, lm_cache["lm"], qs, nprobe, k)
                 ok = bool(np.array_equal(Ir, Iq[:check].cpu().numpy()) and np.array_equal(Dr, Dq[:check].cpu().numpy()))
             res["oracle_parity_ids_and_scores"] = ok
             res["oracle_checked_queries"] = int(check)
