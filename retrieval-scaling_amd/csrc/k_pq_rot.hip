@@ -196,7 +196,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     constexpr int BV = NQ ? 64 : 16;           // vectors per code block
     constexpr int BB = NQ ? 1024 : 16 * M;     // bytes per code block
     constexpr int NL = NQ ? 1 : NF;            // 16-byte code loads per lane and block
-    constexpr int RD = NF >= 2 ? 2 : ROT_D;    // code blocks in flight per wave (M = 128: two 2 KiB blocks — four would not fit 128 VGPRs)
+    // code blocks in flight per wave.  M = 128: two 2 KiB blocks — four would not fit 128 VGPRs.  M = 96 (round 5, the last A/B of the round,
+    // profiles/r05zd_ab_rot_depth.txt): TWO 1.5 KiB blocks = 48 KiB in flight per CU scan 1.5 % faster than four (2.440 against 2.476-2.478 ms,
+    // interleaved on one box; ONE block: 3.13 ms) — the IVF-Flat row streams said the same: past what covers the latency, bytes in flight cost
+    constexpr int RD = (NF >= 2 || BB >= 1536) ? 2 : ROT_D;
     constexpr int NPH = NF + NH + NQ;          // phases = table planes
     constexpr int TAB = NPH * 65536;           // plane p at p * 64 KiB; row = code * 256; a half phase uses 128 B of the row
     constexpr int NG = NQ ? 16 : M / 4;        // gathers per lane per block
