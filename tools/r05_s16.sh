@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 GPU session 16: prefetch wave in k_list_scan2 (measure build switches): IVF-Flat 20M at nlist 2048 / nprobe 128 (64-query groups) and nlist 4096 / nprobe 32 (16-query groups)
+# (historical: the measure-build switches this session drove were removed with the experiment it measured; results: profiles/r05_ivfflat_wide.md)
 set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 GPU session 17: IVF-Flat 20M, nlist 2048 / nprobe 128: 64-query groups (8 waves x 3 stages) against 32-query groups in the 8-wave form with 6 stages (measure build, RSX_LS2_FORM)
+# (historical: the measure-build switches this session drove were removed with the experiment it measured; results: profiles/r05_ivfflat_wide.md)
 set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 GPU session 19: k_list_scan3 ring depth / early issue (measure build), and the queries-per-group thresholds of the IVF-Flat scan
+# (historical: the measure-build switches this session drove were removed with the experiment it measured; results: profiles/r05_ivfflat_wide.md)
 set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

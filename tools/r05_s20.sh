@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 GPU session 20: IVF tests on the new group-size selection; k_list_scan3 K-step stages (D = 3 / 4) against whole-row stages (ROWS, D = 3 / 4 / 5)
+# (historical: the measure-build switches this session drove were removed with the experiment it measured; results: profiles/r05_ivfflat_wide.md)
 set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

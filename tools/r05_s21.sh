@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 GPU session 21: ring depth of k_list_scan2's 16-query form (6 -> 4 / 3: three workgroups per CU) and of the 64-query form (3 -> 2)
+# (historical: the measure-build switches this session drove were removed with the experiment it measured; results: profiles/r05_ivfflat_wide.md)
 set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

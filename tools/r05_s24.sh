@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 GPU session 24: k_list_scan3 with KS K steps per stage (= per barrier) and D stages: (4,1) default, (3,2) (4,2) (3,3) (2,4) (2,2) (2,3)
+# (historical: the measure-build switches this session drove were removed with the experiment it measured; results: profiles/r05_ivfflat_wide.md)
 set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 GPU session 27: code blocks in flight per wave of k_pq_scan_rot (ROT_DEPTH 4 = shipped, 2, 1; variant libraries built beside the product's), headline only
+# (historical: librsx_depth1/2.so were variant builds of k_pq_rot.hip with -DROT_DEPTH=1/2; depth 2 at M = 96 became the product's setting)
 set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
