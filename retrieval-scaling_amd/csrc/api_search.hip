@@ -511,7 +511,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 h->w_itemdesc.ensure(pq_scan_rot_ws(items * ngq, rot_log_cap, nwg));
                 return h->w_itemdesc.p;
             };
-            const int ngq = rot ? pq_scan_rot_ngq(h->M, true) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
+            const int ngq = rot ? pq_scan_rot_ngq(h->M, true, h->pq_q8) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             // rotated layout: persistent workgroups draw items dynamically, so the tile is the whole (average) list — one table
             // staging per (list, query group) — as long as that leaves a few thousand items to balance over 256 CUs
@@ -677,7 +677,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                                  mi_main, vpl, tau_ptr, tau_stride,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
                                                  rws1, rot_log_cap, h->pq_prune, (h->pq_pace & 0xffff), (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
-                                                 use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st)
+                                                 use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st, h->pq_q8)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
                                                      max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,

@@ -73,6 +73,10 @@ __device__ __forceinline__ uint32_t lds_rd32(uint32_t addr) {
     // raw LDS address: the kernels below declare no static LDS, so the dynamic segment starts at 0
     return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)addr);
 }
+typedef unsigned int rot_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rot_v2u lds_rd64(uint32_t addr) {      // ds_read_b64: 2 LDS cycles per wave, bank = (addr / 4) % 64
+    return *reinterpret_cast<const __attribute__((address_space(3))) rot_v2u*>((uintptr_t)addr);
+}
 
 // registers of rotation bytes a phase needs: plane 0 packs 4 per dword, planes >= 1 pack 3 + the plane byte
 __host__ __device__ constexpr int rot_nreg(int plane, int steps) { return plane == 0 ? steps / 4 : (steps + 2) / 3; }
@@ -184,7 +188,14 @@ extern "C" int rsx_debug_rot_wave(uint32_t* out, int n_items) {
 #endif
 
 // NQ = 1: M = 16 (NF = NH = 0): 64-vector blocks, lane (g, i) = vector 16 g + i, every MFMA column used (column 4 g + q = vector group g, query q)
-template <int NF, int NH, bool FILTER, int NQ = 0>
+// G = 2 (round 6, M = 64, filtered): EIGHT queries per pass over a list tile.  A work item carries two 4-query records (k_pq_rot_items,
+// ngq = 2) and a table entry is 8 bytes — the eight queries' int8 values of one (code, m) — fetched by ONE ds_read_b64: 2 LDS cycles
+// per wave like the ds_read_b32 of the 4-query form (256 B/clk against 128), one v_perm for the address, so the look-up side costs
+// the same per (vector, sub-quantiser) for twice the queries; only the MFMA count doubles (two gathers fill an A operand instead of
+// four).  Table image: [h = m >> 5][code][m & 31] x 8 B = two 64 KiB halves with 256-byte rows; lane (g, i) looks up
+// m = 16 g + ((i + s) & 15), i.e. half h = g >> 1 (a per-lane constant that rides in the rotation registers' fourth byte) and
+// slot 16 (g & 1) + ((i + s) & 15): the 32 lanes of a half-wave read 32 different 8-byte slots of their rows = all 64 banks once.
+template <int NF, int NH, bool FILTER, int NQ = 0, int G = 1>
 __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ log_keys,
                                                       uint2* __restrict__ seg_desc, uint32_t* xcd_ctr, uint32_t* prog, int log_cap, int bpw, int pace_arg, int var_arg) {
 #ifdef RSX_MEASURE
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 #else
     constexpr int var = 0;          // the shipped library has no measurement branches
 #endif
+    static_assert(G == 1 || (G == 2 && NF == 1 && NH == 0 && NQ == 0 && FILTER), "the 8-query form exists for the filtered M = 64 scan");
     constexpr int M = 64 * NF + 32 * NH + 16 * NQ;
     constexpr int BV = NQ ? 64 : 16;           // vectors per code block
     constexpr int BB = NQ ? 1024 : 16 * M;     // bytes per code block
@@ -200,16 +212,17 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     // profiles/r05zd_ab_rot_depth.txt): TWO 1.5 KiB blocks = 48 KiB in flight per CU scan 1.5 % faster than four (2.440 against 2.476-2.478 ms,
     // interleaved on one box; ONE block: 3.13 ms) — the IVF-Flat row streams said the same: past what covers the latency, bytes in flight cost
     constexpr int RD = (NF >= 2 || BB >= 1536) ? 2 : ROT_D;
-    constexpr int NPH = NF + NH + NQ;          // phases = table planes
+    constexpr int NPH = G == 2 ? 2 : NF + NH + NQ;     // phases = table planes (G = 2: the two halves m < 32, m >= 32 of the 8-byte-entry table)
     constexpr int TAB = NPH * 65536;           // plane p at p * 64 KiB; row = code * 256; a half phase uses 128 B of the row
+    constexpr int ISZ = 2 * G * 176;           // current / next item: G records each
     constexpr int NG = NQ ? 16 : M / 4;        // gathers per lane per block
-    constexpr int NR1 = NPH > 1 ? rot_nreg(1, NF >= 2 ? 16 : 8) : 0;
-    constexpr int NR0 = (NF >= 1 || NQ) ? 4 : rot_nreg(0, 8);     // M = 32: the half phase IS plane 0
+    constexpr int NR1 = G == 2 ? 6 : NPH > 1 ? rot_nreg(1, NF >= 2 ? 16 : 8) : 0;      // G = 2: all 16 steps as three rotation bytes + the half byte
+    constexpr int NR0 = G == 2 ? 0 : (NF >= 1 || NQ) ? 4 : rot_nreg(0, 8);     // M = 32: the half phase IS plane 0
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) uint32_t rot_s[];
     uint8_t* sb = reinterpret_cast<uint8_t*>(rot_s);
-    PQRotItem* islot = reinterpret_cast<PQRotItem*>(sb + TAB);                  // [2] current / next item record
+    PQRotItem* islot = reinterpret_cast<PQRotItem*>(sb + TAB);                  // [2][G] current / next item's records
 
     const PQScanArgs& a = A.b;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -262,19 +275,23 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     }
 #pragma unroll
     for (int r = 0; r < NR1; r++) {
-        uint32_t v = 0x01000000u;     // byte 3 = plane 1 -> address bit 16
+        uint32_t v = G == 2 ? (uint32_t)(g >> 1) << 24 : 0x01000000u;     // byte 3 = plane 1 (G = 2: the lane's table half) -> address bit 16
 #pragma unroll
         for (int bb = 0; bb < 3; bb++) {
             const int s = r * 3 + bb;
-            const uint32_t rot = NF >= 2 ? (uint32_t)(64 * g + 4 * ((i + s) & 15))
+            const uint32_t rot = G == 2 ? (uint32_t)(128 * (g & 1) + 8 * ((i + s) & 15))                   // 8-byte slots: 16 (g & 1) + ((i + s) & 15)
+                               : NF >= 2 ? (uint32_t)(64 * g + 4 * ((i + s) & 15))
                                          : (uint32_t)(64 * (g & 1) + 4 * ((i + s + 8 * (g >> 1)) & 15));
             v |= (rot & 255u) << (8 * bb);
         }
         R1[r] = v;
     }
-    // B one-hot: K index 16 gK + 4 j + byte; column n picks byte n of every K group (n < 4) — or, M = 16, byte n & 3 of K group n >> 2 only
+    // B one-hot: K index 16 gK + 4 j + byte; column n picks byte n of every K group (n < 4) — or, M = 16, byte n & 3 of K group n >> 2 only.
+    // G = 2: an A operand is two 8-byte gathers, dwords j = 0, 2 hold queries 0-3 and j = 1, 3 queries 4-7: column n < 8 picks byte n & 3 of
+    // the dwords with j & 1 == n >> 2
     const int bsel = NQ ? (((n >> 2) == g) ? (1 << (8 * (n & 3))) : 0) : (n < 4 ? (1 << (8 * n)) : 0);
-    const v4i Bm = {bsel, bsel, bsel, bsel};
+    const int bsel_hi = G == 2 ? ((n >= 4 && n < 8) ? (1 << (8 * (n & 3))) : 0) : bsel;
+    const v4i Bm = {bsel, bsel_hi, bsel, bsel_hi};
     const int vo16 = lane * 16, vo8 = lane * 8;
     // Survivors leave the scan with PLAIN stores into WAVE-PRIVATE LOGS (round 4): every (workgroup, wave, query slot) owns one
     // append-only log of log_cap keys in HBM for the whole launch; the survivors of an item's query k go to the end of the wave's
@@ -288,9 +305,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
     // LDS pipe, and a returning global atomic sits in the wave's in-order vmcnt queue in front of the next item's table loads
     // (measured: 0.6 ms of a 3.8 ms scan for 1.9 M survivors).
     const uint64_t QM = NQ ? (0x1111111111111111ull << (n & 3))         // M = 16: every lane with n & 3 == query
-                           : (n < 4 ? (0x0001000100010001ull << n) : 0ull);   // the four lanes that own query n
+                           : (n < 4 * G ? (0x0001000100010001ull << n) : 0ull);   // the four lanes that own query n (G = 2: n = 4 record + slot)
+    const int rq = G == 2 ? (n >> 2) & 1 : 0;                                // the record of the item this lane's query column belongs to
 
-    const size_t mylog_i = ((size_t)blockIdx.x * 16 + (size_t)w) * 4 + (size_t)nq4;     // this lane's log (query slot nq4 of this wave)
+    const size_t mylog_i = ((size_t)blockIdx.x * 16 + (size_t)w) * (4 * G) + (size_t)(4 * rq + nq4);     // this lane's log (record rq, query slot nq4 of this wave)
     uint64_t* const mylog = log_keys + mylog_i * (size_t)log_cap;
     uint32_t lcur = 0;                    // keys appended to the lane's log so far (equal in all lanes of a query slot); persists across items
     int item = 0;
@@ -298,15 +316,15 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         if (lane == 0) { drawn = atomicAdd(ctr, 1u); }
         item = resolve_draw();
         uint4 r0 = make_uint4(0xffffffffu, 0, 0, 0);       // l = -1: end marker
-        if (lane < 11 && item != 0x7fffffff) r0 = reinterpret_cast<const uint4*>(&items[item])[lane];
-        if (lane < 11) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
+        if (lane < 11 * G && item != 0x7fffffff) r0 = reinterpret_cast<const uint4*>(&items[(size_t)item * G])[lane];
+        if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
         if (lane == 0) islot[0].pad0 = item;
     }
     int buf = 0;
 #pragma unroll 1
     for (;; buf ^= 1) {
         __syncthreads();    // #1: every wave has left the previous item's scan (table free), the item record is in LDS
-        const PQRotItem* it = &islot[buf];
+        const PQRotItem* it = &islot[buf * G];
         const int item_l = __builtin_amdgcn_readfirstlane(it->l);
         if (item_l == -1) break;
         item = __builtin_amdgcn_readfirstlane(it->pad0);
@@ -344,9 +362,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             if (a0 > f1 - 8) a0 = f1 - 8;
             f0 = a0; f1 = a0 + 8;
         }
-        constexpr uint32_t chunk_a = (uint32_t)(TAB + 2 * 176);                    // LDS word: next unassigned chunk sequence number
-        constexpr uint32_t i0_a = (uint32_t)(TAB + 2 * 176 + 4);                   // LDS word: the item's first loop iteration (join)
-        constexpr uint32_t sib_a = (uint32_t)(TAB + 384);                          // LDS [8]: the siblings' progress as last seen
+        constexpr uint32_t chunk_a = (uint32_t)(TAB + ISZ);                        // LDS word: next unassigned chunk sequence number
+        constexpr uint32_t i0_a = (uint32_t)(TAB + ISZ + 4);                       // LDS word: the item's first loop iteration (join)
+        constexpr uint32_t sib_a = (uint32_t)(TAB + ((ISZ + 8 + 31) & ~31));       // LDS [8]: the siblings' progress as last seen (G = 1: TAB + 384)
         const bool family = join_on && !skip_item && f1 - f0 > 1 && item >= f0 && item < f1;
         if (w == 0) {
             if (lane < 8) lds_wr32(sib_a + 4u * (uint32_t)lane, 0x7fffffffu);       // own slot and the lanes beyond the family never count
@@ -355,7 +373,45 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         // ---- stage the group's table: work unit = (code, 4 consecutive m) -> 4 dwords (one per m: byte k = query k, as int8 = u8 - 128).
         // All the loads of a thread's 256 * (M / 4) / 1024 units are issued before the first one is used (round 3: the loop
         // used to pay one L2 round trip per unit, 6 in a row for M = 96).
-        {
+        if constexpr (G == 2) {
+            // eight queries: unit = (code, 4 consecutive m) -> the eight queries' dwords -> four 8-byte entries (bytes 0-3: record 0's
+            // queries, 4-7: record 1's), 32 contiguous bytes of the code's row in half m >> 5
+            const PQRotItem* itb = &islot[buf * G + 1];
+            const int npb = __builtin_amdgcn_readfirstlane(itb->np) & 15;
+            const int64_t qq[8] = {it->q[0], it->q[1], it->q[2], it->q[3], itb->q[0], itb->q[1], itb->q[2], itb->q[3]};
+            constexpr int NU = 256 * (M / 4) / 1024;              // 4
+            uint32_t in[NU][8];
+            const bool live = !((var & 4) || skip_item);
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int e = tid + u * 1024;
+                const int c = e / (M / 4), m4 = e - c * (M / 4);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    in[u][k] = (live && (k < 4 ? k < np : k - 4 < npb)) ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (qq[k] * 256 + c) * M + m4 * 4)) : 0u;
+            }
+            if (live) {
+#pragma unroll
+                for (int u = 0; u < NU; u++) {
+                    const int e = tid + u * 1024;
+                    const int c = e / (M / 4), m4 = e - c * (M / 4);
+                    uint32_t o[2][4];
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const uint32_t a0 = in[u][4 * hh], a1 = in[u][4 * hh + 1], a2 = in[u][4 * hh + 2], a3 = in[u][4 * hh + 3];
+                        const uint32_t t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+                        const uint32_t u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                        o[hh][0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
+                        o[hh][1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u) ^ 0x80808080u;
+                        o[hh][2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u) ^ 0x80808080u;
+                        o[hh][3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u) ^ 0x80808080u;
+                    }
+                    uint8_t* dst = sb + (m4 >> 3) * 65536 + c * 256 + (m4 & 7) * 32;
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(o[0][0], o[1][0], o[0][1], o[1][1]);
+                    *reinterpret_cast<uint4*>(dst + 16) = make_uint4(o[0][2], o[1][2], o[0][3], o[1][3]);
+                }
+            }
+        } else {
             const int64_t q0 = it->q[0], q1 = it->q[1], q2 = it->q[2], q3 = it->q[3];
             constexpr int NU = (256 * (M / 4) + 1023) / 1024;
             const int nunits = ((var & 4) || skip_item) ? 0 : 256 * (M / 4);
@@ -445,7 +501,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             if (lane == 0) { lds_wr32(i0_a, i0v); lds_wr32(chunk_a, (uint32_t)dyn_from); }
         }
         // ---- the lane's share of the item record: accumulator init, score parameters of the query it owns (n < 4)
-        const int cinit = FILTER ? ((NQ || n < 4) ? it->cinit[nq4] : -(1 << 30)) : 0;
+        const PQRotItem* itq = &islot[buf * G + rq];        // the record of this lane's query column
+        const int cinit = FILTER ? ((NQ || n < 4 * G) ? itq->cinit[nq4] : -(1 << 30)) : 0;
         const v4i Ci = {cinit, cinit, cinit, cinit};
         // (the score parameters of the lane's query are read from the item record in LDS where a survivor is scored — rare — instead
         //  of living in ~9 VGPRs through the gather loop: the M = 16 form runs two workgroups per CU on 64 VGPRs)
@@ -535,7 +592,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 }
                 if (dstate == 1 && nA >= nch - 16) {
                     i1 = resolve_draw();
-                    if (lane < 11 && i1 != 0x7fffffff) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
+                    if (lane < 11 * G && i1 != 0x7fffffff) pre = reinterpret_cast<const uint4*>(&items[(size_t)i1 * G])[lane];
                     dstate = 2;
                 }
                 if (dstate == 0 && nA >= nch - 48) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }
@@ -545,7 +602,12 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                 const int b = b0 + 16 * dd;
                 uint32_t gv[NG];
                 // addresses: (plane << 16) | (code << 8) | rotation byte — one v_perm each
-                if (NF >= 1 || NQ) {
+                if constexpr (G == 2) {
+                    const uint32_t cw[4] = {ca[dd][0].x, ca[dd][0].y, ca[dd][0].z, ca[dd][0].w};
+#pragma unroll
+                    for (int s = 0; s < 16; s++)
+                        gv[s] = __builtin_amdgcn_perm(cw[s >> 2], R1[s / 3], 0x0c030000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s % 3));
+                } else if (NF >= 1 || NQ) {
                     const uint32_t cw[4] = {ca[dd][0].x, ca[dd][0].y, ca[dd][0].z, ca[dd][0].w};
 #pragma unroll
                     for (int s = 0; s < 16; s++)
@@ -575,6 +637,17 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                     if (NH) cb[dd] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo8 + NF * 1024, so, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                v4i C = Ci;
+                if constexpr (G == 2) {
+                    rot_v2u g8[NG];
+#pragma unroll
+                    for (int s = 0; s < NG; s++) g8[s] = lds_rd64(gv[s]);
+#pragma unroll
+                    for (int t = 0; t < NG / 2; t++) {
+                        const v4i Av = {(int)g8[2 * t].x, (int)g8[2 * t].y, (int)g8[2 * t + 1].x, (int)g8[2 * t + 1].y};
+                        C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
+                    }
+                } else {
 #ifdef RSX_MEASURE
                 // cost split (tools/ builds only): 16 = no table look-ups (the addresses stand in for the data), 32 = no MFMAs (one VALU
                 // add per quad instead), 64 = no address formation (the code words stand in for the addresses, masked into the table)
@@ -586,7 +659,6 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 #pragma unroll
                     for (int s = 0; s < NG; s++) gv[s] = lds_rd32(gv[s]);
                 }
-                v4i C = Ci;
                 if (var & 32) {
 #pragma unroll
                     for (int t = 0; t < NG / 4; t++) C[t & 3] += (int)(gv[4 * t] ^ gv[4 * t + 1] ^ gv[4 * t + 2] ^ gv[4 * t + 3]) >> 31;
@@ -600,13 +672,13 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
 #else
 #pragma unroll
                 for (int s = 0; s < NG; s++) gv[s] = lds_rd32(gv[s]);
-                v4i C = Ci;
 #pragma unroll
                 for (int t = 0; t < NG / 4; t++) {
                     const v4i Av = {(int)gv[4 * t], (int)gv[4 * t + 1], (int)gv[4 * t + 2], (int)gv[4 * t + 3]};
                     C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
                 }
 #endif
+                }
                 // C[r] (lanes n < 4) = cinit + sum over m of (u8 - 128) for vector 4 g + r of the block and query n
                 if (FILTER) {
                     if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0) && !(var & 1)) {
@@ -614,9 +686,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
                         for (int r = 0; r < 4; r++) {
                             const bool cnd = C[r] >= 0;
                             if (__builtin_amdgcn_ballot_w64(cnd)) {
-                                const float p_dis0 = it->dis0[nq4], p_scale = it->scale[nq4], p_bias = it->bias[nq4];
-                                const int64_t p_off = it->off[nq4];
-                                const uint64_t p_tau = it->tau[nq4];
+                                const float p_dis0 = itq->dis0[nq4], p_scale = itq->scale[nq4], p_bias = itq->bias[nq4];
+                                const int64_t p_off = itq->off[nq4];
+                                const uint64_t p_tau = itq->tau[nq4];
                                 const int64_t pos = NQ ? ((int64_t)b << 6) + 16 * (n >> 2) + 4 * g + r : ((int64_t)b << 4) + 4 * g + r;
                                 const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(C[r] - cinit + 128 * M), p_bias);
                                 const uint64_t key = (cnd && pos < len && b - tb0 < 16 * bpw) ? make_key(sc, (uint32_t)p_off + (uint32_t)pos) : 0ull;
@@ -649,9 +721,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
         // run in the log pool, keys stored, bit 31 = the log was full and keys were dropped; wave 0 parks the next record (or the
         // end marker) and draws the index of the item after it
         __builtin_amdgcn_s_setprio(0);
-        if (FILTER && lane < 4) {
+        if (FILTER && lane < 4 * G) {      // lane = 4 record + slot = its own query column n (g = 0)
             const uint32_t c0 = qstart < (uint32_t)log_cap ? qstart : (uint32_t)log_cap, c1 = lcur < (uint32_t)log_cap ? lcur : (uint32_t)log_cap;
-            seg_desc[((size_t)item * 16 + w) * 4 + lane] = make_uint2((uint32_t)(mylog_i * (size_t)log_cap) + c0, (c1 - c0) | ((lcur > (uint32_t)log_cap && lcur > qstart) ? 0x80000000u : 0u));   // only a run that itself lost keys is flagged
+            seg_desc[(((size_t)item * G + (size_t)(lane >> 2)) * 16 + w) * 4 + (lane & 3)] = make_uint2((uint32_t)(mylog_i * (size_t)log_cap) + c0, (c1 - c0) | ((lcur > (uint32_t)log_cap && lcur > qstart) ? 0x80000000u : 0u));   // only a run that itself lost keys is flagged
         }
 #ifdef RSX_MEASURE
         if (lane == 0 && item < 16384) g_rot_wave[16 * item + w] = (uint32_t)(wall_clock64() - t_scan0);
@@ -663,10 +735,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot(PQScan8Args A, const PQRot
             if (dstate == 0) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }     // empty / pruned / one-iteration items
             if (dstate == 1) {
                 i1 = resolve_draw();
-                if (lane < 11 && i1 != 0x7fffffff) pre = reinterpret_cast<const uint4*>(&items[i1])[lane];
+                if (lane < 11 * G && i1 != 0x7fffffff) pre = reinterpret_cast<const uint4*>(&items[(size_t)i1 * G])[lane];
             }
-            if (lane < 11) reinterpret_cast<uint4*>(&islot[buf ^ 1])[lane] = pre;
-            if (lane == 0) islot[buf ^ 1].pad0 = i1;
+            if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[(buf ^ 1) * G])[lane] = pre;
+            if (lane == 0) islot[(buf ^ 1) * G].pad0 = i1;
         }
     }
 }
@@ -985,37 +1057,41 @@ int pq_scan_rot_max_wgs(int M) {
     return (ncu + 7) & ~7;
 }
 
-template <int NF, int NH, bool FILTER, int NQ = 0>
+// G = records per work item (2: the 8-query form); A.max_items counts WORK ITEMS, the workspace holds G records each
+template <int NF, int NH, bool FILTER, int NQ = 0, int G = 1>
 static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, int log_cap, hipStream_t st) {
     constexpr int M = 64 * NF + 32 * NH + 16 * NQ;
-    const size_t shm = (size_t)(NF + NH + NQ) * 65536 + 384 + 256;   // tables | 2 item records (176 B each) + pacing word | sibling progress [64]
+    // tables | 2 x G item records (176 B each) + pacing words | sibling progress [64]
+    const size_t shm = (size_t)(G == 2 ? 2 : NF + NH + NQ) * 65536 + (size_t)((2 * G * 176 + 8 + 31) & ~31) + 256;
     static DevOnce once;
     static std::atomic<int> failed{0};
     once.once([&] {
-        if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) failed = 1;
+        if (hipFuncSetAttribute((const void*)k_pq_scan_rot<NF, NH, FILTER, NQ, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) failed = 1;
     });
     if (failed) return -1;
     const int nwg = pq_scan_rot_max_wgs(M);
+    const int64_t recs = (int64_t)A.max_items * G;
     PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
-    uint2* seg_desc = pq_scan_rot_ws_desc(desc_ws, A.max_items);
-    uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, A.max_items);
-    uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, A.max_items, log_cap, nwg);
+    uint2* seg_desc = pq_scan_rot_ws_desc(desc_ws, recs);
+    uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, recs);
+    uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
     uint32_t* prog = xcd_ctr + 256;
-    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, 1);
+    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
     static const int var = measure_env("RSX_ROT_VARIANT", 0);
     // one persistent workgroup per CU; never more than the work items
     int64_t grid = nwg;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
-    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER, NQ>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, prog,
+    hipLaunchKernelGGL((k_pq_scan_rot<NF, NH, FILTER, NQ, G>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, prog,
                        log_cap, bpw, A.pace, var);
     if (FILTER && !A.qitems)     // with qitems the runs are consumed in place by k_pq_gather_select
-        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, 1, log_keys, seg_desc,
+        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((recs + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, G, log_keys, seg_desc,
                            A.cand, A.cand_cnt, A.cand_cap);
     return 0;
 }
 
-// M = 16, filtered: sixteen queries per work item (k_pq_scan_rot16); A.max_items counts WORK ITEMS, the workspace holds R16_G records each
-int pq_scan_rot_ngq(int M, bool filtered) { return (M == 16 && filtered) ? R16_G : 1; }
+// 4-query records per work item of the filtered scan: M = 16: sixteen queries (k_pq_scan_rot16); M = 64 with the 8-byte-entry table
+// (q8): eight (k_pq_scan_rot<1, 0, true, 0, 2>)
+int pq_scan_rot_ngq(int M, bool filtered, int q8) { return !filtered ? 1 : M == 16 ? R16_G : (M == 64 && q8) ? 2 : 1; }
 static int launch_pq_scan_rot16(const PQScan8Args& A, int bpw, void* desc_ws, int log_cap, hipStream_t st) {
     constexpr int G = R16_G;
     const size_t shm = (size_t)2 * 65536 + (size_t)2 * G * 176 + 64;
@@ -1048,7 +1124,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
                        int cand_cap, void* item_ws, int log_cap, int prune, int pace, const uint16_t* excl, int32_t* qitems,
-                       int qitems_tmax, hipStream_t st) {
+                       int qitems_tmax, hipStream_t st, int q8) {
     if (a.CB != 0 || !item_ws || log_cap <= 0 || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
     PQScan8Args A;
     A.b = a; A.lut8 = lut8t; A.qp = (const PQQParam*)qparam;
@@ -1062,7 +1138,8 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     switch (a.M) {
         case 16: return f ? launch_pq_scan_rot16(A, vpl, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, log_cap, st);   // 64-vector blocks
         case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, log_cap, st);
-        case 64: return f ? launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, log_cap, st);
+        case 64: return f ? (q8 ? launch_pq_scan_rot_t<1, 0, true, 0, 2>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 0, true>(A, bpw, item_ws, log_cap, st))
+                          : launch_pq_scan_rot_t<1, 0, false>(A, bpw, item_ws, log_cap, st);
         case 96: return f ? launch_pq_scan_rot_t<1, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<1, 1, false>(A, bpw, item_ws, log_cap, st);
         case 128: return f ? launch_pq_scan_rot_t<2, 0, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<2, 0, false>(A, bpw, item_ws, log_cap, st);
         default: return -1;

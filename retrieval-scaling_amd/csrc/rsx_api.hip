@@ -405,6 +405,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_fast_kp") h->pq_fast_kp = std::min(4096, std::max(0, (int)value));     // k_finalize sorts K' <= 4096 candidates in LDS
         else if (s == "pq_filter") h->pq_filter = (int)value;
         else if (s == "pq_prune") h->pq_prune = (int)value;
+        else if (s == "pq_q8") h->pq_q8 = (int)value;
         else if (s == "pq_pace") h->pq_pace = std::max(0, (int)value);
         else if (s == "add_list_mod" || s == "add_list_rem") {
             if (h->kind == KIND_FLAT) RSX_THROW(RSX_ERR_UNSUPPORTED, "%s: IVF indexes only", key);

@@ -193,6 +193,7 @@ struct rsx_index {
                           // lines), bits 8-11 = join offset in tile rows (0 = 2), bits 12-15 = the last n rows of a tile are handed to
                           // the waves dynamically (default 4; 0 = static columns), bit 4 = every chunk dynamic, bit 6 = no issue-
                           // priority rotation
+    int pq_q8 = 1;        // rotated fast scan, M = 64: eight queries per table gather (8-byte entries, ds_read_b64; k_pq_scan_rot<..., 2>) — 0 = the 4-query form
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)

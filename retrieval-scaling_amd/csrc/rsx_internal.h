@@ -301,12 +301,12 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
                        int cand_cap, void* item_ws /* pq_scan_rot_ws(max_items, log_cap, pq_scan_rot_max_wgs(M)) bytes */, int log_cap, int prune, int pace,
                        const uint16_t* excl, int32_t* qitems /* non-null: fill it and leave the runs for k_pq_gather_select */,
-                       int qitems_tmax, hipStream_t st);
+                       int qitems_tmax, hipStream_t st, int q8 = 0 /* filtered M = 64: eight queries per work item (pq_scan_rot_ngq) */);
 // Survivors of the filtered scan (round 4): every (persistent workgroup, wave, query slot) appends to its own LOG of log_cap keys;
 // an 8-byte descriptor per (item, wave, slot) = {index of the run's first key in the log pool, keys stored | bit 31: keys were
 // dropped because the log was full} lets the gather / compaction kernels find an item's runs.
 int pq_scan_rot_max_wgs(int M);     // persistent workgroups of the scan on the current device
-int pq_scan_rot_ngq(int M, bool filtered);   // 4-query records per work item: 1, or 4 for the filtered M = 16 scan (group the pairs by 4 x this;
+int pq_scan_rot_ngq(int M, bool filtered, int q8);   // 4-query records per work item: 1, 2 (M = 64, q8) or 4 for the filtered M = 16 scan (group the pairs by 4 x this;
                                              // size the workspace for max_items x this records and workgroups x this x 64 logs)
 inline size_t pq_scan_rot_ws(int64_t max_items, int log_cap, int nwg) {   // item records + run descriptors + logs + per-XCD counters + progress words
     return (size_t)(max_items + 8) * (176 + 512 + 4) + (size_t)nwg * 64 * (size_t)log_cap * 8 + 1024;

@@ -1,12 +1,16 @@
-"""Offline dense-search driver and multi-shard merge (mirror of reference src/search.py:126-183,
-213-373,810-831 — SURVEY §8 rows a6, a7).
+"""Offline dense-search driver and multi-shard merge (mirror of reference src/search.py:48-108, 126-183,
+213-373, 810-831 — SURVEY §8 rows a6, a7).
 
-What is kept: one `Indexer(cfg).search(all_query_embeddings, n_docs)` call per index, the
-`ctxs` record layout, output paths, skip-if-exists / overwrite, `safe_write_jsonl`, and the merge
-semantics (running concat, stable sort by float(score) descending, cut to n_docs).
-What is not here: query-encoder loading (stays on stock PyTorch-ROCm; pass `query_encoder_fn` or
-pre-computed `questions_embedding`), multi-domain merge / MinHash dedup / BM25 (text
-post-processing, out of scope).
+What is kept: `search_topk(cfg)` exactly as `ric/main_ric.py:27-29` calls it, one
+`Indexer(cfg).search(all_query_embeddings, n_docs)` call per index, the `ctxs` record layout, output paths,
+skip-if-exists / overwrite, the query-embedding cache, `safe_write_jsonl`, and the merge semantics (running concat,
+stable sort by float(score) descending, cut to n_docs).
+The query encoder stays on stock PyTorch-ROCm: `load_query_encoder` / `embed_queries` follow the reference's dispatch on
+the model name and import the host application's packages (`contriever`, `transformers`, `sentence_transformers`,
+`gritlm`) and its `src.data.load_eval_data` only when they are needed — this file replaces the reference's
+`src/search.py` inside the reference tree, where those modules live; outside it the missing module is named in the error.
+`data=`, `questions_embedding=` and `query_encoder_fn=` remain as optional injections (tests, serving, other encoders).
+What is not here: multi-domain merge / MinHash dedup / BM25 (text post-processing, out of scope).
 """
 import copy
 import json
@@ -121,12 +125,102 @@ def post_hoc_merge_topk(cfg):
     return output_path
 
 
-def search_dense_topk(cfg, data=None, questions_embedding=None, query_encoder_fn=None):
-    """reference src/search.py:213-309.
+def _host_module(name, why):
+    """Import a module of the host application (the reference tree) on first use; name it clearly when it is absent."""
+    import importlib
+    try:
+        return importlib.import_module(name)
+    except ImportError as e:
+        raise ImportError(f"search_topk(cfg) needs `{name}` ({why}); it is part of the host application "
+                          f"(RulinShao/retrieval-scaling) and is imported only when no `data=` / `query_encoder_fn=` / "
+                          f"`questions_embedding=` is passed: {e}") from e
 
-    data: list of eval examples with "raw_query" (reference: load_eval_data(cfg)).
-    questions_embedding: [n_valid_queries, d] array, or None to call query_encoder_fn(queries)
-    (the reference loads a HF encoder here; that stage is unchanged PyTorch and is injected).
+
+def _device():
+    import torch
+    return "cuda" if torch.cuda.is_available() else "cpu"
+
+
+def load_query_encoder(cfg):
+    """(encoder, tokenizer, model_name) for cfg.model.query_encoder — the reference's dispatch (src/search.py:236-262):
+    contriever / dragon, drama (HF AutoModel) / sentence-transformers, e5, Qwen3 / ReasonIR, GRIT; eval mode, on the GPU,
+    half precision unless cfg.datastore.index.no_fp16."""
+    name = cfg.model.query_encoder
+    tok_name = cfg_get(cfg.model, "query_tokenizer", name)
+    logging.info(f"Loading model from: {name}")
+    tokenizer = None
+    if "contriever" in name:
+        encoder, tokenizer, _ = _host_module("contriever.src.contriever", "Contriever query encoder").load_retriever(name)
+    elif "dragon" in name or "drama" in name:
+        tf = _host_module("transformers", "HF query encoder")
+        tokenizer = tf.AutoTokenizer.from_pretrained(tok_name)
+        encoder = tf.AutoModel.from_pretrained(name, trust_remote_code=True)
+    elif "sentence-transformers" in name or "e5" in name or "Qwen3" in name:
+        encoder = _host_module("sentence_transformers", "SentenceTransformer query encoder").SentenceTransformer(name)
+    elif "ReasonIR" in name or "GRIT" in name:
+        encoder = _host_module("gritlm", "GritLM query encoder").GritLM(name, torch_dtype="auto", mode="embedding")
+    else:
+        print(f"{name} is not supported!")
+        raise AttributeError(name)
+    encoder.eval()
+    encoder = encoder.to(_device())
+    if not cfg_get(cfg.datastore.index, "no_fp16", False):
+        encoder = encoder.half()
+    return encoder, tokenizer, name
+
+
+def embed_queries(args, queries, model, tokenizer, model_name_or_path):
+    """reference src/search.py:48-108: lowercase / normalise, encode in batches of per_gpu_batch_size, return
+    [n_queries, d] (numpy, as the reference; `args.keep_on_device` keeps the torch tensor in HBM for the engine —
+    SURVEY §8f row 4), and write the cache file when args.cache_query_embedding."""
+    import torch
+    norm = None
+    if cfg_get(args, "normalize_text", False):
+        norm = _host_module("contriever.src.normalize_text", "normalize_text=true").normalize
+    texts = []
+    for q in queries:
+        if cfg_get(args, "lowercase", False):
+            q = q.lower()
+        texts.append(norm(q) if norm else q)
+    bs = int(cfg_get(args, "per_gpu_batch_size", 64))
+    name = model_name_or_path
+    if "sentence-transformers" in name or "e5" in name or "Qwen3" in name:
+        kw = {"prompt_name": "query"} if "Qwen3" in name else {}
+        embeddings = model.encode(texts, batch_size=min(128, bs), **kw)
+    else:
+        model.eval()
+        dev = _device()
+        outs = []
+        with torch.no_grad():
+            for b0 in range(0, len(texts), bs):
+                batch = texts[b0:b0 + bs]
+                if "drama" in name:
+                    out = model.encode_queries(batch, batch, dim=768)
+                elif "ReasonIR" in name or "GRIT" in name:
+                    out = torch.as_tensor(model.encode(batch, instruction="", batch_size=bs))
+                else:
+                    enc = tokenizer.batch_encode_plus(batch, return_tensors="pt", padding=True, truncation=True,
+                                                      max_length=cfg_get(args, "question_maxlength", 512))
+                    out = model(**{k: v.to(dev) for k, v in enc.items()})
+                    if "contriever" not in name:
+                        out = out.last_hidden_state[:, 0, :]
+                outs.append(out)
+        embeddings = torch.cat([o.to(outs[0].device) for o in outs], dim=0) if outs else torch.zeros((0, 0))
+        if not (cfg_get(args, "keep_on_device", False) and embeddings.is_cuda):
+            embeddings = embeddings.cpu().numpy()
+    print(f"Questions embeddings shape: {tuple(embeddings.shape)}")
+    if cfg_get(args, "cache_query_embedding", False):
+        with open(args.query_embedding_save_path, "wb") as fout:
+            pkl.dump(embeddings.cpu().numpy() if hasattr(embeddings, "is_cuda") else embeddings, fout)
+    return embeddings
+
+
+def search_dense_topk(cfg, data=None, questions_embedding=None, query_encoder_fn=None):
+    """reference src/search.py:213-309, callable with `cfg` alone (ric/main_ric.py:27-29).
+
+    data: list of eval examples with "raw_query"; None -> the host application's `src.data.load_eval_data(cfg)` (:264).
+    questions_embedding: [n_valid_queries, d] array; None -> the cache file (:276-279), else `query_encoder_fn(queries)`
+    when given, else `load_query_encoder(cfg)` + `embed_queries(...)` (:236-281).
     """
     eval_args = cfg.evaluation
     groups = _shard_id_groups(cfg.datastore.index)
@@ -134,19 +228,24 @@ def search_dense_topk(cfg, data=None, questions_embedding=None, query_encoder_fn
     if all_exist and not eval_args.search.overwrite:
         logging.info("All search results exist, skipping searching.")
     else:
-        assert data is not None, "search_dense_topk needs the evaluation examples"
+        if data is None:
+            data = _host_module("src.data", "evaluation examples: load_eval_data(cfg)").load_eval_data(cfg)
         queries, valid_query_idx = [], []
         for idx, ex in enumerate(data):
             if ex["raw_query"]:
                 queries.append(ex["raw_query"])
                 valid_query_idx.append(idx)
+        logging.info(f"Searching for {len(queries)} queries from {len(data)} total evaluation samples...")
         cache = cfg_get(eval_args.search, "query_embedding_save_path", "")
         if questions_embedding is None and cfg_get(eval_args.search, "cache_query_embedding", False) and os.path.exists(cache):
+            logging.info(f"Loading query embeddings from {cache}")
             with open(cache, "rb") as fin:
                 questions_embedding = pkl.load(fin)
-        if questions_embedding is None:
-            assert query_encoder_fn is not None, "no query embeddings and no encoder given"
+        if questions_embedding is None and query_encoder_fn is not None:
             questions_embedding = query_encoder_fn(queries)
+        if questions_embedding is None:
+            encoder, tokenizer, name = load_query_encoder(cfg)
+            questions_embedding = embed_queries(eval_args.search, queries, encoder, tokenizer, name)
         if cfg_get(eval_args.search, "cache_query_embedding_only", False):
             return
         if not hasattr(questions_embedding, "is_cuda"):      # a CUDA tensor from the encoder goes to the engine as it is
@@ -169,6 +268,7 @@ def search_dense_topk(cfg, data=None, questions_embedding=None, query_encoder_fn
 
 
 def search_topk(cfg, **kw):
+    """reference src/search.py:827-831 — `search_topk(cfg)` is the whole call (ric/main_ric.py:29)."""
     if cfg_get(cfg.model, "sparse_retriever", None):
         raise NotImplementedError("BM25 search is outside the dense-retrieval path")
     return search_dense_topk(cfg, **kw)

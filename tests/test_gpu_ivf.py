@@ -785,3 +785,41 @@ def test_m64_ragged_groups_tiles_and_starved_logs(gpu):
         D1, I1 = ix.search(q[:5], k)            # a handful of queries: mostly one-query records
         assert_same_results(D1, I1, De[:5], Ie[:5], f"k={k}: five queries")
     ix.set_param("scan_chunk", 0); ix.set_param("pq_log_cap", 0)
+
+
+def test_ivfpq_eight_query_gathers_equal_the_exact_scan(gpu, orc):
+    """Round 6: M = 64 scans EIGHT queries per table gather (8-byte entries, ds_read_b64; work items of two 4-query records).
+    Ragged groups (1 .. 8 queries per list group), several tiles per list, both candidate paths (gather + select in one launch,
+    compaction), starved survivor logs: always the bits of the exact scan and of the 4-query form."""
+    d, n, nlist, M = 512, 70000, 12, 64
+    x = gpu.synth_vectors(d, 12, 1234, 10000, 0.5, 0, n)
+    q = gpu.synth_queries(d, 12, 1234, 10000, 0.5, n, 999, 0.1, 0, 203)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    ix.train(x[:20000]); ix.add(x)
+    for nq, nprobe, k in ((203, 5, 10), (77, 12, 10), (9, 3, 10), (130, 4, 100)):
+        ix.nprobe = nprobe
+        ix.set_param("scan_kernel", 2)
+        De, Ie = ix.search(q[:nq], k)
+        ix.set_param("scan_kernel", 0)
+        fb = {}
+        for q8 in (1, 0):
+            for gather in (1, 0):
+                for chunk in (0, 2048):
+                    ix.set_param("pq_q8", q8); ix.set_param("pq_gather", gather); ix.set_param("scan_chunk", chunk)
+                    ix.set_param("profile", 1)
+                    D, I = ix.search(q[:nq], k)
+                    assert_same_results(D, I, De, Ie, f"nq={nq} nprobe={nprobe} k={k} pq_q8={q8} pq_gather={gather} scan_chunk={chunk}")
+                    fb[(q8, gather, chunk)] = (ix.get_timing("fallback_queries"), ix.get_timing("second_chance_queries"))
+        # a scan that lost survivors would be repaired by the exact re-run and still pass above: both forms must need the same repairs
+        for (q8, gather, chunk), v in fb.items():
+            assert v == fb[(0, gather, chunk)], f"nq={nq} nprobe={nprobe} k={k}: repairs {fb}"
+        ix.set_param("pq_q8", 1); ix.set_param("pq_gather", 1); ix.set_param("scan_chunk", 0)
+    ix.nprobe = 5
+    ix.set_param("scan_kernel", 2)
+    De, Ie = ix.search(q, 10)
+    ix.set_param("scan_kernel", 0)
+    for cap in (64, 4):
+        ix.set_param("pq_log_cap", cap)
+        D, I = ix.search(q, 10)
+        assert_same_results(D, I, De, Ie, f"pq_q8 pq_log_cap={cap}")
+    ix.set_param("pq_log_cap", 0); ix.set_param("profile", 0)

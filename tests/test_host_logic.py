@@ -454,3 +454,72 @@ def test_datastore_api_twin(tmp_path, orc, fake):
     assert len(calls) - n0 == 30 and per_query >= 0.0
     with pytest.raises(RuntimeError):
         DatastoreAPI(make_cfg(tmp, "Flat", [0, 1])).search("q five")
+
+
+def test_search_topk_is_callable_as_main_ric_calls_it(tmp_path, orc, fake, monkeypatch):
+    """ric/main_ric.py:27-29 calls `search_topk(cfg)` with the config alone: the evaluation examples come from the host
+    application's `src.data.load_eval_data`, the query encoder from its Contriever loader (reference src/search.py:236-281),
+    both imported on first use.  Stand-ins for the two host modules; the result must equal the injected-arguments call."""
+    import types
+    import torch
+    import src.search as S
+    tmp = str(tmp_path)
+    embs = write_datastore(tmp, orc)
+    data = [{"raw_query": "Alpha"}, {"raw_query": ""}, {"raw_query": "beta"}, {"raw_query": "Gamma delta"}]
+    table = {"alpha": embs[0][3], "beta": embs[1][5], "gamma delta": embs[0][9]}
+
+    class Tok:
+        def batch_encode_plus(self, batch, return_tensors=None, max_length=None, padding=None, truncation=None):
+            assert return_tensors == "pt" and padding and truncation and max_length == 77
+            self.seen = getattr(self, "seen", []) + [list(batch)]
+            return {"input_ids": torch.tensor([[sorted(table).index(t)] for t in batch])}
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor(np.stack([table[t] for t in sorted(table)]).astype(np.float32)), requires_grad=False)
+        def forward(self, input_ids):
+            return self.w[input_ids[:, 0]]           # contriever models return the pooled embedding itself
+
+    tok = Tok()
+    loaded = []
+    def load_retriever(name):
+        loaded.append(name)
+        return Enc(), tok, None
+    host_data = types.ModuleType("src.data"); host_data.load_eval_data = lambda cfg: [dict(ex) for ex in data]
+    c0 = types.ModuleType("contriever"); c1 = types.ModuleType("contriever.src"); c2 = types.ModuleType("contriever.src.contriever")
+    c2.load_retriever = load_retriever; c0.src = c1; c1.contriever = c2
+    for name, mod in (("src.data", host_data), ("contriever", c0), ("contriever.src", c1), ("contriever.src.contriever", c2)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    cfg = make_cfg(tmp, "Flat", [0, 1])
+    cfg.model = NS(query_encoder="facebook/contriever-msmarco", query_tokenizer="facebook/contriever-msmarco")
+    cfg.datastore.index["no_fp16"] = True       # the stand-in runs on the CPU here
+    cfg.evaluation.search.update(per_gpu_batch_size=2, question_maxlength=77, lowercase=True, normalize_text=False,
+                                 cache_query_embedding=True, query_embedding_save_path=os.path.join(tmp, "qemb.pkl"))
+    assert S.search_topk(cfg) is None           # ONE positional argument
+    assert loaded == ["facebook/contriever-msmarco"]
+    assert tok.seen == [["alpha", "beta"], ["gamma delta"]]          # lowercased, batches of per_gpu_batch_size, empty query skipped
+    out = S.get_search_output_path(cfg, [0, 1])
+    rows = [json.loads(l) for l in open(out)]
+    assert rows[1]["ctxs"] == [None] and [len(r["ctxs"]) for r in (rows[0], rows[2], rows[3])] == [3, 3, 3]
+    qe = np.stack([table["alpha"], table["beta"], table["gamma delta"]]).astype(np.float32)
+    Dw, Iw = orc.flat_search(qe, np.concatenate(embs, 0).astype(np.float32), 3, 0)
+    for r, iw, dw in zip((rows[0], rows[2], rows[3]), Iw, Dw):
+        assert [c["id"] for c in r["ctxs"]] == [[int(i) // 400, int(i) % 400] for i in iw]
+        assert [c["retrieval score"] for c in r["ctxs"]] == [str(float(x)) for x in dw]
+    cached = pickle.load(open(os.path.join(tmp, "qemb.pkl"), "rb"))
+    assert cached.shape == (3, 32)
+    # the same through the injection arguments (what the tests and the serving twin use)
+    cfg2 = make_cfg(tmp, "Flat", [0, 1]); cfg2.evaluation.eval_output_dir = os.path.join(tmp, "out2")
+    S.search_topk(cfg2, data=[dict(ex) for ex in data], questions_embedding=cached)
+    assert [json.loads(l) for l in open(S.get_search_output_path(cfg2, [0, 1]))] == rows
+    # second call: results exist -> nothing is loaded (reference :225-232)
+    loaded.clear(); S.search_topk(cfg); assert loaded == []
+    # outside the host application the missing module is named
+    monkeypatch.delitem(sys.modules, "src.data")
+    cfg3 = make_cfg(tmp, "Flat", [0, 1]); cfg3.evaluation.eval_output_dir = os.path.join(tmp, "out3")
+    with pytest.raises(ImportError, match="src.data"):
+        S.search_topk(cfg3)
+    # build_index(cfg) is the other one-argument call of main_ric.py (:23-25)
+    from src.index import build_index
+    assert len(build_index(make_cfg(tmp, "Flat", [0, 1]))) == 1
