@@ -173,8 +173,13 @@ rsx_index* create_common(int kind, int d, int nlist, int M, int nbits, int metri
         // rsx_set_param "pq_layout" switches an EMPTY index between the two.  (M = 16 — the reference's shipped IVF-PQ config,
         // ric/conf/ivf_pq.yaml:64-78 — joined in round 4, once the survivors went to per-wave logs instead of fixed segments.)
         h->CB_granule = h->CB;
+        // M = 96 (round 6): the SLICED layout (PQ_SLICED: 32-vector blocks cut into 32-sub-quantiser slices) — its scan looks eight
+        // queries up per table gather, which at M = 96 needs the table of one slice at a time (k_pq_scan_sl8).  RSX_PQ_LAYOUT = 0 / 1 / 2
+        // forces granule / rotated / sliced where they apply; "pq_layout" switches an empty index.
         const char* e = getenv("RSX_PQ_LAYOUT");
-        if (pq_rot_applies(M) && !(e && atoi(e) == 0)) h->CB = 0;
+        const int want = e ? atoi(e) : PQ_LAYOUT_DEFAULT;
+        if (pq_rot_applies(M) && want != 0) h->CB = 0;
+        if (pq_sliced_applies(M) && want == 2) h->CB = PQ_SLICED;
         if ((size_t)h->Mpad * 1024 > 160 * 1024) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: M = %d needs more than 160 KiB of LDS for the look-up table", M);
     }
     HIPCHECK(hipSetDevice(device));

@@ -126,8 +126,10 @@ static int64_t max_scan_items(rsx_index* h, int64_t nq, int nprobe, int G, int t
 static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI, bool allow_fast = true);
 
 static bool pq_fast_applies(const rsx_index* h, int k, bool allow_fast) {      // the ONE definition of "this search takes the 8-bit fast scan"
-    bool fast = allow_fast && h->kind == KIND_IVFPQ && h->pq_fast != 0 && h->scan_kernel == 0 && (h->CB == 16 || h->CB == 0) && h->M * 255 < 65536;
+    bool fast = allow_fast && h->kind == KIND_IVFPQ && h->pq_fast != 0 && h->scan_kernel == 0 && (h->CB == 16 || pq_rot_family(h->CB)) && h->M * 255 < 65536;
     if (fast) { int KP, BUF; kp_for(h, k, true, KP, BUF); if (KP > 4096) fast = false; }
+    // the sliced layout has ONE fast kernel: the filtered scan behind the one-launch pre-pass (every other setting takes the exact scan)
+    if (fast && h->CB == PQ_SLICED && !(std::min(h->nprobe, h->nlist) > 1 && h->pq_filter != 0 && h->pq_prepass_fused != 0)) fast = false;
     return fast;
 }
 static bool pq_search_needs_score_rows(const rsx_index* h, int nprobe, int k) {
@@ -211,7 +213,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     StageTimer tm(h, allow_fast ? "" : "fb_");
     const int d = h->d, ld = h->ld;
     // IVFPQ fast path: needs the 16-byte-granule layout, 16-bit integer sums, and K' <= 4096
-    const bool rot = h->kind == KIND_IVFPQ && h->CB == 0;
+    const bool rot = h->kind == KIND_IVFPQ && pq_rot_family(h->CB);      // block layouts (rotated, sliced): transposed tables, work-item scans
+    const bool sliced = h->kind == KIND_IVFPQ && h->CB == PQ_SLICED;
     const bool fast = pq_fast_applies(h, k, allow_fast);
     int KP, BUF;
     kp_for(h, k, fast, KP, BUF);
@@ -511,7 +514,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 h->w_itemdesc.ensure(pq_scan_rot_ws(items * ngq, rot_log_cap, nwg));
                 return h->w_itemdesc.p;
             };
-            const int ngq = rot ? pq_scan_rot_ngq(h->M, true, h->pq_q8) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
+            const int ngq = sliced ? 2 : rot ? pq_scan_rot_ngq(h->M, true, h->pq_q8) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             // rotated layout: persistent workgroups draw items dynamically, so the tile is the whole (average) list — one table
             // staging per (list, query group) — as long as that leaves a few thousand items to balance over 256 CUs

@@ -987,8 +987,8 @@ __global__ __launch_bounds__(256) void k_pq_encode(const void* x, int x_f16, int
         }
         if (plain_out) {
             if (valid) plain_out[i * Mpad + m] = (uint8_t)code;
-        } else if (CB == 0) {      // rotated layout: consecutive m of a vector are not contiguous
-            if (valid) codes[pq_code_addr(drow, m, Mpad, 0)] = (uint8_t)code;
+        } else if (pq_rot_family(CB)) {      // rotated / sliced layout: consecutive m of a vector are not contiguous
+            if (valid) codes[pq_code_addr(drow, m, Mpad, CB)] = (uint8_t)code;
         } else {
             packed |= code << (8 * (m & 3));
             if ((m & 3) == 3) {

@@ -35,6 +35,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef ROT_DEPTH
 #define ROT_DEPTH 4
 #endif
+#ifndef SL8_NB
+#define SL8_NB 8              // k_pq_scan_sl8: blocks of 32 vectors per wave and sub-tile (their partial sums are parked in 4 VGPRs each)
+#endif
+#ifndef SL8_RD
+#define SL8_RD 4              // ... and 1 KiB code loads in flight per wave
+#endif
 constexpr int ROT_D = ROT_DEPTH;   // 16-vector code blocks in flight per wave (16 M bytes each); must divide the tile's blocks per wave
 #ifndef ROT_CW
 #define ROT_CW 4              // items (waves) per workgroup of k_pq_rot_compact
@@ -978,6 +984,267 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot16(PQScan8Args A, const PQR
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Sliced layout (PQ_SLICED, rsx_internal.h), filtered scan: EIGHT queries per table gather at M = 96 — k_pq_scan_sl8 (round 6).
+// The 8-byte-entry table of eight queries is M x 2 KiB: 192 KiB at M = 96, more than a CU's 160 KiB.  The sliced layout stores a
+// 32-vector block as M / 32 slices of 1 KiB (32 sub-quantisers x 32 vectors each), so a pass over ONE slice of a run of blocks needs
+// only that slice's table: 64 KiB ([code][m & 31] x 8 B, 256-byte rows).  Two table slots live in LDS.  A work item's tile is cut
+// into SUB-TILES of 16 waves x NB blocks; per sub-tile a wave passes over its NB blocks once per slice and PARKS the blocks'
+// i32 partial sums in registers between the passes (one MFMA tile = 32 vectors x 8 queries = 4 VGPRs: lane groups g < 2 hold
+// vector i, g >= 2 vector 16 + i, and the one-hot B operand routes K group g to columns 8 (g >> 1) + query — all 16 columns used).
+// Slices are visited in ZIG-ZAG order (0, 1, 2 | 2, 1, 0 | ...): slice 1 keeps slot 1 for the whole item, slices 0 and 2 alternate
+// in slot 0, which is re-staged once per sub-tile — after the pass that used it, before the third pass needs it.
+// Per (32 vectors, slice, 8 queries): one 16-byte code load per lane, 16 v_perm, 16 ds_read_b64 (conflict-free: the 32 lanes of a
+// half-wave read 32 different 8-byte slots), 8 v_mfma_i32_16x16x64_i8 — per (vector, query, sub-quantiser) half the look-up
+// instructions of the 4-query form (k_pq_scan_rot), and a list probed by 5 .. 8 queries is passed over once instead of twice.
+// Work items, thresholds (accumulators start at -threshold: C >= 0 <=> survivor), survivor logs and run descriptors are those of
+// k_pq_scan_rot<.., G = 2>: two 4-query records per item, everything downstream is shared.
+// ---------------------------------------------------------------------------------------
+template <int NS, int NB, int RD>
+__global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ log_keys,
+                                                      uint2* __restrict__ seg_desc, uint32_t* xcd_ctr, int log_cap, int tile_blocks) {
+    static_assert(NS == 3, "zig-zag schedule written for three slices (M = 96)");
+    static_assert(NB % RD == 0, "the prefetch slots rotate with the unrolled block index");
+    constexpr int M = 32 * NS, G = 2;
+    constexpr int BB = 32 * M;                 // bytes per 32-vector block
+    constexpr int TAB = 2 * 65536;             // two table slots
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) uint32_t sl8_s[];
+    uint8_t* sb = reinterpret_cast<uint8_t*>(sl8_s);
+    PQRotItem* islot = reinterpret_cast<PQRotItem*>(sb + TAB);                  // [2][G] current / next item's records
+    const PQScanArgs& a = A.b;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15, n = lane & 15, nq4 = n & 3;
+    // ---- items: XCD b % 8 owns a contiguous range of the list-major item order, its workgroups draw from one counter, an exhausted
+    // range steals from the next XCD's (as k_pq_scan_rot)
+    const int ti = *A.total_items;
+    const int per_xcd = (ti + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    int xlo = xcd * per_xcd;
+    int xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
+    if (xlo >= xhi) return;
+    uint32_t* ctr = xcd_ctr + xcd * 32;
+    int cx = xcd, hops = 0;
+    unsigned drawn = 0;
+    auto resolve_draw = [&]() -> int {
+        for (;;) {
+            const int i2 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+            if (i2 < xhi) return i2;
+            if (hops >= 7) return 0x7fffffff;
+            hops++;
+            cx = (cx + 1) & 7;
+            xlo = cx * per_xcd;
+            xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
+            ctr = xcd_ctr + cx * 32;
+            if (xlo >= xhi) { drawn = 0u; xlo = 0; xhi = 0; continue; }
+            if (lane == 0) drawn = atomicAdd(ctr, 1u);
+        }
+    };
+    // ---- per-lane constants.  Rotation bytes: lane (g, i) reads, at step s, the 8-byte slot 16 (g & 1) + ((i + s) & 15) of its code's
+    // row; three per register, the fourth byte = the table slot of the pass (0 here, 1 in Rb) -> address bit 16
+    uint32_t Ra[6], Rb[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int bb = 0; bb < 3; bb++) { const int s2 = r * 3 + bb; if (s2 < 16) v |= (uint32_t)(128 * (g & 1) + 8 * ((i + s2) & 15)) << (8 * bb); }
+        Ra[r] = v; Rb[r] = v | 0x01000000u;
+    }
+    // B one-hot: an A operand = two 8-byte gathers (dwords 0, 2: queries 0-3; 1, 3: queries 4-7) of vector i (K groups 0, 1) or 16 + i
+    // (K groups 2, 3): column n = 8 (vector half) + query takes byte query & 3 of the dwords with j & 1 == query >> 2 of its half's K groups
+    const bool mine = (n >> 3) == (g >> 1);
+    const int bsel_lo = (mine && (n & 7) < 4) ? (1 << (8 * (n & 3))) : 0;
+    const int bsel_hi = (mine && (n & 7) >= 4) ? (1 << (8 * (n & 3))) : 0;
+    const v4i Bm = {bsel_lo, bsel_hi, bsel_lo, bsel_hi};
+    const int vo16 = lane * 16;
+    const int qn = n & 7;                                                     // my query column: record qn >> 2, slot qn & 3
+    const int rq = qn >> 2;
+    const uint64_t QM = 0x0101010101010101ull << qn;                          // the eight lanes (4 g x 2 vector halves) of my query
+    const size_t mylog_i = ((size_t)blockIdx.x * 16 + (size_t)w) * (4 * G) + (size_t)qn;
+    uint64_t* const mylog = log_keys + mylog_i * (size_t)log_cap;
+    uint32_t lcur = 0;
+    const auto load_records = [&](int it_) -> uint4 {
+        uint4 r0 = make_uint4(0xffffffffu, 0, 0, 0);        // l = -1: end marker
+        if (lane < 11 * G && it_ != 0x7fffffff) r0 = reinterpret_cast<const uint4*>(&items[(size_t)it_ * G])[lane];
+        return r0;
+    };
+    int item = 0;
+    if (w == 0) {
+        if (lane == 0) drawn = atomicAdd(ctr, 1u);
+        item = resolve_draw();
+        const uint4 r0 = load_records(item);
+        if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
+        if (lane == 0) islot[0].pad0 = item;
+    }
+    int buf = 0;
+#pragma unroll 1
+    for (;; buf ^= 1) {
+        __syncthreads();    // #1: every wave has left the previous item's scan (slots free), the records are in LDS
+        const PQRotItem* it0 = &islot[buf * G];
+        const PQRotItem* it1 = it0 + 1;
+        const int item_l = __builtin_amdgcn_readfirstlane(it0->l);
+        if (item_l == -1) break;
+        item = __builtin_amdgcn_readfirstlane(it0->pad0);
+        const int64_t len = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it0->len >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it0->len);
+        const int64_t base_row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it0->base_row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it0->base_row);
+        const int nblk = (int)((len + 63) >> 6) << 1;                          // 32-vector blocks of the list, slab padding included
+        const int tb0 = __builtin_amdgcn_readfirstlane(it0->tile) * tile_blocks;
+        int bend = tb0 + tile_blocks; if (bend > nblk) bend = nblk;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.codes + (base_row >> 5) * (int64_t)BB), 0, nblk * BB, 0x00020000);
+        const int so_oob = nblk * BB;                                          // past the descriptor's end: reads zeros
+        const int nsub = bend > tb0 ? (bend - tb0 + 16 * NB - 1) / (16 * NB) : 0;
+        int qq[8];                                                              // the eight queries (SGPRs: they live through the item's re-stagings)
+#pragma unroll
+        for (int k = 0; k < 8; k++) qq[k] = __builtin_amdgcn_readfirstlane(k < 4 ? it0->q[k] : it1->q[k - 4]);
+        // ---- staging of one slice's table into a slot: unit = (code, 4 consecutive m of the slice) -> the eight queries' dwords ->
+        // four 8-byte entries (bytes 0-3: record 0's queries, 4-7: record 1's) = 32 contiguous bytes of the code's row
+        auto stage_slice = [&](int sl, int slot) {
+            uint32_t in[2][8];
+            // (a query slot without a query holds a valid query index — k_pq_rot_items — and its accumulators start at -2^30: its table is
+            //  loaded like the others, unmasked.  Scalar base + 32-bit lane offset per load; the offset is made opaque so that the
+            //  compiler does not keep sixteen 64-bit addresses alive — spilled — across the item's passes)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int e = tid + u * 1024;
+                uint32_t eoff = (uint32_t)((e >> 3) * M + (e & 7) * 4 + sl * 32);
+                asm volatile("" : "+v"(eoff));
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    in[u][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (int64_t)qq[k] * (256 * M) + eoff));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int e = tid + u * 1024;
+                const int c = e >> 3, m4 = e & 7;
+                uint32_t o[2][4];
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++) {
+                    const uint32_t a0 = in[u][4 * hh], a1 = in[u][4 * hh + 1], a2 = in[u][4 * hh + 2], a3 = in[u][4 * hh + 3];
+                    const uint32_t t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+                    const uint32_t u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                    o[hh][0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
+                    o[hh][1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u) ^ 0x80808080u;
+                    o[hh][2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u) ^ 0x80808080u;
+                    o[hh][3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u) ^ 0x80808080u;
+                }
+                uint8_t* dst = sb + slot * 65536 + c * 256 + m4 * 32;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(o[0][0], o[1][0], o[0][1], o[1][1]);
+                *reinterpret_cast<uint4*>(dst + 16) = make_uint4(o[0][2], o[1][2], o[0][3], o[1][3]);
+            }
+        };
+        // ---- the code stream: step t = (sub-tile, pass, block j) in scan order; the load of step t + RD is issued when step t's
+        // codes have become gather addresses.  Block of (sub-tile st, j): tb0 + 16 (st NB + j) + w; slice of pass p: zig-zag.
+        auto slice_of = [&](int st, int p) -> int { return (st & 1) ? NS - 1 - p : p; };
+        auto code_off = [&](int st, int p, int j) -> int {
+            const int b = tb0 + 16 * (st * NB + j) + w;
+            return (st < nsub && b < bend) ? b * BB + slice_of(st, p) * 1024 : so_oob;
+        };
+        v4u ca[RD];
+#pragma unroll
+        for (int dd = 0; dd < RD; dd++) {
+            ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, code_off(0, 0, dd), 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (w == 0 && lane == 0) drawn = atomicAdd(ctr, 1u);      // the next item's index: resolved after the staging
+        if (nsub > 0) { stage_slice(0, 0); stage_slice(1, 1); }
+        uint4 pre = make_uint4(0xffffffffu, 0, 0, 0);
+        int i1 = 0x7fffffff;
+        if (w == 0) { i1 = resolve_draw(); pre = load_records(i1); }
+        const PQRotItem* itq = &islot[buf * G + rq];
+        const int cinit = itq->cinit[nq4];
+        const v4i Ci = {cinit, cinit, cinit, cinit};
+        const uint32_t qstart = lcur;
+        __syncthreads();    // #2: slices 0 and 1 staged
+        v4i acc[NB];
+#pragma unroll 1
+        for (int st = 0; st < nsub; st++) {
+#pragma unroll 1
+            for (int p = 0; p < NS; p++) {
+                const int sl = slice_of(st, p);
+                const int slot = sl == 1 ? 1 : 0;
+                if (p == NS - 1) {      // the slice of the third pass takes slot 0, free since the first pass
+                    __syncthreads();
+                    stage_slice(sl, 0);
+                    __syncthreads();
+                }
+                // the pass after this one (for the prefetch across the pass boundary)
+                const int pn = p + 1 < NS ? p + 1 : 0, stn = p + 1 < NS ? st : st + 1;
+                const bool first = p == 0, last = p == NS - 1;
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const int b = tb0 + 16 * (st * NB + j) + w;
+                    uint32_t gv[16];
+                    {
+                        const uint32_t cw[4] = {ca[j % RD].x, ca[j % RD].y, ca[j % RD].z, ca[j % RD].w};
+                        if (slot) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 16; s2++)
+                                gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], Rb[s2 / 3], 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
+                        } else {
+#pragma unroll
+                            for (int s2 = 0; s2 < 16; s2++)
+                                gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], Ra[s2 / 3], 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ca[j % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, j + RD < NB ? code_off(st, p, j + RD) : code_off(stn, pn, j + RD - NB), 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (b >= bend) continue;          // wave-uniform: past the tile / the list (the prefetch slot has been refilled)
+                    v4i C = first ? Ci : acc[j];
+                    {
+                        rot_v2u g8[16];
+#pragma unroll
+                        for (int s2 = 0; s2 < 16; s2++) g8[s2] = lds_rd64(gv[s2]);
+#pragma unroll
+                        for (int t = 0; t < 8; t++) {
+                            const v4i Av = {(int)g8[2 * t].x, (int)g8[2 * t].y, (int)g8[2 * t + 1].x, (int)g8[2 * t + 1].y};
+                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
+                        }
+                    }
+                    if (!last) { acc[j] = C; __builtin_amdgcn_sched_barrier(0); continue; }
+                    // C[r] = cinit + sum over all M sub-quantisers of (u8 - 128) for vector 16 (n >> 3) + 4 g + r of block b and query n & 7
+                    if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0)) {
+                        int b5 = b << 5;
+                        asm volatile("" : "+s"(b5));      // opaque: the positions of all NB x 4 rows would otherwise be computed ahead of the pass loop and spilled
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const bool cnd = C[r] >= 0;
+                            if (__builtin_amdgcn_ballot_w64(cnd)) {
+                                const float p_dis0 = itq->dis0[nq4], p_scale = itq->scale[nq4], p_bias = itq->bias[nq4];
+                                const int64_t p_off = itq->off[nq4];
+                                const uint64_t p_tau = itq->tau[nq4];
+                                const uint32_t pos = (uint32_t)b5 + (uint32_t)(16 * (n >> 3) + 4 * g + r);
+                                const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(C[r] - cinit + 128 * M), p_bias);
+                                const uint64_t key = (cnd && pos < (uint32_t)len) ? make_key(sc, (uint32_t)p_off + pos) : 0ull;
+                                const bool pass = key > p_tau;
+                                const uint64_t mq = __builtin_amdgcn_ballot_w64(pass) & QM;      // this step's survivors of MY query
+                                if (pass) {
+                                    const uint32_t slot_k = lcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                                    if (slot_k < (uint32_t)log_cap) mylog[slot_k] = key;   // beyond: counted, dropped -> the query is re-run exactly
+                                }
+                                lcur += (uint32_t)__builtin_popcountll(mq);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- item epilogue: the wave's 4 G run descriptors (lane = 4 record + slot = its own query column, g = 0, vector half 0), then
+        // wave 0 parks the next item's records
+        if (lane < 4 * G) {
+            const uint32_t c0 = qstart < (uint32_t)log_cap ? qstart : (uint32_t)log_cap, c1 = lcur < (uint32_t)log_cap ? lcur : (uint32_t)log_cap;
+            seg_desc[(((size_t)item * G + (size_t)(lane >> 2)) * 16 + w) * 4 + (lane & 3)] =
+                make_uint2((uint32_t)(mylog_i * (size_t)log_cap) + c0, (c1 - c0) | ((lcur > (uint32_t)log_cap && lcur > qstart) ? 0x80000000u : 0u));
+        }
+        if (w == 0) {
+            if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[(buf ^ 1) * G])[lane] = pre;
+            if (lane == 0) islot[(buf ^ 1) * G].pad0 = i1;
+        }
+    }
+}
+
 // One wave per work item: append the item's (wave, query) survivor segments to the candidate rows of its queries — the only
 // atomics of the filtered scan live here, one reservation per (item, query), in a kernel with thousands of independent waves.
 __global__ __launch_bounds__(64 * ROT_CW) void k_pq_rot_compact(const PQRotItem* __restrict__ items, const int32_t* total_items, int ngq,
@@ -1118,6 +1385,33 @@ static int launch_pq_scan_rot16(const PQScan8Args& A, int bpw, void* desc_ws, in
     return 0;
 }
 
+template <int NS, int NB, int RD>
+static int launch_pq_scan_sl8_t(const PQScan8Args& A, int vpl, void* desc_ws, int log_cap, hipStream_t st) {
+    constexpr int G = 2, M = 32 * NS;
+    const size_t shm = (size_t)2 * 65536 + (size_t)2 * G * 176 + 64;
+    static DevOnce once;
+    static std::atomic<int> failed{0};
+    once.once([&] {
+        if (hipFuncSetAttribute((const void*)k_pq_scan_sl8<NS, NB, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) failed = 1;
+    });
+    if (failed) return -1;
+    const int nwg = pq_scan_rot_max_wgs(M);
+    const int64_t recs = (int64_t)A.max_items * G;
+    PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
+    uint2* seg_desc = pq_scan_rot_ws_desc(desc_ws, recs);
+    uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, recs);
+    uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
+    uint32_t* prog = xcd_ctr + 256;
+    hipLaunchKernelGGL((k_pq_rot_items<M, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
+    int64_t grid = nwg;
+    if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
+    hipLaunchKernelGGL((k_pq_scan_sl8<NS, NB, RD>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, 32 * vpl);
+    if (!A.qitems)
+        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((recs + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, G, log_keys, seg_desc,
+                           A.cand, A.cand_cnt, A.cand_cap);
+    return 0;
+}
+
 // returns 0 on launch, -1 if this M has no rotated kernel.  tau_key == null: unfiltered (every score to a.temp).
 int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qparam, const int32_t* pairs_sorted,
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
@@ -1125,7 +1419,8 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
                        const uint64_t* tau_key, int64_t tau_stride, uint64_t* cand, unsigned long long* cand_cnt,
                        int cand_cap, void* item_ws, int log_cap, int prune, int pace, const uint16_t* excl, int32_t* qitems,
                        int qitems_tmax, hipStream_t st, int q8) {
-    if (a.CB != 0 || !item_ws || log_cap <= 0 || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
+    if (!pq_rot_family(a.CB) || !item_ws || log_cap <= 0 || !pq_rot_applies(a.M) || a.M != a.Mpad || max_items <= 0 || max_items > 0x7fffff00) return -1;
+    if (a.CB == PQ_SLICED && (!tau_key || !pq_sliced_applies(a.M))) return -1;      // the sliced layout has the filtered 8-query scan only
     PQScan8Args A;
     A.b = a; A.lut8 = lut8t; A.qp = (const PQQParam*)qparam;
     A.pairs_sorted = pairs_sorted; A.pair_off = pair_off; A.group_off = group_off; A.total_groups = total_groups;
@@ -1135,6 +1430,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     A.prune = prune; A.pace = pace; A.excl = excl; A.qitems = qitems; A.qitems_tmax = qitems_tmax;
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
+    if (a.CB == PQ_SLICED) return launch_pq_scan_sl8_t<3, SL8_NB, SL8_RD>(A, vpl, item_ws, log_cap, st);
     switch (a.M) {
         case 16: return f ? launch_pq_scan_rot16(A, vpl, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, log_cap, st);   // 64-vector blocks
         case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, log_cap, st);
@@ -1171,17 +1467,21 @@ extern "C" int rsx_debug_pp4_trace(uint64_t* out) { return hipMemcpyFromSymbol(o
 // per-query byte table: 0.77 ms per 1024 queries x 16384 rows; this form shares the table image between four queries and uses
 // the scan's conflict-free gathers and the MFMA adder.
 constexpr int PP4_MAXSEG = 8;
-template <int NF, int NH, bool BIG = false>
+// SL > 0 (round 6): the SLICED layout (PQ_SLICED) with SL slices: 32-vector blocks, a 1 KiB slice = 16 bytes per lane; the four-query
+// table image keeps 256-byte rows — slices 2 p and 2 p + 1 share plane p (bytes 0-127 / 128-255: bank = m % 32 either way) — and an
+// MFMA tile holds 32 vectors x 4 queries (K groups 0, 1: vector i -> columns 0-3; K groups 2, 3: vector 16 + i -> columns 4-7).
+template <int NF, int NH, bool BIG = false, int SL = 0>
 __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t nq) {
-    constexpr int M = 64 * NF + 32 * NH;
+    constexpr int M = SL ? 32 * SL : 64 * NF + 32 * NH;
     constexpr int PP4_SH = M > 96 ? 4 : 3;
     constexpr int NB = ((255 * M + 1) >> PP4_SH) + 1;        // bins of (sum + 1) >> PP4_SH
     constexpr int NBW = (NB + 1) / 2;                        // dwords of one query's histogram
-    constexpr int NPH = NF + NH;
+    constexpr int NPH = SL ? (SL + 1) / 2 : NF + NH;
     constexpr int TAB = NPH * 65536;
-    constexpr int NG = M / 4;
-    constexpr int NR1 = NPH > 1 ? rot_nreg(1, NF >= 2 ? 16 : 8) : 0;
-    constexpr int NR0 = NF >= 1 ? 4 : rot_nreg(0, 8);
+    constexpr int NG = SL ? 16 * SL : M / 4;               // gathers per lane and block (SL: 32-vector blocks)
+    constexpr int NR1 = SL ? 6 : NPH > 1 ? rot_nreg(1, NF >= 2 ? 16 : 8) : 0;
+    constexpr int NR0 = SL ? 0 : NF >= 1 ? 4 : rot_nreg(0, 8);
+    constexpr int BVEC = SL ? 32 : 16;                       // vectors per code block
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) uint32_t pp4_s[];
@@ -1214,17 +1514,18 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
     }
 #pragma unroll
     for (int r = 0; r < NR1; r++) {
-        uint32_t v = 0x01000000u;
+        uint32_t v = SL ? 0u : 0x01000000u;              // SL: plane / row-half bits are ORed in per slice
 #pragma unroll
         for (int bb = 0; bb < 3; bb++) {
             const int s = r * 3 + bb;
-            const uint32_t rot = NF >= 2 ? (uint32_t)(64 * g + 4 * ((i + s) & 15))
+            const uint32_t rot = SL ? (s < 16 ? (uint32_t)(64 * (g & 1) + 4 * ((i + s) & 15)) : 0u)       // dword slot 16 (g & 1) + ((i + s) & 15) of the row half
+                               : NF >= 2 ? (uint32_t)(64 * g + 4 * ((i + s) & 15))
                                          : (uint32_t)(64 * (g & 1) + 4 * ((i + s + 8 * (g >> 1)) & 15));
             v |= (rot & 255u) << (8 * bb);
         }
         R1[r] = v;
     }
-    const int bsel = n < 4 ? (1 << (8 * n)) : 0;
+    const int bsel = SL ? ((n < 8 && (n >> 2) == (g >> 1)) ? (1 << (8 * (n & 3))) : 0) : (n < 4 ? (1 << (8 * n)) : 0);
     const v4i Bm = {bsel, bsel, bsel, bsel};
     // ---- the four tables, staged exactly like a scan item's (unit = (code, 4 consecutive m) -> 4 dwords, byte k = query k as int8)
     {
@@ -1255,8 +1556,8 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
             o.z = __builtin_amdgcn_perm(u1, t1, 0x05040100u) ^ 0x80808080u;
             o.w = __builtin_amdgcn_perm(u1, t1, 0x07060302u) ^ 0x80808080u;
             const int m = m4 * 4;
-            const int p = m < 64 * NF ? (m >> 6) : NF;
-            const int slot = m < 64 * NF ? (m & 63) : (m - 64 * NF);
+            const int p = SL ? (m >> 6) : m < 64 * NF ? (m >> 6) : NF;
+            const int slot = SL ? (m & 63) : m < 64 * NF ? (m & 63) : (m - 64 * NF);       // SL: slice (m >> 5) & 1 = the row half
             *reinterpret_cast<uint4*>(sb + p * 65536 + c * 256 + slot * 4) = o;
         }
     }
@@ -1271,8 +1572,8 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
     }
     l = __builtin_amdgcn_readfirstlane(l); j0 = __builtin_amdgcn_readfirstlane(j0);
     int nrows = (int)(len < a.pre_rows ? len : a.pre_rows);
-    int nblk = __builtin_amdgcn_readfirstlane((nrows + 15) >> 4);
-    const uint8_t* lp = a.codes + ((l >= 0 ? a.list_base[l] : 0) >> 4) * (int64_t)(16 * M);
+    int nblk = __builtin_amdgcn_readfirstlane((nrows + BVEC - 1) / BVEC);
+    const uint8_t* lp = a.codes + ((l >= 0 ? a.list_base[l] : 0) / BVEC) * (int64_t)(BVEC * M);
     uint16_t* mysum = sums + (size_t)grp * a.pre_rows;
     int nseg = 1;
     if (BIG) {
@@ -1314,21 +1615,21 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
         const int32_t* sg = segs + grp * (PP4_MAXSEG * 4) + 4 * sgi;
         const int32_t ls = __builtin_amdgcn_readfirstlane(sg[0]);
         nrows = __builtin_amdgcn_readfirstlane(sg[1]); shift = __builtin_amdgcn_readfirstlane(sg[2]);
-        nblk = (nrows + 15) >> 4;
-        lp = a.codes + (a.list_base[ls] >> 4) * (int64_t)(16 * M);
+        nblk = (nrows + BVEC - 1) / BVEC;
+        lp = a.codes + (a.list_base[ls] / BVEC) * (int64_t)(BVEC * M);
     }
     // ---- scan: wave wq of the slot takes blocks wq, wq + 4, ...; PD blocks in flight per wave (register slots refilled in place
     // right after their codes have become gather addresses, as in k_pq_scan_rot; the prologue issues in slot order so that one
     // s_waitcnt serves the loop entry and the back edge)
     {
-        constexpr int PD = 4;
-        constexpr int NFx = NF > 0 ? NF : 1;
+        constexpr int PD = SL ? 2 : 4;
+        constexpr int NFx = SL ? SL : NF > 0 ? NF : 1;
         v4u ca[PD][NFx]; v2u cb[PD];
         auto fetch = [&](int b, v4u (&xa)[NFx], v2u& xb) {
-            const uint8_t* bp = lp + (int64_t)b * (16 * M);
+            const uint8_t* bp = lp + (int64_t)b * (BVEC * M);
 #pragma unroll
-            for (int p = 0; p < NF; p++) xa[p] = *reinterpret_cast<const v4u*>(bp + p * 1024 + lane * 16);
-            if (NH) xb = *reinterpret_cast<const v2u*>(bp + NF * 1024 + lane * 8);
+            for (int p = 0; p < (SL ? SL : NF); p++) xa[p] = *reinterpret_cast<const v4u*>(bp + p * 1024 + lane * 16);
+            if (NH && !SL) xb = *reinterpret_cast<const v2u*>(bp + NF * 1024 + lane * 8);
             __builtin_amdgcn_sched_barrier(0);
         };
         const int blast = nblk > 0 ? nblk - 1 : 0;
@@ -1344,19 +1645,28 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
             for (int d = 0; d < PD; d++) {
                 const int b = b0 + 4 * d;        // past the sample's end the slot holds the last block again: summed, not stored (a
                 uint32_t gv[NG];                 // `break` here would make every slot's wait a vmcnt(0): the exit path has no younger loads)
-                if (NF >= 1) {
+                if constexpr (SL > 0) {
+#pragma unroll
+                    for (int sl = 0; sl < SL; sl++) {
+                        const uint32_t cw[4] = {ca[d][sl].x, ca[d][sl].y, ca[d][sl].z, ca[d][sl].w};
+                        const uint32_t orv = ((uint32_t)(sl >> 1) << 24) | ((sl & 1) ? 0x00808080u : 0u);        // plane sl >> 1, row half sl & 1
+#pragma unroll
+                        for (int s = 0; s < 16; s++)
+                            gv[16 * sl + s] = __builtin_amdgcn_perm(cw[s >> 2], R1[s / 3] | orv, 0x0c030000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s % 3));
+                    }
+                } else if (NF >= 1) {
                     const uint32_t cw[4] = {ca[d][0].x, ca[d][0].y, ca[d][0].z, ca[d][0].w};
 #pragma unroll
                     for (int s = 0; s < 16; s++)
                         gv[s] = __builtin_amdgcn_perm(cw[s >> 2], R0[s >> 2], 0x0c0c0000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s & 3));
                 }
-                if (NF >= 2) {
+                if (NF >= 2 && !SL) {
                     const uint32_t cw[4] = {ca[d][NFx - 1].x, ca[d][NFx - 1].y, ca[d][NFx - 1].z, ca[d][NFx - 1].w};
 #pragma unroll
                     for (int s = 0; s < 16; s++)
                         gv[16 + s] = __builtin_amdgcn_perm(cw[s >> 2], R1[s / 3], 0x0c030000u | ((uint32_t)(4 + (s & 3)) << 8) | (uint32_t)(s % 3));
                 }
-                if (NH) {
+                if (NH && !SL) {
                     const uint32_t cw[2] = {cb[d].x, cb[d].y};
 #pragma unroll
                     for (int s = 0; s < 8; s++) {
@@ -1377,10 +1687,11 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
                     C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
                 }
                 // lanes (g, n): C[r] = sum over m of (u8 - 128) for vector 4 g + r of the block and query n; my slot's query is n == grp
-                if (n == grp && b < nblk) {
+                // (SL: vector 16 (n >> 2) + 4 g + r and query n & 3, n < 8)
+                if ((SL ? (n < 8 && (n & 3) == grp) : n == grp) && b < nblk) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int pos = b * 16 + 4 * g + r;
+                        const int pos = SL ? b * 32 + 16 * (n >> 2) + 4 * g + r : b * 16 + 4 * g + r;
                         if (BIG) {
                             const int v = C[r] + 128 * M + 1 + shift;          // shifted sum + 1; < 1: below every score the bound could certify
                             if (pos < nrows && v >= 1) atomicAdd(&hq[(v >> PP4_SH) >> 1], 1u << (16 * ((v >> PP4_SH) & 1)));
@@ -1401,7 +1712,7 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
     const int tg = (wq << 6) | lane;                     // thread within the slot
     int32_t* hs = hist + grp * 256;
     int32_t* cs = ctl + grp * 8;
-    const int N = nblk * 16;
+    const int N = nblk * BVEC;
     auto find_bin = [&](int want) -> int {              // wave 0 of the slot: the bin holding the want-th largest; leaves the rank inside it in cs[1]
         const int h0 = hs[4 * lane], h1 = hs[4 * lane + 1], h2 = hs[4 * lane + 2], h3 = hs[4 * lane + 3];
         const int sum4 = h0 + h1 + h2 + h3;
@@ -1487,26 +1798,27 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
     PP4_MARK(6);
 }
 
-template <int NF, int NH>
+template <int NF, int NH, int SL = 0>
 static void launch_pq_prepass4_t(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
-    const size_t shm = (size_t)(NF + NH) * 65536 + (size_t)4 * a.pre_rows * 2 + (1024 + 32) * 4 + 64;
+    const size_t shm = (size_t)(SL ? (SL + 1) / 2 : NF + NH) * 65536 + (size_t)4 * a.pre_rows * 2 + (1024 + 32) * 4 + 64;
     static DevSize attr;
-    attr.grow(shm, [&] { (void)hipFuncSetAttribute((const void*)k_pq_prepass4<NF, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
-    hipLaunchKernelGGL((k_pq_prepass4<NF, NH>), dim3((unsigned)((nq + 3) / 4)), dim3(1024), shm, st, a, nq);
+    attr.grow(shm, [&] { (void)hipFuncSetAttribute((const void*)k_pq_prepass4<NF, NH, false, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
+    hipLaunchKernelGGL((k_pq_prepass4<NF, NH, false, SL>), dim3((unsigned)((nq + 3) / 4)), dim3(1024), shm, st, a, nq);
 }
-template <int NF, int NH>
+template <int NF, int NH, int SL = 0>
 static void launch_pq_prepass4_big_t(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
-    constexpr int M = 64 * NF + 32 * NH;
+    constexpr int M = SL ? 32 * SL : 64 * NF + 32 * NH;
     constexpr int NBW = ((((255 * M + 1) >> (M > 96 ? 4 : 3)) + 1) + 1) / 2;
-    const size_t shm = (size_t)(NF + NH) * 65536 + (size_t)(4 * NBW + 32 + 4 * PP4_MAXSEG * 4 + 4) * 4 + 64;
+    const size_t shm = (size_t)(SL ? (SL + 1) / 2 : NF + NH) * 65536 + (size_t)(4 * NBW + 32 + 4 * PP4_MAXSEG * 4 + 4) * 4 + 64;
     static DevOnce once;
-    once.once([&] { (void)hipFuncSetAttribute((const void*)k_pq_prepass4<NF, NH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
-    hipLaunchKernelGGL((k_pq_prepass4<NF, NH, true>), dim3((unsigned)((nq + 3) / 4)), dim3(1024), shm, st, a, nq);
+    once.once([&] { (void)hipFuncSetAttribute((const void*)k_pq_prepass4<NF, NH, true, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
+    hipLaunchKernelGGL((k_pq_prepass4<NF, NH, true, SL>), dim3((unsigned)((nq + 3) / 4)), dim3(1024), shm, st, a, nq);
 }
 // the BIG form (histogram of the sums, samples of any size over several lists): 0 on launch, -1 when it does not apply
 int launch_pq_prepass4_big(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
     if (nq <= 0) return 0;
-    if (a.CB != 0 || a.pre_rows <= 0 || a.pre_rows > 32768) return -1;        // 16-bit counters
+    if (!pq_rot_family(a.CB) || a.pre_rows <= 0 || a.pre_rows > 32768) return -1;        // 16-bit counters
+    if (a.CB == PQ_SLICED) { if (a.Mpad != 96) return -1; launch_pq_prepass4_big_t<0, 0, 3>(a, nq, st); return 0; }
     switch (a.Mpad) {
         case 32: launch_pq_prepass4_big_t<0, 1>(a, nq, st); return 0;
         case 64: launch_pq_prepass4_big_t<1, 0>(a, nq, st); return 0;
@@ -1524,7 +1836,8 @@ int pq_prepass4_max_rows(int M) {
 }
 int launch_pq_prepass4(const PQPrepassArgs& a, int64_t nq, hipStream_t st) {
     if (nq <= 0) return 0;
-    if (a.CB != 0 || a.pre_rows <= 0 || a.pre_rows % 64 || a.pre_rows > pq_prepass4_max_rows(a.Mpad)) return -1;
+    if (!pq_rot_family(a.CB) || a.pre_rows <= 0 || a.pre_rows % 64 || a.pre_rows > pq_prepass4_max_rows(a.Mpad)) return -1;
+    if (a.CB == PQ_SLICED) { if (a.Mpad != 96) return -1; launch_pq_prepass4_t<0, 0, 3>(a, nq, st); return 0; }
     switch (a.Mpad) {
         case 32: launch_pq_prepass4_t<0, 1>(a, nq, st); return 0;
         case 64: launch_pq_prepass4_t<1, 0>(a, nq, st); return 0;
@@ -1567,7 +1880,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot_exact(PQScanArgs a) {
         for (int m0 = 0; m0 < a.M; m0 += 8) {
             uint32_t code[8];
 #pragma unroll
-            for (int t = 0; t < 8; t++) code[t] = a.codes[pq_code_addr(row0 + pos, m0 + t, a.Mpad, 0)];
+            for (int t = 0; t < 8; t++) code[t] = a.codes[pq_code_addr(row0 + pos, m0 + t, a.Mpad, a.CB)];
 #pragma unroll
             for (int t = 0; t < 8; t++) sum += rot_lut_s[(m0 + t) * 256 + code[t]];
         }
@@ -1578,7 +1891,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot_exact(PQScanArgs a) {
 int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st) {
     const int64_t pairs = a.nq * a.nprobe;
     if (pairs <= 0 || a.max_chunks <= 0) return 0;
-    if (a.CB != 0 || !pq_rot_applies(a.M)) return -1;
+    if (!pq_rot_family(a.CB) || !pq_rot_applies(a.M)) return -1;
     const size_t shm = (size_t)a.Mpad * 1024;
     static DevSize attr;
     bool attr_ok = true;

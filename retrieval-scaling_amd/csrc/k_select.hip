@@ -553,6 +553,43 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             }
             cf[0] = nf[0]; cf[1] = nf[1]; ch = nh;
         }
+    } else if (a.CB == PQ_SLICED) {
+        // sliced layout (rsx_internal.h): lut8 is [q][code][M]; lane (g, i) of a wave sums the entries of its 16 bytes per slice of
+        // vector 16 (g >> 1) + i of a 32-vector block, the two lanes of a vector are added with one shuffle; one block ahead
+        const int M = a.Mpad, NS = M >> 5;
+        const int g = lane >> 4, i = lane & 15;
+        const int nblk = nslab * 2;
+        const uint8_t* lbase = a.codes + ((l >= 0 ? a.list_base[l] : 0) >> 5) * (int64_t)(32 * M);
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        uint4 cf[4], nf[4];
+        auto fetch = [&](int b, uint4 (&c)[4]) {
+            const uint8_t* bp = lbase + (int64_t)b * (32 * M) + lane * 16;
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) c[sl] = sl < NS ? *reinterpret_cast<const uint4*>(bp + sl * 1024) : make_uint4(0u, 0u, 0u, 0u);
+        };
+        if (wu < nblk) fetch(wu, cf);
+#pragma unroll 1
+        for (int b = wu; b < nblk; b += 16) {
+            fetch(b + 16 < nblk ? b + 16 : b, nf);
+            uint32_t acc = 0;
+#pragma unroll 1
+            for (int sl = 0; sl < NS; sl++) {
+                const uint4 c4 = sl == 0 ? cf[0] : sl == 1 ? cf[1] : sl == 2 ? cf[2] : cf[3];
+                const uint32_t wds[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                for (int s2 = 0; s2 < 16; s2++) {
+                    const int m = 32 * sl + 16 * (g & 1) + ((i + s2) & 15);
+                    acc += tab[((wds[s2 >> 2] >> (8 * (s2 & 3))) & 255u) * M + m];
+                }
+            }
+            acc += __shfl_xor(acc, 16);
+            if ((g & 1) == 0) {
+                const int64_t pos = (int64_t)b * 32 + 16 * (g >> 1) + i;
+                sums[pos] = (pos < len) ? (uint16_t)(acc + 1u) : (uint16_t)0;
+            }
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) cf[sl] = nf[sl];
+        }
     } else
     for (int s = w; s < nslab; s += 16) {
         const uint8_t* sp = a.codes + ((a.list_base[l] >> 6) + s) * (int64_t)(64 * a.Mpad) + lane * 16;
@@ -608,7 +645,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                     uint32_t acc = 0;
                     for (int m = 0; m < a.Mpad; m++) {
                         const uint32_t code = a.codes[pq_code_addr(row0 + pos, m, a.Mpad, a.CB)];
-                        acc += a.CB == 0 ? tab[code * a.Mpad + m] : tab[m * 256 + code];
+                        acc += pq_rot_family(a.CB) ? tab[code * a.Mpad + m] : tab[m * 256 + code];
                     }
                     v = (int)acc + shift;
                 }
@@ -1015,12 +1052,12 @@ __device__ inline float pq_exact_sum(const uint8_t* sp, int v, int M, const floa
 // Rotated layout (CB = 0): the M code bytes of a vector through pq_code_addr, eight at a time so that the
 // byte -> table-entry loads of different m overlap; summed in m order like the granule form.
 __device__ inline float pq_exact_sum_rot(const uint8_t* codes, int64_t row, int M, const float* T, const float* qv,
-                                         const float* codebooks, int dsub) {
+                                         const float* codebooks, int dsub, int CB = 0) {
     float sum = 0.0f;
     for (int m0 = 0; m0 < M; m0 += 8) {
         uint32_t code[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) code[j] = codes[pq_code_addr(row, m0 + j, M, 0)];
+        for (int j = 0; j < 8; j++) code[j] = codes[pq_code_addr(row, m0 + j, M, CB)];
         float t[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -1061,16 +1098,13 @@ __device__ inline void rot16_bytes(uint32_t (&w)[4], int i) {     // byte t of t
         w[0] = r0; w[1] = r1; w[2] = r2; w[3] = r3;
     }
 }
-__device__ inline float pq_exact_sum_rot_wide(const uint8_t* codes, int64_t row, int M, const float* qv, const float* codebooks) {
+__device__ inline float pq_exact_sum_rot_wide(const uint8_t* codes, int64_t row, int M, const float* qv, const float* codebooks, int CB = 0) {
     const int i = (int)(row & 15);
-    const uint8_t* base = codes + (row >> 4) * (int64_t)(16 * M);
-    const int NF = M >> 6, nrun = M >> 4;
-    // run r < 4 NF: the 16-byte piece of lane group r & 3 in phase r >> 2; later runs: the two 8-byte pieces of lane groups
-    // h and h + 2 of the half phase (h = r & 1) — read as two 8-byte halves either way
+    const int nrun = M >> 4;
+    // the piece of a run as two 8-byte halves (pq_piece_ptrs: rotated or sliced layout)
     auto piece = [&](int r, uint2& lo, uint2& hi) {
         const uint8_t* p0; const uint8_t* p1;
-        if (r < 4 * NF) { p0 = base + (r >> 2) * 1024 + ((r & 3) * 16 + i) * 16; p1 = p0 + 8; }
-        else { const int h = r & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
+        pq_piece_ptrs(codes, row, M, CB, r, p0, p1);
         lo = *reinterpret_cast<const uint2*>(p0); hi = *reinterpret_cast<const uint2*>(p1);
     };
     uint2 nlo, nhi;
@@ -1167,16 +1201,14 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         uint8_t* cbytes = reinterpret_cast<uint8_t*>(ent + (size_t)KP * es);                      // [KP][M] (M >= 32: staged by pieces)
         const bool pieces = M >= 32 && (M & 15) == 0;
         if (pieces) {
-            const int NF = M >> 6, nrun = M >> 4;
+            const int nrun = M >> 4;
             for (int u = tid; u < KP * nrun; u += nt) {
                 const int c = u / nrun, run = u - c * nrun;
                 const int64_t row = srow[c];
                 if (row < 0) continue;
                 const int i = (int)(row & 15);
-                const uint8_t* base = a.codes + (row >> 4) * (int64_t)(16 * M);
                 const uint8_t* p0; const uint8_t* p1;
-                if (run < 4 * NF) { p0 = base + (run >> 2) * 1024 + ((run & 3) * 16 + i) * 16; p1 = p0 + 8; }
-                else { const int h = run & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
+                pq_piece_ptrs(a.codes, row, M, a.CB, run, p0, p1);
                 const uint2 lo2 = *reinterpret_cast<const uint2*>(p0), hi2 = *reinterpret_cast<const uint2*>(p1);
                 uint32_t w[4] = {lo2.x, lo2.y, hi2.x, hi2.y};
                 rot16_bytes(w, i);
@@ -1189,7 +1221,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             const int c = e / M, m = e - c * M;
             const int64_t row = srow[c];
             if (row < 0) continue;
-            const uint32_t code = pieces ? (uint32_t)cbytes[(size_t)c * M + m] : (uint32_t)a.codes[pq_code_addr(row, m, M, 0)];
+            const uint32_t code = pieces ? (uint32_t)cbytes[(size_t)c * M + m] : (uint32_t)a.codes[pq_code_addr(row, m, M, a.CB)];
             const float* qs = qv + m * 8;
             const float* cw = a.codebooks + ((int64_t)m * 256 + code) * 8;
             const float4 x = ((const float4*)cw)[0], y = ((const float4*)cw)[1];
@@ -1225,8 +1257,8 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             const float dis0 = plds ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
             const int64_t slab = row >> 6; const int v = (int)(row & 63);
             const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-            const float sum = a.CB == 0 ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
-                                                                  : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub))
+            const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB)
+                                                                  : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub, a.CB))
                             : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                          : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
             sord[c] = f2ord((dis0 + sum) + 0.0f);
@@ -1476,8 +1508,8 @@ __global__ __launch_bounds__(256) void k_pq_rescore_all(FinalizeArgs a, uint64_t
         const float dis0 = a.probe_dis0[q * a.nprobe + lo];
         const int64_t slab = row >> 6; const int v = (int)(row & 63);
         const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-        const float sum = a.CB == 0 ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks)
-                                                              : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub))
+        const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB)
+                                                              : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub, a.CB))
                         : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                      : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
         cand[q * cand_cap + c] = make_key(dis0 + sum, idx);
@@ -1709,14 +1741,11 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         if (NRUN == 1) {     // M = 16: 64-vector blocks of 1 KiB: vector v's 16 bytes at v * 16, byte s = sub-quantiser (v + s) & 15
             x.w16 = *reinterpret_cast<const uint4*>(a.codes + (x.r >> 6) * 1024 + (x.r & 63) * 16);
         } else {             // 16-vector blocks (pq_exact_sum_rot_wide's pieces), 16 sub-quantisers per run in m order
-            const int i = (int)(x.r & 15);
-            const uint8_t* base = a.codes + (x.r >> 4) * (int64_t)(16 * M);
 #pragma unroll
             for (int run = 0; run < FT_RUNS; run++) {
                 if (run >= nrun) break;
                 const uint8_t* p0; const uint8_t* p1;
-                if (run < 4 * NF) { p0 = base + (run >> 2) * 1024 + ((run & 3) * 16 + i) * 16; p1 = p0 + 8; }
-                else { const int h = run & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
+                pq_piece_ptrs(a.codes, x.r, M, a.CB, run, p0, p1);
                 x.lo2[run] = *reinterpret_cast<const uint2*>(p0); x.hi2[run] = *reinterpret_cast<const uint2*>(p1);
             }
         }
@@ -1893,7 +1922,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
 }
 // sort capacity of k_pq_final_tab for this (M, k), 0 when the kernel does not apply (layout, or the table + sort do not fit the LDS)
 int pq_final_tab_capacity(int M, int CB, int k) {
-    if (CB != 0 || !pq_rot_applies(M)) return 0;
+    if (!pq_rot_family(CB) || !pq_rot_applies(M)) return 0;
     const auto fits = [&](int P) { return (size_t)M * 1024 + (size_t)P * 12 + 16 + (256 + 16) * 4 + 64 <= (size_t)160 * 1024; };
     int P = 64; while (P < k + 16) P <<= 1;
     if (fits(P)) return P;
@@ -1941,7 +1970,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t st) {
     // a handful of queries leave the chip idle: 16 waves per query and the parallel table-entry form of the IVF-PQ re-score
     const size_t base20 = (((size_t)a.KP * 20 + 15) / 16) * 16;
     const size_t par_shm = ((base20 + (size_t)a.KP * (a.M + 1) * 4 + 15) / 16) * 16 + (size_t)a.KP * a.M;      // entries + the staged code bytes
-    a.par_entries = (a.kind == KIND_IVFPQ && a.pq_rescore && a.CB == 0 && !a.lut32 && a.dsub == 8 && a.nq <= 64 && par_shm <= 64 * 1024) ? 1 : 0;
+    a.par_entries = (a.kind == KIND_IVFPQ && a.pq_rescore && pq_rot_family(a.CB) && !a.lut32 && a.dsub == 8 && a.nq <= 64 && par_shm <= 64 * 1024) ? 1 : 0;
     a.rank_sort = (a.KP <= FIN_RANK_MAX && a.nq <= 64) ? 1 : 0;     // fewer barriers, more instructions: a latency trade, not a throughput one
     if (a.rank_sort) shm = base20 + (size_t)a.KP * 12 + 16;       // the second copy shares the table-entry region (used earlier)
     if (a.par_entries) { shm = std::max(shm, par_shm); waves = 16; }

@@ -383,7 +383,7 @@ int rsx_get(rsx_index_t* h, const char* key, int64_t* out) {
         else if (s == "device") *out = h->device;
         else if (s == "max_k") *out = 4096;
         else if (s == "query_batch") *out = h->query_batch;
-        else if (s == "pq_layout") *out = (h->kind == KIND_IVFPQ && h->CB == 0) ? 1 : 0;
+        else if (s == "pq_layout") *out = h->kind != KIND_IVFPQ ? 0 : h->CB == 0 ? 1 : h->CB == PQ_SLICED ? 2 : 0;
         else if (s == "hbm_bytes") *out = (int64_t)(h->data.bytes + h->ids.bytes + h->norms.bytes);
         else if (s == "workspace_bytes") *out = workspace_bytes(h);
         else RSX_THROW(RSX_ERR_INVALID, "unknown property '%s'", key);
@@ -417,7 +417,8 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
             if (h->kind != KIND_IVFPQ) RSX_THROW(RSX_ERR_UNSUPPORTED, "pq_layout: IVFPQ only");
             if (h->ntotal + h->ndropped > 0) RSX_THROW(RSX_ERR_INVALID, "pq_layout must be set before the first add");
             if ((int)value == 1 && !pq_rot_applies(h->M)) RSX_THROW(RSX_ERR_UNSUPPORTED, "pq_layout=1 (rotated) needs M in {16, 32, 64, 96, 128}");
-            h->CB = (int)value == 1 ? 0 : h->CB_granule;
+            if ((int)value == 2 && !pq_sliced_applies(h->M)) RSX_THROW(RSX_ERR_UNSUPPORTED, "pq_layout=2 (sliced) needs M = 96");
+            h->CB = (int)value == 1 ? 0 : (int)value == 2 ? PQ_SLICED : h->CB_granule;
         }
         else if (s == "ivf_filter") h->ivf_filter = (int)value;
         else if (s == "ivf_pre_lists") h->ivf_pre_lists = std::max(0, (int)value);

@@ -152,6 +152,9 @@ struct rsx_index {
     int kind = 0, d = 0, metric = 0, device = 0;
     int nlist = 1, M = 0, nbits = 8, Mpad = 0, CB = 16, dsub = 0;   // CB: code layout (rsx_internal.h), 0 = rotated
     int CB_granule = 16;
+#ifndef PQ_LAYOUT_DEFAULT
+#define PQ_LAYOUT_DEFAULT 1      // RSX_PQ_LAYOUT unset: 1 = rotated wherever it applies, 2 = additionally the sliced layout for M = 96
+#endif
     int nprobe = 1;
     bool trained = false;
     int64_t ntotal = 0;

@@ -89,9 +89,21 @@ constexpr int CCS = 16;   // counter stride in 8-byte words: cand_cnt[q * CCS]
 //             M = 16: block of 64 vectors = 1 KiB; lane (g, i) owns vector 16 g + i and reads its 16 contiguous bytes at lane*16
 //             (byte s: m = (i + s) & 15); the table row of a code holds the 16 entries twice (bytes 0-63 and 64-127), lane groups
 //             of even / odd g use one copy each, so the 32 lanes of a half-wave again hit 32 different banks.
-// Lists start on 64-vector boundaries in both layouts and a 64-vector slab is 64*Mpad bytes in both.
+//   CB = PQ_SLICED (-1; "sliced", round 6, M % 32 == 0): block of 32 vectors = 32*M bytes, cut into M/32 SLICES of 1 KiB — slice s holds
+//             sub-quantisers 32 s .. 32 s + 31 of all 32 vectors.  Within a slice a wave lane (g, i) = (lane >> 4, lane & 15) owns vector
+//             16 (g >> 1) + i and reads 16 contiguous bytes at lane*16 (byte b: m = 32 s + 16 (g & 1) + ((i + b) & 15)).  The 32 lanes of
+//             a half-wave hold 32 different m % 32 at every step, as in the rotated layout — but a pass over ONE slice needs only that
+//             slice's table (64 KiB with 8-byte entries = eight queries per ds_read_b64), so a scan can keep two slices' tables in
+//             LDS and restage the third behind a pass (k_pq_scan_sl8).  A 16-sub-quantiser run of a vector is one 16-byte piece.
+// Lists start on 64-vector boundaries in all layouts and a 64-vector slab is 64*Mpad bytes in all of them.
 // ---------------------------------------------------------------------------------------
+constexpr int PQ_SLICED = -1;
 __host__ __device__ inline int64_t pq_code_addr(int64_t row, int m, int Mpad, int CB) {
+    if (CB == PQ_SLICED) {
+        const int v = (int)(row & 31), i = v & 15, mm = m & 31;
+        const int lane = 16 * (2 * (v >> 4) + (mm >> 4)) + i;
+        return (row >> 5) * (int64_t)(32 * Mpad) + (m >> 5) * 1024 + lane * 16 + (((mm & 15) - i) & 15);
+    }
     if (CB != 0) {
         const int64_t slab = row >> 6; const int v = (int)(row & 63);
         const int g = m / CB, b = m - g * CB;
@@ -111,6 +123,23 @@ __host__ __device__ inline int64_t pq_code_addr(int64_t row, int m, int Mpad, in
     return base + NF * 1024 + (16 * g + i) * 8 + s;
 }
 __host__ __device__ inline bool pq_rot_applies(int M) { return M == 16 || (M % 32 == 0 && M >= 32 && M <= 128); }
+__host__ __device__ inline bool pq_sliced_applies(int M) { return M == 96; }      // the M whose 8-query table (M * 2 KiB) exceeds the LDS
+__host__ __device__ inline bool pq_rot_family(int CB) { return CB == 0 || CB == PQ_SLICED; }     // block layouts: transposed tables, work-item scans
+// The two 8-byte halves of the piece that holds sub-quantisers 16 run .. 16 run + 15 of vector `row` (M >= 32, rotated or sliced layout);
+// rotated left by row & 15 bytes (rot16_bytes, k_select.hip) the 16 bytes are the codes in m order.
+__device__ inline void pq_piece_ptrs(const uint8_t* codes, int64_t row, int M, int CB, int run, const uint8_t*& p0, const uint8_t*& p1) {
+    const int i = (int)(row & 15);
+    if (CB == PQ_SLICED) {
+        p0 = codes + (row >> 5) * (int64_t)(32 * M) + (run >> 1) * 1024 + (16 * (2 * (int)((row >> 4) & 1) + (run & 1)) + i) * 16; p1 = p0 + 8;
+        return;
+    }
+    const uint8_t* base = codes + (row >> 4) * (int64_t)(16 * M);
+    const int NF = M >> 6;
+    // run < 4 NF: the 16-byte piece of lane group run & 3 in phase run >> 2; later runs: the two 8-byte pieces of lane groups h and h + 2
+    // of the half phase (h = run & 1)
+    if (run < 4 * NF) { p0 = base + (run >> 2) * 1024 + ((run & 3) * 16 + i) * 16; p1 = p0 + 8; }
+    else { const int h = run & 1; p0 = base + NF * 1024 + (h * 16 + i) * 8; p1 = base + NF * 1024 + ((h + 2) * 16 + i) * 8; }
+}
 
 // Inverted-list directory on the device (one entry per list; Flat uses a single list 0).
 //   base : first storage row of the list (PQ: multiple of 64 = slab aligned; flat rows: of 16)

@@ -19,7 +19,7 @@ int main() {
     // 1. bijection per slab, all layouts the engine can choose
     struct L { int M, Mpad, CB; };
     const L layouts[] = {{8, 16, 16}, {12, 16, 16}, {16, 16, 16}, {16, 16, 0}, {32, 32, 0}, {32, 32, 16}, {48, 48, 16}, {64, 64, 0}, {96, 96, 0}, {96, 96, 16},
-                         {128, 128, 0}, {160, 160, 4}, {20, 32, 4}};
+                         {128, 128, 0}, {160, 160, 4}, {20, 32, 4}, {96, 96, PQ_SLICED}, {64, 64, PQ_SLICED}, {32, 32, PQ_SLICED}, {128, 128, PQ_SLICED}};
     for (const L& l : layouts) {
         for (int64_t slab = 0; slab < 3; slab++) {
             std::set<int64_t> seen;
@@ -73,6 +73,27 @@ int main() {
                 std::set<int> banks;     // table row: 64 dwords, entry m at dword m (copy 0) and 16 + m (copy 1); lane group g uses copy g & 1
                 for (int lane = 32 * h; lane < 32 * h + 32; lane++) { const int g = lane >> 4, i = lane & 15; banks.insert((16 * (g & 1) + ((i + s) & 15)) % 32); }
                 if (banks.size() != 32) return fail("M = 16 banks", 16, s, h);
+            }
+    }
+    // 3. sliced layout (PQ_SLICED): lane (g, i) of a 32-vector block reads, per slice, 16 contiguous bytes at slice * 1024 + lane * 16 whose
+    // byte b is sub-quantiser 32 slice + 16 (g & 1) + ((i + b) & 15) of vector 16 (g >> 1) + i; the 8-byte-entry table of a slice is
+    // [code][m & 31] x 8 B (256-byte rows): ds_read_b64 banks = (addr / 4) % 64, so a half wave must address 32 different 8-byte slots;
+    // the four-query pre-pass image is [code][m & 31] x 4 B per row half: bank = m % 32
+    for (int M : {32, 64, 96, 128}) {
+        for (int blk = 0; blk < 5; blk++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int g = lane >> 4, i = lane & 15;
+                for (int sl = 0; sl < M / 32; sl++)
+                    for (int b = 0; b < 16; b++) {
+                        const int m = 32 * sl + 16 * (g & 1) + ((i + b) & 15);
+                        if (pq_code_addr(blk * 32 + 16 * (g >> 1) + i, m, M, PQ_SLICED) != (int64_t)blk * 32 * M + sl * 1024 + lane * 16 + b) return fail("sliced byte", M, lane, b);
+                    }
+            }
+        for (int s = 0; s < 16; s++)
+            for (int h = 0; h < 2; h++) {
+                std::set<int> slots;
+                for (int lane = 32 * h; lane < 32 * h + 32; lane++) { const int g = lane >> 4, i = lane & 15; slots.insert(16 * (g & 1) + ((i + s) & 15)); }
+                if (slots.size() != 32) return fail("sliced banks", M, s, h);
             }
     }
     std::printf("layouts ok\n");

@@ -58,15 +58,15 @@ def test_golden_ivfflat(gpu, orc):
     assert_same_results(D2, I2, Dr, Ir, "nprobe>nlist")
 
 
-@pytest.mark.parametrize("name,layout", [("ivfpq_d64_m16", 1), ("ivfpq_d64_m16", 0), ("ivfpq_d768_m96", 1), ("ivfpq_d768_m96", 0)])
+@pytest.mark.parametrize("name,layout", [("ivfpq_d64_m16", 1), ("ivfpq_d64_m16", 0), ("ivfpq_d768_m96", 2), ("ivfpq_d768_m96", 1), ("ivfpq_d768_m96", 0)])
 def test_golden_ivfpq(gpu, orc, name, layout):
-    """layout 1 = the rotated code layout (k_pq_rot.hip: conflict-free table gathers, the default for M in {16, 32, 64, 96, 128} — M = 16,
-    the reference's shipped IVF-PQ config, since round 4), layout 0 = the granule layout (k_pq.hip); both must give the oracle's
-    bits through every scan variant."""
+    """layout 1 = the rotated code layout (k_pq_rot.hip: conflict-free table gathers, the default for M in {16, 32, 64, 128} — M = 16,
+    the reference's shipped IVF-PQ config, since round 4), layout 2 = the sliced layout (round 6, M = 96: eight queries per table
+    gather, k_pq_scan_sl8), layout 0 = the granule layout (k_pq.hip); all must give the oracle's bits through every scan variant."""
     g = load_golden(name)
     x, q = regen_gpu(gpu, g)
     ix = gpu.IndexIVFPQ(gpu.IndexFlatIP(g["d"]), g["d"], g["nlist"], g["M"], 8, gpu.METRIC_INNER_PRODUCT)
-    assert ix._get("pq_layout") == 1, "the rotated layout is the default for M in {16, 32, 64, 96, 128}"
+    assert ix._get("pq_layout") in (1, 2), "a block layout is the default for M in {16, 32, 64, 96, 128}"
     ix.set_param("pq_layout", layout)
     assert ix._get("pq_layout") == layout
     name = f"{name} layout={layout}"
@@ -164,7 +164,7 @@ def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
     codes = orc.pq_encode(cb, orc.residuals(cen, x32, a))
     lm = orc.ListMajor(a, np.arange(n), codes, nlist)
     ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
-    assert ix._get("pq_layout") == (1 if M in (16, 32, 64, 96, 128) else 0)
+    assert ix._get("pq_layout") == (0 if M not in (16, 32, 64, 96, 128) else ix._get("pq_layout") if M == 96 else 1)
     if gran16:
         ix.set_param("pq_layout", 0)
         assert ix._get("pq_layout") == 0
@@ -177,7 +177,7 @@ def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
         assert_same_results(D, I, Dr, Ir, f"d={d} M={M} nprobe={nprobe}")
 
 
-@pytest.mark.parametrize("layout", [1, 0])
+@pytest.mark.parametrize("layout", [2, 1, 0])
 def test_ivfpq_many_survivors(gpu, orc, layout):
     """Large K' (weak threshold): tens of thousands of keys pass the in-kernel filter, survivor segments and candidate rows
     overflow — every query must then be flagged and repaired by the exact re-run, never silently lose a candidate."""
@@ -195,13 +195,13 @@ def test_ivfpq_many_survivors(gpu, orc, layout):
             ix.set_param("pq_fast_kp", kp); ix.set_param("scan_chunk", chunk)
             D, I = ix.search(q, k)
             assert_same_results(D, I, De, Ie, f"layout={layout} K'={kp} scan_chunk={chunk}")
-    if layout == 1:
+    if layout >= 1:
         # round 4: survivors go to per-wave logs; starved logs (64 / 4 keys each) must flag every query that lost a key
         ix.set_param("pq_fast_kp", 0); ix.set_param("scan_chunk", 0)
         for cap in (64, 4):
             ix.set_param("pq_log_cap", cap); ix.set_param("profile", 1)
             D, I = ix.search(q, k)
-            assert_same_results(D, I, De, Ie, f"layout=1 pq_log_cap={cap}")
+            assert_same_results(D, I, De, Ie, f"layout={layout} pq_log_cap={cap}")
         assert ix.get_timing("fallback_overflow_queries") > 0, "4-key logs cannot hold this batch's survivors"
         ix.set_param("pq_log_cap", 0); ix.set_param("profile", 0)
     # k = 300 -> K' = 512 on its own
@@ -823,3 +823,61 @@ def test_ivfpq_eight_query_gathers_equal_the_exact_scan(gpu, orc):
         D, I = ix.search(q, 10)
         assert_same_results(D, I, De, Ie, f"pq_q8 pq_log_cap={cap}")
     ix.set_param("pq_log_cap", 0); ix.set_param("profile", 0)
+
+
+@pytest.mark.parametrize("nlist,n", [(6, 100000), (40, 60000)])
+def test_ivfpq_sliced_layout_eight_query_scan(gpu, orc, nlist, n):
+    """Round 6, M = 96: the sliced code layout (32-vector blocks cut into 32-sub-quantiser slices) and its scan k_pq_scan_sl8 —
+    eight queries per table gather, two table slots in LDS, the third slice re-staged once per sub-tile, partial sums parked in
+    registers.  Long lists (several sub-tiles and, with a small scan chunk, several tiles per list), short lists (a ragged last
+    sub-tile), ragged query groups, both candidate paths, both threshold pre-passes, starved survivor logs, large k: always the
+    bits of the exact scan, the same repairs as the rotated layout's 4-query scan, and the rotated layout's results."""
+    d, M = 768, 96
+    x = gpu.synth_vectors(d, nlist, 1234, 10000, 0.5, 0, n)
+    q = gpu.synth_queries(d, nlist, 1234, 10000, 0.5, n, 999, 0.1, 0, 203)
+    res = {}
+    for layout in (2, 1):
+        ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+        ix.set_param("pq_layout", layout)
+        assert ix._get("pq_layout") == layout
+        ix.train(x[:20000]); ix.add(x)
+        for nq, nprobe, k in ((203, 5, 10), (77, min(nlist, 12), 10), (9, 3, 10), (130, 4, 100), (66, 3, 1000), (5, 1, 10)):
+            ix.nprobe = nprobe
+            ix.set_param("scan_kernel", 2)
+            De, Ie = ix.search(q[:nq], k)
+            ix.set_param("scan_kernel", 0)
+            for gather in (1, 0):
+                for chunk in (0, 4096):
+                    for pre4 in (1, 0):
+                        ix.set_param("pq_gather", gather); ix.set_param("scan_chunk", chunk); ix.set_param("pq_prepass4", pre4)
+                        ix.set_param("profile", 1)
+                        D, I = ix.search(q[:nq], k)
+                        tag = f"layout={layout} nq={nq} nprobe={nprobe} k={k} pq_gather={gather} scan_chunk={chunk} pq_prepass4={pre4}"
+                        assert_same_results(D, I, De, Ie, tag)
+                        key = (nq, nprobe, k, gather, chunk, pre4)
+                        rep = (ix.get_timing("fallback_queries"), ix.get_timing("second_chance_queries"))
+                        if layout == 2:
+                            res[key] = (D, I, rep)
+                        else:       # a scan that lost survivors would be repaired by the exact re-run: both layouts must need the same repairs
+                            assert np.array_equal(res[key][0], D) and np.array_equal(res[key][1], I), tag
+                            assert res[key][2] == rep, f"{tag}: repairs {res[key][2]} (sliced) vs {rep} (rotated)"
+            ix.set_param("pq_gather", 1); ix.set_param("scan_chunk", 0); ix.set_param("pq_prepass4", 1)
+        if layout == 2:
+            ix.nprobe = 5
+            ix.set_param("scan_kernel", 2)
+            De, Ie = ix.search(q, 10)
+            ix.set_param("scan_kernel", 0)
+            for cap in (64, 4):
+                ix.set_param("pq_log_cap", cap)
+                D, I = ix.search(q, 10)
+                assert_same_results(D, I, De, Ie, f"sliced pq_log_cap={cap}")
+            ix.set_param("pq_log_cap", 0)
+            # codes come back in list order through the layout-independent export
+            cen, cb = ix.get_centroids(), ix.get_codebooks()
+            x32 = x.astype(np.float32)
+            a, _ = orc.assign_ip(cen, x32[:3000])
+            codes = orc.pq_encode(cb, orc.residuals(cen, x32[:3000], a))
+            for l in range(min(nlist, 4)):
+                c, ids = ix.get_list(l)
+                sel = ids < 3000
+                assert np.array_equal(c[sel], codes[ids[sel]]), f"list {l} codes through the sliced layout"

@@ -24,10 +24,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=2, help="every setting is timed this many times, interleaved")
     ap.add_argument("--set", action="append", default=[], help="comma-separated name=value engine parameters; k=.. / nprobe=.. / batch=.. are search arguments")
+    ap.add_argument("--layouts", default="", help="comma-separated pq_layout values: one index per layout over the same vectors (same centroids and codebooks), "
+                    "every setting is timed on each, interleaved, and all results are compared with the first's")
     args = ap.parse_args()
     import torch, rsx
     dev = torch.device("cuda", 0)
-    ix = rsx.IndexIVFPQ(rsx.IndexFlatIP(D), D, args.nlist, args.m, 8, rsx.METRIC_INNER_PRODUCT, device=0)
+    layouts = [int(v) for v in args.layouts.split(",") if v != ""] or [None]
+    ixs = []
+    for lay in layouts:
+        jx = rsx.IndexIVFPQ(rsx.IndexFlatIP(D), D, args.nlist, args.m, 8, rsx.METRIC_INNER_PRODUCT, device=0)
+        if lay is not None:
+            jx.set_param("pq_layout", float(lay))
+        ixs.append(jx)
+    ix = ixs[0]
     nt = min(args.n, 256 * args.nlist)
     xt = torch.empty((nt, D), dtype=torch.float16, device=dev)
     stride = max(1, args.n // nt)
@@ -35,10 +44,14 @@ def main():
         nb = min(4096, nt - b)
         rsx.synth_vectors(D, NC, SC, SX, 0.5, (b * stride) % max(1, args.n - nb), nb, out=xt[b:b + nb])
     t0 = time.time(); ix.train(xt); del xt
+    for jx in ixs[1:]:
+        jx.set_centroids(ix.get_centroids()); jx.set_codebooks(ix.get_codebooks())
     buf = torch.empty((1_000_000, D), dtype=torch.float16, device=dev)
     for c0 in range(0, args.n, 1_000_000):
         nb = min(1_000_000, args.n - c0)
-        rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb]); ix.add(buf[:nb])
+        rsx.synth_vectors(D, NC, SC, SX, 0.5, c0, nb, out=buf[:nb])
+        for jx in ixs:
+            jx.add(buf[:nb])
     del buf
     print(f"[exp] build {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
     nsteps = args.warmup + args.steps
@@ -49,7 +62,8 @@ def main():
     ref = {}
     out = []
     for rnd in range(args.rounds):
-        for s in settings:
+      for s in settings:
+        for lay, ix in zip(layouts, ixs):
             kv = dict(x.split("=") for x in s.split(",")) if s else {}
             k = int(kv.pop("k", args.k)); nprobe = int(kv.pop("nprobe", args.nprobe)); nq = int(kv.pop("batch", args.batch))
             ix.nprobe = nprobe
@@ -80,7 +94,7 @@ def main():
                 ref[key] = (Dn, In)
             for name in kv:      # back to defaults for the next setting
                 ix.set_param(name, {"pq_pace": float(128 | (4 << 12)), "pq_pre_rows": 4096.0, "scan_chunk": 0.0, "pq_prune": 0.0, "pq_fast_kp": 0.0}.get(name, 1.0))
-            r = {"set": s, "round": rnd, "qps": round(args.steps * nq / el, 1), "ms_per_step": round(el / args.steps * 1e3, 4), "stages": st,
+            r = {"set": s, "layout": lay, "round": rnd, "qps": round(args.steps * nq / el, 1), "ms_per_step": round(el / args.steps * 1e3, 4), "stages": st,
                  "fallback_queries": fb, "fb_stage_ms_total": fbst, "fb_launches": fbl, "fallback_overflow": fbo, "second_chance_queries": sec, "cand_mean": round(ck, 1), "cand_max": ckm, "same_as_first": same}
             print(json.dumps(r), flush=True); out.append(r)
 
