@@ -267,7 +267,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         HIPCHECK(hipEventRecord(h->ev_fork, h->st));
         HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
         launch_pq_lut8(nullptr, h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad, nullptr, 0,
-                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, rot ? 1 : 0, h->st2, 1, lut32_out);
+                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, sliced ? 2 : rot ? 1 : 0, h->st2, 1, lut32_out);
         HIPCHECK(hipEventRecord(h->ev_lut, h->st2));
         side_join.armed = true;
     }
@@ -496,7 +496,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             if (fused_lut && h->dsub == 8 && h->lut_tiled != 0) { h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad)); lut_ws = h->w_lutws.p; }
             if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_lut, 0));     // the tables were built beside the probe selection
             launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
-                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, rot ? 1 : 0, h->st, side_lut ? 2 : 0,
+                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, sliced ? 2 : rot ? 1 : 0, h->st, side_lut ? 2 : 0,
                            fused_lut ? lut32_out : nullptr);
             tm.mark("lut8");
             int rot_log_cap = 64;

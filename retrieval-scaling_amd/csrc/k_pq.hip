@@ -336,8 +336,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8(const float* lut32, int M, int 
         float mn = s_mn[m];
         float u = rintf((v - mn) * inv);
         u = fminf(fmaxf(u, 0.0f), 255.0f);
-        if (transposed) lut8[(q * 256 + c) * Mpad + m] = (uint8_t)u;   // [q][code][m]: the rotated-layout scans
-        else lut8[(q * Mpad + m) * 256 + c] = (uint8_t)u;
+        lut8[pq_lut8_index(q, c, m, Mpad, transposed)] = (uint8_t)u;   // 1: [q][code][m], the rotated-layout scans; 2: sliced
         float err = fabsf(v - (mn + scale * u));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
@@ -426,7 +425,7 @@ __global__ __launch_bounds__(256) void k_pq_lut8f(const float* Q32, int ldq, con
         }
         if (transposed) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) lut8[(q * 256 + lane * 4 + j) * Mpad + m] = (uint8_t)(pk >> (8 * j));
+            for (int j = 0; j < 4; j++) lut8[pq_lut8_index(q, lane * 4 + j, m, Mpad, transposed)] = (uint8_t)(pk >> (8 * j));
         } else *(uint32_t*)&lut8[(q * Mpad + m) * 256 + lane * 4] = pk;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off));
@@ -572,7 +571,7 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
         for (int e = tid; e < nqc * 256; e += 256) {
             const int qi = e >> 8, c = e & 255;
             const uint2 v8 = *reinterpret_cast<const uint2*>(lt_obuf + (size_t)e * LT_MB);
-            uint8_t* dst = lut8 + ((q0 + qi) * 256 + c) * Mpad + m0;
+            uint8_t* dst = lut8 + pq_lut8_index(q0 + qi, c, m0, Mpad, transposed);      // LT_MB = 8 consecutive m: one run in both transposed forms
             if (m0 + LT_MB <= Mpad) *reinterpret_cast<uint2*>(dst) = v8;
             else for (int t = 0; m0 + t < Mpad; t++) dst[t] = lt_obuf[(size_t)e * LT_MB + t];
         }

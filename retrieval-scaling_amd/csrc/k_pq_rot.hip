@@ -36,10 +36,22 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define ROT_DEPTH 4
 #endif
 #ifndef SL8_NB
-#define SL8_NB 8              // k_pq_scan_sl8: blocks of 32 vectors per wave and sub-tile (their partial sums are parked in 4 VGPRs each)
+#define SL8_NB 16              // k_pq_scan_sl8: blocks of 32 vectors per wave and sub-tile (their partial sums are parked in 4 VGPRs each)
+#endif
+#ifndef SL8_VAR
+#define SL8_VAR 0
+#endif
+#ifndef SL8_PR
+#define SL8_PR 1              // ... blocks a wave keeps one issue priority for
+#endif
+#ifndef SL8_JL
+#define SL8_JL 1              // ... the middle pass requests its share of the third slice's table behind block JL and writes it behind block JW
+#endif
+#ifndef SL8_JW
+#define SL8_JW 5
 #endif
 #ifndef SL8_RD
-#define SL8_RD 4              // ... and 1 KiB code loads in flight per wave
+#define SL8_RD 2              // ... and 1 KiB code loads in flight per wave
 #endif
 constexpr int ROT_D = ROT_DEPTH;   // 16-vector code blocks in flight per wave (16 M bytes each); must divide the tile's blocks per wave
 #ifndef ROT_CW
@@ -1005,7 +1017,8 @@ template <int NS, int NB, int RD>
 __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ log_keys,
                                                       uint2* __restrict__ seg_desc, uint32_t* xcd_ctr, int log_cap, int tile_blocks) {
     static_assert(NS == 3, "zig-zag schedule written for three slices (M = 96)");
-    static_assert(NB % RD == 0, "the prefetch slots rotate with the unrolled block index");
+    static_assert((NS * NB) % RD == 0 && RD <= NB, "the prefetch slot of a step is a compile-time function of (pass, block)");
+    static_assert(NB % 2 == 0, "two blocks' partial sums share a register");
     constexpr int M = 32 * NS, G = 2;
     constexpr int BB = 32 * M;                 // bytes per 32-vector block
     constexpr int TAB = 2 * 65536;             // two table slots
@@ -1013,6 +1026,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
     extern __shared__ __attribute__((aligned(16))) uint32_t sl8_s[];
     uint8_t* sb = reinterpret_cast<uint8_t*>(sl8_s);
     PQRotItem* islot = reinterpret_cast<PQRotItem*>(sb + TAB);                  // [2][G] current / next item's records
+    constexpr uint32_t cntA_a = (uint32_t)(TAB + 2 * G * 176);                 // LDS word: waves that have left the first pass, counted over the item's sub-tiles
+    constexpr uint32_t cntS_a = cntA_a + 4;                                    // LDS word: waves that have written their share of the re-staged slot
     const PQScanArgs& a = A.b;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1099,21 +1114,23 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
 #pragma unroll
         for (int k = 0; k < 8; k++) qq[k] = __builtin_amdgcn_readfirstlane(k < 4 ? it0->q[k] : it1->q[k - 4]);
         // ---- staging of one slice's table into a slot: unit = (code, 4 consecutive m of the slice) -> the eight queries' dwords ->
-        // four 8-byte entries (bytes 0-3: record 0's queries, 4-7: record 1's) = 32 contiguous bytes of the code's row
-        auto stage_slice = [&](int sl, int slot) {
-            uint32_t in[2][8];
-            // (a query slot without a query holds a valid query index — k_pq_rot_items — and its accumulators start at -2^30: its table is
-            //  loaded like the others, unmasked.  Scalar base + 32-bit lane offset per load; the offset is made opaque so that the
-            //  compiler does not keep sixteen 64-bit addresses alive — spilled — across the item's passes)
+        // four 8-byte entries (bytes 0-3: record 0's queries, 4-7: record 1's) = 32 contiguous bytes of the code's row.  Two units per
+        // thread; issue (16 loads in flight) and write-out are separate so that the loads can travel behind scan blocks.
+        // (a query slot without a query holds a valid query index — k_pq_rot_items — and its accumulators start at -2^30: its table is
+        //  loaded like the others, unmasked.  Scalar base + 32-bit lane offset per load; the offset is made opaque so that the
+        //  compiler does not keep sixteen 64-bit addresses alive — spilled — across the item's passes)
+        uint32_t sin[2][8];
+        auto stage_issue = [&](int sl) {
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int e = tid + u * 1024;
-                uint32_t eoff = (uint32_t)((e >> 3) * M + (e & 7) * 4 + sl * 32);
+                uint32_t eoff = (uint32_t)((tid + u * 1024) * 4 + sl * 8192);       // lut8 is [q][slice][code][32]: thread e takes dword e of the slice's 8 KiB
                 asm volatile("" : "+v"(eoff));
 #pragma unroll
                 for (int k = 0; k < 8; k++)
-                    in[u][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (int64_t)qq[k] * (256 * M) + eoff));
+                    sin[u][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (int64_t)qq[k] * (256 * M) + eoff));
             }
+        };
+        auto stage_write = [&](int slot) {
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int e = tid + u * 1024;
@@ -1121,7 +1138,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
                 uint32_t o[2][4];
 #pragma unroll
                 for (int hh = 0; hh < 2; hh++) {
-                    const uint32_t a0 = in[u][4 * hh], a1 = in[u][4 * hh + 1], a2 = in[u][4 * hh + 2], a3 = in[u][4 * hh + 3];
+                    const uint32_t a0 = sin[u][4 * hh], a1 = sin[u][4 * hh + 1], a2 = sin[u][4 * hh + 2], a3 = sin[u][4 * hh + 3];
                     const uint32_t t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
                     const uint32_t u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
                     o[hh][0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
@@ -1147,80 +1164,129 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
             ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, code_off(0, 0, dd), 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (w == 0 && lane == 0) drawn = atomicAdd(ctr, 1u);      // the next item's index: resolved after the staging
-        if (nsub > 0) { stage_slice(0, 0); stage_slice(1, 1); }
+        if (nsub > 0) { stage_issue(0); stage_write(0); stage_issue(1); stage_write(1); }
+        // the next item is drawn JUST IN TIME (k_pq_scan_rot, round 3): the query groups of a list are adjacent in the item order, so the
+        // workgroups that draw them are the ones that come free one after the other — they start within a couple of microseconds of each
+        // other, walk the same sub-tiles in the same order at the same pace, and the second finds the code lines in the XCD's L2.  (Drawn
+        // one item ahead, siblings started tens of microseconds apart: 14.6 GB fetched for 9.6 GB of codes.)  Wave 0 draws at the start
+        // of the item's last pass and requests the records half-way through it.
         uint4 pre = make_uint4(0xffffffffu, 0, 0, 0);
         int i1 = 0x7fffffff;
-        if (w == 0) { i1 = resolve_draw(); pre = load_records(i1); }
+        int dstate = 0;                       // wave 0: 0 = not drawn, 1 = draw in flight, 2 = records requested
+        if (w == 0 && lane == 0) { lds_wr32(cntA_a, 0u); lds_wr32(cntS_a, 0u); }       // the item's pass counters
         const PQRotItem* itq = &islot[buf * G + rq];
         const int cinit = itq->cinit[nq4];
-        const v4i Ci = {cinit, cinit, cinit, cinit};
         const uint32_t qstart = lcur;
-        __syncthreads();    // #2: slices 0 and 1 staged
-        v4i acc[NB];
-#pragma unroll 1
-        for (int st = 0; st < nsub; st++) {
-#pragma unroll 1
-            for (int p = 0; p < NS; p++) {
-                const int sl = slice_of(st, p);
-                const int slot = sl == 1 ? 1 : 0;
-                if (p == NS - 1) {      // the slice of the third pass takes slot 0, free since the first pass
-                    __syncthreads();
-                    stage_slice(sl, 0);
-                    __syncthreads();
+        __syncthreads();    // #2: slices 0 and 1 staged, counters zero
+        // ---- one pass of a wave over its NB blocks of sub-tile st.  P = 0: first pass (accumulators start at -threshold), P = 1:
+        // middle pass — the wave's share of the third slice's table is requested behind block JL and written into slot 0 behind block
+        // JW, once every wave has left the first pass (cntA); P = 2: last pass — waits until every wave has written its share (cntS),
+        // then the sums are complete: survivors.  No barrier: a wave that is early waits on a counter, nobody else does.
+        // Parked partial sums: after one or two passes a sum of (u8 - 128) over <= 64 sub-quantisers lies in [-8192, 8128] — 16 bits.  Blocks
+        // 2 t and 2 t + 1 share the four registers accp[t] (low / high half): a sub-tile of 16 x NB blocks costs 2 NB VGPRs, which is what
+        // sets the number of table re-stagings per item (64 KiB each through the fabric).  The threshold joins in the last pass.
+        uint32_t accp[NB / 2][4];
+        uint32_t xacc = 0;
+        auto pass = [&](auto PC, int st) {
+            constexpr int P = decltype(PC)::value;
+            constexpr int JL = SL8_JL, JW = SL8_JW < NB ? SL8_JW : NB - 1;
+            const int sl = slice_of(st, P);
+            const int pn = P + 1 < NS ? P + 1 : 0, stn = P + 1 < NS ? st : st + 1;       // the pass after this one (prefetch across the boundary)
+#if !(SL8_VAR & 17)     // (16 = no waiting on the pass counters — races, timing only)
+            if (P == 2) { while ((int)(lds_rd32_volatile(cntS_a) - (uint32_t)(16 * (st + 1))) < 0) __builtin_amdgcn_s_sleep(1); }
+#endif
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const int b = tb0 + 16 * (st * NB + j) + w;
+                if (P == 2 && w == 0 && st == nsub - 1) {
+                    if (j == 0 && dstate == 0) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }
+                    if (j == NB / 2 && dstate == 1) { i1 = resolve_draw(); pre = load_records(i1); dstate = 2; }
                 }
-                // the pass after this one (for the prefetch across the pass boundary)
-                const int pn = p + 1 < NS ? p + 1 : 0, stn = p + 1 < NS ? st : st + 1;
-                const bool first = p == 0, last = p == NS - 1;
-#pragma unroll
-                for (int j = 0; j < NB; j++) {
-                    const int b = tb0 + 16 * (st * NB + j) + w;
-                    uint32_t gv[16];
-                    {
-                        const uint32_t cw[4] = {ca[j % RD].x, ca[j % RD].y, ca[j % RD].z, ca[j % RD].w};
-                        if (slot) {
-#pragma unroll
-                            for (int s2 = 0; s2 < 16; s2++)
-                                gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], Rb[s2 / 3], 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
-                        } else {
-#pragma unroll
-                            for (int s2 = 0; s2 < 16; s2++)
-                                gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], Ra[s2 / 3], 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
-                        }
+#if !(SL8_VAR & 8)      // (8 = no issue-priority rotation)
+                // the four waves of a SIMD (w, w + 4, w + 8, w + 12) take turns at the top issue priority, SL8_PR blocks each: the arbiter
+                // favours the oldest wave otherwise, and here every wave waits for the slowest once per sub-tile
+                if (j % SL8_PR == 0) {
+                    switch ((j / SL8_PR + P * (NB / SL8_PR) + st + (w >> 2)) & 3) {
+                        case 0: __builtin_amdgcn_s_setprio(3); break;
+                        case 1: __builtin_amdgcn_s_setprio(2); break;
+                        case 2: __builtin_amdgcn_s_setprio(1); break;
+                        default: __builtin_amdgcn_s_setprio(0); break;
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    ca[j % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, j + RD < NB ? code_off(st, p, j + RD) : code_off(stn, pn, j + RD - NB), 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (b >= bend) continue;          // wave-uniform: past the tile / the list (the prefetch slot has been refilled)
-                    v4i C = first ? Ci : acc[j];
-                    {
-                        rot_v2u g8[16];
+                }
+#endif
+                uint32_t gv[16];
+#if SL8_VAR & 2         // (2 = the code stream and the table re-staging alone: no look-ups, no sums)
+                xacc ^= ca[(P * NB + j) % RD].x ^ ca[(P * NB + j) % RD].y ^ ca[(P * NB + j) % RD].z ^ ca[(P * NB + j) % RD].w;
 #pragma unroll
-                        for (int s2 = 0; s2 < 16; s2++) g8[s2] = lds_rd64(gv[s2]);
+                for (int s2 = 0; s2 < 16; s2++) gv[s2] = 0;
+#else
+                {
+                    const uint32_t cw[4] = {ca[(P * NB + j) % RD].x, ca[(P * NB + j) % RD].y, ca[(P * NB + j) % RD].z, ca[(P * NB + j) % RD].w};
 #pragma unroll
-                        for (int t = 0; t < 8; t++) {
-                            const v4i Av = {(int)g8[2 * t].x, (int)g8[2 * t].y, (int)g8[2 * t + 1].x, (int)g8[2 * t + 1].y};
-                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
-                        }
-                    }
-                    if (!last) { acc[j] = C; __builtin_amdgcn_sched_barrier(0); continue; }
-                    // C[r] = cinit + sum over all M sub-quantisers of (u8 - 128) for vector 16 (n >> 3) + 4 g + r of block b and query n & 7
-                    if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0)) {
-                        int b5 = b << 5;
-                        asm volatile("" : "+s"(b5));      // opaque: the positions of all NB x 4 rows would otherwise be computed ahead of the pass loop and spilled
+                    for (int s2 = 0; s2 < 16; s2++)
+                        gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], P == 1 ? Rb[s2 / 3] : Ra[s2 / 3], 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                ca[(P * NB + j) % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, j + RD < NB ? code_off(st, P, j + RD) : code_off(stn, pn, j + RD - NB), 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (b < bend && !(SL8_VAR & 2)) {          // wave-uniform: inside the tile and the list (the prefetch slot has been refilled either way)
+                    v4i C = {0, 0, 0, 0};
+                    if (P > 0) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const bool cnd = C[r] >= 0;
+                            const int v = (j & 1) ? (int)accp[j >> 1][r] >> 16 : __builtin_amdgcn_sbfe((int)accp[j >> 1][r], 0, 16);
+                            C[r] = P == 2 ? v + cinit : v;
+                        }
+                    }
+                    // sixteen 8-byte gathers in four groups, two groups in flight: the next group is requested before this one's two MFMAs
+                    rot_v2u ga[4], gb[4];
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; s2++) ga[s2] = lds_rd64(gv[s2]);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        if (q4 < 3) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 4; s2++) { if (q4 & 1) ga[s2] = lds_rd64(gv[4 * (q4 + 1) + s2]); else gb[s2] = lds_rd64(gv[4 * (q4 + 1) + s2]); }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (q4 & 1) {
+                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)gb[0].x, (int)gb[0].y, (int)gb[1].x, (int)gb[1].y}, Bm, C, 0, 0, 0);
+                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)gb[2].x, (int)gb[2].y, (int)gb[3].x, (int)gb[3].y}, Bm, C, 0, 0, 0);
+                        } else {
+                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)ga[0].x, (int)ga[0].y, (int)ga[1].x, (int)ga[1].y}, Bm, C, 0, 0, 0);
+                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)ga[2].x, (int)ga[2].y, (int)ga[3].x, (int)ga[3].y}, Bm, C, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (P < 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (P == 0 && !(j & 1)) accp[j >> 1][r] = (uint32_t)C[r] & 0xffffu;
+                            else if (j & 1) accp[j >> 1][r] = __builtin_amdgcn_perm((uint32_t)C[r], accp[j >> 1][r], 0x05040100u);      // {acc.b0, acc.b1, C.b0, C.b1}
+                            else accp[j >> 1][r] = __builtin_amdgcn_perm((uint32_t)C[r], accp[j >> 1][r], 0x03020504u);               // {C.b0, C.b1, acc.b2, acc.b3}
+                        }
+                    }
+                    else if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0)) {
+                        // C[r] = cinit + sum over all M sub-quantisers of (u8 - 128) for vector 16 (n >> 3) + 4 g + r of block b and query n & 7
+                        int b5 = b << 5;
+                        asm volatile("" : "+s"(b5));      // opaque: the positions of all NB x 4 rows would otherwise be computed ahead of the pass loop and spilled
+                        // (rolled: this rare path is instantiated once per unrolled block of the last pass — unrolled four ways it was two
+                        //  thirds of the kernel's code, and the scan loop has to stay inside the instruction cache)
+#pragma unroll 1
+                        for (int r = 0; r < 4; r++) {
+                            const int Cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
+                            const bool cnd = Cr >= 0;
                             if (__builtin_amdgcn_ballot_w64(cnd)) {
                                 const float p_dis0 = itq->dis0[nq4], p_scale = itq->scale[nq4], p_bias = itq->bias[nq4];
                                 const int64_t p_off = itq->off[nq4];
                                 const uint64_t p_tau = itq->tau[nq4];
                                 const uint32_t pos = (uint32_t)b5 + (uint32_t)(16 * (n >> 3) + 4 * g + r);
-                                const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(C[r] - cinit + 128 * M), p_bias);
+                                const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(Cr - cinit + 128 * M), p_bias);
                                 const uint64_t key = (cnd && pos < (uint32_t)len) ? make_key(sc, (uint32_t)p_off + pos) : 0ull;
-                                const bool pass = key > p_tau;
-                                const uint64_t mq = __builtin_amdgcn_ballot_w64(pass) & QM;      // this step's survivors of MY query
-                                if (pass) {
+                                const bool pass_ = key > p_tau;
+                                const uint64_t mq = __builtin_amdgcn_ballot_w64(pass_) & QM;      // this step's survivors of MY query
+                                if (pass_) {
                                     const uint32_t slot_k = lcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
                                     if (slot_k < (uint32_t)log_cap) mylog[slot_k] = key;   // beyond: counted, dropped -> the query is re-run exactly
                                 }
@@ -1229,8 +1295,31 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#if !(SL8_VAR & 1)      // (cost-split builds of tools/build_variant.sh: 1 = no re-staging — wrong sums, timing only)
+                if (P == 1 && j == JL) stage_issue(slice_of(st, 2));
+                if (P == 1 && j == JW) {
+#if !(SL8_VAR & 16)
+                    while ((int)(lds_rd32_volatile(cntA_a) - (uint32_t)(16 * (st + 1))) < 0) __builtin_amdgcn_s_sleep(1);
+#endif
+                    stage_write(0);
+                }
+#endif
             }
+            if (P == 0 && lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + cntA_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (P == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's table writes have left before it reports them
+                if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + cntS_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+#pragma unroll 1
+        for (int st = 0; st < nsub; st++) {
+            pass(std::integral_constant<int, 0>{}, st);
+            pass(std::integral_constant<int, 1>{}, st);
+            pass(std::integral_constant<int, 2>{}, st);
         }
+        __builtin_amdgcn_s_setprio(0);
+        if ((SL8_VAR & 2) && xacc == 0x12345678u) mylog[0] = xacc;
         // ---- item epilogue: the wave's 4 G run descriptors (lane = 4 record + slot = its own query column, g = 0, vector half 0), then
         // wave 0 parks the next item's records
         if (lane < 4 * G) {
@@ -1239,6 +1328,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
                 make_uint2((uint32_t)(mylog_i * (size_t)log_cap) + c0, (c1 - c0) | ((lcur > (uint32_t)log_cap && lcur > qstart) ? 0x80000000u : 0u));
         }
         if (w == 0) {
+            if (dstate == 0) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }     // empty items
+            if (dstate == 1) { i1 = resolve_draw(); pre = load_records(i1); }
             if (lane < 11 * G) reinterpret_cast<uint4*>(&islot[(buf ^ 1) * G])[lane] = pre;
             if (lane == 0) islot[(buf ^ 1) * G].pad0 = i1;
         }
@@ -1538,10 +1629,11 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
             const int e = tid + u * 1024;
             const int ee = e < nunits ? e : 0;
             const int c = ee / (M / 4), m4 = ee - c * (M / 4);
-            in[u][0] = *reinterpret_cast<const uint32_t*>(a.lut8 + (qa * 256 + c) * M + m4 * 4);
-            in[u][1] = np > 1 ? *reinterpret_cast<const uint32_t*>(a.lut8 + (qb * 256 + c) * M + m4 * 4) : 0u;
-            in[u][2] = np > 2 ? *reinterpret_cast<const uint32_t*>(a.lut8 + (qc * 256 + c) * M + m4 * 4) : 0u;
-            in[u][3] = np > 3 ? *reinterpret_cast<const uint32_t*>(a.lut8 + (qd * 256 + c) * M + m4 * 4) : 0u;
+            const int64_t eo = SL ? pq_lut8_index(0, c, m4 * 4, M, 2) : (int64_t)c * M + m4 * 4;      // within a query's 256 M table bytes
+            in[u][0] = *reinterpret_cast<const uint32_t*>(a.lut8 + qa * 256 * M + eo);
+            in[u][1] = np > 1 ? *reinterpret_cast<const uint32_t*>(a.lut8 + qb * 256 * M + eo) : 0u;
+            in[u][2] = np > 2 ? *reinterpret_cast<const uint32_t*>(a.lut8 + qc * 256 * M + eo) : 0u;
+            in[u][3] = np > 3 ? *reinterpret_cast<const uint32_t*>(a.lut8 + qd * 256 * M + eo) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < NU; u++) {

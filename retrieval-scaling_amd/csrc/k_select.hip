@@ -554,7 +554,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             cf[0] = nf[0]; cf[1] = nf[1]; ch = nh;
         }
     } else if (a.CB == PQ_SLICED) {
-        // sliced layout (rsx_internal.h): lut8 is [q][code][M]; lane (g, i) of a wave sums the entries of its 16 bytes per slice of
+        // sliced layout (rsx_internal.h): lut8 is [q][slice][code][32]; lane (g, i) of a wave sums the entries of its 16 bytes per slice of
         // vector 16 (g >> 1) + i of a 32-vector block, the two lanes of a vector are added with one shuffle; one block ahead
         const int M = a.Mpad, NS = M >> 5;
         const int g = lane >> 4, i = lane & 15;
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #pragma unroll
                 for (int s2 = 0; s2 < 16; s2++) {
                     const int m = 32 * sl + 16 * (g & 1) + ((i + s2) & 15);
-                    acc += tab[((wds[s2 >> 2] >> (8 * (s2 & 3))) & 255u) * M + m];
+                    acc += tab[((sl * 256 + ((wds[s2 >> 2] >> (8 * (s2 & 3))) & 255u)) << 5) + (m & 31)];       // lut8: [slice][code][32]
                 }
             }
             acc += __shfl_xor(acc, 16);
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                     uint32_t acc = 0;
                     for (int m = 0; m < a.Mpad; m++) {
                         const uint32_t code = a.codes[pq_code_addr(row0 + pos, m, a.Mpad, a.CB)];
-                        acc += pq_rot_family(a.CB) ? tab[code * a.Mpad + m] : tab[m * 256 + code];
+                        acc += tab[pq_lut8_index(0, (int)code, m, a.Mpad, a.CB == PQ_SLICED ? 2 : a.CB == 0 ? 1 : 0)];
                     }
                     v = (int)acc + shift;
                 }

@@ -153,7 +153,7 @@ struct rsx_index {
     int nlist = 1, M = 0, nbits = 8, Mpad = 0, CB = 16, dsub = 0;   // CB: code layout (rsx_internal.h), 0 = rotated
     int CB_granule = 16;
 #ifndef PQ_LAYOUT_DEFAULT
-#define PQ_LAYOUT_DEFAULT 1      // RSX_PQ_LAYOUT unset: 1 = rotated wherever it applies, 2 = additionally the sliced layout for M = 96
+#define PQ_LAYOUT_DEFAULT 2      // RSX_PQ_LAYOUT unset: 1 = rotated wherever it applies, 2 = additionally the sliced layout for M = 96
 #endif
     int nprobe = 1;
     bool trained = false;

@@ -124,7 +124,13 @@ __host__ __device__ inline int64_t pq_code_addr(int64_t row, int m, int Mpad, in
 }
 __host__ __device__ inline bool pq_rot_applies(int M) { return M == 16 || (M % 32 == 0 && M >= 32 && M <= 128); }
 __host__ __device__ inline bool pq_sliced_applies(int M) { return M == 96; }      // the M whose 8-query table (M * 2 KiB) exceeds the LDS
-__host__ __device__ inline bool pq_rot_family(int CB) { return CB == 0 || CB == PQ_SLICED; }     // block layouts: transposed tables, work-item scans
+__host__ __device__ inline bool pq_rot_family(int CB) { return CB == 0 || CB == PQ_SLICED; }
+// 8-bit table layouts (launch_pq_lut8 `transposed`): 0 = [q][m][code] (granule scans), 1 = [q][code][m] (rotated layout: a code's row feeds
+// the table image), 2 = [q][slice m >> 5][code][m & 31] (sliced layout: the 8 KiB table of one (query, slice) is contiguous — the scan
+// re-stages single slices, and a [code][m] table would hand it a third of every cache line it touches)
+__host__ __device__ inline int64_t pq_lut8_index(int64_t q, int c, int m, int Mpad, int mode) {
+    return mode == 0 ? (q * Mpad + m) * 256 + c : mode == 1 ? (q * 256 + c) * Mpad + m : ((q * (Mpad >> 5) + (m >> 5)) * 256 + c) * 32 + (m & 31);
+}     // block layouts: transposed tables, work-item scans
 // The two 8-byte halves of the piece that holds sub-quantisers 16 run .. 16 run + 15 of vector `row` (M >= 32, rotated or sliced layout);
 // rotated left by row & 15 bytes (rot16_bytes, k_select.hip) the 16 bytes are the codes in m order.
 __device__ inline void pq_piece_ptrs(const uint8_t* codes, int64_t row, int M, int CB, int run, const uint8_t*& p0, const uint8_t*& p1) {
@@ -269,7 +275,7 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
                     int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
                     void* qparam /* [nq] {scale, bias, eps, pad} */,
                     void* ws /* pq_lut8_tiled_ws(nq, Mpad) bytes -> tiled build (dsub 8), or null */,
-                    int transposed /* 0: lut8 [nq][Mpad][256]; 1: [nq][256][Mpad] (rotated-layout scans) */, hipStream_t st,
+                    int transposed /* pq_lut8_index: 0: lut8 [nq][Mpad][256]; 1: [nq][256][Mpad] (rotated-layout scans); 2: [nq][Mpad/32][256][32] (sliced) */, hipStream_t st,
                     int phase = 0 /* tiled build only: 1 = the tables (independent of the probe selection), 2 = the per-query parameters */,
                     float* lut32_out = nullptr /* fused forms only: also store the fp32 tables [nq][Mpad][256] (k_pq_final_tab reads them) */);
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad);
