@@ -347,15 +347,19 @@ def main():
     launches_per_step = max(1.0, scan_launches / args.steps)
     ms_per_launch = scan_ms / max(1.0, scan_launches)
     sec = ms_per_launch * 1e-3
-    rot = index._get("pq_layout") == 1
-    kernel = "k_pq_scan_rot" if rot else "k_pq_scan8"
+    layout = index._get("pq_layout")                              # 2 = sliced (M = 96 default), 1 = rotated, 0 = granule
+    rot = layout in (1, 2)
+    kernel = "k_pq_scan_sl8" if layout == 2 else "k_pq_scan_rot" if rot else "k_pq_scan8"
+    gq = int(index.get_timing("scan_group_queries") or 4)       # queries per table gather of that kernel
     # HBM roofline: the codes of every list probed at least once must cross HBM once per batch (list-major scan) — that is the
     # kernel's algorithmic HBM traffic; PMC FETCH_SIZE (`traffic`) shows what actually crossed.
     alg_bytes = scanned_unique * args.m / launches_per_step
     achieved = alg_bytes / sec / 1e9 if sec > 0 else 0.0
-    # LDS side: one 4-byte table gather per lane per (vector, sub-quantiser, group of 4 queries); ds_read_b32 peak = 128 B/clk/CU
-    lds_bytes = scanned_group * args.m * 4 / launches_per_step
-    lds_peak = 128.0 * 256 * 2.4e9 / 1e9
+    # LDS side: one table gather per lane per (vector, sub-quantiser, query group): 8 bytes (ds_read_b64, peak 256 B/clk/CU) for the
+    # eight-query scans, 4 bytes (ds_read_b32, peak 128 B/clk/CU) for the four-query ones
+    gather_bytes = 8 if gq == 8 else 4
+    lds_bytes = scanned_group * args.m * gather_bytes / launches_per_step
+    lds_peak = (256.0 if gq == 8 else 128.0) * 256 * 2.4e9 / 1e9
 
     # recall@k of the first timed batch against the exact streaming ground truth (all shards merged)
     D1, I1 = step(args.warmup)
@@ -544,6 +548,14 @@ def main():
 
     if rank == 0:
         traffic, traffic_note, mfma_busy = load_pmc_traffic(n_total, world, kernel)
+        # what the counters say the dominant kernel is bound by.  k_pq_scan_sl8 (round 6): 0.6-0.8 instructions per SIMD
+        # issue turn, LDS array a third busy, matrix pipe a third busy — none saturated — while its L2-miss traffic (codes + table slices +
+        # sibling re-reads) runs at 5.5-5.8 TB/s, nine tenths of what this chip delivers into LDS (6.2 TB/s measured): memory bound.
+        # k_pq_scan_rot (rounds 2-5): CU bound — one instruction per issue turn on every SIMD (profiles/r05_scan_plateau.md section 5).
+        bound_note = ("memory: L2-miss traffic (roofline.traffic) at ~0.9 of the measured 6.2 TB/s fill rate; SQ issue 0.6-0.8 per turn, LDS ~0.35, "
+                      "MFMA ~0.36 busy (profiles/r06_sliced_scan.md)" if kernel == "k_pq_scan_sl8" else
+                      "cu (lds gather issue): one instruction per 4-clock issue turn on every SIMD, LDS 0.61, MFMA 0.30 busy "
+                      "(profiles/r05_scan_plateau.md)" if kernel == "k_pq_scan_rot" else "lds bank conflicts (granule layout)")
         res = {
             "metric": "queries/sec + recall@10, 100M x 768 IVF-PQ nprobe=32 batch=1024",
             "value": round(args.steps * nq / elapsed, 2),
@@ -561,11 +573,11 @@ def main():
             "recall_informative": recall2,
             "config": {"workload": f"{n_total}x{D} IVF-PQ M={args.m} nbits=8 nlist={args.nlist} nprobe={args.nprobe} "
                                    f"batch={nq} k={k}, inner product, by_residual",
-                       "vectors_per_gpu": n_local, "code_layout": "rotated" if rot else "granule",
+                       "vectors_per_gpu": n_local, "code_layout": {2: "sliced", 1: "rotated"}.get(layout, "granule"),
                        "parallelism": (f"index sharded by inverted lists (l % {world} == rank) over {world} GPU(s)" if list_shards
                                        else f"index sharded by id range over {world} GPU(s)"),
                        "dist_backend": (args.dist_backend if world > 1 else None)},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm" if kernel != "k_pq_scan_rot" else "cu (lds gather issue)", "bound_by_counters": bound_note, "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms_per_launch, 4),
                          "launches_per_step": launches_per_step,
@@ -575,8 +587,12 @@ def main():
                          "mfma_busy": (round(mfma_busy, 4) if mfma_busy else None),      # north_star's MFMA-busy counter: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), same stamped PMC session
                          "lds": {"achieved": round(lds_bytes / sec / 1e9, 1) if sec > 0 else None, "peak": round(lds_peak, 1), "unit": "GB/s",
                                  "frac": round(lds_bytes / sec / 1e9 / lds_peak, 4) if sec > 0 else None,
-                                 "note": "4-byte ds_read_b32 table gathers: one per lane per (vector, sub-quantiser, group of <= 4 "
-                                         "queries); peak = 128 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS)"},
+                                 "queries_per_gather": gq,
+                                 "gather_padding_ratio": (round(scanned_group * gq / scanned, 4) if scanned > 0 else None),
+                                 "note": f"{gather_bytes}-byte table gathers ({'ds_read_b64' if gq == 8 else 'ds_read_b32'}): one per lane per (vector, "
+                                         f"sub-quantiser, group of <= {gq} queries); peak = {256 if gq == 8 else 128} B/clk/CU x 256 CUs x 2.4 GHz "
+                                         "(MI355X_MICROARCH.md, LDS); gather_padding_ratio = group slots / (vector, query) pairs: the share of "
+                                         "every gather that serves an empty query slot"},
                          "logical": {"bytes_per_launch": scanned * args.m / launches_per_step,
                                      "effective_GBs": round(scanned * args.m / launches_per_step / sec / 1e9, 1) if sec > 0 else None,
                                      "note": "SURVEY 8(d): sum over (query, probed list) of len*M; an EFFECTIVE rate (one HBM read serves "

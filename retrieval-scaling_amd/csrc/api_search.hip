@@ -451,10 +451,12 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         h->timing["scanned_vectors"] += tot;
         // the same batch seen list-major: vectors of every list probed at least once (what HBM must deliver), and vectors x
         // groups of 4 probing queries (what the IVF-PQ fast scan gathers)
+        // (queries per table gather of the scan this index takes: 8 for the sliced layout and the M = 64 eight-query form, 16 at M = 16, else 4)
+        const int gq = h->kind == KIND_IVFPQ && pq_rot_family(h->CB) ? (sliced ? 8 : 4 * pq_scan_rot_ngq(h->M, true, h->pq_q8)) : 4;
         double uniq = 0, grp = 0;
         for (int l = 0; l < nlist; l++)
-            if (pc[(size_t)l]) { uniq += (double)h->h_len[(size_t)l]; grp += (double)h->h_len[(size_t)l] * ((pc[(size_t)l] + 3) / 4); }
-        h->timing["scanned_unique_vectors"] += uniq; h->timing["scanned_group_vectors"] += grp;
+            if (pc[(size_t)l]) { uniq += (double)h->h_len[(size_t)l]; grp += (double)h->h_len[(size_t)l] * ((pc[(size_t)l] + gq - 1) / gq); }
+        h->timing["scanned_unique_vectors"] += uniq; h->timing["scanned_group_vectors"] += grp; h->timing["scan_group_queries"] = (double)gq;
         tm.mark("count");
     }
     // host-side bound on a query's row of the score buffer: the nprobe longest (padded) lists

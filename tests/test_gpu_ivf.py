@@ -66,7 +66,7 @@ def test_golden_ivfpq(gpu, orc, name, layout):
     g = load_golden(name)
     x, q = regen_gpu(gpu, g)
     ix = gpu.IndexIVFPQ(gpu.IndexFlatIP(g["d"]), g["d"], g["nlist"], g["M"], 8, gpu.METRIC_INNER_PRODUCT)
-    assert ix._get("pq_layout") in (1, 2), "a block layout is the default for M in {16, 32, 64, 96, 128}"
+    assert ix._get("pq_layout") == (2 if g["M"] == 96 else 1), "a block layout is the default for M in {16, 32, 64, 96, 128}: sliced for M = 96, else rotated"
     ix.set_param("pq_layout", layout)
     assert ix._get("pq_layout") == layout
     name = f"{name} layout={layout}"
@@ -164,7 +164,7 @@ def test_ivfpq_shapes_vs_oracle(gpu, orc, d, M, nlist):
     codes = orc.pq_encode(cb, orc.residuals(cen, x32, a))
     lm = orc.ListMajor(a, np.arange(n), codes, nlist)
     ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
-    assert ix._get("pq_layout") == (0 if M not in (16, 32, 64, 96, 128) else ix._get("pq_layout") if M == 96 else 1)
+    assert ix._get("pq_layout") == (0 if M not in (16, 32, 64, 96, 128) else 2 if M == 96 else 1)
     if gran16:
         ix.set_param("pq_layout", 0)
         assert ix._get("pq_layout") == 0
@@ -728,9 +728,9 @@ def test_one_call_of_many_batches_equals_batch_by_batch(gpu, M):
         ix.add(x[n:])                              # lists overflow: the payload moves
 
 
-@pytest.mark.parametrize("M,d", [(96, 768), (32, 256), (64, 256), (128, 256)])
+@pytest.mark.parametrize("M,d", [(96, 768), (-96, 768), (32, 256), (64, 256), (128, 256)])
 def test_large_k_prepass_histogram_form(gpu, M, d):
-    """Large k on the rotated layout: the threshold pre-pass in its four-queries-per-workgroup histogram form
+    """Large k on the block layouts (M = 96: sliced, the default; -96: rotated): the threshold pre-pass in its four-queries-per-workgroup histogram form
     (k_pq_prepass4<.., BIG>: samples of up to 32768 rows spanning up to eight lists, the threshold at the lower edge of the
     histogram bin that holds the k-th largest integer sum) against the one-query form (pq_prepass4 = 2), no pre-pass kernel of
     this family (0) and the exact kernel.  Lists from a few rows to tens of thousands: closest lists shorter than k, than the
@@ -741,8 +741,12 @@ def test_large_k_prepass_histogram_form(gpu, M, d):
     pl = rng.dirichlet(np.full(nlist, 0.3))                 # very uneven lists
     x = (cen[rng.choice(nlist, n, p=pl)] + 0.6 * rng.randn(n, d)).astype(np.float16)
     q = (x[rng.randint(0, n, nq)].astype(np.float32) + 0.2 * rng.randn(nq, d)).astype(np.float16)
+    rotated96 = M < 0
+    M = abs(M)
     ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
-    assert ix._get("pq_layout") == 1
+    assert ix._get("pq_layout") == (2 if M == 96 else 1)
+    if rotated96:
+        ix.set_param("pq_layout", 1)
     ix.train(x[:40000]); ix.add(x); ix.nprobe = 16
     ls = ix.list_sizes()
     assert ls.min() < 1000 and ls.max() > 5000, "the test wants lists shorter than k and lists longer than the sample"

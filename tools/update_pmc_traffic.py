@@ -18,11 +18,11 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000_000
 ng = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 cur = sqlite3.connect(db).cursor()
 rows = cur.execute("select kernel_name, avg(value), count(*), avg(duration) from counters_collection "
-                   "where counter_name = 'FETCH_SIZE' and (kernel_name like '%k_pq_scan_rot%' or kernel_name like '%k_pq_scan8%') "
+                   "where counter_name = 'FETCH_SIZE' and (kernel_name like '%k_pq_scan_sl8%' or kernel_name like '%k_pq_scan_rot%' or kernel_name like '%k_pq_scan8%') "
                    "group by kernel_name order by avg(duration) desc").fetchall()
 assert rows, "no IVF-PQ scan kernel in the PMC pass"
 name, val, cnt, dur = rows[0]
-kernel = "k_pq_scan_rot" if "k_pq_scan_rot" in name else "k_pq_scan8"
+kernel = "k_pq_scan_sl8" if "k_pq_scan_sl8" in name else "k_pq_scan_rot" if "k_pq_scan_rot" in name else "k_pq_scan8"
 res = {"kernel": kernel, "kernel_name": name.split("(")[0].replace("void ", ""), "n": n, "n_gpus": ng,
        "hbm_bytes_per_launch": val * 1024.0 * 2.0, "fetch_size_kib_avg": val, "dispatches": cnt, "avg_us_under_pmc": dur / 1e3,
        "source_sha256": kernel_source_hash(), "date": datetime.date.today().isoformat(),
