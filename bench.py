@@ -343,6 +343,7 @@ def main():
     scanned_group = index.get_timing("scanned_group_vectors")    # vectors x groups of <= 4 probing queries
     cand_keys = index.get_timing("cand_keys")                    # keys that passed the in-kernel filter
     cand_keys_max = index.get_timing("cand_keys_max")
+    gq = int(index.get_timing("scan_group_queries") or 4)       # queries per table gather of the scan kernel
     index.set_param("profile", 0)
     launches_per_step = max(1.0, scan_launches / args.steps)
     ms_per_launch = scan_ms / max(1.0, scan_launches)
@@ -350,7 +351,7 @@ def main():
     layout = index._get("pq_layout")                              # 2 = sliced (M = 96 default), 1 = rotated, 0 = granule
     rot = layout in (1, 2)
     kernel = "k_pq_scan_sl8" if layout == 2 else "k_pq_scan_rot" if rot else "k_pq_scan8"
-    gq = int(index.get_timing("scan_group_queries") or 4)       # queries per table gather of that kernel
+
     # HBM roofline: the codes of every list probed at least once must cross HBM once per batch (list-major scan) — that is the
     # kernel's algorithmic HBM traffic; PMC FETCH_SIZE (`traffic`) shows what actually crossed.
     alg_bytes = scanned_unique * args.m / launches_per_step

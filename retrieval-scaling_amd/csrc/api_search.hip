@@ -276,7 +276,9 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     fa.kind = h->kind; fa.metric = h->metric; fa.state = state; fa.KP = KP; fa.k = k; fa.nq = nq;
     // Flat / IVF-Flat re-score rows of 2 d bytes that sit anywhere in HBM: only the k + max(8, k / 16) best approximate candidates the
     // certificate needs, not the power of two the selection and the sort round them up to (round 5: k = 1000 re-read 2048 rows per query)
-    if (h->kind != KIND_IVFPQ && allow_fast) fa.KPv = std::min(KP, k + std::max(8, k / 16));
+    // (only where the certificate runs — `certify`: with flat_cert = 0 there is no second pass, and the uncertified mode keeps re-ranking all
+    //  K' candidates as it always did: ADVICE r5)
+    if (h->kind != KIND_IVFPQ && allow_fast && certify) fa.KPv = std::min(KP, k + std::max(8, k / 16));
     fa.list_base = h->d_base.as<int64_t>();
     fa.ids = (h->kind == KIND_FLAT && !h->custom_ids) ? nullptr : h->ids.as<int64_t>();
     fa.Q32 = h->w_q32.as<float>(); fa.ldq = ld; fa.d = d;
@@ -669,6 +671,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // candidate gather + selection in one launch when the (probe rank, tile) table of a query is small (rsx_internal.h)
                 gs_tmax = (int)((maxlen + tile_rows - 1) / tile_rows);
                 use_gather = rot && h->pq_gather != 0 && pq_gather_select_applies(nprobe, gs_tmax, KP);
+                if (rot && h->pq_gather != 0 && !use_gather) h->timing["pq_gather_declined"] += 1;
                 if (use_gather) {
                     h->w_qitems.ensure((size_t)nq * nprobe * gs_tmax * 4);
                     gs.probe_list = h->w_probelist.as<int32_t>(); gs.list_len = h->d_len.as<int64_t>(); gs.nprobe = nprobe;

@@ -41,6 +41,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef SL8_VAR
 #define SL8_VAR 0
 #endif
+#ifndef SL8_AUX
+#define SL8_AUX 0             // ... cache policy of the code loads (2 = non-temporal)
+#endif
 #ifndef SL8_PR
 #define SL8_PR 1              // ... blocks a wave keeps one issue priority for
 #endif
@@ -1161,7 +1164,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
         v4u ca[RD];
 #pragma unroll
         for (int dd = 0; dd < RD; dd++) {
-            ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, code_off(0, 0, dd), 0);
+            ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, code_off(0, 0, dd), SL8_AUX);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (nsub > 0) { stage_issue(0); stage_write(0); stage_issue(1); stage_write(1); }
@@ -1228,7 +1231,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
-                ca[(P * NB + j) % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, j + RD < NB ? code_off(st, P, j + RD) : code_off(stn, pn, j + RD - NB), 0);
+                ca[(P * NB + j) % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, j + RD < NB ? code_off(st, P, j + RD) : code_off(stn, pn, j + RD - NB), SL8_AUX);
                 __builtin_amdgcn_sched_barrier(0);
                 if (b < bend && !(SL8_VAR & 2)) {          // wave-uniform: inside the tile and the list (the prefetch slot has been refilled either way)
                     v4i C = {0, 0, 0, 0};

@@ -447,7 +447,9 @@ static size_t gather_select_lds(int nprobe, int tmax, int KP) {
     return (size_t)KP * 8 + (size_t)GS_LCAP * 8 + (256 + 8 + 8) * 4 + (size_t)nprobe * tmax * 4 + (size_t)nprobe * tmax * 16 * (2 + 8) + 64;
 }
 bool pq_gather_select_applies(int nprobe, int tmax, int KP) {
-    return tmax >= 1 && tmax <= 16 && nprobe <= 256 && (int64_t)nprobe * tmax * 16 <= 16384 && KP <= 4096 && gather_select_lds(nprobe, tmax, KP) <= 96 * 1024;
+    return tmax >= 1 && tmax <= 16 && nprobe <= 256 && (int64_t)nprobe * tmax * 16 <= 16384 && KP <= 4096 && gather_select_lds(nprobe, tmax, KP) <= 150 * 1024;
+    // (150 KiB: round 5's prefix arrays took the per-run LDS from 2 to 10 bytes, and under the old 96 KiB cap shapes like nprobe 128 x 4 tiles
+    //  silently went back to the compaction + selection launches — ADVICE r5; a declined shape is counted: rsx_get_timing "pq_gather_declined")
 }
 void launch_pq_gather_select(const PQGatherArgs& a, int64_t nq, hipStream_t st) {
     if (nq <= 0) return;
@@ -1698,7 +1700,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         if (lane == 0 && cntv) atomicAdd(&ctl[7], cntv);
         __syncthreads();
         FT_MARK2(0);
-        if (ctl[7] > a.k) {
+        if (ctl[7] > a.k && a.qparam) {       // (without the per-query error bounds there is no cut: every key of the row is re-scored — ADVICE r5)
             const uint32_t ak = kth_word(a.k);               // a lower bound of the k-th largest approximate score word
             const float eps = reinterpret_cast<const float*>(a.qparam)[q * 4 + 2];
             float cf = ord2f(ak) - 2.0f * eps;

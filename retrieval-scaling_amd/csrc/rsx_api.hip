@@ -302,7 +302,9 @@ int rsx_merge_topk(int nshards, int64_t nq, int k, int metric, const float* D, c
                    int device) {
     return guarded([&] {
         if (nshards <= 0 || nq < 0 || k <= 0 || !D || !I || !Do || !Io) RSX_THROW(RSX_ERR_INVALID, "merge_topk: bad arguments");
-        if (k > 8192) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_topk: k = %d exceeds 8192", k);
+        // one launch holds nshards x k <= 16384 keys; beyond that the merge runs in rounds over groups of blocks, which need k <= 8192 (ADVICE r5:
+        // the pre-check used to refuse every k > 8192, also nshards = 1 with k = 16384, which one launch handles)
+        if (k > 8192 && (int64_t)nshards * k > 16384) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_topk: %d shards x k = %d: more than 16384 keys per query need k <= 8192", nshards, k);
         if (nq == 0) return;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); RSX_THROW(RSX_ERR_HIP, "no HIP device available: librsx has no CPU path"); }
@@ -342,7 +344,7 @@ int rsx_merge_packed(int nshards, int64_t nq, int k, int metric, const int64_t* 
                      void* stream) {
     return guarded([&] {
         if (nshards <= 0 || nq < 0 || k <= 0 || !packed || !Do || !Io) RSX_THROW(RSX_ERR_INVALID, "merge_packed: bad arguments");
-        if (k > 8192) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_packed: k = %d exceeds 8192", k);
+        if (k > 8192 && (int64_t)nshards * k > 16384) RSX_THROW(RSX_ERR_UNSUPPORTED, "merge_packed: %d shards x k = %d: more than 16384 keys per query need k <= 8192", nshards, k);
         if (nq == 0) return;
         if (!is_device_ptr(packed) || !is_device_ptr(Do) || !is_device_ptr(Io)) RSX_THROW(RSX_ERR_INVALID, "merge_packed: device pointers only");
         HIPCHECK(hipSetDevice(device));

@@ -195,3 +195,35 @@ def test_flat_save_load_streams_in_chunks(gpu, tmp_path):
         assert np.array_equal(D, D2) and np.array_equal(I, I2)
         jx.add_with_ids(x[:5], ids[:5] + 10 ** 9) if with_ids else jx.add(x[:5])
         assert jx.ntotal == n + 5
+
+
+@pytest.mark.parametrize("kind", ["flat", "ivfflat"])
+def test_large_k_second_certificate_pass_settles_near_ties(gpu, orc, kind):
+    """k_finalize at large k re-scores the k + max(8, k / 16) best approximate candidates first and certifies against that cut; a
+    query it cannot clear gets the rest of its K' = 2048 state row re-scored and a second certificate (this path had no
+    test).  Data that forces it: 1500 fp16 vectors within a hair of the query (their scores differ by less than the certificate's
+    error bound, so the 1062nd approximate score cannot be separated from the 1000th exact one) and 18 500 far ones (the 2048th
+    candidate is far below): the first certificate fails, the second clears — bit-equal to the oracle without an exact re-run."""
+    rng = np.random.RandomState(5)
+    d, n, near, k, nq = 256, 20000, 1500, 1000, 24
+    c = rng.randn(d).astype(np.float32)
+    x = (0.3 * rng.randn(n, d)).astype(np.float16)
+    pos = rng.permutation(n)[:near]
+    x[pos] = (c[None, :] + 0.002 * rng.randn(near, d)).astype(np.float16)
+    q = (c[None, :] + 0.001 * rng.randn(nq, d)).astype(np.float16)
+    if kind == "flat":
+        ix = gpu.IndexFlatIP(d)
+    else:
+        ix = gpu.IndexIVFFlat(None, d, 4, gpu.METRIC_INNER_PRODUCT)
+        cen = rng.randn(4, d).astype(np.float32); cen[0] = c
+        ix.set_centroids(cen); ix.nprobe = 4
+    ix.add(x)
+    assert ix.storage_dtype == "float16"
+    ix.set_param("profile", 1)
+    D, I = ix.search(q, k)
+    Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), k, 0)
+    assert_same_results(D, I, Dr, Ir, f"{kind} k = 1000 over near-ties")
+    assert ix.get_timing("fallback_queries") == 0, "the second certificate pass (K' = 2048) must clear what the first (1062 candidates) cannot"
+    # the near cluster really is inside the first cut's error bound: the k-th and the 1062nd exact scores are closer than one part in 10^4
+    Dn, _ = orc.flat_search(q.astype(np.float32), x.astype(np.float32), 1100, 0)
+    assert np.all((Dn[:, k - 1] - Dn[:, 1061]) < 1e-4 * np.abs(Dn[:, k - 1]))

@@ -25,7 +25,7 @@ def make_case(rng, ns, nq, k, ties):
     return D, I
 
 
-@pytest.mark.parametrize("ns,k", [(8, 4096), (5, 4096), (3, 8192), (33, 1000), (8, 2048), (8, 2049), (64, 300)])
+@pytest.mark.parametrize("ns,k", [(8, 4096), (5, 4096), (3, 8192), (33, 1000), (8, 2048), (8, 2049), (64, 300), (1, 16384), (1, 10000)])
 @pytest.mark.parametrize("ties", [False, True])
 def test_merge_in_rounds_matches_reference_rule(gpu, ns, k, ties):
     import torch
@@ -45,6 +45,10 @@ def test_merge_in_rounds_matches_reference_rule(gpu, ns, k, ties):
 
 
 def test_merge_refuses_k_above_8192(gpu):
+    """... only where the merge needs rounds (more than 16384 keys per query): one shard of k = 16384 is a single launch."""
     D = np.zeros((2, 1, 8193), np.float32); I = np.zeros((2, 1, 8193), np.int64)
+    with pytest.raises(RuntimeError):
+        gpu.merge_topk(D, I)
+    D = np.zeros((1, 1, 16385), np.float32); I = np.zeros((1, 1, 16385), np.int64)
     with pytest.raises(RuntimeError):
         gpu.merge_topk(D, I)
