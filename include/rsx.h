@@ -68,7 +68,10 @@ int rsx_flat_create(int d, int metric, int device, rsx_index_t** out);
 int rsx_ivfflat_create(int d, int nlist, int metric, int device, rsx_index_t** out);
 
 /* faiss.IndexIVFPQ(quantizer, d, nlist, M, nbits, METRIC_INNER_PRODUCT) — src/indicies/ivf_pq.py:147-153
- * by_residual = true (FAISS default). nbits must be 8. */
+ * by_residual = true (FAISS default). nbits must be 8.  The coarse quantiser is the reference's IndexFlatIP (ivf_pq.py:146) for
+ * either metric.  RSX_METRIC_INNER_PRODUCT (what the reference passes) takes the certified 8-bit-table fast scans;
+ * RSX_METRIC_L2 (round 6) ranks by the squared distance to the decoded vector c_l + r^ — a table per (query, list) pair, so it
+ * is served by the exact scan (k_pq_scan_l2), every code layout, any k <= 4096 (tests/test_gpu_ivf.py::test_ivfpq_l2_metric_vs_oracle). */
 int rsx_ivfpq_create(int d, int nlist, int M, int nbits, int metric, int device, rsx_index_t** out);
 
 /* ONE handle over several GPUs of the node, single process — SURVEY.md 8(b)/(e).  The reference's offline driver makes one

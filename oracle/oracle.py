@@ -180,14 +180,15 @@ def ivfflat_search(metric, centroids, lm, xq, nprobe, k):
     return D, I
 
 
-def ivfpq_search(centroids, codebooks, lm, xq, nprobe, k, heap=False):
+def ivfpq_search(centroids, codebooks, lm, xq, nprobe, k, heap=False, metric=0):
+    """metric 0: inner product (what the reference builds); 1: squared L2 to the decoded vector (orc_ivfpq_search_l2)."""
     centroids, codebooks, xq = _f32(centroids), _f32(codebooks), _f32(xq)
     codes = np.ascontiguousarray(lm.payload, dtype=np.uint8)
     nq, d = xq.shape
     M = codebooks.shape[0]
     D = np.empty((nq, k), dtype=np.float32)
     I = np.empty((nq, k), dtype=np.int64)
-    fn = lib().orc_ivfpq_search_heap if heap else lib().orc_ivfpq_search
+    fn = lib().orc_ivfpq_search_l2 if metric else lib().orc_ivfpq_search_heap if heap else lib().orc_ivfpq_search
     fn(d, centroids.shape[0], M, _p(centroids, c_f32p), _p(codebooks, c_f32p), _p(lm.list_off, c_i64p),
        _p(codes, c_u8p), _p(lm.ids, c_i64p), ctypes.c_int64(nq), _p(xq, c_f32p), nprobe, k,
        _p(D, c_f32p), _p(I, c_i64p))

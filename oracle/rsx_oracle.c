@@ -15,7 +15,8 @@
  *   reference call site                         FAISS 1.8.0 routine restated here
  *   src/indicies/flat.py:139                    IndexFlatIP::search      -> orc_flat_search
  *   src/indicies/ivf_flat.py:225 (+:73 nprobe)  IndexIVFFlat::search     -> orc_ivfflat_search
- *   src/indicies/ivf_pq.py:230  (+:77 nprobe)   IndexIVFPQ::search       -> orc_ivfpq_search
+ *   src/indicies/ivf_pq.py:230  (+:77 nprobe)   IndexIVFPQ::search       -> orc_ivfpq_search (inner product, what the reference builds)
+ *                                                                         -> orc_ivfpq_search_l2 (METRIC_L2 over the same IP quantiser)
  *   src/indicies/ivf_flat.py:143, ivf_pq.py:146 IndexFlatIP quantizer    -> orc_coarse_probe / orc_assign_ip
  *   src/indicies/ivf_*.py train (:162/:166)     Clustering::train, ProductQuantizer::train
  *                                                                         -> orc_kmeans / orc_pq_train
@@ -396,6 +397,49 @@ void orc_ivfpq_search(int d, int nlist, int M, const float* centroids, const flo
         }
         orc_topk_finish(&t, D + q * k, I + q * k);
         free(t.h); free(pid); free(ps); free(T);
+    }
+}
+
+/* IndexIVFPQ::search, METRIC_L2, by_residual (an IndexIVFPQ built over the reference's inner-product coarse quantiser,
+ * src/indicies/ivf_pq.py:146, with metric_type L2 — the reference itself only ever passes METRIC_INNER_PRODUCT, :152; this is the
+ * other metric `north_star` names).  FAISS's definition: the squared distance between the query and the DECODED vector
+ * c_l + r^, i.e. ||(q - c_l) - r^||^2 = sum over m of ||(q - c_l)_m - codebook[m][code_m]||^2.  Canonical arithmetic here: the
+ * residual query qr = q - c_l in fp32 (one rounding per component), each table entry one sequential fmaf chain over the sub-vector
+ * (df = qr - cb, acc = fma(df, df, acc), accumulator from +0), distance = (((0 + T[0][c0]) + T[1][c1]) + ...) — the generic
+ * scanner's order; FAISS's precomputed-table form (||q - c||^2 + ||r^||^2 + 2 <c, r^> - 2 <q, r^>) differs from it only in
+ * rounding.  Lists are probed by INNER PRODUCT (the quantiser's own metric).  Result order: distance ascending, ties by id. */
+void orc_ivfpq_search_l2(int d, int nlist, int M, const float* centroids, const float* codebooks,
+                         const int64_t* list_off, const uint8_t* codes, const int64_t* ids,
+                         int64_t nq, const float* xq, int nprobe, int k, float* D, int64_t* I) {
+    if (nprobe > nlist) nprobe = nlist;
+    const int dsub = d / M;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t q = 0; q < nq; q++) {
+        int64_t* pid = (int64_t*)malloc(sizeof(int64_t) * (size_t)nprobe);
+        float* ps = (float*)malloc(sizeof(float) * (size_t)nprobe);
+        float* T = (float*)malloc(sizeof(float) * (size_t)M * 256);
+        float* qr = (float*)malloc(sizeof(float) * (size_t)d);
+        orc_coarse_probe(d, nlist, centroids, 1, xq + q * d, nprobe, pid, ps);
+        orc_topk t = { (orc_cand*)malloc(sizeof(orc_cand) * (size_t)(k > 0 ? k : 1)), k, 0, 1 };
+        for (int j = 0; j < nprobe; j++) {
+            int64_t l = pid[j];
+            if (l < 0 || list_off[l + 1] == list_off[l]) continue;
+            for (int t2 = 0; t2 < d; t2++) qr[t2] = xq[q * d + t2] - centroids[l * d + t2];
+            for (int m = 0; m < M; m++)
+                for (int c = 0; c < 256; c++) {
+                    const float* cw = codebooks + ((int64_t)m * 256 + c) * dsub;
+                    float acc = 0.0f;
+                    for (int t2 = 0; t2 < dsub; t2++) { float df = qr[m * dsub + t2] - cw[t2]; acc = fmaf(df, df, acc); }
+                    T[m * 256 + c] = acc;
+                }
+            for (int64_t r = list_off[l]; r < list_off[l + 1]; r++) {
+                float dis = 0.0f;
+                for (int m = 0; m < M; m++) dis += T[m * 256 + codes[r * M + m]];
+                orc_topk_push(&t, dis, ids[r]);
+            }
+        }
+        orc_topk_finish(&t, D + q * k, I + q * k);
+        free(t.h); free(pid); free(ps); free(T); free(qr);
     }
 }
 

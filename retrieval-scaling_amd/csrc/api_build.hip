@@ -160,8 +160,8 @@ rsx_index* create_common(int kind, int d, int nlist, int M, int nbits, int metri
     if (kind == KIND_IVFPQ) {
         if (nbits != 8) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: only nbits = 8 is implemented (got %d)", nbits);
         if (M <= 0 || d % M != 0) RSX_THROW(RSX_ERR_INVALID, "IVFPQ: d (%d) must be a multiple of M (%d)", d, M);
-        if (metric != RSX_METRIC_INNER_PRODUCT)
-            RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ: only METRIC_INNER_PRODUCT is implemented (the reference builds every index with it)");
+        // METRIC_INNER_PRODUCT is what the reference builds (src/indicies/ivf_pq.py:147-153) and what the fast scans serve; METRIC_L2 — squared
+        // distance to the decoded vector over the same inner-product coarse quantiser — is served by the exact per-(query, list) scan (round 6)
         h->M = M; h->nbits = nbits; h->dsub = d / M;
         h->Mpad = (int)round_up(M, 4);
         h->CB = (h->Mpad % 16 == 0) ? 16 : 4;

@@ -126,7 +126,7 @@ static int64_t max_scan_items(rsx_index* h, int64_t nq, int nprobe, int G, int t
 static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, int k, float* dD, int64_t* dI, bool allow_fast = true);
 
 static bool pq_fast_applies(const rsx_index* h, int k, bool allow_fast) {      // the ONE definition of "this search takes the 8-bit fast scan"
-    bool fast = allow_fast && h->kind == KIND_IVFPQ && h->pq_fast != 0 && h->scan_kernel == 0 && (h->CB == 16 || pq_rot_family(h->CB)) && h->M * 255 < 65536;
+    bool fast = allow_fast && h->kind == KIND_IVFPQ && h->metric == RSX_METRIC_INNER_PRODUCT && h->pq_fast != 0 && h->scan_kernel == 0 && (h->CB == 16 || pq_rot_family(h->CB)) && h->M * 255 < 65536;
     if (fast) { int KP, BUF; kp_for(h, k, true, KP, BUF); if (KP > 4096) fast = false; }
     // the sliced layout has ONE fast kernel: the filtered scan behind the one-launch pre-pass (every other setting takes the exact scan)
     if (fast && h->CB == PQ_SLICED && !(std::min(h->nprobe, h->nlist) > 1 && h->pq_filter != 0 && h->pq_prepass_fused != 0)) fast = false;
@@ -477,7 +477,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     const bool fused_lut = pq_fused_lut;
 
     if (h->kind == KIND_IVFPQ) {
-        if (!fused_lut) {
+        const bool pq_l2 = h->metric == RSX_METRIC_L2;      // per-(query, list) tables, built inside the scan (k_pq_scan_l2)
+        if (!fused_lut && !pq_l2) {
             h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4);
             launch_pq_lut(h->w_q32.as<float>(), ld, nq, d, h->M, h->Mpad, h->d_codebooks.as<float>(), h->w_lut.as<float>(), h->st);
             tm.mark("lut");
@@ -694,7 +695,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             }
             if (!done) RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ fast scan: no kernel for M=%d", h->M);
         }
-        if (!done && h->scan_kernel != 1 && h->CB == 16) {
+        if (!done && h->scan_kernel != 1 && h->CB == 16 && !pq_l2) {
             // v2: list-major, two queries per LDS read
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             int vpl = 8;
@@ -728,7 +729,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             }
             a.slabs_per_chunk = (int)spc;
             a.max_chunks = (int)((max_slabs + spc - 1) / spc);
-            if ((rot ? launch_pq_scan_rot_exact(a, h->st) : launch_pq_scan(a, h->st)) != 0)
+            if ((pq_l2 ? launch_pq_scan_l2(a, h->w_q32.as<float>(), ld, h->d_centroids.as<float>(), h->d_codebooks.as<float>(), d, h->dsub, h->st)
+                       : rot ? launch_pq_scan_rot_exact(a, h->st) : launch_pq_scan(a, h->st)) != 0)
                 RSX_THROW(RSX_ERR_UNSUPPORTED, "IVFPQ scan: no kernel for M=%d", h->M);
         }
         h->timing[allow_fast ? "scan_launches" : "fb_scan_launches"] += 1;

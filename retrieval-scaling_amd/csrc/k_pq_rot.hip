@@ -1983,6 +1983,72 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot_exact(PQScanArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// IVF-PQ with METRIC_L2 (round 6; the reference only ever builds METRIC_INNER_PRODUCT, src/indicies/ivf_pq.py:147-153 — this is the
+// other metric `north_star` names): squared distance to the decoded vector, ||(q - c_l) - r^||^2 = sum_m ||(q - c_l)_m - cb[m][code_m]||^2.
+// The table depends on the (query, list) PAIR, so there is no shared-table fast scan: workgroup = (query, probed list, chunk of slabs)
+// builds the pair's fp32 table in LDS (M x 256 fmaf chains of dsub terms: the oracle's arithmetic, orc_ivfpq_search_l2) and scans
+// its chunk with one thread per vector, sums in m order.  Scores leave NEGATED (every selection downstream keeps the largest keys;
+// k_finalize hands back the distance).  Any code layout (byte loads through pq_code_addr): correct first, not tuned — 2 x 256 x M x dsub
+// flops of table build per (query, list, chunk) bound it, not the scan.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_pq_scan_l2(PQScanArgs a, const float* __restrict__ Q32, int ldq, const float* __restrict__ centroids,
+                                                     const float* __restrict__ codebooks, int d, int dsub) {
+    extern __shared__ __attribute__((aligned(16))) float l2_tab[];          // [Mpad][256], then the residual query [d]
+    float* qr = l2_tab + (size_t)a.Mpad * 256;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t pair = blockIdx.x;
+    const int chunk = blockIdx.y;
+    const int32_t l = a.probe_list[pair];
+    if (l < 0) return;
+    const int64_t len = a.list_len[l];
+    const int64_t nslab = (len + 63) >> 6;
+    const int64_t s0 = (int64_t)chunk * a.slabs_per_chunk;
+    if (s0 >= nslab) return;
+    int64_t s1 = s0 + a.slabs_per_chunk; if (s1 > nslab) s1 = nslab;
+    const int64_t q = pair / a.nprobe;
+    const int j = (int)(pair - q * a.nprobe);
+    float* out = a.temp + q * a.tstride + a.seg_start[q * (a.nprobe + 1) + j];
+    for (int t = tid; t < d; t += 1024) qr[t] = __fsub_rn(Q32[q * ldq + t], centroids[(int64_t)l * d + t]);
+    __syncthreads();
+    for (int e = tid; e < a.Mpad * 256; e += 1024) {
+        const int m = e >> 8, c = e & 255;
+        float acc = 0.0f;
+        if (m < a.M) {
+            const float* cw = codebooks + ((int64_t)m * 256 + c) * dsub;
+            for (int t = 0; t < dsub; t++) { const float df = __fsub_rn(qr[m * dsub + t], cw[t]); acc = __fmaf_rn(df, df, acc); }
+        }
+        l2_tab[e] = acc;
+    }
+    __syncthreads();
+    const int64_t row0 = a.list_base[l];
+    for (int64_t s = s0 + w; s < s1; s += 16) {
+        const int64_t pos = s * 64 + lane;
+        float sum = 0.0f;
+        for (int m0 = 0; m0 < a.M; m0 += 4) {
+            uint32_t code[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) code[t] = (m0 + t < a.M) ? a.codes[pq_code_addr(row0 + pos, m0 + t, a.Mpad, a.CB)] : 0u;
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (m0 + t < a.M) sum += l2_tab[(m0 + t) * 256 + code[t]];
+        }
+        out[pos] = (pos < len) ? -sum : -__builtin_inff();
+    }
+}
+
+int launch_pq_scan_l2(const PQScanArgs& a, const float* Q32, int ldq, const float* centroids, const float* codebooks, int d, int dsub, hipStream_t st) {
+    const int64_t pairs = a.nq * a.nprobe;
+    if (pairs <= 0 || a.max_chunks <= 0) return 0;
+    const size_t shm = (size_t)a.Mpad * 1024 + (size_t)d * 4;
+    if (shm > (size_t)160 * 1024) return -1;
+    static DevSize attr;
+    bool attr_ok = true;
+    attr.grow(shm, [&] { attr_ok = hipFuncSetAttribute((const void*)k_pq_scan_l2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess; });
+    if (!attr_ok) return -1;
+    hipLaunchKernelGGL(k_pq_scan_l2, dim3((unsigned)pairs, (unsigned)a.max_chunks), dim3(1024), shm, st, a, Q32, ldq, centroids, codebooks, d, dsub);
+    return 0;
+}
+
 int launch_pq_scan_rot_exact(const PQScanArgs& a, hipStream_t st) {
     const int64_t pairs = a.nq * a.nprobe;
     if (pairs <= 0 || a.max_chunks <= 0) return 0;

@@ -263,6 +263,8 @@ struct PQScanArgs {
     int slabs_per_chunk; int max_chunks;
 };
 int launch_pq_scan(const PQScanArgs& a, hipStream_t st);  // returns 0, or -1 if the LDS request cannot be met
+// IVF-PQ, METRIC_L2: per-(query, list) table of squared sub-vector distances built in LDS, exact scan, scores = -distance (k_pq_rot.hip)
+int launch_pq_scan_l2(const PQScanArgs& a, const float* Q32, int ldq, const float* centroids, const float* codebooks, int d, int dsub, hipStream_t st);
 // list-major two-queries-per-LDS-read scan; pairs grouped by list in groups of 2 (launch_group_pairs)
 int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int32_t* pair_off, const int32_t* group_off,
                     const int32_t* total_groups, const int32_t* item_off, const int32_t* total_items, int nlist,

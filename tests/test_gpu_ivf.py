@@ -885,3 +885,55 @@ def test_ivfpq_sliced_layout_eight_query_scan(gpu, orc, nlist, n):
                 c, ids = ix.get_list(l)
                 sel = ids < 3000
                 assert np.array_equal(c[sel], codes[ids[sel]]), f"list {l} codes through the sliced layout"
+
+
+@pytest.mark.parametrize("d,M,nlist,layout", [(768, 96, 16, 2), (768, 96, 16, 1), (768, 96, 16, 0), (128, 64, 8, 1), (64, 16, 7, 1), (96, 12, 8, 0), (256, 32, 5, 1)])
+def test_ivfpq_l2_metric_vs_oracle(gpu, orc, d, M, nlist, layout):
+    """IndexIVFPQ(IndexFlatIP, ..., METRIC_L2) — the metric the reference never passes (src/indicies/ivf_pq.py:147-153 builds METRIC_INNER_PRODUCT)
+    but `north_star` names: squared distance to the decoded vector c_l + r^, lists probed by the inner-product quantiser, results by distance
+    ascending with ties by id.  Every code layout, ragged lists, duplicated vectors (exact distance ties), k beyond the probed vectors (padding
+    -1 / +inf), nprobe = nlist equal to the exhaustive decode-and-compare; ids and fp32 distances bit-equal to orc_ivfpq_search_l2."""
+    n, nq = 5000, 33
+    x = orc.synth_vectors(d, nlist, 81, 82, 0.5, 0, n)
+    x[200:230] = x[9]                                  # identical vectors -> identical codes -> exact ties
+    q = np.concatenate([x[9:10], orc.synth_queries(d, nlist, 81, 82, 0.5, n, 83, 0.1, 0, nq - 1)], 0)
+    x32, q32 = x.astype(np.float32), q.astype(np.float32)
+    cen = orc.kmeans(0, x32, nlist, 4, 1234)
+    a, _ = orc.assign_ip(cen, x32)
+    cb = orc.pq_train(orc.residuals(cen, x32, a)[:2000], M, 3, 1234)
+    codes = orc.pq_encode(cb, orc.residuals(cen, x32, a))
+    lm = orc.ListMajor(a, np.arange(n), codes, nlist)
+    ix = gpu.IndexIVFPQ(gpu.IndexFlatIP(d), d, nlist, M, 8, gpu.METRIC_L2)
+    if ix._get("pq_layout") != layout:
+        ix.set_param("pq_layout", layout)
+    assert ix._get("pq_layout") == layout and ix.metric_type == gpu.METRIC_L2
+    ix.set_centroids(cen); ix.set_codebooks(cb)
+    ix.add(x[:1234]); ix.add(x[1234:])
+    for l in range(nlist):                            # same lists and codes as the inner-product index: the metric only changes the search
+        c, ids = ix.get_list(l)
+        assert np.array_equal(ids, np.nonzero(a == l)[0]) and np.array_equal(c, codes[a == l])
+    for nprobe, k in ((1, 10), (3, 20), (nlist, 50), (2, 4000)):
+        ix.nprobe = nprobe
+        D, I = ix.search(q, k)
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, nprobe, k, metric=1)
+        assert_same_results(D, I, Dr, Ir, f"IVF-PQ L2 d={d} M={M} layout={layout} nprobe={nprobe} k={k}")
+    # nprobe = nlist: the exhaustive answer — distances to the decoded vectors, checked against numpy in fp64
+    ix.nprobe = nlist
+    D, I = ix.search(q[:5], 10)
+    dsub = d // M
+    dec = cen[a] + cb[np.arange(M)[None, :], codes].reshape(n, d)
+    dist = ((q32[:5, None, :].astype(np.float64) - dec[None].astype(np.float64)) ** 2).sum(-1)
+    for qi in range(5):
+        want = np.sort(dist[qi])[:10]
+        assert np.allclose(D[qi], want, rtol=2e-5, atol=1e-4), "distances are those to the decoded vectors"
+    # save / load keeps the metric
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "l2.rsx")
+        gpu.write_index(ix, path)
+        jx = gpu.read_index(path)
+        assert jx.metric_type == gpu.METRIC_L2
+        jx.nprobe = 3
+        D2, I2 = jx.search(q, 20)
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, 3, 20, metric=1)
+        assert_same_results(D2, I2, Dr, Ir, "IVF-PQ L2 after save / load")

@@ -64,6 +64,41 @@ def test_adc_matches_decoded_inner_product(orc):
         assert np.allclose(adc, ref, rtol=1e-4, atol=1e-3)
 
 
+def test_ivfpq_l2_is_the_distance_to_the_decoded_vector(orc):
+    """orc_ivfpq_search_l2 (IndexIVFPQ over the inner-product quantiser with METRIC_L2): with every list probed the result is the
+    brute-force L2 ranking of the DECODED vectors c_l + r^ (numpy fp64), distances to fp32 rounding; with nprobe < nlist the same
+    ranking restricted to the lists the inner-product quantiser picks; ties by id; padding -1 / +inf."""
+    g = load_golden("ivfpq_d64_m16")
+    x, q = regen(orc, g)
+    x32, q32 = x.astype(np.float32), q.astype(np.float32)
+    cen, cb = g["centroids"], g["codebooks"]
+    a, _ = orc.assign_ip(cen, x32)
+    codes = orc.pq_encode(cb, orc.residuals(cen, x32, a))
+    M = cb.shape[0]
+    dec = (np.concatenate([cb[m, codes[:, m]] for m in range(M)], axis=1) + cen[a]).astype(np.float64)
+    lm = orc.ListMajor(a, np.arange(g["n"]), codes, g["nlist"])
+    k = 10
+    D, I = orc.ivfpq_search(cen, cb, lm, q32, g["nlist"], k, metric=1)
+    dist = ((q32[:, None, :].astype(np.float64) - dec[None]) ** 2).sum(-1)
+    for qi in range(q32.shape[0]):
+        want = np.sort(dist[qi])[:k]
+        assert np.allclose(D[qi], want, rtol=1e-5, atol=1e-4)
+        assert np.all(np.diff(D[qi]) >= 0)
+        assert np.allclose(dist[qi, I[qi]], D[qi], rtol=1e-5, atol=1e-4)
+    npb = 3
+    pid, _ = orc.coarse_probe(cen, q32, npb)
+    D3, I3 = orc.ivfpq_search(cen, cb, lm, q32, npb, k, metric=1)
+    for qi in range(q32.shape[0]):
+        ok = np.isin(a, pid[qi])
+        cand = np.nonzero(ok)[0]
+        order = cand[np.lexsort((cand, dist[qi, cand]))][:k]
+        got = I3[qi][I3[qi] >= 0]
+        assert np.allclose(dist[qi, got], D3[qi][: len(got)], rtol=1e-5, atol=1e-4)
+        assert set(got.tolist()) == set(order[: len(got)].tolist()) or np.allclose(np.sort(dist[qi, got]), np.sort(dist[qi, order[: len(got)]]), rtol=1e-6)
+    Dp, Ip = orc.ivfpq_search(cen, cb, lm, q32[:2], 1, 5000, metric=1)      # k beyond the probed vectors
+    assert (Ip[:, -1] == -1).all() and np.isposinf(Dp[:, -1]).all()
+
+
 def test_nprobe_all_lists_is_exhaustive(orc):
     g = load_golden("ivfflat_d768")
     x, q = regen(orc, g)
