@@ -81,7 +81,7 @@ void ensure_capacity(rsx_index* h, const std::vector<int64_t>& need, bool exact)
         HIPCHECK(hipMemcpyAsync(nb2.p, nbase.data(), nb, hipMemcpyHostToDevice, h->st));
         h->d_len.ensure(nb);
         HIPCHECK(hipMemcpyAsync(h->d_len.p, h->h_len.data(), nb, hipMemcpyHostToDevice, h->st));
-        int64_t unit_rows = (h->kind == KIND_IVFPQ) ? 64 : 1;
+        int64_t unit_rows = (h->kind == KIND_IVFPQ) ? h->row_align() : 1;      // PQ codes move in whole slabs / slice-major groups
         int64_t unit_bytes = (int64_t)rb * unit_rows;
         launch_copy_lists(h->nlist, ob.as<int64_t>(), nb2.as<int64_t>(), h->d_len.as<int64_t>(), h->data.as<uint8_t>(),
                           (uint8_t*)ndata, unit_rows, unit_bytes, (need_ids && h->ids.p) ? h->ids.as<int64_t>() : nullptr,

@@ -1031,6 +1031,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
     PQRotItem* islot = reinterpret_cast<PQRotItem*>(sb + TAB);                  // [2][G] current / next item's records
     constexpr uint32_t cntA_a = (uint32_t)(TAB + 2 * G * 176);                 // LDS word: waves that have left the first pass, counted over the item's sub-tiles
     constexpr uint32_t cntS_a = cntA_a + 4;                                    // LDS word: waves that have written their share of the re-staged slot
+    constexpr uint32_t cntB_a = cntA_a + 8;                                    // LDS word: waves that have written their share of the item's slice-1 table
     const PQScanArgs& a = A.b;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1110,8 +1111,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
         const int nblk = (int)((len + 63) >> 6) << 1;                          // 32-vector blocks of the list, slab padding included
         const int tb0 = __builtin_amdgcn_readfirstlane(it0->tile) * tile_blocks;
         int bend = tb0 + tile_blocks; if (bend > nblk) bend = nblk;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.codes + (base_row >> 5) * (int64_t)BB), 0, nblk * BB, 0x00020000);
-        const int so_oob = nblk * BB;                                          // past the descriptor's end: reads zeros
+        const int np0 = __builtin_amdgcn_readfirstlane(it0->np) & 15, np1 = __builtin_amdgcn_readfirstlane(it1->np) & 15;
+        // (the list starts on a group boundary: block b of the list, slice s -> pq_sliced_off(b, s); the descriptor covers whole groups)
+        const int so_oob = ((nblk + PQ_SLICED_GB - 1) / PQ_SLICED_GB) * (PQ_SLICED_GB * BB);      // past the descriptor's end: reads zeros
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.codes + (base_row >> 5) * (int64_t)BB), 0, so_oob, 0x00020000);
         const int nsub = bend > tb0 ? (bend - tb0 + 16 * NB - 1) / (16 * NB) : 0;
         int qq[8];                                                              // the eight queries (SGPRs: they live through the item's re-stagings)
 #pragma unroll
@@ -1119,9 +1122,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
         // ---- staging of one slice's table into a slot: unit = (code, 4 consecutive m of the slice) -> the eight queries' dwords ->
         // four 8-byte entries (bytes 0-3: record 0's queries, 4-7: record 1's) = 32 contiguous bytes of the code's row.  Two units per
         // thread; issue (16 loads in flight) and write-out are separate so that the loads can travel behind scan blocks.
-        // (a query slot without a query holds a valid query index — k_pq_rot_items — and its accumulators start at -2^30: its table is
-        //  loaded like the others, unmasked.  Scalar base + 32-bit lane offset per load; the offset is made opaque so that the
-        //  compiler does not keep sixteen 64-bit addresses alive — spilled — across the item's passes)
+        // (the tables of query slots WITHOUT a query are not fetched — three slots in ten are empty on the bench batch, and every slice
+        //  of table crosses the fabric like a code line does; their accumulators start at -2^30, whatever the slot's table bytes are.
+        //  Scalar base + 32-bit lane offset per load; the offset is made opaque so that the compiler does not keep sixteen 64-bit
+        //  addresses alive — spilled — across the item's passes)
         uint32_t sin[2][8];
         auto stage_issue = [&](int sl) {
 #pragma unroll
@@ -1129,8 +1133,11 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
                 uint32_t eoff = (uint32_t)((tid + u * 1024) * 4 + sl * 8192);       // lut8 is [q][slice][code][32]: thread e takes dword e of the slice's 8 KiB
                 asm volatile("" : "+v"(eoff));
 #pragma unroll
-                for (int k = 0; k < 8; k++)
-                    sin[u][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (int64_t)qq[k] * (256 * M) + eoff));
+                for (int k = 0; k < 8; k++) {
+                    sin[u][k] = 0u;
+                    if (k < 4 ? k < np0 : k - 4 < np1)        // wave-uniform
+                        sin[u][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (int64_t)qq[k] * (256 * M) + eoff));
+                }
             }
         };
         auto stage_write = [&](int slot) {
@@ -1159,7 +1166,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
         auto slice_of = [&](int st, int p) -> int { return (st & 1) ? NS - 1 - p : p; };
         auto code_off = [&](int st, int p, int j) -> int {
             const int b = tb0 + 16 * (st * NB + j) + w;
-            return (st < nsub && b < bend) ? b * BB + slice_of(st, p) * 1024 : so_oob;
+            return (st < nsub && b < bend) ? (b / PQ_SLICED_GB) * (PQ_SLICED_GB * BB) + slice_of(st, p) * (PQ_SLICED_GB * 1024) + (b % PQ_SLICED_GB) * 1024 : so_oob;
         };
         v4u ca[RD];
 #pragma unroll
@@ -1167,7 +1174,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
             ca[dd] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, code_off(0, 0, dd), SL8_AUX);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (nsub > 0) { stage_issue(0); stage_write(0); stage_issue(1); stage_write(1); }
+        // only slice 0 is staged ahead of the scan; slice 1 (slot 1, needed by the second pass) travels behind the first pass of the
+        // first sub-tile, like the re-stagings (cntB)
+        if (nsub > 0) { stage_issue(0); stage_write(0); }
         // the next item is drawn JUST IN TIME (k_pq_scan_rot, round 3): the query groups of a list are adjacent in the item order, so the
         // workgroups that draw them are the ones that come free one after the other — they start within a couple of microseconds of each
         // other, walk the same sub-tiles in the same order at the same pace, and the second finds the code lines in the XCD's L2.  (Drawn
@@ -1176,11 +1185,11 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
         uint4 pre = make_uint4(0xffffffffu, 0, 0, 0);
         int i1 = 0x7fffffff;
         int dstate = 0;                       // wave 0: 0 = not drawn, 1 = draw in flight, 2 = records requested
-        if (w == 0 && lane == 0) { lds_wr32(cntA_a, 0u); lds_wr32(cntS_a, 0u); }       // the item's pass counters
+        if (w == 0 && lane == 0) { lds_wr32(cntA_a, 0u); lds_wr32(cntS_a, 0u); lds_wr32(cntB_a, 0u); }       // the item's pass counters
         const PQRotItem* itq = &islot[buf * G + rq];
         const int cinit = itq->cinit[nq4];
         const uint32_t qstart = lcur;
-        __syncthreads();    // #2: slices 0 and 1 staged, counters zero
+        __syncthreads();    // #2: slice 0 staged, counters zero
         // ---- one pass of a wave over its NB blocks of sub-tile st.  P = 0: first pass (accumulators start at -threshold), P = 1:
         // middle pass — the wave's share of the third slice's table is requested behind block JL and written into slot 0 behind block
         // JW, once every wave has left the first pass (cntA); P = 2: last pass — waits until every wave has written its share (cntS),
@@ -1195,6 +1204,9 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
             constexpr int JL = SL8_JL, JW = SL8_JW < NB ? SL8_JW : NB - 1;
             const int sl = slice_of(st, P);
             const int pn = P + 1 < NS ? P + 1 : 0, stn = P + 1 < NS ? st : st + 1;       // the pass after this one (prefetch across the boundary)
+#if !(SL8_VAR & 16)
+            if (P == 1 && st == 0) { while ((int)(lds_rd32_volatile(cntB_a) - 16u) < 0) __builtin_amdgcn_s_sleep(1); }
+#endif
 #if !(SL8_VAR & 17)     // (16 = no waiting on the pass counters — races, timing only)
             if (P == 2) { while ((int)(lds_rd32_volatile(cntS_a) - (uint32_t)(16 * (st + 1))) < 0) __builtin_amdgcn_s_sleep(1); }
 #endif
@@ -1299,6 +1311,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (P == 0 && st == 0 && j == JL) stage_issue(1);
+                if (P == 0 && st == 0 && j == JW) stage_write(1);
 #if !(SL8_VAR & 1)      // (cost-split builds of tools/build_variant.sh: 1 = no re-staging — wrong sums, timing only)
                 if (P == 1 && j == JL) stage_issue(slice_of(st, 2));
                 if (P == 1 && j == JW) {
@@ -1308,6 +1322,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
                     stage_write(0);
                 }
 #endif
+            }
+            if (P == 0 && st == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + cntB_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (P == 0 && lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sb + cntA_a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (P == 1) {
@@ -1721,9 +1739,9 @@ __global__ __launch_bounds__(1024) void k_pq_prepass4(PQPrepassArgs a, int64_t n
         constexpr int NFx = SL ? SL : NF > 0 ? NF : 1;
         v4u ca[PD][NFx]; v2u cb[PD];
         auto fetch = [&](int b, v4u (&xa)[NFx], v2u& xb) {
-            const uint8_t* bp = lp + (int64_t)b * (BVEC * M);
+            const uint8_t* bp = lp + (SL ? pq_sliced_off(b, 0, M) : (int64_t)b * (BVEC * M));      // SL: the list starts on a group boundary
 #pragma unroll
-            for (int p = 0; p < (SL ? SL : NF); p++) xa[p] = *reinterpret_cast<const v4u*>(bp + p * 1024 + lane * 16);
+            for (int p = 0; p < (SL ? SL : NF); p++) xa[p] = *reinterpret_cast<const v4u*>(bp + p * (SL ? PQ_SLICED_GB * 1024 : 1024) + lane * 16);
             if (NH && !SL) xb = *reinterpret_cast<const v2u*>(bp + NF * 1024 + lane * 8);
             __builtin_amdgcn_sched_barrier(0);
         };

@@ -565,9 +565,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         const int wu = __builtin_amdgcn_readfirstlane(w);
         uint4 cf[4], nf[4];
         auto fetch = [&](int b, uint4 (&c)[4]) {
-            const uint8_t* bp = lbase + (int64_t)b * (32 * M) + lane * 16;
+            const uint8_t* bp = lbase + pq_sliced_off(b, 0, M) + lane * 16;           // the list starts on a group boundary
 #pragma unroll
-            for (int sl = 0; sl < 4; sl++) c[sl] = sl < NS ? *reinterpret_cast<const uint4*>(bp + sl * 1024) : make_uint4(0u, 0u, 0u, 0u);
+            for (int sl = 0; sl < 4; sl++) c[sl] = sl < NS ? *reinterpret_cast<const uint4*>(bp + sl * (PQ_SLICED_GB * 1024)) : make_uint4(0u, 0u, 0u, 0u);
         };
         if (wu < nblk) fetch(wu, cf);
 #pragma unroll 1

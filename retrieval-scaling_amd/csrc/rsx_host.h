@@ -253,7 +253,8 @@ struct rsx_index {
     DevBuf sh_D, sh_I, sh_q, sh_oD, sh_oI;      // parent-device gather / merge buffers
     int64_t sh_next_id = 0;                      // next sequential id of the logical index
 
-    int row_align() const { return kind == KIND_IVFPQ ? 64 : (kind == KIND_FLAT ? 128 : 64); }
+    // rows a list's storage starts on and grows by: 64-vector slabs of PQ codes — 512 (a slice-major group of 16 blocks) in the sliced layout
+    int row_align() const { return kind == KIND_IVFPQ ? (CB == PQ_SLICED ? 32 * PQ_SLICED_GB : 64) : (kind == KIND_FLAT ? 128 : 64); }
     size_t row_bytes() const { return kind == KIND_IVFPQ ? (size_t)Mpad : (size_t)ld * (storage_f16 ? 2 : 4); }
 };
 

@@ -89,20 +89,28 @@ constexpr int CCS = 16;   // counter stride in 8-byte words: cand_cnt[q * CCS]
 //             M = 16: block of 64 vectors = 1 KiB; lane (g, i) owns vector 16 g + i and reads its 16 contiguous bytes at lane*16
 //             (byte s: m = (i + s) & 15); the table row of a code holds the 16 entries twice (bytes 0-63 and 64-127), lane groups
 //             of even / odd g use one copy each, so the 32 lanes of a half-wave again hit 32 different banks.
-//   CB = PQ_SLICED (-1; "sliced", round 6, M % 32 == 0): block of 32 vectors = 32*M bytes, cut into M/32 SLICES of 1 KiB — slice s holds
+//   CB = PQ_SLICED (-1; "sliced", round 6, M % 32 == 0): block of 32 vectors, cut into M/32 SLICES of 1 KiB — slice s holds
 //             sub-quantisers 32 s .. 32 s + 31 of all 32 vectors.  Within a slice a wave lane (g, i) = (lane >> 4, lane & 15) owns vector
 //             16 (g >> 1) + i and reads 16 contiguous bytes at lane*16 (byte b: m = 32 s + 16 (g & 1) + ((i + b) & 15)).  The 32 lanes of
 //             a half-wave hold 32 different m % 32 at every step, as in the rotated layout — but a pass over ONE slice needs only that
 //             slice's table (64 KiB with 8-byte entries = eight queries per ds_read_b64), so a scan can keep two slices' tables in
 //             LDS and restage the third behind a pass (k_pq_scan_sl8).  A 16-sub-quantiser run of a vector is one 16-byte piece.
-// Lists start on 64-vector boundaries in all layouts and a 64-vector slab is 64*Mpad bytes in all of them.
+//             PQ_SLICED_GB = 16 consecutive blocks (512 vectors) form a GROUP stored slice-major: [group][slice][block in group][1 KiB] —
+//             the 16 waves of a scan workgroup read the same slice of 16 consecutive blocks at a time, one contiguous 16 KiB run instead of
+//             sixteen 1 KiB pieces 3 KiB apart.  Lists of this layout start on 512-vector boundaries (rsx_index::row_align).
+// Lists start on 64-vector boundaries in the other layouts and a 64-vector slab is 64*Mpad bytes in them.
 // ---------------------------------------------------------------------------------------
 constexpr int PQ_SLICED = -1;
+constexpr int PQ_SLICED_GB = 16;          // blocks per slice-major group
+// byte offset of slice `sl` of the 32-vector block `blk` (absolute, or relative to a group-aligned list start) in the sliced layout
+__host__ __device__ inline int64_t pq_sliced_off(int64_t blk, int sl, int Mpad) {
+    return (blk / PQ_SLICED_GB) * (int64_t)(PQ_SLICED_GB * 32 * Mpad) + (int64_t)sl * (PQ_SLICED_GB * 1024) + (blk % PQ_SLICED_GB) * 1024;
+}
 __host__ __device__ inline int64_t pq_code_addr(int64_t row, int m, int Mpad, int CB) {
     if (CB == PQ_SLICED) {
         const int v = (int)(row & 31), i = v & 15, mm = m & 31;
         const int lane = 16 * (2 * (v >> 4) + (mm >> 4)) + i;
-        return (row >> 5) * (int64_t)(32 * Mpad) + (m >> 5) * 1024 + lane * 16 + (((mm & 15) - i) & 15);
+        return pq_sliced_off(row >> 5, m >> 5, Mpad) + lane * 16 + (((mm & 15) - i) & 15);
     }
     if (CB != 0) {
         const int64_t slab = row >> 6; const int v = (int)(row & 63);
@@ -136,7 +144,7 @@ __host__ __device__ inline int64_t pq_lut8_index(int64_t q, int c, int m, int Mp
 __device__ inline void pq_piece_ptrs(const uint8_t* codes, int64_t row, int M, int CB, int run, const uint8_t*& p0, const uint8_t*& p1) {
     const int i = (int)(row & 15);
     if (CB == PQ_SLICED) {
-        p0 = codes + (row >> 5) * (int64_t)(32 * M) + (run >> 1) * 1024 + (16 * (2 * (int)((row >> 4) & 1) + (run & 1)) + i) * 16; p1 = p0 + 8;
+        p0 = codes + pq_sliced_off(row >> 5, run >> 1, M) + (16 * (2 * (int)((row >> 4) & 1) + (run & 1)) + i) * 16; p1 = p0 + 8;
         return;
     }
     const uint8_t* base = codes + (row >> 4) * (int64_t)(16 * M);

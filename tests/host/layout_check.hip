@@ -21,12 +21,13 @@ int main() {
     const L layouts[] = {{8, 16, 16}, {12, 16, 16}, {16, 16, 16}, {16, 16, 0}, {32, 32, 0}, {32, 32, 16}, {48, 48, 16}, {64, 64, 0}, {96, 96, 0}, {96, 96, 16},
                          {128, 128, 0}, {160, 160, 4}, {20, 32, 4}, {96, 96, PQ_SLICED}, {64, 64, PQ_SLICED}, {32, 32, PQ_SLICED}, {128, 128, PQ_SLICED}};
     for (const L& l : layouts) {
+        const int unit = l.CB == PQ_SLICED ? 32 * PQ_SLICED_GB : 64;       // the sliced layout is slice-major over groups of 16 blocks = 512 vectors
         for (int64_t slab = 0; slab < 3; slab++) {
             std::set<int64_t> seen;
-            for (int v = 0; v < 64; v++)
+            for (int v = 0; v < unit; v++)
                 for (int m = 0; m < l.Mpad; m++) {
-                    const int64_t a = pq_code_addr(slab * 64 + v, m, l.Mpad, l.CB);
-                    if (a < slab * 64 * l.Mpad || a >= (slab + 1) * 64 * l.Mpad) return fail("address outside the slab", l.M, v, m);
+                    const int64_t a = pq_code_addr(slab * unit + v, m, l.Mpad, l.CB);
+                    if (a < slab * unit * l.Mpad || a >= (slab + 1) * unit * l.Mpad) return fail("address outside the slab / group", l.M, v, m);
                     if (!seen.insert(a).second) return fail("two (row, m) share a byte", l.M, v, m);
                 }
         }
@@ -80,13 +81,18 @@ int main() {
     // [code][m & 31] x 8 B (256-byte rows): ds_read_b64 banks = (addr / 4) % 64, so a half wave must address 32 different 8-byte slots;
     // the four-query pre-pass image is [code][m & 31] x 4 B per row half: bank = m % 32
     for (int M : {32, 64, 96, 128}) {
-        for (int blk = 0; blk < 5; blk++)
+        // the same slice of the 16 blocks of a group is ONE contiguous 16 KiB run (what the 16 waves of a scan workgroup read at a time)
+        for (int grp = 0; grp < 3; grp++)
+            for (int sl = 0; sl < M / 32; sl++)
+                for (int bi = 0; bi < PQ_SLICED_GB; bi++)
+                    if (pq_sliced_off(grp * PQ_SLICED_GB + bi, sl, M) != (int64_t)grp * PQ_SLICED_GB * 32 * M + sl * PQ_SLICED_GB * 1024 + bi * 1024) return fail("group run", M, sl, bi);
+        for (int blk = 0; blk < 37; blk++)
             for (int lane = 0; lane < 64; lane++) {
                 const int g = lane >> 4, i = lane & 15;
                 for (int sl = 0; sl < M / 32; sl++)
                     for (int b = 0; b < 16; b++) {
                         const int m = 32 * sl + 16 * (g & 1) + ((i + b) & 15);
-                        if (pq_code_addr(blk * 32 + 16 * (g >> 1) + i, m, M, PQ_SLICED) != (int64_t)blk * 32 * M + sl * 1024 + lane * 16 + b) return fail("sliced byte", M, lane, b);
+                        if (pq_code_addr(blk * 32 + 16 * (g >> 1) + i, m, M, PQ_SLICED) != pq_sliced_off(blk, sl, M) + lane * 16 + b) return fail("sliced byte", M, lane, b);
                     }
             }
         for (int s = 0; s < 16; s++)
