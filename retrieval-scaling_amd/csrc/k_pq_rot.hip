@@ -2005,7 +2005,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot_exact(PQScanArgs a) {
 // IVF-PQ with METRIC_L2 (round 6; the reference only ever builds METRIC_INNER_PRODUCT, src/indicies/ivf_pq.py:147-153 — this is the
 // other metric `north_star` names): squared distance to the decoded vector, ||(q - c_l) - r^||^2 = sum_m ||(q - c_l)_m - cb[m][code_m]||^2.
 // The table depends on the (query, list) PAIR, so there is no shared-table fast scan: workgroup = (query, probed list, chunk of slabs)
-// builds the pair's fp32 table in LDS (M x 256 fmaf chains of dsub terms: the oracle's arithmetic, orc_ivfpq_search_l2) and scans
+// builds the pair's fp32 table in LDS (M x 256 fmaf chains of dsub terms: the arithmetic the CPU restatement under oracle/ fixes for this metric) and scans
 // its chunk with one thread per vector, sums in m order.  Scores leave NEGATED (every selection downstream keeps the largest keys;
 // k_finalize hands back the distance).  Any code layout (byte loads through pq_code_addr): correct first, not tuned — 2 x 256 x M x dsub
 // flops of table build per (query, list, chunk) bound it, not the scan.
