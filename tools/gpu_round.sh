@@ -19,7 +19,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 O=$PWD/gpurun_out
 FAST="--cpu-queries 0 --no-recall --no-configs"
 for s in "$@"; do
