@@ -454,7 +454,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         // the same batch seen list-major: vectors of every list probed at least once (what HBM must deliver), and vectors x
         // groups of 4 probing queries (what the IVF-PQ fast scan gathers)
         // (queries per table gather of the scan this index takes: 8 for the sliced layout and the M = 64 eight-query form, 16 at M = 16, else 4)
-        const int gq = h->kind == KIND_IVFPQ && pq_rot_family(h->CB) ? (sliced ? 8 : 4 * pq_scan_rot_ngq(h->M, true, h->pq_q8)) : 4;
+        const bool sl8_ = sliced && (h->pq_q8 == 2 || (h->pq_q8 != 0 && nq * (int64_t)nprobe >= (int64_t)3 * nlist && h->ntotal >= (int64_t)4096 * nlist));
+        const int gq = h->kind == KIND_IVFPQ && pq_rot_family(h->CB) ? (sliced ? (sl8_ ? 8 : 4) : 4 * pq_scan_rot_ngq(h->M, true, h->pq_q8)) : 4;
         double uniq = 0, grp = 0;
         for (int l = 0; l < nlist; l++)
             if (pc[(size_t)l]) { uniq += (double)h->h_len[(size_t)l]; grp += (double)h->h_len[(size_t)l] * ((pc[(size_t)l] + gq - 1) / gq); }
@@ -519,7 +520,11 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 h->w_itemdesc.ensure(pq_scan_rot_ws(items * ngq, rot_log_cap, nwg));
                 return h->w_itemdesc.p;
             };
-            const int ngq = sliced ? 2 : rot ? pq_scan_rot_ngq(h->M, true, h->pq_q8) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
+            // sliced layout: eight queries per gather (two records per item) where lists are long and shared by several queries; a handful of
+            // queries (about one per probed list) or short lists take the four-query single-pass scan (k_pq_scan_sl4).  pq_q8: 1 = choose,
+            // 2 = always eight, 0 = always four
+            const bool sl_eight = sliced && (h->pq_q8 == 2 || (h->pq_q8 != 0 && pairs >= (int64_t)3 * nlist && h->ntotal >= (int64_t)4096 * nlist));
+            const int ngq = sliced ? (sl_eight ? 2 : 1) : rot ? pq_scan_rot_ngq(h->M, true, h->pq_q8) : 1;     // the filtered scan's 4-query records per work item (M = 16: 4)
             int64_t avg_slabs = std::max<int64_t>(1, (h->ntotal / std::max(1, nlist) + 63) / 64);
             // rotated layout: persistent workgroups draw items dynamically, so the tile is the whole (average) list — one table
             // staging per (list, query group) — as long as that leaves a few thousand items to balance over 256 CUs
@@ -686,7 +691,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                                                  mi_main, vpl, tau_ptr, tau_stride,
                                                  h->w_cand.as<uint64_t>(), h->w_candcnt.as<unsigned long long>(), cand_cap,
                                                  rws1, rot_log_cap, h->pq_prune, (h->pq_pace & 0xffff), (fused_pre && rot) ? h->w_excl.as<uint16_t>() : nullptr,
-                                                 use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st, h->pq_q8)
+                                                 use_gather ? h->w_qitems.as<int32_t>() : nullptr, gs_tmax, h->st, sliced ? (sl_eight ? 1 : 0) : h->pq_q8)
                             : launch_pq_scan8_filter(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                      total_groups, item_off, total_items, nlist,
                                                      max_scan_items(h, nq, nprobe, 4, tile_rows), vpl, tau_ptr, tau_stride,

@@ -1001,6 +1001,223 @@ __global__ __launch_bounds__(1024) void k_pq_scan_rot16(PQScan8Args A, const PQR
 
 
 // ---------------------------------------------------------------------------------------
+// Sliced layout, FOUR queries per gather — k_pq_scan_sl4 (round 6).  The eight-query scan pays where lists are long and probed by
+// many queries; a handful of queries (one per list: single-query latency, batch 64) or short lists (one rank of an 8-GPU run: 3 k
+// vectors per list) prefer the rotated scan's shape: all slices' tables resident, ONE pass per block.  This is that shape on the
+// sliced layout: the four queries' dword table keeps 256-byte rows — slices 2 p and 2 p + 1 share plane p (bytes 0-127 / 128-255:
+// bank = m % 32 either way, every ds_read_b32 gather conflict-free) — M KiB in all; per 32-vector block a wave loads its M / 32
+// slices (16 bytes per lane each), forms 16 addresses per slice (one v_perm each), gathers, and the one-hot B operand routes
+// K groups 0, 1 (vector i) to columns 0-3 and K groups 2, 3 (vector 16 + i) to columns 4-7: M / 8 MFMAs per block.  One 4-query
+// record per item; items one ahead, static block columns — its batches have no sibling groups to keep in step.
+// ---------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(1024) void k_pq_scan_sl4(PQScan8Args A, const PQRotItem* __restrict__ items, uint64_t* __restrict__ log_keys,
+                                                      uint2* __restrict__ seg_desc, uint32_t* xcd_ctr, int log_cap, int tile_blocks) {
+    constexpr int M = 32 * NS;
+    constexpr int BB = 32 * M;
+    constexpr int NPL = (NS + 1) / 2;
+    constexpr int TAB = NPL * 65536;
+    constexpr int RD = 2;                      // 32-vector blocks (NS KiB each) in flight per wave
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) uint32_t sl4_s[];
+    uint8_t* sb = reinterpret_cast<uint8_t*>(sl4_s);
+    PQRotItem* islot = reinterpret_cast<PQRotItem*>(sb + TAB);                  // [2] current / next item record
+    const PQScanArgs& a = A.b;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15, n = lane & 15, nq4 = n & 3;
+    const int ti = *A.total_items;
+    const int per_xcd = (ti + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    int xlo = xcd * per_xcd;
+    int xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
+    if (xlo >= xhi) return;
+    uint32_t* ctr = xcd_ctr + xcd * 32;
+    int cx = xcd, hops = 0;
+    unsigned drawn = 0;
+    auto resolve_draw = [&]() -> int {
+        for (;;) {
+            const int i2 = xlo + (int)__builtin_amdgcn_readfirstlane(drawn);
+            if (i2 < xhi) return i2;
+            if (hops >= 7) return 0x7fffffff;
+            hops++;
+            cx = (cx + 1) & 7;
+            xlo = cx * per_xcd;
+            xhi = xlo + per_xcd; if (xhi > ti) xhi = ti;
+            ctr = xcd_ctr + cx * 32;
+            if (xlo >= xhi) { drawn = 0u; xlo = 0; xhi = 0; continue; }
+            if (lane == 0) drawn = atomicAdd(ctr, 1u);
+        }
+    };
+    // rotation bytes: dword slot 16 (g & 1) + ((i + s) & 15) of the row half; plane and row half are ORed in per slice
+    uint32_t R[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int bb = 0; bb < 3; bb++) { const int s2 = r * 3 + bb; if (s2 < 16) v |= (uint32_t)(64 * (g & 1) + 4 * ((i + s2) & 15)) << (8 * bb); }
+        R[r] = v;
+    }
+    const int bsel = (n < 8 && (n >> 2) == (g >> 1)) ? (1 << (8 * (n & 3))) : 0;
+    const v4i Bm = {bsel, bsel, bsel, bsel};
+    const int vo16 = lane * 16;
+    const uint64_t QM = n < 8 ? (0x0011001100110011ull << nq4) : 0ull;       // the eight lanes (4 g x 2 vector halves) of query n & 3
+    const size_t mylog_i = ((size_t)blockIdx.x * 16 + (size_t)w) * 4 + (size_t)nq4;
+    uint64_t* const mylog = log_keys + mylog_i * (size_t)log_cap;
+    uint32_t lcur = 0;
+    const auto load_record = [&](int it_) -> uint4 {
+        uint4 r0 = make_uint4(0xffffffffu, 0, 0, 0);
+        if (lane < 11 && it_ != 0x7fffffff) r0 = reinterpret_cast<const uint4*>(&items[it_])[lane];
+        return r0;
+    };
+    int item = 0;
+    if (w == 0) {
+        if (lane == 0) drawn = atomicAdd(ctr, 1u);
+        item = resolve_draw();
+        const uint4 r0 = load_record(item);
+        if (lane < 11) reinterpret_cast<uint4*>(&islot[0])[lane] = r0;
+        if (lane == 0) islot[0].pad0 = item;
+    }
+    int buf = 0;
+#pragma unroll 1
+    for (;; buf ^= 1) {
+        __syncthreads();    // #1: every wave has left the previous item's scan (tables free), the record is in LDS
+        const PQRotItem* it = &islot[buf];
+        const int item_l = __builtin_amdgcn_readfirstlane(it->l);
+        if (item_l == -1) break;
+        item = __builtin_amdgcn_readfirstlane(it->pad0);
+        const int np = __builtin_amdgcn_readfirstlane(it->np) & 15;
+        const int64_t len = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->len >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->len);
+        const int64_t base_row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it->base_row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)it->base_row);
+        const int nblk = (int)((len + 63) >> 6) << 1;
+        const int tb0 = __builtin_amdgcn_readfirstlane(it->tile) * tile_blocks;
+        int bend = tb0 + tile_blocks; if (bend > nblk) bend = nblk;
+        const int so_oob = ((nblk + PQ_SLICED_GB - 1) / PQ_SLICED_GB) * (PQ_SLICED_GB * BB);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.codes + (base_row >> 5) * (int64_t)BB), 0, so_oob, 0x00020000);
+        int nmine = bend > tb0 + w ? (bend - (tb0 + w) + 15) >> 4 : 0;
+        auto blk_off = [&](int j) -> int {     // byte offset of slice 0 of my j-th block
+            const int b = tb0 + w + 16 * j;
+            return j < nmine ? (b / PQ_SLICED_GB) * (PQ_SLICED_GB * BB) + (b % PQ_SLICED_GB) * 1024 : so_oob;
+        };
+        v4u ca[RD][NS];
+#pragma unroll
+        for (int dd = 0; dd < RD; dd++) {
+            const int so = blk_off(dd);
+#pragma unroll
+            for (int sl = 0; sl < NS; sl++) ca[dd][sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, so == so_oob ? so_oob : so + sl * (PQ_SLICED_GB * 1024), 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (w == 0 && lane == 0) drawn = atomicAdd(ctr, 1u);      // the next item's index: resolved after the staging
+        // ---- stage the four queries' table: unit = (code, 4 consecutive m) -> 4 dwords (byte k = query k as int8); lut8 is [q][slice][code][32]
+        {
+            int qq[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) qq[k] = __builtin_amdgcn_readfirstlane(it->q[k]);
+            constexpr int NU = 256 * (M / 4) / 1024;
+            uint32_t in[NU][4];
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int e = tid + u * 1024;
+                const int c = e / (M / 4), m4 = e - c * (M / 4);
+                const uint32_t eo = (uint32_t)pq_lut8_index(0, c, m4 * 4, M, 2);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    in[u][k] = k < np ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (int64_t)qq[k] * (256 * M) + eo)) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int e = tid + u * 1024;
+                const int c = e / (M / 4), m4 = e - c * (M / 4);
+                const uint32_t t0 = __builtin_amdgcn_perm(in[u][1], in[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[u][1], in[u][0], 0x07030602u);
+                const uint32_t u0 = __builtin_amdgcn_perm(in[u][3], in[u][2], 0x05010400u), u1 = __builtin_amdgcn_perm(in[u][3], in[u][2], 0x07030602u);
+                uint4 o;
+                o.x = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
+                o.y = __builtin_amdgcn_perm(u0, t0, 0x07060302u) ^ 0x80808080u;
+                o.z = __builtin_amdgcn_perm(u1, t1, 0x05040100u) ^ 0x80808080u;
+                o.w = __builtin_amdgcn_perm(u1, t1, 0x07060302u) ^ 0x80808080u;
+                const int m = m4 * 4;
+                *reinterpret_cast<uint4*>(sb + (m >> 6) * 65536 + c * 256 + (m & 63) * 4) = o;       // slice (m >> 5) & 1 = the row half
+            }
+        }
+        uint4 pre = make_uint4(0xffffffffu, 0, 0, 0);
+        int i1 = 0x7fffffff;
+        if (w == 0) { i1 = resolve_draw(); pre = load_record(i1); }
+        const int cinit = n < 8 ? it->cinit[nq4] : -(1 << 30);
+        const uint32_t qstart = lcur;
+        __syncthreads();    // #2: tables staged
+#pragma unroll 1
+        for (int j0 = 0; j0 < nmine; j0 += RD) {
+#pragma unroll
+            for (int dd = 0; dd < RD; dd++) {
+                const int j = j0 + dd;
+                const int b = tb0 + w + 16 * j;
+                // slice by slice: 16 addresses (one v_perm each), the slot's code registers refilled with the same slice of the block RD
+                // ahead, 16 gathers, 4 MFMAs — the sums of all slices accumulate in C
+                v4i C = {cinit, cinit, cinit, cinit};
+                const int so_n = blk_off(j + RD);
+#pragma unroll
+                for (int sl = 0; sl < NS; sl++) {
+                    uint32_t gv[16];
+                    {
+                        const uint32_t cw[4] = {ca[dd][sl].x, ca[dd][sl].y, ca[dd][sl].z, ca[dd][sl].w};
+                        const uint32_t orv = ((uint32_t)(sl >> 1) << 24) | ((sl & 1) ? 0x00808080u : 0u);
+#pragma unroll
+                        for (int s2 = 0; s2 < 16; s2++)
+                            gv[s2] = __builtin_amdgcn_perm(cw[s2 >> 2], R[s2 / 3] | orv, 0x0c030000u | ((uint32_t)(4 + (s2 & 3)) << 8) | (uint32_t)(s2 % 3));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ca[dd][sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo16, so_n == so_oob ? so_oob : so_n + sl * (PQ_SLICED_GB * 1024), 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < nmine) {          // wave-uniform
+#pragma unroll
+                        for (int s2 = 0; s2 < 16; s2++) gv[s2] = lds_rd32(gv[s2]);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const v4i Av = {(int)gv[4 * t], (int)gv[4 * t + 1], (int)gv[4 * t + 2], (int)gv[4 * t + 3]};
+                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bm, C, 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (j >= nmine) continue;          // wave-uniform
+                // C[r] (lanes n < 8) = cinit + sum over m of (u8 - 128) for vector 16 (n >> 2) + 4 g + r of the block and query n & 3
+                if (__builtin_amdgcn_ballot_w64((C[0] & C[1] & C[2] & C[3]) >= 0)) {
+#pragma unroll 1
+                    for (int r = 0; r < 4; r++) {
+                        const int Cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
+                        const bool cnd = Cr >= 0;
+                        if (__builtin_amdgcn_ballot_w64(cnd)) {
+                            const float p_dis0 = it->dis0[nq4], p_scale = it->scale[nq4], p_bias = it->bias[nq4];
+                            const int64_t p_off = it->off[nq4];
+                            const uint64_t p_tau = it->tau[nq4];
+                            const uint32_t pos = ((uint32_t)b << 5) + (uint32_t)(16 * ((n >> 2) & 1) + 4 * g + r);
+                            const float sc = p_dis0 + __fmaf_rn(p_scale, (float)(Cr - cinit + 128 * M), p_bias);
+                            const uint64_t key = (cnd && pos < (uint32_t)len) ? make_key(sc, (uint32_t)p_off + pos) : 0ull;
+                            const bool pass_ = key > p_tau;
+                            const uint64_t mq = __builtin_amdgcn_ballot_w64(pass_) & QM;
+                            if (pass_) {
+                                const uint32_t slot_k = lcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                                if (slot_k < (uint32_t)log_cap) mylog[slot_k] = key;
+                            }
+                            lcur += (uint32_t)__builtin_popcountll(mq);
+                        }
+                    }
+                }
+            }
+        }
+        if (lane < 4) {
+            const uint32_t c0 = qstart < (uint32_t)log_cap ? qstart : (uint32_t)log_cap, c1 = lcur < (uint32_t)log_cap ? lcur : (uint32_t)log_cap;
+            seg_desc[((size_t)item * 16 + w) * 4 + lane] =
+                make_uint2((uint32_t)(mylog_i * (size_t)log_cap) + c0, (c1 - c0) | ((lcur > (uint32_t)log_cap && lcur > qstart) ? 0x80000000u : 0u));
+        }
+        if (w == 0) {
+            if (lane < 11) reinterpret_cast<uint4*>(&islot[buf ^ 1])[lane] = pre;
+            if (lane == 0) islot[buf ^ 1].pad0 = i1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Sliced layout (PQ_SLICED, rsx_internal.h), filtered scan: EIGHT queries per table gather at M = 96 — k_pq_scan_sl8 (round 6).
 // The 8-byte-entry table of eight queries is M x 2 KiB: 192 KiB at M = 96, more than a CU's 160 KiB.  The sliced layout stores a
 // 32-vector block as M / 32 slices of 1 KiB (32 sub-quantisers x 32 vectors each), so a pass over ONE slice of a run of blocks needs
@@ -1524,6 +1741,32 @@ static int launch_pq_scan_sl8_t(const PQScan8Args& A, int vpl, void* desc_ws, in
     return 0;
 }
 
+template <int NS>
+static int launch_pq_scan_sl4_t(const PQScan8Args& A, int vpl, void* desc_ws, int log_cap, hipStream_t st) {
+    constexpr int M = 32 * NS;
+    const size_t shm = (size_t)((NS + 1) / 2) * 65536 + (size_t)2 * 176 + 64;
+    static DevOnce once;
+    static std::atomic<int> failed{0};
+    once.once([&] {
+        if (hipFuncSetAttribute((const void*)k_pq_scan_sl4<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) failed = 1;
+    });
+    if (failed) return -1;
+    const int nwg = pq_scan_rot_max_wgs(M);
+    PQRotItem* items = reinterpret_cast<PQRotItem*>(desc_ws);
+    uint2* seg_desc = pq_scan_rot_ws_desc(desc_ws, A.max_items);
+    uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, A.max_items);
+    uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, A.max_items, log_cap, nwg);
+    uint32_t* prog = xcd_ctr + 256;
+    hipLaunchKernelGGL((k_pq_rot_items<M, true>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, 1);
+    int64_t grid = nwg;
+    if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
+    hipLaunchKernelGGL((k_pq_scan_sl4<NS>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, 32 * vpl);
+    if (!A.qitems)
+        hipLaunchKernelGGL(k_pq_rot_compact, dim3((unsigned)((A.max_items + ROT_CW - 1) / ROT_CW)), dim3(64 * ROT_CW), 0, st, items, A.total_items, 1, log_keys, seg_desc,
+                           A.cand, A.cand_cnt, A.cand_cap);
+    return 0;
+}
+
 // returns 0 on launch, -1 if this M has no rotated kernel.  tau_key == null: unfiltered (every score to a.temp).
 int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qparam, const int32_t* pairs_sorted,
                        const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
@@ -1542,7 +1785,7 @@ int launch_pq_scan_rot(const PQScanArgs& a, const uint8_t* lut8t, const void* qp
     A.prune = prune; A.pace = pace; A.excl = excl; A.qitems = qitems; A.qitems_tmax = qitems_tmax;
     const int bpw = 4 * vpl;   // tile = 16 waves x bpw blocks x 16 vectors = 1024 vpl vectors, as k_pq_scan8's
     const bool f = tau_key != nullptr;
-    if (a.CB == PQ_SLICED) return launch_pq_scan_sl8_t<3, SL8_NB, SL8_RD>(A, vpl, item_ws, log_cap, st);
+    if (a.CB == PQ_SLICED) return q8 ? launch_pq_scan_sl8_t<3, SL8_NB, SL8_RD>(A, vpl, item_ws, log_cap, st) : launch_pq_scan_sl4_t<3>(A, vpl, item_ws, log_cap, st);
     switch (a.M) {
         case 16: return f ? launch_pq_scan_rot16(A, vpl, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 0, false, 1>(A, vpl, item_ws, log_cap, st);   // 64-vector blocks
         case 32: return f ? launch_pq_scan_rot_t<0, 1, true>(A, bpw, item_ws, log_cap, st) : launch_pq_scan_rot_t<0, 1, false>(A, bpw, item_ws, log_cap, st);

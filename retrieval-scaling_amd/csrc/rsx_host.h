@@ -196,7 +196,9 @@ struct rsx_index {
                           // lines), bits 8-11 = join offset in tile rows (0 = 2), bits 12-15 = the last n rows of a tile are handed to
                           // the waves dynamically (default 4; 0 = static columns), bit 4 = every chunk dynamic, bit 6 = no issue-
                           // priority rotation
-    int pq_q8 = 1;        // rotated fast scan, M = 64: eight queries per table gather (8-byte entries, ds_read_b64; k_pq_scan_rot<..., 2>) — 0 = the 4-query form
+    int pq_q8 = 1;        // eight queries per table gather (8-byte entries, ds_read_b64): rotated layout M = 64 (k_pq_scan_rot<..., 2>; 0 = the 4-query form);
+                          // sliced layout (M = 96): 1 = k_pq_scan_sl8 for batches with >= 3 probing queries per list on lists of >= 4096 vectors on average,
+                          // else the four-query single-pass k_pq_scan_sl4; 2 = always eight, 0 = always four
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
     int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)

@@ -850,32 +850,36 @@ def test_ivfpq_sliced_layout_eight_query_scan(gpu, orc, nlist, n):
             ix.set_param("scan_kernel", 2)
             De, Ie = ix.search(q[:nq], k)
             ix.set_param("scan_kernel", 0)
-            for gather in (1, 0):
-                for chunk in (0, 4096):
-                    for pre4 in (1, 0):
-                        ix.set_param("pq_gather", gather); ix.set_param("scan_chunk", chunk); ix.set_param("pq_prepass4", pre4)
-                        ix.set_param("profile", 1)
-                        D, I = ix.search(q[:nq], k)
-                        tag = f"layout={layout} nq={nq} nprobe={nprobe} k={k} pq_gather={gather} scan_chunk={chunk} pq_prepass4={pre4}"
-                        assert_same_results(D, I, De, Ie, tag)
-                        key = (nq, nprobe, k, gather, chunk, pre4)
-                        rep = (ix.get_timing("fallback_queries"), ix.get_timing("second_chance_queries"))
-                        if layout == 2:
-                            res[key] = (D, I, rep)
-                        else:       # a scan that lost survivors would be repaired by the exact re-run: both layouts must need the same repairs
-                            assert np.array_equal(res[key][0], D) and np.array_equal(res[key][1], I), tag
-                            assert res[key][2] == rep, f"{tag}: repairs {res[key][2]} (sliced) vs {rep} (rotated)"
-            ix.set_param("pq_gather", 1); ix.set_param("scan_chunk", 0); ix.set_param("pq_prepass4", 1)
+            # sliced layout: the eight-query multi-pass scan (pq_q8 = 2: k_pq_scan_sl8) AND the four-query single-pass one (0: k_pq_scan_sl4);
+            # the library chooses between them by batch and list size (1)
+            for q8 in ((2, 0, 1) if layout == 2 else (1,)):
+                for gather in (1, 0):
+                    for chunk in (0, 4096):
+                        for pre4 in (1, 0):
+                            ix.set_param("pq_q8", q8); ix.set_param("pq_gather", gather); ix.set_param("scan_chunk", chunk); ix.set_param("pq_prepass4", pre4)
+                            ix.set_param("profile", 1)
+                            D, I = ix.search(q[:nq], k)
+                            tag = f"layout={layout} nq={nq} nprobe={nprobe} k={k} pq_q8={q8} pq_gather={gather} scan_chunk={chunk} pq_prepass4={pre4}"
+                            assert_same_results(D, I, De, Ie, tag)
+                            key = (nq, nprobe, k, gather, chunk, pre4)
+                            rep = (ix.get_timing("fallback_queries"), ix.get_timing("second_chance_queries"))
+                            if layout == 2 and q8 == 2:
+                                res[key] = (D, I, rep)
+                            else:   # a scan that lost survivors would be repaired by the exact re-run: every form must need the same repairs
+                                assert np.array_equal(res[key][0], D) and np.array_equal(res[key][1], I), tag
+                                assert res[key][2] == rep, f"{tag}: repairs {res[key][2]} (sliced, eight queries) vs {rep}"
+            ix.set_param("pq_q8", 1); ix.set_param("pq_gather", 1); ix.set_param("scan_chunk", 0); ix.set_param("pq_prepass4", 1)
         if layout == 2:
             ix.nprobe = 5
             ix.set_param("scan_kernel", 2)
             De, Ie = ix.search(q, 10)
             ix.set_param("scan_kernel", 0)
-            for cap in (64, 4):
-                ix.set_param("pq_log_cap", cap)
-                D, I = ix.search(q, 10)
-                assert_same_results(D, I, De, Ie, f"sliced pq_log_cap={cap}")
-            ix.set_param("pq_log_cap", 0)
+            for q8 in (2, 0):
+                for cap in (64, 4):
+                    ix.set_param("pq_q8", q8); ix.set_param("pq_log_cap", cap)
+                    D, I = ix.search(q, 10)
+                    assert_same_results(D, I, De, Ie, f"sliced pq_q8={q8} pq_log_cap={cap}")
+            ix.set_param("pq_log_cap", 0); ix.set_param("pq_q8", 1)
             # codes come back in list order through the layout-independent export
             cen, cb = ix.get_centroids(), ix.get_codebooks()
             x32 = x.astype(np.float32)
