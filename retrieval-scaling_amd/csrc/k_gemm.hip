@@ -728,7 +728,10 @@ void launch_flat_gemm_filter(const __half* Q16, int nq_pad, int nq, const void* 
             ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
                       ? pr.multiProcessorCount : 256;
         }
-        const int slots = ((ncu / 8) / F.qt) * F.qt;           // per XCD, a multiple of the query tiles
+        int slots = ((ncu / 8) / F.qt) * F.qt;                 // per XCD, a multiple of the query tiles
+#ifdef FG2_SLOTS                                               // (A/B builds: fewer walking workgroups per XCD = a smaller L2 footprint)
+        if (slots > FG2_SLOTS) slots = (FG2_SLOTS / F.qt) * F.qt;
+#endif
         unsigned grid = (unsigned)F.ntiles;
         if (walk_on && slots > 0 && nv < ((int64_t)1 << 31) && F.ntiles >= (int64_t)4 * 8 * (slots / F.qt)) {
             F.walk = 1; grid = 8u * (unsigned)slots;
