@@ -1223,10 +1223,15 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl4(PQScan8Args A, const PQRot
 // 32-vector block as M / 32 slices of 1 KiB (32 sub-quantisers x 32 vectors each), so a pass over ONE slice of a run of blocks needs
 // only that slice's table: 64 KiB ([code][m & 31] x 8 B, 256-byte rows).  Two table slots live in LDS.  A work item's tile is cut
 // into SUB-TILES of 16 waves x NB blocks; per sub-tile a wave passes over its NB blocks once per slice and PARKS the blocks'
-// i32 partial sums in registers between the passes (one MFMA tile = 32 vectors x 8 queries = 4 VGPRs: lane groups g < 2 hold
-// vector i, g >= 2 vector 16 + i, and the one-hot B operand routes K group g to columns 8 (g >> 1) + query — all 16 columns used).
+// partial sums in registers between the passes (one MFMA tile = 32 vectors x 8 queries: lane groups g < 2 hold vector i, g >= 2
+// vector 16 + i, and the one-hot B operand routes K group g to columns 8 (g >> 1) + query — all 16 columns used; after one or two
+// passes a sum fits 16 bits, so two blocks share four VGPRs and NB = 16 blocks cost 32).
 // Slices are visited in ZIG-ZAG order (0, 1, 2 | 2, 1, 0 | ...): slice 1 keeps slot 1 for the whole item, slices 0 and 2 alternate
-// in slot 0, which is re-staged once per sub-tile — after the pass that used it, before the third pass needs it.
+// in slot 0, which is re-staged once per sub-tile BEHIND the middle pass: every wave requests its share of the slice's table behind
+// block SL8_JL, writes it behind block SL8_JW once an LDS counter says that all waves have left the first pass (slot 0 is free),
+// and the third pass waits on a second counter (all shares written).  No s_barrier inside an item.
+// What bounds it (profiles/r06_sliced_scan.md): the L2-miss traffic — codes + table slices + sibling re-reads, 12.1 GB per launch at
+// the rate this chip streams 256 private streams (5.0 - 5.7 TB/s); the CU side alone is ~1.5 ms.
 // Per (32 vectors, slice, 8 queries): one 16-byte code load per lane, 16 v_perm, 16 ds_read_b64 (conflict-free: the 32 lanes of a
 // half-wave read 32 different 8-byte slots), 8 v_mfma_i32_16x16x64_i8 — per (vector, query, sub-quantiser) half the look-up
 // instructions of the 4-query form (k_pq_scan_rot), and a list probed by 5 .. 8 queries is passed over once instead of twice.
