@@ -23,7 +23,7 @@ int64_t workspace_bytes(const rsx_index* h) {
                             &h->w_temp, &h->w_lut, &h->w_lutws, &h->w_state, &h->w_D, &h->w_I, &h->w_qin, &h->w_pairs, &h->w_flag, &h->w_x,
                             &h->w_partial, &h->w_assign, &h->w_dest, &h->w_idsin, &h->w_misc, &h->w_lut8, &h->w_qparam, &h->w_uncertain,
                             &h->w_fbq, &h->w_fbD, &h->w_fbI, &h->w_cand, &h->w_candcnt, &h->w_itemdesc, &h->w_tau, &h->w_excl, &h->w_state2, &h->w_addcnt, &h->w_addstart, &h->w_qitems, &h->w_tiews, &h->sh_D, &h->sh_I, &h->sh_q,
-                            &h->sh_oD, &h->sh_oI};
+                            &h->sh_oD, &h->sh_oI, &h->codes_plain /* derived from the payload on demand, dropped by the next add */};
     int64_t t = 0;
     for (const DevBuf* b : bufs) t += (int64_t)b->bytes;
     return t;

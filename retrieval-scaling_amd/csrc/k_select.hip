@@ -1100,13 +1100,15 @@ __device__ inline void rot16_bytes(uint32_t (&w)[4], int i) {     // byte t of t
         w[0] = r0; w[1] = r1; w[2] = r2; w[3] = r3;
     }
 }
-__device__ inline float pq_exact_sum_rot_wide(const uint8_t* codes, int64_t row, int M, const float* qv, const float* codebooks, int CB = 0) {
-    const int i = (int)(row & 15);
+__device__ inline float pq_exact_sum_rot_wide(const uint8_t* codes, int64_t row, int M, const float* qv, const float* codebooks, int CB = 0,
+                                              const uint8_t* plain = nullptr) {
+    const int i = plain ? 0 : (int)(row & 15);       // the row-major copy holds the bytes in m order already: nothing to rotate back
     const int nrun = M >> 4;
-    // the piece of a run as two 8-byte halves (pq_piece_ptrs: rotated or sliced layout)
+    // the piece of a run as two 8-byte halves (pq_piece_ptrs: rotated or sliced layout; or straight from the row-major copy)
     auto piece = [&](int r, uint2& lo, uint2& hi) {
         const uint8_t* p0; const uint8_t* p1;
-        pq_piece_ptrs(codes, row, M, CB, r, p0, p1);
+        if (plain) { p0 = plain + row * M + r * 16; p1 = p0 + 8; }
+        else pq_piece_ptrs(codes, row, M, CB, r, p0, p1);
         lo = *reinterpret_cast<const uint2*>(p0); hi = *reinterpret_cast<const uint2*>(p1);
     };
     uint2 nlo, nhi;
@@ -1259,7 +1261,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             const float dis0 = plds ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
             const int64_t slab = row >> 6; const int v = (int)(row & 63);
             const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-            const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB)
+            const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB, a.codes_plain)
                                                                   : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub, a.CB))
                             : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                          : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
@@ -1510,7 +1512,7 @@ __global__ __launch_bounds__(256) void k_pq_rescore_all(FinalizeArgs a, uint64_t
         const float dis0 = a.probe_dis0[q * a.nprobe + lo];
         const int64_t slab = row >> 6; const int v = (int)(row & 63);
         const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-        const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB)
+        const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB, a.codes_plain)
                                                               : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub, a.CB))
                         : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                      : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
@@ -1747,7 +1749,8 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
             for (int run = 0; run < FT_RUNS; run++) {
                 if (run >= nrun) break;
                 const uint8_t* p0; const uint8_t* p1;
-                pq_piece_ptrs(a.codes, x.r, M, a.CB, run, p0, p1);
+                if (a.codes_plain) { p0 = a.codes_plain + x.r * M + run * 16; p1 = p0 + 8; }
+                else pq_piece_ptrs(a.codes, x.r, M, a.CB, run, p0, p1);
                 x.lo2[run] = *reinterpret_cast<const uint2*>(p0); x.hi2[run] = *reinterpret_cast<const uint2*>(p1);
             }
         }
@@ -1761,7 +1764,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
 #pragma unroll
             for (int j = 0; j < 16; j++) sum += ft_T[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 255u)];
         } else {
-            const int i = (int)(x.r & 15);
+            const int i = a.codes_plain ? 0 : (int)(x.r & 15);
 #pragma unroll
             for (int run = 0; run < FT_RUNS; run++) {
                 if (run >= nrun) break;
@@ -1922,6 +1925,27 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     if (tid == 0) a.uncertain[q] = 0;
     FT_MARK(6);
 }
+// Row-major copy of the codes for the finalize kernels (large K'): one thread per (storage row, 16-sub-quantiser run) reads the run's piece
+// of the scan layout, rotates it back into m order and writes 16 contiguous bytes.
+__global__ __launch_bounds__(256) void k_pq_plain_rows(const uint8_t* __restrict__ codes, int64_t nrows, int M, int CB, uint8_t* __restrict__ out) {
+    const int nrun = M >> 4;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nrows * nrun) return;
+    const int64_t row = e / nrun;
+    const int run = (int)(e - row * nrun);
+    const uint8_t* p0; const uint8_t* p1;
+    pq_piece_ptrs(codes, row, M, CB, run, p0, p1);
+    const uint2 lo = *reinterpret_cast<const uint2*>(p0), hi = *reinterpret_cast<const uint2*>(p1);
+    uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+    rot16_bytes(w, (int)(row & 15));
+    *reinterpret_cast<uint4*>(out + row * M + run * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+void launch_pq_plain_rows(const uint8_t* codes, int64_t nrows, int M, int CB, uint8_t* out, hipStream_t st) {
+    if (nrows <= 0) return;
+    const int64_t units = nrows * (M >> 4);
+    hipLaunchKernelGGL(k_pq_plain_rows, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, codes, nrows, M, CB, out);
+}
+
 // sort capacity of k_pq_final_tab for this (M, k), 0 when the kernel does not apply (layout, or the table + sort do not fit the LDS)
 int pq_final_tab_capacity(int M, int CB, int k) {
     if (!pq_rot_family(CB) || !pq_rot_applies(M)) return 0;

@@ -432,6 +432,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "pq_final_tab") h->pq_final_tab = (int)value;
         else if (s == "overlap") h->overlap = (int)value;
         else if (s == "pq_gather") h->pq_gather = (int)value;
+        else if (s == "pq_plain_codes") h->pq_plain_codes = (int)value;
         else if (s == "pq_prepass4") h->pq_prepass4 = (int)value;
         else if (s == "ivf_qtiles") h->ivf_qtiles = (int)value;
         else if (s == "pq_prepass_fused") h->pq_prepass_fused = (int)value;

@@ -180,6 +180,8 @@ struct rsx_index {
     bool storage_decided = false;
     bool custom_ids = false;  // Flat: ids array only when the caller supplied ids
     DevBuf data, ids, norms;
+    DevBuf codes_plain;               // IVF-PQ, block layouts: row-major copy of the codes for large-K' finalizes, built on demand (api_search.hip)
+    uint64_t plain_gen = ~0ull; const void* plain_of = nullptr;
     std::vector<int64_t> h_base, h_len, h_cap;
     DevBuf d_base, d_len;
     int64_t total_cap = 0;
@@ -204,6 +206,7 @@ struct rsx_index {
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
     int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scans: 1 = choose 16 / 64 / 128 probing queries per group from the queries per list, 2 / 4 / 8 = force 32 / 64 / 128, 0 = always 16
     int pq_prepass4 = 1;     // rotated fast scan, full batches: threshold pre-pass with four queries per workgroup on the scan's table format (1 = small and large k, 2 = small k only, 0 = never)
+    int pq_plain_codes = 1;  // block layouts, K' >= 256: finalize from a row-major copy of the codes (built on demand, M bytes per vector)
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
     int pq_final_tab = 1;    // rotated fast scan: finalize from the complete candidate row with the fp32 table in LDS (1 = when K' >= 512 or dsub > 8 and as the second chance, 2 = always, 0 = never)
     int pq_log_cap = 0;      // rotated fast scan: keys per survivor log (0 = from the pool budget); tests shrink it to force the overflow path

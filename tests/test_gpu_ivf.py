@@ -941,3 +941,37 @@ def test_ivfpq_l2_metric_vs_oracle(gpu, orc, d, M, nlist, layout):
         D2, I2 = jx.search(q, 20)
         Dr, Ir = orc.ivfpq_search(cen, cb, lm, q32, 3, 20, metric=1)
         assert_same_results(D2, I2, Dr, Ir, "IVF-PQ L2 after save / load")
+
+
+@pytest.mark.parametrize("layout", [2, 1])
+def test_large_k_finalize_from_the_row_major_code_copy(gpu, orc, layout):
+    """K' >= 256 (the reference's n_docs = 100 ... 2000): the finalize kernels fetch a candidate's code bytes from a row-major copy of the
+    codes that is built on demand and dropped by the next add (rsx_set_param "pq_plain_codes").  Same bits with and without it, against
+    the exact kernel, across adds (the copy must follow the index), list growth (re-layout) and save / load."""
+    d, n, nlist, M = 768, 60000, 10, 96
+    x = gpu.synth_vectors(d, 10, 1234, 10000, 0.5, 0, n)
+    q = gpu.synth_queries(d, 10, 1234, 10000, 0.5, n, 999, 0.1, 0, 70)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    ix.set_param("pq_layout", layout)
+    ix.train(x[:20000]); ix.add(x[:25000]); ix.nprobe = 4
+    for rnd, upto in enumerate((25000, 40000, n)):
+        if rnd:
+            ix.add(x[(25000, 40000)[rnd - 1]:upto])           # the copy of the previous state is stale now
+        for k in (100, 1000, 2000):
+            ix.set_param("scan_kernel", 2)
+            De, Ie = ix.search(q, k)
+            ix.set_param("scan_kernel", 0)
+            for plain in (1, 0, 1):
+                ix.set_param("pq_plain_codes", plain); ix.set_param("profile", 1)
+                D, I = ix.search(q, k)
+                assert_same_results(D, I, De, Ie, f"layout={layout} ntotal={upto} k={k} pq_plain_codes={plain}")
+        ix.set_param("profile", 1); ix.search(q, 100)
+        assert ix.get_timing("plain_codes_builds") <= 1, "the copy is built once per index state, not per search"
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "i.rsx")
+        gpu.write_index(ix, path)
+        jx = gpu.read_index(path); jx.nprobe = 4
+        D, I = jx.search(q, 1000)
+        ix.set_param("scan_kernel", 2); De, Ie = ix.search(q, 1000); ix.set_param("scan_kernel", 0)
+        assert_same_results(D, I, De, Ie, f"layout={layout} after save / load, k = 1000")
