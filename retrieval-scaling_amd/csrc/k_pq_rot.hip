@@ -47,12 +47,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef SL8_PR
 #define SL8_PR 1              // ... blocks a wave keeps one issue priority for
 #endif
-#ifndef SL8_JL
-#define SL8_JL 1              // ... the middle pass requests its share of the third slice's table behind block JL and writes it behind block JW
-#endif
-#ifndef SL8_JW
-#define SL8_JW 5
-#endif
 #ifndef SL8_RD
 #define SL8_RD 2              // ... and 1 KiB code loads in flight per wave
 #endif
@@ -1227,9 +1221,10 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl4(PQScan8Args A, const PQRot
 // vector 16 + i, and the one-hot B operand routes K group g to columns 8 (g >> 1) + query — all 16 columns used; after one or two
 // passes a sum fits 16 bits, so two blocks share four VGPRs and NB = 16 blocks cost 32).
 // Slices are visited in ZIG-ZAG order (0, 1, 2 | 2, 1, 0 | ...): slice 1 keeps slot 1 for the whole item, slices 0 and 2 alternate
-// in slot 0, which is re-staged once per sub-tile BEHIND the middle pass: every wave requests its share of the slice's table behind
-// block SL8_JL, writes it behind block SL8_JW once an LDS counter says that all waves have left the first pass (slot 0 is free),
-// and the third pass waits on a second counter (all shares written).  No s_barrier inside an item.
+// in slot 0, which is re-staged once per sub-tile BEHIND the middle pass: every wave requests its share of the slice's table (two
+// units of eight dwords, one at a time) behind early blocks of the pass and writes it a few blocks later, once an LDS counter says that
+// all waves have left the first pass (slot 0 is free); the third pass waits on a second counter (all shares written).  No s_barrier
+// inside an item.
 // What bounds it (profiles/r06_sliced_scan.md): the L2-miss traffic — codes + table slices + sibling re-reads, 12.1 GB per launch at
 // the rate this chip streams 256 private streams (5.0 - 5.7 TB/s); the CU side alone is ~1.5 ms.
 // Per (32 vectors, slice, 8 queries): one 16-byte code load per lane, 16 v_perm, 16 ds_read_b64 (conflict-free: the 32 lanes of a
@@ -1348,29 +1343,29 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
         //  of table crosses the fabric like a code line does; their accumulators start at -2^30, whatever the slot's table bytes are.
         //  Scalar base + 32-bit lane offset per load; the offset is made opaque so that the compiler does not keep sixteen 64-bit
         //  addresses alive — spilled — across the item's passes)
-        uint32_t sin[2][8];
-        auto stage_issue = [&](int sl) {
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
+        // (behind scan blocks the two units travel ONE AT A TIME — eight registers in flight instead of sixteen: they pay for the third code
+        //  load in flight per wave)
+        uint32_t sin[8];
+        auto stage_issue = [&](int sl, int u) {
+            {
                 uint32_t eoff = (uint32_t)((tid + u * 1024) * 4 + sl * 8192);       // lut8 is [q][slice][code][32]: thread e takes dword e of the slice's 8 KiB
                 asm volatile("" : "+v"(eoff));
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    sin[u][k] = 0u;
+                    sin[k] = 0u;
                     if (k < 4 ? k < np0 : k - 4 < np1)        // wave-uniform
-                        sin[u][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (int64_t)qq[k] * (256 * M) + eoff));
+                        sin[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(A.lut8 + (int64_t)qq[k] * (256 * M) + eoff));
                 }
             }
         };
-        auto stage_write = [&](int slot) {
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
+        auto stage_write = [&](int slot, int u) {
+            {
                 const int e = tid + u * 1024;
                 const int c = e >> 3, m4 = e & 7;
                 uint32_t o[2][4];
 #pragma unroll
                 for (int hh = 0; hh < 2; hh++) {
-                    const uint32_t a0 = sin[u][4 * hh], a1 = sin[u][4 * hh + 1], a2 = sin[u][4 * hh + 2], a3 = sin[u][4 * hh + 3];
+                    const uint32_t a0 = sin[4 * hh], a1 = sin[4 * hh + 1], a2 = sin[4 * hh + 2], a3 = sin[4 * hh + 3];
                     const uint32_t t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
                     const uint32_t u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
                     o[hh][0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u) ^ 0x80808080u;
@@ -1398,7 +1393,7 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
         }
         // only slice 0 is staged ahead of the scan; slice 1 (slot 1, needed by the second pass) travels behind the first pass of the
         // first sub-tile, like the re-stagings (cntB)
-        if (nsub > 0) { stage_issue(0); stage_write(0); }
+        if (nsub > 0) { stage_issue(0, 0); stage_write(0, 0); stage_issue(0, 1); stage_write(0, 1); }
         // the next item is drawn JUST IN TIME (k_pq_scan_rot, round 3): the query groups of a list are adjacent in the item order, so the
         // workgroups that draw them are the ones that come free one after the other — they start within a couple of microseconds of each
         // other, walk the same sub-tiles in the same order at the same pace, and the second finds the code lines in the XCD's L2.  (Drawn
@@ -1423,7 +1418,8 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
         uint32_t xacc = 0;
         auto pass = [&](auto PC, int st) {
             constexpr int P = decltype(PC)::value;
-            constexpr int JL = SL8_JL, JW = SL8_JW < NB ? SL8_JW : NB - 1;
+            // unit 0 of the wave's share is requested behind block JL0 and written behind JW0, unit 1 behind JL1 / JW1
+            constexpr int JL0 = 1 < NB ? 1 : 0, JW0 = NB >= 8 ? NB / 2 - 1 : (NB > 2 ? 2 : NB - 1), JL1 = JW0 + 1 < NB ? JW0 + 1 : NB - 1, JW1 = NB - 2 > JL1 ? NB - 2 : NB - 1;
             const int sl = slice_of(st, P);
             const int pn = P + 1 < NS ? P + 1 : 0, stn = P + 1 < NS ? st : st + 1;       // the pass after this one (prefetch across the boundary)
 #if !(SL8_VAR & 16)
@@ -1533,15 +1529,23 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (P == 0 && st == 0 && j == JL) stage_issue(1);
-                if (P == 0 && st == 0 && j == JW) stage_write(1);
+                if (P == 0 && st == 0) {
+                    if (j == JL0) stage_issue(1, 0);
+                    if (j == JW0) stage_write(1, 0);
+                    if (j == JL1) stage_issue(1, 1);
+                    if (j == JW1) stage_write(1, 1);
+                }
 #if !(SL8_VAR & 1)      // (cost-split builds of tools/build_variant.sh: 1 = no re-staging — wrong sums, timing only)
-                if (P == 1 && j == JL) stage_issue(slice_of(st, 2));
-                if (P == 1 && j == JW) {
+                if (P == 1) {
+                    if (j == JL0) stage_issue(slice_of(st, 2), 0);
+                    if (j == JW0) {
 #if !(SL8_VAR & 16)
-                    while ((int)(lds_rd32_volatile(cntA_a) - (uint32_t)(16 * (st + 1))) < 0) __builtin_amdgcn_s_sleep(1);
+                        while ((int)(lds_rd32_volatile(cntA_a) - (uint32_t)(16 * (st + 1))) < 0) __builtin_amdgcn_s_sleep(1);
 #endif
-                    stage_write(0);
+                        stage_write(0, 0);
+                    }
+                    if (j == JL1) stage_issue(slice_of(st, 2), 1);
+                    if (j == JW1) stage_write(0, 1);
                 }
 #endif
             }
