@@ -15,13 +15,16 @@ def _data(orc, rng, d, n, nq, ncent):
     return x, q
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(10))
 def test_random_ivfpq(gpu, orc, seed):
+    """Round 6: the draw also covers the metric (inner product / L2), the code layout (granule / rotated / sliced where they apply) and the
+    knobs that pick between scan and finalize kernels (eight / four queries per gather, the row-major code copy, gather + select)."""
     rng = np.random.RandomState(100 + seed)
-    d, M = [(768, 96), (96, 96), (128, 16), (64, 32)][seed]
+    d, M = [(768, 96), (96, 96), (128, 16), (64, 32), (768, 96), (768, 96), (256, 64), (768, 96), (192, 96), (512, 128)][seed]
     nlist = int(rng.choice([3, 8, 32]))
     n = int(rng.choice([700, 5000, 16000]))
-    nq = int(rng.choice([1, 5, 70]))
+    nq = int(rng.choice([1, 5, 70])) if seed < 4 else int(rng.choice([1, 9, 70, 140]))
+    metric = 0 if seed < 4 else int(rng.randint(0, 2))
     x, q = _data(orc, rng, d, n, nq, nlist)
     x32 = x.astype(np.float32)
     cen = orc.kmeans(0, x32, nlist, 2, 7)
@@ -29,15 +32,22 @@ def test_random_ivfpq(gpu, orc, seed):
     res = orc.residuals(cen, x32, a)
     cb = orc.pq_train(res[:2000], M, 1, 7)
     lm = orc.ListMajor(a, np.arange(n), orc.pq_encode(cb, res), nlist)
-    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, 0)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, metric)
+    knobs = {}
+    if seed >= 4:
+        layouts = [0] + ([1] if M in (16, 32, 64, 96, 128) else []) + ([2] if M == 96 else [])
+        knobs = {"pq_layout": int(rng.choice(layouts)), "pq_q8": int(rng.choice([0, 1, 2])), "pq_plain_codes": int(rng.randint(0, 2)),
+                 "pq_gather": int(rng.randint(0, 2)), "pq_prepass4": int(rng.choice([0, 1, 2]))}
+        for name, v in knobs.items():
+            ix.set_param(name, v)
     ix.set_centroids(cen); ix.set_codebooks(cb)
     for c0 in range(0, n, 7001):                      # several add calls: list growth / re-layout
         ix.add(x[c0:c0 + 7001])
     for nprobe, k in [(1, 1), (2, 10), (nlist, 10), (max(2, nlist // 2), 300), (nlist, 4096)]:
         ix.nprobe = nprobe
         D, I = ix.search(q, k)
-        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q.astype(np.float32), nprobe, k)
-        assert_same_results(D, I, Dr, Ir, f"ivfpq seed={seed} d={d} M={M} nlist={nlist} n={n} nq={nq} nprobe={nprobe} k={k}")
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, q.astype(np.float32), nprobe, k, metric=metric)
+        assert_same_results(D, I, Dr, Ir, f"ivfpq seed={seed} d={d} M={M} metric={metric} nlist={nlist} n={n} nq={nq} nprobe={nprobe} k={k} {knobs}")
 
 
 @pytest.mark.parametrize("seed", range(4))
