@@ -259,6 +259,13 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         rsx_index* h; bool armed = false;
         ~SideJoin() { if (armed && h->st2) (void)hipStreamSynchronize(h->st2); }
     } side_join{h};
+    // k_pq_lut_once's per-tile counters: zeroed when (re)allocated, left zeroed by every launch
+    auto lut_sync = [&]() -> uint32_t* {
+        if (h->lut_tiled < 2) return nullptr;
+        const size_t need = pq_lut8_sync_bytes(nq);
+        if (need > h->w_lutsync.bytes) { h->w_lutsync.ensure(need); HIPCHECK(hipMemsetAsync(h->w_lutsync.p, 0, h->w_lutsync.bytes, h->st)); HIPCHECK(hipStreamSynchronize(h->st)); }
+        return h->w_lutsync.as<uint32_t>();
+    };
     if (side_lut) {
         ensure_side_stream(h);
         h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
@@ -267,7 +274,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         HIPCHECK(hipEventRecord(h->ev_fork, h->st));
         HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
         launch_pq_lut8(nullptr, h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad, nullptr, 0,
-                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, sliced ? 2 : rot ? 1 : 0, h->st2, 1, lut32_out);
+                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, sliced ? 2 : rot ? 1 : 0, h->st2, 1, lut32_out, lut_sync());
         HIPCHECK(hipEventRecord(h->ev_lut, h->st2));
         side_join.armed = true;
     }
@@ -500,11 +507,20 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             h->w_uncertain.ensure((size_t)nq * 4);
             void* lut_ws = nullptr;
             if (fused_lut && h->dsub == 8 && h->lut_tiled != 0) { h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad)); lut_ws = h->w_lutws.p; }
-            if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_lut, 0));     // the tables were built beside the probe selection
-            launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
-                           h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, sliced ? 2 : rot ? 1 : 0, h->st, side_lut ? 2 : 0,
-                           fused_lut ? lut32_out : nullptr);
-            tm.mark("lut8");
+            // the 8-bit tables + per-query parameters; pg: the (query, probe) pairs grouped by list in the same launches (matrix-core form only).
+            // Called once the scan's tile size is known (the grouping needs it)
+            bool tables_built = false;
+            auto build_tables = [&](const PairGroupArgs* pg) {
+                if (tables_built) return;
+                tables_built = true;
+                if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_lut, 0));     // the tables were built beside the probe selection
+                launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
+                               h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, sliced ? 2 : rot ? 1 : 0, h->st, side_lut ? 2 : 0,
+                               fused_lut ? lut32_out : nullptr, (lut_ws && !side_lut) ? lut_sync() : nullptr, pg);
+                tm.mark("lut8");
+            };
+            const bool group_in_tables = lut_ws && !side_lut && h->lut_tiled >= 2 && h->pq_group_fused != 0 && pairs <= PG_MAX_PAIRS &&
+                                         nlist <= PG_BLOCKS * PG_MAX_LPB;
             int rot_log_cap = 64;
             auto rot_desc = [&](int64_t items, int ngq) -> void* {   // work-item records + run descriptors + survivor logs of the rotated-layout scan
                 // the log pool = (persistent workgroups x 64 logs x log_cap keys): 1 / 2 / 4 GiB by k, never more than a quarter of the
@@ -609,6 +625,19 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     h->w_excl.ensure((size_t)nq * 2);
                     pa.cand = h->w_cand.as<uint64_t>(); pa.cand_cap = cand_cap; pa.tile_rows = tile_rows; pa.excl = h->w_excl.as<uint16_t>();
                 }
+                if (group_in_tables) {      // the pairs grouped by list by extra workgroups of the table launch
+                    if (!h->w_pgflags.p) { h->w_pgflags.ensure((size_t)PG_BLOCKS * 16); HIPCHECK(hipMemsetAsync(h->w_pgflags.p, 0, (size_t)PG_BLOCKS * 16, h->st)); }
+                    PairGroupArgs pg{};
+                    pg.probe_list = h->w_probelist.as<int32_t>(); pg.list_len = h->d_len.as<int64_t>();
+                    pg.pair_off = pair_off; pg.group_off = group_off; pg.item_off = item_off; pg.total_groups = total_groups; pg.total_items = total_items;
+                    pg.pairs_sorted = pairs_sorted; pg.flags = h->w_pgflags.as<uint32_t>();
+                    pg.npairs = (int)pairs; pg.nlist = nlist; pg.G = 4 * ngq; pg.tile_rows = tile_rows; pg.tile_cap = 0; pg.nb = PG_BLOCKS;
+                    if (++h->pg_epoch == 0) h->pg_epoch = 1;
+                    pg.epoch = h->pg_epoch;
+                    build_tables(&pg);
+                    grouped_early = true;
+                }
+                build_tables(nullptr);
                 if (side_lut) {       // the (list, tile, group) work items of the scan: built beside the pre-pass (they need the probes only)
                     HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_probe, 0));
                     launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4 * ngq, cnt, cursor, pair_off, group_off, total_groups,
@@ -634,6 +663,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     t.parked = false; t.tau = nullptr; t.ntau = 0;
                 }
             } else {
+                build_tables(nullptr);
                 h->w_temp.ensure((size_t)nq * tmax * 4);       // this form scores a prefix / everything into the score rows
                 a.temp = h->w_temp.as<float>();
                 launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4, cnt, cursor, pair_off, group_off, total_groups,
@@ -664,7 +694,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // arrive twice (the prefix keys above the threshold come back through the candidate buffer).
                 // (the selection wrote only the K'-th key of each query and reset the query's candidate counter)
                 tm.mark("select0");
-                if (grouped_early) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_group, 0));
+                if (grouped_early) { if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_group, 0)); }
                 else launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4 * ngq, cnt, cursor, pair_off, group_off, total_groups,
                                         pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                         h->st);

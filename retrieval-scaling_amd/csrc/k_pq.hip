@@ -580,31 +580,38 @@ __global__ __launch_bounds__(256) void k_pq_lut_tiled(const float* Q32, int ldq,
 
 // one wave per query: the per-query sums over m (lanes over m, tree order — any fixed order is fine: scale, bias and
 // eps only have to be the values the scan and the certificate both use)
-__global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, const float* mnmx, const float* errb,
-                                                  const float* probe_dis0, int nprobe, PQQParam* qp) {
-    const int64_t q = blockIdx.x;
-    const int lane = threadIdx.x;
+// AGENT: the (min, max) pairs and errors were stored by other workgroups of the SAME launch (k_pq_lut_once): agent-scope loads
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool AGENT>
+__device__ __forceinline__ void pq_qparam_wave(int64_t q, int lane, int M, int Mpad, const float* mnmx, const float* errb,
+                                               const float* probe_dis0, int nprobe, PQQParam* qp) {
     const float* mm = mnmx + q * Mpad * 2;
     float absmax_sum = 0.0f, maxrange = 0.0f, e_quant = 0.0f, bias = 0.0f, d0 = 0.0f;
+    float mn_[2] = {0.0f, 0.0f}, mx_[2] = {0.0f, 0.0f};      // this lane's (min, max) pairs, m = lane and lane + 64 (Mpad <= 128 keeps both; else re-read)
     for (int m = lane; m < Mpad; m += 64) {
-        const float mn = mm[2 * m], mx = mm[2 * m + 1];
+        const float mn = AGENT ? ld_agent(mm + 2 * m) : mm[2 * m], mx = AGENT ? ld_agent(mm + 2 * m + 1) : mm[2 * m + 1];
+        if (m < 128) { mn_[m >> 6] = mn; mx_[m >> 6] = mx; }
         absmax_sum += fmaxf(fabsf(mn), fabsf(mx));
         maxrange = fmaxf(maxrange, mx - mn);
-        e_quant += errb[q * Mpad + m];
+        e_quant += AGENT ? ld_agent(errb + q * Mpad + m) : errb[q * Mpad + m];
         bias += mn;
     }
     float mr = maxrange;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mr = fmaxf(mr, __shfl_xor(mr, off));
     // largest integer sum any code vector can reach with this query's table: per sub-quantiser the entry of its maximum,
-    // quantised exactly as k_pq_lut_tiled<1> does (rint((mx - mn) / scale) clamped to 255) — the bound pair pruning uses
+    // quantised exactly as the table builder does (rint((mx - mn) / scale) clamped to 255) — the bound pair pruning uses
     const float inv_s = 1.0f / (mr > 0.0f ? mr / 255.0f : 1.0f);
     float smax = 0.0f;
+    for (int m = lane; m < Mpad; m += 64) {
+        const float mn = m < 128 ? mn_[m >> 6] : (AGENT ? ld_agent(mm + 2 * m) : mm[2 * m]), mx = m < 128 ? mx_[m >> 6] : (AGENT ? ld_agent(mm + 2 * m + 1) : mm[2 * m + 1]);
 #ifdef RSX_MEASURE
-    for (int m = lane; m < Mpad; m += 64) smax += lut_coarsen(fminf(fmaxf(rintf((mm[2 * m + 1] - mm[2 * m]) * inv_s), 0.0f), 255.0f)) + (g_lut_step > 1 ? (float)g_lut_step : 0.0f);
+        smax += lut_coarsen(fminf(fmaxf(rintf((mx - mn) * inv_s), 0.0f), 255.0f)) + (g_lut_step > 1 ? (float)g_lut_step : 0.0f);
 #else
-    for (int m = lane; m < Mpad; m += 64) smax += fminf(fmaxf(rintf((mm[2 * m + 1] - mm[2 * m]) * inv_s), 0.0f), 255.0f);
+        smax += fminf(fmaxf(rintf((mx - mn) * inv_s), 0.0f), 255.0f);
 #endif
+    }
     for (int j = lane; j < nprobe; j += 64) { float d = probe_dis0[q * nprobe + j]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -622,14 +629,208 @@ __global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, c
         qp[q] = r;
     }
 }
+__global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, const float* mnmx, const float* errb,
+                                                  const float* probe_dis0, int nprobe, PQQParam* qp) {
+    pq_qparam_wave<false>(blockIdx.x, threadIdx.x, M, Mpad, mnmx, errb, probe_dis0, nprobe, qp);
+}
+
+// ---------------------------------------------------------------------------------------
+// The same tables on the matrix cores, in two launches instead of three (round 6; lut_tiled = 2).  The VALU form above costs 20 + 35 us
+// (+ 5 for the parameters) per 1024 queries for 0.4 GFLOP: 60-odd VALU instructions and 12 dependent ds_bpermute shuffles per (query,
+// sub-quantiser) and pass.  Here an entry is a column of a v_mfma_f32_32x32x2_f32 product — on gfx950 bit for bit the k-ordered fmaf
+// chain (k_gemm.hip), i.e. exactly the value the VALU form computes:
+//   * a wave owns ONE sub-quantiser m and the tile's 32 queries: A = 32 codewords x 2 dims per instruction (8 code tiles x 4 K steps,
+//     32 registers for the whole codebook slice), B = the 32 queries' sub-vectors; lane (j, h) ends up with query j's entries of the 16
+//     codes (r & 3) + 8 (r >> 2) + 4 h of every tile: min / max / error reductions are IN-LANE but for one exchange with lane ^ 32;
+//   * PASS 0 leaves the (min, max) pairs, PASS 1 recomputes the entries (32 MFMAs) and quantises them with the query's scale; the bytes
+//     leave through a padded LDS image [query][code] x 4 sub-quantisers as 4-byte runs of both transposed layouts;
+//   * the last workgroup of a query tile to finish PASS 1 (a counter per tile; the errors of its siblings read with agent-scope loads,
+//     stored with agent-scope stores: no fences — an agent-scope release / acquire pair is a write-back / invalidate of the whole L2,
+//     measured 0.5 ms per launch) derives the tile's PQQParam records when the coarse scores exist, i.e. when the launch follows the
+//     probe selection in stream order, and resets the counter for the next launch.
+// (One launch with the tile's workgroups meeting at a counter between the passes was built and measured first: 77 us — every hand-over
+//  is a memory round trip of 2-3 us and the waiters hold their CU slots; profiles/r06_fixed_cost.md.)
+// ---------------------------------------------------------------------------------------
+#define LM_Q 32
+#define LM_MB 4
+typedef float lm_f16 __attribute__((ext_vector_type(16)));
+template <int PASS>
+__global__ __launch_bounds__(256) void k_pq_lut_mfma(const float* Q32, int ldq, const float* codebooks, int M, int Mpad, int64_t nq,
+                                                     float* mnmx, float* errb, uint8_t* lut8, int mode, float* lut32_out,
+                                                     uint32_t* sync, const float* probe_dis0, int nprobe, PQQParam* qp, PairGroupArgs pg) {
+    __shared__ float s_scale[2 * LM_Q];
+    __shared__ int s_last;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lt_obuf[];      // [LM_Q][257] dwords: byte mi of dword (query, code) = sub-quantiser m0 + mi
+    unsigned bid = blockIdx.x;
+    if (PASS == 1 && pg.nb > 0) {      // the first pg.nb workgroups group the (query, probe) pairs by list (rsx_internal.h: group_pairs_block)
+        __shared__ int32_t pg_hist[PG_MAX_LPB + 16];
+        if (bid < (unsigned)pg.nb) { group_pairs_block(pg, (int)bid, pg_hist); return; }
+        bid -= (unsigned)pg.nb;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, hh = lane >> 5;
+    const int nmb = (Mpad + LM_MB - 1) / LM_MB, nqt = (int)((nq + LM_Q - 1) / LM_Q);
+    const int rest = (int)(bid >> 3);
+    const int qt = (rest / nmb) * 8 + (int)(bid & 7);
+    if (qt >= nqt) return;
+    const int m0 = (rest % nmb) * LM_MB, m = m0 + w;
+    const int64_t q0 = (int64_t)qt * LM_Q, q = q0 + j;
+    const int nqc = (int)((nq - q0) < LM_Q ? (nq - q0) : LM_Q);
+    const bool mreal = m < M, mpad = m < Mpad, qok = j < nqc;
+    // operands: dims 2 kk + h of the lane's query / codeword (K step kk: lanes 0-31 feed dim 2 kk, lanes 32-63 dim 2 kk + 1 — chain order)
+    float bq[4] = {0.f, 0.f, 0.f, 0.f}, ac[8][4];
+    if (mreal && qok) {
+        const float4* p = reinterpret_cast<const float4*>(Q32 + q * ldq + m * 8);
+        const float4 x = p[0], y = p[1];
+        bq[0] = hh ? x.y : x.x; bq[1] = hh ? x.w : x.z; bq[2] = hh ? y.y : y.x; bq[3] = hh ? y.w : y.z;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        ac[t][0] = ac[t][1] = ac[t][2] = ac[t][3] = 0.f;
+        if (mreal) {
+            const float4* p = reinterpret_cast<const float4*>(codebooks + ((int64_t)m * 256 + 32 * t + j) * 8);
+            const float4 x = p[0], y = p[1];
+            ac[t][0] = hh ? x.y : x.x; ac[t][1] = hh ? x.w : x.z; ac[t][2] = hh ? y.y : y.x; ac[t][3] = hh ? y.w : y.z;
+        }
+    }
+    // (dep: a value of the previous tile's reductions — through an opaque asm it becomes this tile's accumulator zero, so the tiles are
+    //  computed one after the other: left alone the compiler computes all 8 first and spills 128 accumulators)
+    auto tile = [&](int t, float dep) {
+        lm_f16 acc;
+        float z = 0.0f;
+        asm volatile("" : "+v"(z) : "v"(dep));
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = z;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][kk], bq[kk], acc, 0, 0, 0);
+        return acc;
+    };
+    if (PASS == 0) {        // (min, max) per (query, m)
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const lm_f16 v = tile(t, mn);
+#pragma unroll
+            for (int r = 0; r < 16; r++) { mn = fminf(mn, v[r]); mx = fmaxf(mx, v[r]); }
+        }
+        mn = fminf(mn, __shfl_xor(mn, 32)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (hh == 0 && qok && mpad) *reinterpret_cast<float2*>(mnmx + (q * Mpad + m) * 2) = make_float2(mn, mx);
+        return;
+    }
+    // the queries' scales: 8 threads per query over m (max is order-free)
+    {
+        const int qi = tid >> 3, part = tid & 7;
+        float r = 0.0f;
+        if (qi < nqc) {
+            const float2* mm = reinterpret_cast<const float2*>(mnmx + (q0 + qi) * Mpad * 2);
+#pragma unroll 4
+            for (int mm_ = part; mm_ < Mpad; mm_ += 8) { const float2 p = mm[mm_]; r = fmaxf(r, p.y - p.x); }
+        }
+        r = fmaxf(r, __shfl_xor(r, 1)); r = fmaxf(r, __shfl_xor(r, 2)); r = fmaxf(r, __shfl_xor(r, 4));
+        if (part == 0 && qi < nqc) {
+            const float scale = r > 0.0f ? r / 255.0f : 1.0f;
+            s_scale[qi] = scale; s_scale[LM_Q + qi] = 1.0f / scale;
+        }
+    }
+    const float mn = (qok && mpad) ? mnmx[(q * Mpad + m) * 2] : 0.0f;
+    __syncthreads();
+    const float scale = qok ? s_scale[j] : 1.0f, inv = qok ? s_scale[LM_Q + j] : 1.0f;
+    float err = 0.0f;
+    uint8_t* ob = lt_obuf + ((size_t)j * 257) * 4 + w;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const lm_f16 v = tile(t, err);
+        if (lut32_out && mreal && qok) {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<float4*>(lut32_out + (q * Mpad + m) * 256 + 32 * t + 8 * g + 4 * hh) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float u = rintf((v[r] - mn) * inv);
+            u = fminf(fmaxf(u, 0.0f), 255.0f);
+#ifdef RSX_MEASURE
+            u = lut_coarsen(u);
+#endif
+            ob[(size_t)c * 4] = (uint8_t)u;
+            err = fmaxf(err, fabsf(v[r] - (mn + scale * u)));
+        }
+    }
+    err = fmaxf(err, __shfl_xor(err, 32));
+    if (hh == 0 && qok && mpad) st_agent(errb + q * Mpad + m, err);
+    __syncthreads();
+    if (mode == 0) {        // [q][m][code]: 4 consecutive codes of one sub-quantiser per store
+        for (int e = tid; e < nqc * LM_MB * 64; e += 256) {
+            const int qi = e / (LM_MB * 64), mi = (e / 64) % LM_MB, c4 = (e % 64) * 4;
+            if (m0 + mi >= Mpad) continue;
+            const uint8_t* src = lt_obuf + ((size_t)qi * 257 + c4) * 4 + mi;
+            const uint32_t v4 = (uint32_t)src[0] | ((uint32_t)src[4] << 8) | ((uint32_t)src[8] << 16) | ((uint32_t)src[12] << 24);
+            *reinterpret_cast<uint32_t*>(lut8 + pq_lut8_index(q0 + qi, c4, m0 + mi, Mpad, 0)) = v4;
+        }
+    } else {                // [q][code][m] / [q][slice][code][m & 31]: the 4 sub-quantisers of one code per store
+        for (int e = tid; e < nqc * 256; e += 256) {
+            const int qi = e >> 8, c = e & 255;
+            const uint32_t v4 = *reinterpret_cast<const uint32_t*>(lt_obuf + ((size_t)qi * 257 + c) * 4);
+            uint8_t* dst = lut8 + pq_lut8_index(q0 + qi, c, m0, Mpad, mode);
+            if (m0 + LM_MB <= Mpad) *reinterpret_cast<uint32_t*>(dst) = v4;
+            else for (int t = 0; m0 + t < Mpad; t++) dst[t] = (uint8_t)(v4 >> (8 * t));
+        }
+    }
+    if (!qp) return;
+    // the tile's last workgroup: per-query parameters, counter back to zero.  Eight threads per query, every load independent of every
+    // other (one wave per query as in k_pq_qparam would be 8 queries in turn per wave, 2-3 us of agent-scope round trips each); the
+    // sums in a fixed order (m strided by 8 per thread, then a three-step tree): any fixed order is fine, see k_pq_qparam
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&sync[qt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(nmb - 1);
+    __syncthreads();
+    if (!s_last) return;
+    {
+        const int qi = tid >> 3, part = tid & 7;
+        const int64_t qq = q0 + qi;
+        float absmax_sum = 0.0f, maxrange = 0.0f, e_quant = 0.0f, bias = 0.0f, smax = 0.0f, d0 = 0.0f;
+        if (qi < nqc) {
+            const float2* mm = reinterpret_cast<const float2*>(mnmx + qq * Mpad * 2);
+            const float inv_s = s_scale[LM_Q + qi];
+#pragma unroll 4
+            for (int mm_ = part; mm_ < Mpad; mm_ += 8) {
+                const float2 p = mm[mm_];
+                absmax_sum += fmaxf(fabsf(p.x), fabsf(p.y));
+                maxrange = fmaxf(maxrange, p.y - p.x);
+                e_quant += ld_agent(errb + qq * Mpad + mm_);
+                bias += p.x;
+#ifdef RSX_MEASURE
+                smax += lut_coarsen(fminf(fmaxf(rintf((p.y - p.x) * inv_s), 0.0f), 255.0f)) + (g_lut_step > 1 ? (float)g_lut_step : 0.0f);
+#else
+                smax += fminf(fmaxf(rintf((p.y - p.x) * inv_s), 0.0f), 255.0f);
+#endif
+            }
+            for (int jj = part; jj < nprobe; jj += 8) { const float d = probe_dis0[qq * nprobe + jj]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            absmax_sum += __shfl_xor(absmax_sum, off); e_quant += __shfl_xor(e_quant, off); bias += __shfl_xor(bias, off);
+            smax += __shfl_xor(smax, off);
+            maxrange = fmaxf(maxrange, __shfl_xor(maxrange, off)); d0 = fmaxf(d0, __shfl_xor(d0, off));
+        }
+        if (part == 0 && qi < nqc) {
+            const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
+            const float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;       // the fp32 slack: see pq_qparam_wave
+            PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + pq_round_slack(M) * B; r.pad = smax;
+            qp[qq] = r;
+        }
+    }
+    if (tid == 0) __hip_atomic_store(&sync[qt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad) { return (size_t)nq * Mpad * 3 * 4; }   // mnmx + err
+size_t pq_lut8_sync_bytes(int64_t nq) { return (size_t)((nq + LM_Q - 1) / LM_Q + 8) * 2 * 4; }   // k_pq_lut_mfma<1>: a counter per query tile (zero between launches)
 
 size_t pq_lut8_fused_lds(int M, int Mpad, int dsub) { return ((size_t)Mpad * 256 + (size_t)M * dsub + 3 * (size_t)Mpad) * 4; }
 
 void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
                     int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8, void* qparam, void* ws, int transposed,
-                    hipStream_t st, int phase, float* lut32_out) {
+                    hipStream_t st, int phase, float* lut32_out, uint32_t* sync, const PairGroupArgs* pg) {
     if (nq <= 0) return;
     if (phase != 0 && !(ws && dsub == 8 && !lut32)) return;     // only the tiled build splits into tables (1) + per-query parameters (2)
     if (lut32) {
@@ -654,6 +855,19 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
         const size_t osm = transposed ? (size_t)LT_QC * 256 * LT_MB : 0;
         static DevOnce once;
         if (osm) once.once([&] { hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm); });
+        if (sync && phase != 2) {      // matrix-core form; with phase 0 (the coarse scores exist) the per-query parameters come from its second launch
+            const int64_t nmb4 = (Mpad + LM_MB - 1) / LM_MB, nqt4 = (((nq + LM_Q - 1) / LM_Q) + 7) / 8;
+            const size_t osm4 = (size_t)LM_Q * 257 * 4;
+            const dim3 grid4((unsigned)(nmb4 * nqt4 * 8));
+            PairGroupArgs pg0{};
+            if (pg) pg0 = *pg;
+            PairGroupArgs pgn{};
+            hipLaunchKernelGGL(k_pq_lut_mfma<0>, grid4, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed,
+                               lut32_out, sync, probe_dis0, nprobe, (PQQParam*)nullptr, pgn);
+            hipLaunchKernelGGL(k_pq_lut_mfma<1>, dim3(grid4.x + (unsigned)pg0.nb), dim3(256), osm4, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed,
+                               lut32_out, sync, probe_dis0, nprobe, phase == 0 ? (PQQParam*)qparam : (PQQParam*)nullptr, pg0);
+            return;
+        }
         if (phase != 2) {
             hipLaunchKernelGGL(k_pq_lut_tiled<0>, grid, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed, (float*)nullptr);
             hipLaunchKernelGGL(k_pq_lut_tiled<1>, grid, dim3(256), osm, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed, lut32_out);

@@ -202,7 +202,10 @@ struct rsx_index {
                           // sliced layout (M = 96): 1 = k_pq_scan_sl8 for batches with >= 3 probing queries per list on lists of >= 4096 vectors on average,
                           // else the four-query single-pass k_pq_scan_sl4; 2 = always eight, 0 = always four
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
-    int lut_tiled = 1;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries (0 = one workgroup per query)
+    int pq_group_fused = 1;   // the (query, probe) pairs grouped by list by extra workgroups of the table launch (0 = its own four launches)
+    uint32_t pg_epoch = 0;    // ... whose hand-over words carry this launch counter
+    int lut_tiled = 2;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries: 2 = one launch (k_pq_lut_once), 1 = two passes
+                          // + parameters in three launches, 0 = one workgroup per query
     int pq_prepass_fused = 1;   // filtered fast scan: threshold pre-pass in one launch (0 = grouping + scan + selection)
     int ivf_qtiles = 1;      // IVF-Flat LDS-DMA scans: 1 = choose 16 / 64 / 128 probing queries per group from the queries per list, 2 / 4 / 8 = force 32 / 64 / 128, 0 = always 16
     int pq_prepass4 = 1;     // rotated fast scan, full batches: threshold pre-pass with four queries per workgroup on the scan's table format (1 = small and large k, 2 = small k only, 0 = never)
@@ -224,7 +227,7 @@ struct rsx_index {
     int64_t temp_budget = (int64_t)16 << 30;
 
     // workspace
-    DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_state,
+    DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_lutsync, w_pgflags, w_state,
         w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart, w_qitems, w_tiews;
     std::map<std::string, double> timing;
 

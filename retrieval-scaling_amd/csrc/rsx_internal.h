@@ -280,6 +280,7 @@ int launch_pq_scan2(const PQScanArgs& a, const int32_t* pairs_sorted, const int3
 // 8-bit table fast scan (4 queries per LDS read) — approximate scores, certified by k_finalize
 // lut32 null -> fused form: the fp32 table is built in LDS from Q32 [nq, ldq] and the codebooks (needs
 // pq_lut8_fused_lds(M, Mpad, dsub) <= 160 KiB); otherwise quantises the given fp32 tables.
+struct PairGroupArgs;
 size_t pq_lut8_fused_lds(int M, int Mpad, int dsub);
 void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
                     int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8,
@@ -287,8 +288,12 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
                     void* ws /* pq_lut8_tiled_ws(nq, Mpad) bytes -> tiled build (dsub 8), or null */,
                     int transposed /* pq_lut8_index: 0: lut8 [nq][Mpad][256]; 1: [nq][256][Mpad] (rotated-layout scans); 2: [nq][Mpad/32][256][32] (sliced) */, hipStream_t st,
                     int phase = 0 /* tiled build only: 1 = the tables (independent of the probe selection), 2 = the per-query parameters */,
-                    float* lut32_out = nullptr /* fused forms only: also store the fp32 tables [nq][Mpad][256] (k_pq_final_tab reads them) */);
+                    float* lut32_out = nullptr /* fused forms only: also store the fp32 tables [nq][Mpad][256] (k_pq_final_tab reads them) */,
+                    uint32_t* sync = nullptr /* tiled build: pq_lut8_sync_bytes(nq) of ZEROED counters -> the matrix-core form (k_pq_lut_mfma; with
+                                                phase 0 the per-query parameters too); the kernel leaves them zeroed */,
+                    const struct PairGroupArgs* pg = nullptr /* matrix-core form: also group the (query, probe) pairs by list (extra workgroups) */);
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad);
+size_t pq_lut8_sync_bytes(int64_t nq);
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
                     const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                     const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
@@ -426,6 +431,105 @@ void launch_group_pairs(const int32_t* probe_list, int64_t npairs, int nlist, in
                         int32_t* cursor, int32_t* pair_off, int32_t* group_off, int32_t* total_groups,
                         int32_t* pairs_sorted, const int64_t* list_len, int tile_rows, int32_t* item_off,
                         int32_t* total_items, int nprobe, int jmin, int jmax, int tile_cap, hipStream_t st);
+// The same grouping as EXTRA WORKGROUPS of another launch (round 6): the four launches above are ~24 us of launch floors and round trips in
+// front of the scan for a few microseconds of work.  Blocks 0 .. nb - 1 of the host kernel (k_pq_lut_mfma<1>: it follows the probe
+// selection in stream order and has LDS to spare) each own nlist / nb consecutive lists: histogram of their lists over ALL pairs in LDS,
+// local offsets, a chained hand-over of the block totals (block b waits for blocks < b: they are dispatched before it, so the wait is
+// safe), then the scatter.  flags: [nb][4] words = {pairs, groups, items, epoch}: a block's totals are valid once its epoch word equals
+// the launch's epoch (the host increments it per launch: no reset pass).  Full probe-rank range only (jmin = 0, jmax = nprobe).
+struct PairGroupArgs {
+    const int32_t* probe_list; const int64_t* list_len;
+    int32_t *pair_off, *group_off, *item_off, *total_groups, *total_items, *pairs_sorted;
+    uint32_t* flags;
+    int npairs, nlist, G, tile_rows, tile_cap, nb;
+    uint32_t epoch;
+};
+#define PG_BLOCKS 32
+#define PG_MAX_LPB 2048                 // lists per block the LDS histogram holds (nlist <= 65536 with 32 blocks)
+#define PG_MAX_PAIRS 131072             // every block reads all pairs twice
+#ifdef __HIPCC__
+__device__ inline void group_pairs_block(const PairGroupArgs& g, int b, int32_t* hist /* LDS: PG_MAX_LPB + 16 ints */) {
+    const int t = (int)threadIdx.x, nt = (int)blockDim.x, lane = t & 63, w = t >> 6, nw = nt >> 6;
+    int32_t* sc = hist + PG_MAX_LPB;           // [12] cross-wave scratch
+    __builtin_amdgcn_s_setprio(3);             // a latency chain beside the host kernel's throughput work on the same CUs: first pick of the issue slots
+    const int lpb = (g.nlist + g.nb - 1) / g.nb, lo = b * lpb;
+    int hi = lo + lpb; if (hi > g.nlist) hi = g.nlist;
+    const int nl = hi > lo ? hi - lo : 0;
+    for (int i = t; i < nl; i += nt) hist[i] = 0;
+    __syncthreads();
+    // every block reads ALL pairs, twice: 16-byte loads, eight in flight per thread (one load per loop turn was 128 exposed L2 round trips)
+    const int np4 = ((reinterpret_cast<uintptr_t>(g.probe_list) & 15) == 0) ? g.npairs >> 2 : 0;
+    const int4* pl4 = reinterpret_cast<const int4*>(g.probe_list);
+    auto for_pairs = [&](auto&& f) {
+        for (int i0 = t; i0 < np4; i0 += 8 * nt) {
+            int4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * nt; v[u] = i < np4 ? pl4[i] : make_int4(-1, -1, -1, -1); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = 4 * (i0 + u * nt); f(v[u].x, i); f(v[u].y, i + 1); f(v[u].z, i + 2); f(v[u].w, i + 3); }
+        }
+        for (int i = 4 * np4 + t; i < g.npairs; i += nt) f(g.probe_list[i], i);
+    };
+    for_pairs([&](int32_t l, int) { if (l >= lo && l < hi) atomicAdd(&hist[l - lo], 1); });
+    __syncthreads();
+    auto ntiles = [&](int l) {
+        int32_t n = (int32_t)((g.list_len[l] + g.tile_rows - 1) / g.tile_rows);
+        return (g.tile_cap > 0 && n > g.tile_cap) ? g.tile_cap : n;
+    };
+    const int per = (lpb + nt - 1) / nt, l0 = t * per;
+    int l1 = l0 + per; if (l1 > nl) l1 = nl;
+    int32_t ap = 0, ag = 0, ai = 0;
+    for (int i = l0; i < l1; i++) { const int c = hist[i], ng = (c + g.G - 1) / g.G; ap += c; ag += ng; if (g.tile_rows > 0 && ng) ai += ng * ntiles(lo + i); }
+    // exclusive scan of (ap, ag, ai) over the block
+    int32_t ia = ap, ib = ag, ic = ai;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t ya = __shfl_up(ia, off), yb = __shfl_up(ib, off), yc = __shfl_up(ic, off);
+        if (lane >= off) { ia += ya; ib += yb; ic += yc; }
+    }
+    if (lane == 63) { sc[w] = ia; sc[4 + w] = ib; sc[8 + w] = ic; }
+    __syncthreads();
+    int32_t wa = 0, wb = 0, wc = 0, ta = 0, tb = 0, tc = 0;
+    for (int k = 0; k < nw && k < 4; k++) { if (k < w) { wa += sc[k]; wb += sc[4 + k]; wc += sc[8 + k]; } ta += sc[k]; tb += sc[4 + k]; tc += sc[8 + k]; }
+    ap = ia - ap + wa; ag = ib - ag + wb; ai = ic - ai + wc;          // exclusive, block-local
+    // publish the block totals, then collect the predecessors'
+    if (t == 0) {
+        __hip_atomic_store(&g.flags[4 * b], (uint32_t)ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g.flags[4 * b + 1], (uint32_t)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g.flags[4 * b + 2], (uint32_t)tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        __hip_atomic_store(&g.flags[4 * b + 3], g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int32_t pa = 0, pb = 0, pc = 0;
+    if (t < b) {
+        while (__hip_atomic_load(&g.flags[4 * t + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.epoch) __builtin_amdgcn_s_sleep(1);
+        pa = (int32_t)__hip_atomic_load(&g.flags[4 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pb = (int32_t)__hip_atomic_load(&g.flags[4 * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pc = (int32_t)__hip_atomic_load(&g.flags[4 * t + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                 // sc is free again
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { pa += __shfl_xor(pa, off); pb += __shfl_xor(pb, off); pc += __shfl_xor(pc, off); }
+    if (lane == 0) { sc[w] = pa; sc[4 + w] = pb; sc[8 + w] = pc; }
+    __syncthreads();
+    int32_t ba = 0, bb = 0, bc = 0;
+    for (int k = 0; k < nw && k < 4; k++) { ba += sc[k]; bb += sc[4 + k]; bc += sc[8 + k]; }
+    if (b == g.nb - 1 && t == 0) {
+        g.pair_off[g.nlist] = ba + ta; g.group_off[g.nlist] = bb + tb; *g.total_groups = bb + tb;
+        if (g.tile_rows > 0) { g.item_off[g.nlist] = bc + tc; *g.total_items = bc + tc; }
+    }
+    ap += ba; ag += bb; ai += bc;
+    for (int i = l0; i < l1; i++) {
+        const int c = hist[i], ng = (c + g.G - 1) / g.G;
+        g.pair_off[lo + i] = ap; g.group_off[lo + i] = ag;
+        if (g.tile_rows > 0) { g.item_off[lo + i] = ai; if (ng) ai += ng * ntiles(lo + i); }
+        hist[i] = ap;                // from here on: the list's write cursor
+        ap += c; ag += ng;
+    }
+    __syncthreads();
+    for_pairs([&](int32_t l, int i) { if (l >= lo && l < hi) g.pairs_sorted[atomicAdd(&hist[l - lo], 1)] = i; });
+}
+#endif
 struct FinalizeArgs {
     int kind; int metric;
     const uint64_t* state; int KP; int k; int64_t nq;

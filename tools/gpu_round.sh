@@ -5,7 +5,7 @@
 #   tests      pytest -m gpu (stop at first failure; PYTEST_ARGS narrows it)     tests_all: without -x
 #   smoke      __graft_entry__.smoke()
 #   bench      the default bench line (all configs)                               bench_fast: headline only
-#   prof       rocprofv3 --kernel-trace --stats of the headline bench  -> ${TAG}_rocprof_stats_ivfpq100M.md
+#   prof       rocprofv3 --kernel-trace --stats of the headline bench  -> ${TAG}_rocprof_stats_ivfpq100M.md + ${TAG}_timeline.md (last batch)
 #   pmc_fetch  FETCH_SIZE pass -> ${TAG}_pmc_fetch_size.md + stamped pmc_traffic.json
 #   pmc_sq     two SQ counter passes of the scan kernel -> ${TAG}_pmc_sq_counters.md
 #   per_rank   one rank of an N = 2 / 4 / 8 run and of config 5 on this one GPU -> ${TAG}_per_rank_workloads.txt
@@ -42,6 +42,7 @@ for s in "$@"; do
     prof)
       ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG -- python $OLDPWD/bench.py --steps 5 --warmup 2 $FAST ${BENCH_ARGS:-} > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof.log ); echo "exit $?" >> $O/${TAG}_prof.log
       python tools/rocprof_summary.py $O/prof/${TAG}_results.db $O/${TAG}_rocprof_stats_ivfpq100M.md "IVF-PQ 100M x 768, M=96, nlist=4096, nprobe=32, batch=1024 (python bench.py --steps 5 --warmup 2 $FAST ${BENCH_ARGS:-})"
+      python tools/timeline.py $O/prof/${TAG}_results.db $O/${TAG}_timeline.md > /dev/null
       rm -rf $O/prof ;;
     pmc_fetch)
       ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc.log ); echo "exit $?" >> $O/${TAG}_pmc.log
