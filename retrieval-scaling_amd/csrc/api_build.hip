@@ -123,6 +123,7 @@ const void* stage_rows(rsx_index* h, DevBuf& buf, const void* x, int64_t n, int 
 void set_centroids(rsx_index* h, const float* c) {
     size_t n = (size_t)h->nlist * h->d;
     h->h_centroids.assign(c, c + n);
+    h->cent_gen++;
     h->d_centroids.ensure(n * 4);
     HIPCHECK(hipMemcpyAsync(h->d_centroids.p, h->h_centroids.data(), n * 4, hipMemcpyHostToDevice, h->st));
     HIPCHECK(hipStreamSynchronize(h->st));

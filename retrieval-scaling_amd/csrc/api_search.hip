@@ -153,16 +153,20 @@ static void rerun_uncertified(rsx_index* h, int64_t nq, const void* dq, int dtyp
                               size_t temp_bytes_per_query, const std::function<void()>& second_chance = nullptr) {
     std::vector<int32_t> bad_v;
     const int32_t* bad;
+    const bool coarse_live = h->coarse_flags_live;
+    h->coarse_flags_live = false;
     auto read_flags = [&]() {
-        if (nq <= 4096 && h->pin_flags.ensure(4096 * 4)) {
-            HIPCHECK(hipMemcpyAsync(h->pin_flags.p, h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
-            bad = h->pin_flags.as<int32_t>();
-        } else {
-            bad_v.resize((size_t)nq);
-            HIPCHECK(hipMemcpyAsync(bad_v.data(), h->w_uncertain.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->st));
-            bad = bad_v.data();
-        }
+        // the fast coarse quantiser's per-query flags (k_coarse_pick: 2 = its candidate row overflowed or a score was not finite) sit behind the
+        // certificate's [nq, 2 nq): one copy fetches both, and a flagged query goes to the exact re-run whatever the certificate said
+        const size_t words = (size_t)nq * (coarse_live ? 2 : 1);
+        int32_t* dst;
+        if (nq <= 4096 && h->pin_flags.ensure(8192 * 4)) dst = h->pin_flags.as<int32_t>();
+        else { bad_v.resize(words); dst = bad_v.data(); }
+        HIPCHECK(hipMemcpyAsync(dst, h->w_uncertain.p, words * 4, hipMemcpyDeviceToHost, h->st));
         HIPCHECK(hipStreamSynchronize(h->st));
+        if (coarse_live)
+            for (int64_t q = 0; q < nq; q++) if (dst[(size_t)(nq + q)]) { dst[(size_t)q] |= 2; h->timing["coarse_redo_queries"] += 1.0; }
+        bad = dst;
     };
     read_flags();
     if (second_chance) {
@@ -221,9 +225,18 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     tm.mark("start");
     // queries: fp32 copy (exact re-rank, coarse quantiser, LUT) [nq, ld]; fp16 copy for the scans
     h->w_q32.ensure((size_t)nq * ld * 4);
-    launch_convert_to_f32(dq, dtype == RSX_F16, d, nq, d, h->w_q32.as<float>(), ld, h->st);
     int64_t nq_pad = nq > 128 ? round_up(nq, 256) : 128;   // query tiles: 128 (k_flat_gemm) or 256 (k_flat_gemm2)
     const bool certify = h->kind != KIND_IVFPQ && allow_fast && h->flat_cert != 0;
+    // fast coarse quantiser (round 6): fp16 MFMA scores of all lists + exact chains of the candidates; needs the re-run machinery behind it
+    const int np0 = std::min(h->nprobe, h->nlist);
+    const bool coarse_fast = h->kind != KIND_FLAT && allow_fast && h->coarse_fast != 0 && (h->kind == KIND_IVFPQ ? fast : certify) && nq >= 32 &&
+                             np0 <= CP_MAXPROBE && h->nlist <= CP_MAXLIST && h->nlist > np0 && !h->h_centroids.empty() &&
+                             coarse_pick_lds(h->nlist, d, np0) <= 150 * 1024;
+    if (h->kind == KIND_IVFPQ && coarse_fast) {
+        h->w_q16.ensure((size_t)round_up(nq, 128) * ld * 2);
+        launch_convert_to_f32_f16(dq, dtype == RSX_F16, d, nq, d, h->w_q32.as<float>(), h->w_q16.as<__half>(), ld, round_up(nq, 128), h->st);
+    } else
+        launch_convert_to_f32(dq, dtype == RSX_F16, d, nq, d, h->w_q32.as<float>(), ld, h->st);
     if (h->kind != KIND_IVFPQ) {
         h->w_q16.ensure((size_t)nq_pad * ld * 2);
         h->w_flag.ensure(sizeof(int));
@@ -233,9 +246,10 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     h->w_state.ensure((size_t)nq * KP * 8);
     uint64_t* state = h->w_state.as<uint64_t>();
     tm.mark("convert");
-    // Round 4: the 8-bit tables depend on the queries only — their build (k_pq_lut_tiled<0/1>, ~80 us per 1024 queries) starts here
-    // on the side stream and runs beside the coarse quantiser and the probe selection (~115 us); the per-query parameters
-    // (k_pq_qparam: they need the coarse scores) follow on the main stream once both have finished.
+    // Round 4 (overlap = 1, no longer the default): the 8-bit tables depend on the queries only — their build starts here on the side
+    // stream and runs beside the coarse quantiser and the probe selection; the per-query parameters (k_pq_qparam: they need the coarse
+    // scores) follow on the main stream once both have finished.  Round 6 measured the three cross-stream joins of a batch at ~12 us
+    // each (profiles/r06_fixed_cost.md): the default is one stream, with the table build, the parameters and the pair grouping in two launches.
     const bool pq_fused_lut = h->kind == KIND_IVFPQ && fast && pq_lut8_fused_lds(h->M, h->Mpad, h->dsub) <= 160 * 1024 - 64;
     const bool side_lut = pq_fused_lut && h->overlap != 0 && h->dsub == 8 && h->lut_tiled != 0 && nq >= 64;
     // the finalize-from-the-row kernel (k_pq_final_tab) will serve this batch: let the table builder store the fp32 tables for it
@@ -299,7 +313,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         //   L2: the ranking score adds -|x|^2/2 (fp32)  (d + 4) 2^-24 |x|^2  (folded into the absolute term)
         const float u24 = 5.9604645e-8f, u11 = 4.8828125e-4f;
         const float xmax = sqrtf(h->max_norm2) * 1.0000002f;
-        h->w_uncertain.ensure((size_t)nq * 4);
+        h->w_uncertain.ensure((size_t)nq * 8);
         fa.uncertain = h->w_uncertain.as<int32_t>();
         fa.cert_xmax = xmax;
         fa.cert_rel = ((float)d + 2.0f) * u24 * 1.01f + (h->storage_f16 ? 0.0f : u11 * 1.002f);
@@ -434,20 +448,46 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     const int nprobe = std::min(h->nprobe, nlist);
     // 1. coarse quantiser (exact fp32) + top-nprobe
     const int nlp = (int)round_up(nlist, 4);   // row stride of the coarse scores: 16-byte aligned rows for k_select
-    h->w_coarse.ensure((size_t)nq * nlp * 4);
-    launch_gemm_exact_scores(h->w_q32.p, 0, nq, ld, h->d_centroids.as<float>(), nlist, d, h->w_coarse.as<float>(), nlp, h->st);
-    tm.mark("coarse");
-    int KPp = std::max(16, pow2ceil(nprobe));
-    int BUFp = std::max(2 * KPp, 256);
-    h->w_probekeys.ensure((size_t)nq * KPp * 8);
-    select_rows(h, h->w_coarse.as<float>(), nlp, nullptr, 0, nlist, 0, nq, KPp, BUFp, nprobe, h->w_probekeys.as<uint64_t>(), false);
-    // 2. probe set-up
     const int pad_to = (h->kind == KIND_IVFPQ) ? 64 : 16;
     h->w_probelist.ensure((size_t)nq * nprobe * 4);
     h->w_dis0.ensure((size_t)nq * nprobe * 4);
     h->w_segstart.ensure((size_t)nq * (nprobe + 1) * 8);
-    launch_probe_setup(h->w_probekeys.as<uint64_t>(), KPp, nq, nprobe, h->d_len.as<int64_t>(), pad_to,
-                       h->w_probelist.as<int32_t>(), h->w_dis0.as<float>(), h->w_segstart.as<int64_t>(), h->st);
+    if (coarse_fast) {
+        const int64_t nqp = h->kind == KIND_IVFPQ ? round_up(nq, 128) : nq_pad;
+        const int64_t nl128 = round_up(nlist, 128);
+        if (h->cent16_gen != h->cent_gen || !h->cent16.p) {       // the centroids' fp16 copy + the norm bound, once per centroid set
+            h->cent16.ensure((size_t)nl128 * ld * 2);
+            launch_convert_to_f16(h->d_centroids.p, 0, nlist, d, h->cent16.as<__half>(), ld, nl128, nullptr, h->st);
+            double mx = 0.0;
+            for (int l = 0; l < nlist; l++) { double n2 = 0.0; for (int t = 0; t < d; t++) { const double v = h->h_centroids[(size_t)l * d + t]; n2 += v * v; } mx = std::max(mx, n2); }
+            h->cent_cmax = (float)(std::sqrt(mx) * 1.000001);
+            h->cent16_gen = h->cent_gen;
+        }
+        h->w_coarse.ensure((size_t)nqp * nlp * 4);
+        launch_coarse_approx(h->w_q16.as<__half>(), nqp, h->cent16.as<__half>(), nlist, ld, h->w_coarse.as<float>(), nlp, h->st);
+        tm.mark("coarse");
+        h->w_uncertain.ensure((size_t)nq * 8);
+        CoarsePickArgs cp{};
+        cp.approx = h->w_coarse.as<float>(); cp.nlp = nlp; cp.nlist = nlist; cp.Q32 = h->w_q32.as<float>(); cp.ld = ld; cp.d = d;
+        cp.C = h->d_centroids.as<float>(); cp.cmax = h->cent_cmax;
+        cp.ef = (dtype == RSX_F16 ? 1.0f : 2.0f) * 4.8828125e-4f;        // centroids rounded to fp16; fp32 queries as well
+        cp.nprobe = nprobe; cp.list_len = h->d_len.as<int64_t>(); cp.pad_to = pad_to;
+        cp.probe_list = h->w_probelist.as<int32_t>(); cp.dis0 = h->w_dis0.as<float>(); cp.seg_start = h->w_segstart.as<int64_t>();
+        cp.bad = h->w_uncertain.as<int32_t>() + nq;
+        launch_coarse_pick(cp, nq, h->st);
+        h->coarse_flags_live = true;
+    } else {
+        h->w_coarse.ensure((size_t)nq * nlp * 4);
+        launch_gemm_exact_scores(h->w_q32.p, 0, nq, ld, h->d_centroids.as<float>(), nlist, d, h->w_coarse.as<float>(), nlp, h->st);
+        tm.mark("coarse");
+        int KPp = std::max(16, pow2ceil(nprobe));
+        int BUFp = std::max(2 * KPp, 256);
+        h->w_probekeys.ensure((size_t)nq * KPp * 8);
+        select_rows(h, h->w_coarse.as<float>(), nlp, nullptr, 0, nlist, 0, nq, KPp, BUFp, nprobe, h->w_probekeys.as<uint64_t>(), false);
+        // 2. probe set-up
+        launch_probe_setup(h->w_probekeys.as<uint64_t>(), KPp, nq, nprobe, h->d_len.as<int64_t>(), pad_to,
+                           h->w_probelist.as<int32_t>(), h->w_dis0.as<float>(), h->w_segstart.as<int64_t>(), h->st);
+    }
     if (side_lut) HIPCHECK(hipEventRecord(h->ev_probe, h->st));
     tm.mark("select_probe");
     if (h->profile >= 2) {
@@ -504,7 +544,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // 8-bit tables, 4 queries per LDS read; approximate scores, certified in k_finalize
             h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
             h->w_qparam.ensure((size_t)nq * 16);
-            h->w_uncertain.ensure((size_t)nq * 4);
+            h->w_uncertain.ensure((size_t)nq * 8);
             void* lut_ws = nullptr;
             if (fused_lut && h->dsub == 8 && h->lut_tiled != 0) { h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad)); lut_ws = h->w_lutws.p; }
             // the 8-bit tables + per-query parameters; pg: the (query, probe) pairs grouped by list in the same launches (matrix-core form only).

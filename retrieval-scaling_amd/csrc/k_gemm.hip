@@ -696,6 +696,17 @@ static bool fg2_applies(int nq_pad, int x_f16, int ld) {
     return !off && x_f16 && nq_pad % 256 == 0 && ld % 64 == 0;
 }
 
+// Coarse quantiser, fast form (round 6): APPROXIMATE scores of all centroids from the fp16 MFMA tile kernel — 6.4 GFLOP in ~15 us
+// where the bit-exact f32-input chain (k_gemm_exact) needs 65; k_coarse_pick (k_select.hip) re-scores the few centroids that can be
+// among a query's nprobe best with the exact chain.  Q16: [nq_pad][ld] (nq_pad % 128 == 0), C16: [round_up(nlist, 128)][ld] fp16
+// copies, zero padded; S: [nq_pad][lds_] fp32.
+void launch_coarse_approx(const __half* Q16, int64_t nq_pad, const __half* C16, int nlist, int ld, float* S, int64_t lds_, hipStream_t st) {
+    if (nq_pad <= 0 || nlist <= 0) return;
+    FlatFilterArgs F{};
+    hipLaunchKernelGGL((k_flat_gemm<true, false>), dim3((unsigned)(nq_pad / 128), (unsigned)((nlist + 127) / 128)), dim3(256), 0, st, Q16, (const void*)C16,
+                       (int64_t)0, (int64_t)nlist, ld, (const float*)nullptr, S, lds_, F);
+}
+
 void launch_flat_gemm(const __half* Q16, int nq_pad, const void* X, int x_f16, int64_t v0, int64_t nv, int ld,
                       const float* bias, float* temp, int64_t tstride, hipStream_t st) {
     if (nv <= 0 || nq_pad <= 0) return;

@@ -25,6 +25,26 @@ void launch_convert_to_f32(const void* src, int src_f16, int64_t src_ld, int64_t
     hipLaunchKernelGGL(k_to_f32, dim3(blocks), dim3(256), 0, st, src, src_f16, src_ld, n_rows, d, dst, ld);
 }
 
+// both copies of a query batch in one launch (IVF-PQ with the certified fp16 coarse quantiser): fp32 [n_rows][ld] and fp16 [pad_rows_to][ld]
+__global__ void k_to_f32_f16(const void* src, int src_f16, int64_t src_ld, int64_t n_rows, int d, float* dst32, __half* dst16, int ld, int64_t pad_rows_to) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = pad_rows_to * ld;
+    for (; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld; const int t = (int)(i - r * ld);
+        float v = 0.0f;
+        if (r < n_rows && t < d) v = src_f16 ? __half2float(((const __half*)src)[r * src_ld + t]) : ((const float*)src)[r * src_ld + t];
+        if (r < n_rows) dst32[i] = v;
+        dst16[i] = __float2half_rn(v);
+    }
+}
+void launch_convert_to_f32_f16(const void* src, int src_f16, int64_t src_ld, int64_t n_rows, int d, float* dst32, __half* dst16, int ld,
+                               int64_t pad_rows_to, hipStream_t st) {
+    const int64_t total = pad_rows_to * ld;
+    if (total <= 0) return;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_to_f32_f16, dim3(blocks), dim3(256), 0, st, src, src_f16, src_ld, n_rows, d, dst32, dst16, ld, pad_rows_to);
+}
+
 // rows [n_rows, pad_rows_to) and columns [d, ld) are zero-filled.  *flag |= 1 if an fp32 input
 // value is not exactly representable in fp16.
 __global__ void k_to_f16(const void* src, int src_f16, int64_t n_rows, int d, __half* dst, int ld,

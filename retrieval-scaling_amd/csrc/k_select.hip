@@ -800,6 +800,209 @@ void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int npr
 }
 
 // ---------------------------------------------------------------------------------------
+// Probe selection of the fast coarse quantiser (round 6): one workgroup per query turns the APPROXIMATE centroid scores of
+// launch_coarse_approx into the EXACT top-nprobe — the lists, their exact scores (the oracle's `s = fmaf(x[t], c[t], s)` chain, what
+// k_gemm_exact computes for all 4096) and the probe set-up — in one launch:
+//   1. the nprobe-th largest approximate score a_n (a bit-by-bit walk over the row's order-preserving keys, held in registers);
+//   2. candidates = every centroid with approximate score >= a_n - 2 e, e = a bound on |approximate - exact| for ANY centroid of this
+//      query (fp16 rounding of both operands, fp32 accumulation, Cauchy-Schwarz with the largest centroid norm).  A centroid below that
+//      line is beaten by nprobe others for certain, so the true top-nprobe — ties included — lies among the candidates;
+//   3. the exact chain of each candidate (one lane each, its centroid row streamed with 16-byte loads), keys (score, list), bitonic sort;
+//   4. probe lists, coarse scores and the query's row layout (what k_probe_setup writes).
+// More candidates than the row holds (nprobe + 16, rounded up to 16s: mass ties, a zero query) or a non-finite score anywhere: bad[q] = 2 — the query is re-run by the exact path
+// with the certificate's other failures (rerun_uncertified); the probes written for it are still valid lists.
+// ---------------------------------------------------------------------------------------
+#ifdef RSX_MEASURE
+__device__ uint64_t g_cp_trace[256 * 8];          // tools/ builds only: [workgroup < 256][mark] wall clock (10 ns ticks) of k_coarse_pick's phases
+extern "C" int rsx_debug_cp_trace(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp_trace), sizeof(uint64_t) * 256 * 8) == hipSuccess ? 0 : -1; }
+#define CP_MARK(i) do { if (blockIdx.x < 256 && threadIdx.x == 0) g_cp_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define CP_MARK(i) do { } while (0)
+#endif
+template <int KPT, int NLD>      // keys per thread (a multiple of 4): nlist <= 256 KPT; 16-byte loads per thread and row chunk: cmax_rt <= 8 NLD
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_coarse_pick(CoarsePickArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cp_lds[];
+    __shared__ uint64_t skey[CP_CMAX], sorted[CP_CMAX];
+    __shared__ int32_t cand[CP_CMAX];
+    __shared__ int64_t lens[CP_MAXPROBE];
+    __shared__ uint32_t wcnt[2][4][4];
+    __shared__ float red[4];
+    __shared__ int s_cnt, s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t q = blockIdx.x;
+    const int nlist = a.nlist, d = a.d, dp = (d + CP_CH - 1) / CP_CH * CP_CH;
+    float* xq = reinterpret_cast<float*>(cp_lds);              // [dp]: the query, zero padded to whole chunks
+    float* stage = xq + dp;                                    // [cmax_rt][CP_RS]
+    if (tid == 0) { s_cnt = 0; s_bad = 0; }
+    CP_MARK(0);
+    float ss = 0.0f;
+    for (int t = tid; t < dp; t += 256) { const float v = t < d ? a.Q32[q * a.ld + t] : 0.0f; xq[t] = v; ss = __fmaf_rn(v, v, ss); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) red[w] = ss;
+    // the row's order-preserving keys stay in registers: keys 4 u .. 4 u + 3 of thread tid = lists 4 (tid + 256 u) .. + 3 (0 = no list: below
+    // every real key)
+    bool badl = false;
+    uint32_t rk[KPT];
+    const float4* arow = reinterpret_cast<const float4*>(a.approx + q * a.nlp);          // nlp % 4 == 0
+#pragma unroll
+    for (int u = 0; u < KPT / 4; u++) {
+        const int i = 4 * (tid + 256 * u);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nlist) v = arow[tid + 256 * u];          // (the row's tail beyond nlist, < 4 floats, is inside the row's stride)
+        const float sv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j2 = 0; j2 < 4; j2++) {
+            rk[4 * u + j2] = 0u;
+            if (i + j2 < nlist) {
+                if (!(fabsf(sv[j2]) < __builtin_inff())) badl = true;
+                rk[4 * u + j2] = f2ord(sv[j2] + 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+    CP_MARK(1);
+    const float xn = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    // 1. a lower bound of the nprobe-th largest key, within 2^-15 of it: its top 24 bits, two per step — the largest v (low 8 bits clear) with
+    // |{keys >= v}| >= nprobe.  Counting is ballots and a few words exchanged per step — a radix histogram of 4096 keys that share their leading
+    // bytes is thousands of LDS atomics on two or three counters.  (A bound is enough: the candidate line below only moves down with it.)
+    uint32_t prefix = 0u;
+    for (int bit = 30, it = 0; bit >= 8; bit -= 2, it++) {
+        uint32_t c1 = 0u, c2 = 0u, c3 = 0u;
+        const uint32_t v1 = prefix | (1u << bit), v2 = prefix | (2u << bit), v3 = prefix | (3u << bit);
+#pragma unroll
+        for (int u = 0; u < KPT; u++) {
+            c1 += (uint32_t)__popcll(__ballot(rk[u] >= v1)); c2 += (uint32_t)__popcll(__ballot(rk[u] >= v2)); c3 += (uint32_t)__popcll(__ballot(rk[u] >= v3));
+        }
+        if (lane == 0) { wcnt[it & 1][w][0] = c1; wcnt[it & 1][w][1] = c2; wcnt[it & 1][w][2] = c3; }
+        __syncthreads();
+        const uint32_t t1 = wcnt[it & 1][0][0] + wcnt[it & 1][1][0] + wcnt[it & 1][2][0] + wcnt[it & 1][3][0];
+        const uint32_t t2 = wcnt[it & 1][0][1] + wcnt[it & 1][1][1] + wcnt[it & 1][2][1] + wcnt[it & 1][3][1];
+        const uint32_t t3 = wcnt[it & 1][0][2] + wcnt[it & 1][1][2] + wcnt[it & 1][2][2] + wcnt[it & 1][3][2];
+        const uint32_t np = (uint32_t)a.nprobe;
+        prefix = t3 >= np ? v3 : t2 >= np ? v2 : t1 >= np ? v1 : prefix;
+    }
+    // 2. candidates
+    CP_MARK(2);
+    const float an = ord2f(prefix);
+    const float e = xn * (a.cmax * (a.ef * 1.002f + (float)d * 2.4e-7f) + sqrtf((float)d) * 1.2e-7f);
+    float T = an - 2.0f * e;
+    T -= fabsf(T) * 1e-6f + 1e-30f;
+    if (!(fabsf(T) < __builtin_inff())) badl = true;
+    const uint32_t Tk = f2ord(T);
+#pragma unroll
+    for (int u = 0; u < KPT; u++) {
+        const int i = 4 * (tid + 256 * (u >> 2)) + (u & 3);
+        if (rk[u] >= Tk && i < nlist) { const int pos = atomicAdd(&s_cnt, 1); if (pos < a.cmax_rt) cand[pos] = i; }
+    }
+    if (tid < CP_CMAX) sorted[tid] = 0ull;
+    __syncthreads();
+    const int ncand = s_cnt < a.cmax_rt ? s_cnt : a.cmax_rt;
+    if (s_cnt > a.cmax_rt || s_cnt < a.nprobe) badl = true;
+    // 3. exact chains: lane = candidate.  The rows arrive in chunks of CP_CH dimensions, fetched by ALL threads (coalesced, every load
+    // independent; a lane streaming its own 3 KB row exposes one L2 round trip per 128-byte line) into an LDS stage whose row stride of
+    // CP_RS floats keeps 16-byte reads conflict-free; the next chunk's loads are in flight while the lanes run the current one
+    uint64_t key = 0ull;
+    float s = 0.0f;
+    const int myl = tid < ncand ? cand[tid] : 0;
+    CP_MARK(3);
+    constexpr int C4 = CP_CH / 4;           // float4 per row chunk
+    const bool vec = (d & 3) == 0;
+    const int nld = (ncand * C4 + 255) / 256;
+    float4 preA[NLD], preB[NLD];          // TWO chunks in flight: the rows come from beyond the L2 (12.6 MB of centroids, 123 MB of row reads per batch)
+    auto fetch = [&](float4* pre, int t0) {
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int i = tid + 256 * u, r = i / C4, c = i % C4;
+            if (u < nld && r < ncand && t0 < dp) {
+                const float* src = a.C + (int64_t)cand[r] * d + t0 + 4 * c;
+                if (vec) { if (t0 + 4 * c < d) pre[u] = *reinterpret_cast<const float4*>(src); }
+                else {
+                    if (t0 + 4 * c < d) pre[u].x = src[0];
+                    if (t0 + 4 * c + 1 < d) pre[u].y = src[1];
+                    if (t0 + 4 * c + 2 < d) pre[u].z = src[2];
+                    if (t0 + 4 * c + 3 < d) pre[u].w = src[3];
+                }
+            }
+        }
+    };
+    auto step = [&](float4* pre, int t0) {          // chunk t0 (in `pre`) -> LDS, its registers re-armed with chunk t0 + 2 CP_CH, the lanes' chains over it
+        if (t0) __syncthreads();          // the lanes are done with the previous chunk
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int i = tid + 256 * u, r = i / C4, c = i % C4;
+            if (u < nld && r < ncand) *reinterpret_cast<float4*>(stage + r * CP_RS + 4 * c) = pre[u];
+        }
+        __syncthreads();
+        fetch(pre, t0 + 2 * CP_CH);
+        if (tid < ncand) {
+            const float4* row = reinterpret_cast<const float4*>(stage + tid * CP_RS);
+            const float4* xx = reinterpret_cast<const float4*>(xq + t0);
+#pragma unroll 8
+            for (int t = 0; t < C4; t++) {
+                const float4 c = row[t], x = xx[t];
+                s = __fmaf_rn(x.x, c.x, s); s = __fmaf_rn(x.y, c.y, s); s = __fmaf_rn(x.z, c.z, s); s = __fmaf_rn(x.w, c.w, s);
+            }
+        }
+    };
+    fetch(preA, 0);
+    fetch(preB, CP_CH);
+    for (int t0 = 0; t0 < dp; t0 += 2 * CP_CH) {
+        step(preA, t0);
+        if (t0 + CP_CH < dp) step(preB, t0 + CP_CH);
+    }
+    if (tid < ncand) {
+        if (!(fabsf(s) < __builtin_inff())) badl = true;
+        key = make_key(s, (uint32_t)myl);
+    }
+    if (tid < CP_CMAX) skey[tid] = key;
+    if (badl) s_bad = 1;
+    __syncthreads();
+    CP_MARK(4);
+    // order by rank: the keys are distinct (they carry the list number)
+    if (tid < ncand && key) {
+        int rank = 0;
+        for (int j2 = 0; j2 < ncand; j2++) rank += skey[j2] > key;
+        sorted[rank] = key;
+    }
+    __syncthreads();
+    // 4. probes + row layout
+    CP_MARK(5);
+    if (tid < a.nprobe) {
+        const uint64_t kk = sorted[tid];
+        const int32_t l = kk ? (int32_t)key_idx(kk) : -1;
+        a.probe_list[q * a.nprobe + tid] = l;
+        a.dis0[q * a.nprobe + tid] = kk ? key_score(kk) : -__builtin_inff();
+        const int64_t len = l >= 0 ? a.list_len[l] : 0;
+        lens[tid] = (len + a.pad_to - 1) / a.pad_to * a.pad_to;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int64_t off = 0;
+        int64_t* ssg = a.seg_start + q * (a.nprobe + 1);
+        for (int j = 0; j < a.nprobe; j++) { ssg[j] = off; off += lens[j]; }
+        ssg[a.nprobe] = off;
+        a.bad[q] = s_bad ? 2 : 0;
+    }
+    CP_MARK(6);
+}
+int coarse_pick_cmax(int nprobe) { int c = (nprobe + 16 + 15) / 16 * 16; return c > CP_CMAX ? CP_CMAX : c; }      // candidate rows: nprobe + a margin
+size_t coarse_pick_lds(int nlist, int d, int nprobe) { return ((size_t)((d + CP_CH - 1) / CP_CH * CP_CH) + (size_t)coarse_pick_cmax(nprobe) * CP_RS) * 4; }
+void launch_coarse_pick(const CoarsePickArgs& a0, int64_t nq, hipStream_t st) {
+    if (nq <= 0) return;
+    CoarsePickArgs a = a0;
+    a.cmax_rt = coarse_pick_cmax(a.nprobe);
+    const size_t shm = coarse_pick_lds(a.nlist, a.d, a.nprobe);
+    const int ki = a.nlist <= 1024 ? 0 : a.nlist <= 4096 ? 1 : 2, li = a.cmax_rt <= 48 ? 0 : 1;
+    void (*const kerns[3][2])(CoarsePickArgs) = {{k_coarse_pick<4, 6>, k_coarse_pick<4, 8>}, {k_coarse_pick<16, 6>, k_coarse_pick<16, 8>}, {k_coarse_pick<64, 6>, k_coarse_pick<64, 8>}};
+    auto kern = kerns[ki][li];
+    static DevSize attr[6];
+    attr[2 * ki + li].grow(shm, [&] { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
+    hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), shm, st, a);
+}
+
+// ---------------------------------------------------------------------------------------
 // Group the (query, probe) pairs by inverted list so that a list's vectors are streamed from
 // HBM once for all the queries of the batch that probe it (list-major scheduling).
 // ---------------------------------------------------------------------------------------

@@ -163,7 +163,8 @@ struct rsx_index {
     // beside the coarse quantiser + probe selection, the pair grouping beside the threshold pre-pass
     hipStream_t st2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_probe = nullptr, ev_lut = nullptr, ev_group = nullptr;
-    int overlap = 1;          // 0 = everything on one stream
+    int overlap = 0;          // 1 = IVF-PQ table build and pair grouping on a side stream beside the coarse quantiser / the pre-pass (rounds 4-5; round 6:
+                              // three cross-stream joins of ~12 us each cost what the overlap buys — one stream, fewer and fused launches instead)
     ~rsx_index() {
         if (st2) { (void)hipSetDevice(device); (void)hipStreamDestroy(st2); }
         for (hipEvent_t e : {ev_fork, ev_probe, ev_lut, ev_group}) if (e) (void)hipEventDestroy(e);
@@ -173,6 +174,11 @@ struct rsx_index {
     // trained parameters
     std::vector<float> h_centroids, h_codebooks;
     DevBuf d_centroids, d_codebooks;
+    DevBuf cent16;            // fp16 copy of the centroids, [round_up(nlist, 128)][ld] zero padded: the fast coarse quantiser's operand (built on demand)
+    uint64_t cent_gen = 0, cent16_gen = 0;   // set_centroids counts; the copy belongs to cent16_gen
+    float cent_cmax = 0.0f;   // >= the largest centroid norm (with the copy)
+    int coarse_fast = 1;      // coarse quantiser: fp16 MFMA scores + exact re-score of the candidates (k_coarse_pick), 0 = the exact GEMM for all lists
+    bool coarse_flags_live = false;   // this batch's k_coarse_pick wrote per-query flags behind w_uncertain's
 
     // storage.  PQ: slab layout bytes.  Flat/IVFFlat: rows of ld elements (fp16 or fp32).
     int ld = 0;               // row stride (elements) of flat rows: d rounded up to 64

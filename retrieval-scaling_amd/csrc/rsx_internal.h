@@ -170,6 +170,8 @@ struct ListDir {
 
 // k_misc.hip
 void launch_convert_to_f32(const void* src, int src_f16, int64_t src_ld, int64_t n_rows, int d, float* dst, int ld, hipStream_t st);
+void launch_convert_to_f32_f16(const void* src, int src_f16, int64_t src_ld, int64_t n_rows, int d, float* dst32, __half* dst16, int ld,
+                               int64_t pad_rows_to, hipStream_t st);
 void launch_convert_to_f16(const void* src, int src_f16, int64_t n_rows, int d, __half* dst, int ld,
                            int64_t pad_rows_to, int* not_representable_flag, hipStream_t st);
 void launch_check_f16(const float* x, int64_t count, int* flag, hipStream_t st);
@@ -424,6 +426,24 @@ void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
 int pq_prepass4_max_rows(int M);
 int launch_pq_prepass4(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
 int launch_pq_prepass4_big(const PQPrepassArgs& a, int64_t nq, hipStream_t st);   // large samples (<= 32768 rows, several lists): histogram form
+// fast coarse quantiser (k_gemm.hip: launch_coarse_approx; k_select.hip: k_coarse_pick)
+#define CP_CMAX 64             // most candidates a query may have (its nprobe best by approximate score + everything within 2 e of the last)
+#define CP_CH 128              // dimensions per staged chunk of the candidates' centroid rows
+#define CP_RS (CP_CH + 4)      // ... whose LDS row stride keeps ds_read_b128 of 16 consecutive lanes on 64 different banks
+#define CP_MAXPROBE 48         // (more probes = more candidate rows than two chunks in flight fit in 128 registers; the exact GEMM serves them)
+#define CP_MAXLIST 16384       // the row's keys live in LDS
+struct CoarsePickArgs {
+    const float* approx; int64_t nlp; int nlist;      // [nq][nlp] approximate scores
+    const float* Q32; int ld; int d; const float* C;  // exact operands: queries [nq][ld], centroids [nlist][d]
+    float cmax;                                       // >= the largest centroid L2 norm
+    float ef;                                         // relative rounding of the approximate operands: 2^-11 per fp16-rounded side
+    int nprobe; const int64_t* list_len; int pad_to;
+    int32_t* probe_list; float* dis0; int64_t* seg_start; int32_t* bad;
+    int cmax_rt;                                      // set by the launcher: candidate rows of this launch (coarse_pick_cmax)
+};
+size_t coarse_pick_lds(int nlist, int d, int nprobe);
+void launch_coarse_approx(const __half* Q16, int64_t nq_pad, const __half* C16, int nlist, int ld, float* S, int64_t lds_, hipStream_t st);
+void launch_coarse_pick(const CoarsePickArgs& a, int64_t nq, hipStream_t st);
 void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
                         int pad_to, int32_t* probe_list, float* probe_dis0, int64_t* seg_start, hipStream_t st);
 // tile_rows > 0: also build the (list, tile, group) work-item table: item_off[nlist+1], total_items

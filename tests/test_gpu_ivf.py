@@ -697,6 +697,89 @@ def test_round4_engine_knobs_never_change_a_result(gpu, orc, M, d):
                     assert_same_results(D, I, De, Ie, f"M={M} k={k} overlap={overlap} pq_final_tab={tab} sample={mult}x/{mx}")
 
 
+@pytest.mark.parametrize("M,d,nlist", [(96, 768, 16), (16, 768, 40), (64, 256, 7), (20, 160, 16)])
+def test_round6_table_build_and_grouping_forms_never_change_a_result(gpu, orc, M, d, nlist):
+    """Round 6: the 8-bit tables from the matrix cores (lut_tiled 2: k_pq_lut_mfma, per-query parameters in its tail) against the VALU
+    forms (1: two passes + k_pq_qparam, 0: one workgroup per query), the pair grouping as extra workgroups of the table launch
+    (pq_group_fused) against its own launches, one stream against two — every combination returns the exact kernel's bits; batch sizes
+    around the 32-query tile of the matrix-core form, several searches in a row (the hand-over words and tile counters carry over)."""
+    n = 50000
+    x = gpu.synth_vectors(d, 16, 1234, 10000, 0.5, 0, n)
+    q = gpu.synth_queries(d, 16, 1234, 10000, 0.5, n, 999, 0.1, 0, 200)
+    ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+    ix.train(x[:20000]); ix.add(x); ix.nprobe = min(8, nlist)
+    for nq, k in ((200, 10), (33, 10), (1, 5), (97, 120), (64, 10)):
+        ix.set_param("scan_kernel", 2)
+        De, Ie = ix.search(q[:nq], k)
+        ix.set_param("scan_kernel", 0)
+        for overlap, tiled, fused in ((0, 2, 1), (0, 2, 0), (1, 2, 1), (0, 1, 1), (1, 1, 0), (0, 0, 1), (0, 2, 1)):
+            ix.set_param("overlap", overlap); ix.set_param("lut_tiled", tiled); ix.set_param("pq_group_fused", fused)
+            D, I = ix.search(q[:nq], k)
+            assert_same_results(D, I, De, Ie, f"M={M} nq={nq} k={k} overlap={overlap} lut_tiled={tiled} pq_group_fused={fused}")
+    ix.set_param("overlap", 0); ix.set_param("lut_tiled", 2); ix.set_param("pq_group_fused", 1)
+
+
+@pytest.mark.parametrize("kind", ["ivfpq", "ivfflat"])
+@pytest.mark.parametrize("d,nlist,nprobe", [(768, 256, 32), (96, 130, 7), (100, 64, 32), (64, 1024, 48), (128, 4500, 20), (64, 300, 49)])
+def test_round6_fast_coarse_quantiser_is_exact(gpu, orc, kind, d, nlist, nprobe):
+    """Round 6: the coarse quantiser from fp16 MFMA scores + exact chains of the candidates (k_coarse_pick) must select exactly the lists —
+    and pass on exactly the coarse scores — of the exact GEMM: results equal the oracle's and the coarse_fast = 0 run's bit for bit, for
+    fp16 and fp32 queries, near-duplicate centroids (ties within the rounding of the approximate scores), an exact duplicate (tie by list
+    number), a query of huge norm, one with a NaN, and — where the index has the lists for it — a cluster of 80 nearly equal centroids that
+    overflows the candidate rows of the queries near it: those leave through the exact re-run (counted), the batch must not.  nprobe 49 is
+    one more than the fast form serves: the exact GEMM takes it."""
+    rng = np.random.RandomState(5)
+    n, nq, k = 40000, 70, 10
+    x = gpu.synth_vectors(d, 64, 1234, 10000, 0.5, 0, n)
+    x32 = x.astype(np.float32)
+    cen = orc.kmeans(0, x32, nlist, 2, 7)
+    cen[1::7] = cen[0::7][: len(cen[1::7])] * (1.0 + 2e-4 * rng.randn(len(cen[1::7]), 1).astype(np.float32))     # near-duplicates of other centroids
+    cen[5] = cen[4]                                                                                               # an exact duplicate: tie by list number
+    crowd = nlist >= 256 and nprobe <= 100
+    if crowd:
+        cen[100:180] = cen[99] * (1.0 + 1e-5 * rng.randn(80, 1).astype(np.float32))
+    q = gpu.synth_queries(d, 64, 1234, 10000, 0.5, n, 999, 0.1, 0, nq).astype(np.float32)
+    q[9] *= 3000.0
+    if crowd:
+        q[20:23] = cen[99] * (1.0 + 0.01 * rng.randn(3, d).astype(np.float32))
+    q32 = q + (1e-3 * rng.randn(nq, d)).astype(np.float32)      # not fp16-representable
+    a, _ = orc.assign_ip(cen, x32)
+    if kind == "ivfpq":
+        M = 16 if d % 16 == 0 else 4
+        ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+        ix.set_centroids(cen)
+        res = orc.residuals(cen, x32, a)
+        cb = orc.pq_train(res[:3000], M, 1, 7)
+        ix.set_codebooks(cb)
+        lm = orc.ListMajor(a, np.arange(n), orc.pq_encode(cb, res), nlist)
+    else:
+        ix = gpu.IndexIVFFlat(None, d, nlist, gpu.METRIC_INNER_PRODUCT)
+        ix.set_centroids(cen)
+        lm = orc.ListMajor(a, np.arange(n), x32, nlist)
+    ix.add(x); ix.nprobe = nprobe
+    for qq, what in ((q.astype(np.float16), "fp16 queries"), (q32, "fp32 queries")):
+        qf = qq.astype(np.float32)
+        if kind == "ivfpq":
+            Dr, Ir = orc.ivfpq_search(cen, cb, lm, qf, nprobe, k)
+        else:
+            Dr, Ir = orc.ivfflat_search(0, cen, lm, qf, nprobe, k)
+        ix.set_param("profile", 1)
+        ix.set_param("coarse_fast", 1)
+        D1, I1 = ix.search(qq, k)
+        redo = ix.get_timing("coarse_redo_queries")
+        ix.set_param("coarse_fast", 0)
+        D0, I0 = ix.search(qq, k)
+        ix.set_param("coarse_fast", 1); ix.set_param("profile", 0)
+        assert_same_results(D0, I0, Dr, Ir, f"{kind} {what}: exact coarse quantiser vs oracle")
+        assert_same_results(D1, I1, Dr, Ir, f"{kind} {what}: fast coarse quantiser vs oracle")
+        assert (3 if crowd and nprobe <= 48 else 0) <= redo <= 20, f"{kind} {what}: {redo} queries re-run for the coarse quantiser"
+    qn = q.copy(); qn[8, 0] = np.nan
+    ix.set_param("coarse_fast", 1); D1, I1 = ix.search(qn, k)
+    ix.set_param("coarse_fast", 0); D0, I0 = ix.search(qn, k)
+    ix.set_param("coarse_fast", 1)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0, equal_nan=True), f"{kind}: a query with a NaN"
+
+
 @pytest.mark.parametrize("M", [96, 16])
 def test_one_call_of_many_batches_equals_batch_by_batch(gpu, M):
     """One index.search call with several internal batches (the reference hands ALL its queries to one call, src/search.py:296;
