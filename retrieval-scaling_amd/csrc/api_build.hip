@@ -155,6 +155,9 @@ rsx_index* create_common(int kind, int d, int nlist, int M, int nbits, int metri
     if (device < 0 || device >= ndev) RSX_THROW(RSX_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
     std::unique_ptr<rsx_index> h(new rsx_index());
     h->kind = kind; h->d = d; h->metric = metric; h->device = device;
+#ifndef RSX_FLAGS_IN_HBM
+    h->w_uncertain.host_mapped = true;
+#endif
     h->nlist = (kind == KIND_FLAT) ? 1 : nlist;
     if (kind != KIND_FLAT && nlist <= 0) RSX_THROW(RSX_ERR_INVALID, "nlist must be positive (got %d)", nlist);
     h->ld = (int)round_up(d, 64);

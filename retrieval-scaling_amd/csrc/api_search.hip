@@ -158,12 +158,19 @@ static void rerun_uncertified(rsx_index* h, int64_t nq, const void* dq, int dtyp
     auto read_flags = [&]() {
         // the fast coarse quantiser's per-query flags (k_coarse_pick: 2 = its candidate row overflowed or a score was not finite) sit behind the
         // certificate's [nq, 2 nq): one copy fetches both, and a flagged query goes to the exact re-run whatever the certificate said
+        // (the flag words live in page-locked host memory mapped into the device: the kernels wrote them across the bus, no copy command)
         const size_t words = (size_t)nq * (coarse_live ? 2 : 1);
         int32_t* dst;
-        if (nq <= 4096 && h->pin_flags.ensure(8192 * 4)) dst = h->pin_flags.as<int32_t>();
-        else { bad_v.resize(words); dst = bad_v.data(); }
-        HIPCHECK(hipMemcpyAsync(dst, h->w_uncertain.p, words * 4, hipMemcpyDeviceToHost, h->st));
-        HIPCHECK(hipStreamSynchronize(h->st));
+        if (h->w_uncertain.host_mapped) {
+            HIPCHECK(hipStreamSynchronize(h->st));
+            bad_v.assign(h->w_uncertain.as<int32_t>(), h->w_uncertain.as<int32_t>() + words);
+            dst = bad_v.data();
+        } else {
+            if (nq <= 4096 && h->pin_flags.ensure(8192 * 4)) dst = h->pin_flags.as<int32_t>();
+            else { bad_v.resize(words); dst = bad_v.data(); }
+            HIPCHECK(hipMemcpyAsync(dst, h->w_uncertain.p, words * 4, hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(hipStreamSynchronize(h->st));
+        }
         if (coarse_live)
             for (int64_t q = 0; q < nq; q++) if (dst[(size_t)(nq + q)]) { dst[(size_t)q] |= 2; h->timing["coarse_redo_queries"] += 1.0; }
         bad = dst;
@@ -273,13 +280,6 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         rsx_index* h; bool armed = false;
         ~SideJoin() { if (armed && h->st2) (void)hipStreamSynchronize(h->st2); }
     } side_join{h};
-    // k_pq_lut_once's per-tile counters: zeroed when (re)allocated, left zeroed by every launch
-    auto lut_sync = [&]() -> uint32_t* {
-        if (h->lut_tiled < 2) return nullptr;
-        const size_t need = pq_lut8_sync_bytes(nq);
-        if (need > h->w_lutsync.bytes) { h->w_lutsync.ensure(need); HIPCHECK(hipMemsetAsync(h->w_lutsync.p, 0, h->w_lutsync.bytes, h->st)); HIPCHECK(hipStreamSynchronize(h->st)); }
-        return h->w_lutsync.as<uint32_t>();
-    };
     if (side_lut) {
         ensure_side_stream(h);
         h->w_lut8.ensure((size_t)nq * h->Mpad * 256);
@@ -288,7 +288,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         HIPCHECK(hipEventRecord(h->ev_fork, h->st));
         HIPCHECK(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
         launch_pq_lut8(nullptr, h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad, nullptr, 0,
-                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, sliced ? 2 : rot ? 1 : 0, h->st2, 1, lut32_out, lut_sync());
+                       h->w_lut8.as<uint8_t>(), h->w_qparam.p, h->w_lutws.p, sliced ? 2 : rot ? 1 : 0, h->st2, 1, lut32_out);
         HIPCHECK(hipEventRecord(h->ev_lut, h->st2));
         side_join.armed = true;
     }
@@ -556,7 +556,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_lut, 0));     // the tables were built beside the probe selection
                 launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
                                h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, sliced ? 2 : rot ? 1 : 0, h->st, side_lut ? 2 : 0,
-                               fused_lut ? lut32_out : nullptr, (lut_ws && !side_lut) ? lut_sync() : nullptr, pg);
+                               fused_lut ? lut32_out : nullptr, (lut_ws && !side_lut && h->lut_tiled >= 2) ? 1 : 0, pg);
                 tm.mark("lut8");
             };
             const bool group_in_tables = lut_ws && !side_lut && h->lut_tiled >= 2 && h->pq_group_fused != 0 && pairs <= PG_MAX_PAIRS &&

@@ -15,6 +15,7 @@ rsx_index* sharded_create(int kind, int d, int nlist, int M, int nbits, int metr
     if (ndev <= 0 || !devices) RSX_THROW(RSX_ERR_INVALID, "sharded_create: need at least one device");
     if (ndev > 64) RSX_THROW(RSX_ERR_INVALID, "sharded_create: %d shards", ndev);
     std::unique_ptr<rsx_index> p(new rsx_index());
+    p->w_uncertain.host_mapped = true;
     try {
         for (int r = 0; r < ndev; r++) p->shards.push_back(create_common(kind, d, nlist, M, nbits, metric, devices[r]));
     } catch (...) {
@@ -282,6 +283,7 @@ rsx_index* sharded_load(const char* path, int ndev, const int* devices) {
     if (ns <= 0 || ns > 64) RSX_THROW(RSX_ERR_IO, "bad shard count in %s", path);
     if (ndev <= 0 || !devices) RSX_THROW(RSX_ERR_INVALID, "load_sharded: need at least one device");
     std::unique_ptr<rsx_index> p(new rsx_index());
+    p->w_uncertain.host_mapped = true;
     try {
         for (int r = 0; r < ns; r++)   // more shards than devices: several shards share a device
             p->shards.push_back(load_impl((std::string(path) + ".shard" + std::to_string(r)).c_str(), devices[r % ndev]));

@@ -644,10 +644,9 @@ __global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, c
 //     codes (r & 3) + 8 (r >> 2) + 4 h of every tile: min / max / error reductions are IN-LANE but for one exchange with lane ^ 32;
 //   * PASS 0 leaves the (min, max) pairs, PASS 1 recomputes the entries (32 MFMAs) and quantises them with the query's scale; the bytes
 //     leave through a padded LDS image [query][code] x 4 sub-quantisers as 4-byte runs of both transposed layouts;
-//   * the last workgroup of a query tile to finish PASS 1 (a counter per tile; the errors of its siblings read with agent-scope loads,
-//     stored with agent-scope stores: no fences — an agent-scope release / acquire pair is a write-back / invalidate of the whole L2,
-//     measured 0.5 ms per launch) derives the tile's PQQParam records when the coarse scores exist, i.e. when the launch follows the
-//     probe selection in stream order, and resets the counter for the next launch.
+//   * the per-query parameters come from the tile's first workgroup of PASS 1, with the quantisation error BOUNDED (scale / 2 per entry)
+//     instead of measured — a measured sum needs every workgroup of the tile: a counter, agent-scope round trips and a tail of ~8 us
+//     (built and measured: 48 us against 40 for the two launches);
 // (One launch with the tile's workgroups meeting at a counter between the passes was built and measured first: 77 us — every hand-over
 //  is a memory round trip of 2-3 us and the waiters hold their CU slots; profiles/r06_fixed_cost.md.)
 // ---------------------------------------------------------------------------------------
@@ -656,10 +655,9 @@ __global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, c
 typedef float lm_f16 __attribute__((ext_vector_type(16)));
 template <int PASS>
 __global__ __launch_bounds__(256) void k_pq_lut_mfma(const float* Q32, int ldq, const float* codebooks, int M, int Mpad, int64_t nq,
-                                                     float* mnmx, float* errb, uint8_t* lut8, int mode, float* lut32_out,
-                                                     uint32_t* sync, const float* probe_dis0, int nprobe, PQQParam* qp, PairGroupArgs pg) {
+                                                     float* mnmx, uint8_t* lut8, int mode, float* lut32_out,
+                                                     const float* probe_dis0, int nprobe, PQQParam* qp, PairGroupArgs pg) {
     __shared__ float s_scale[2 * LM_Q];
-    __shared__ int s_last;
     extern __shared__ __attribute__((aligned(16))) uint8_t lt_obuf[];      // [LM_Q][257] dwords: byte mi of dword (query, code) = sub-quantiser m0 + mi
     unsigned bid = blockIdx.x;
     if (PASS == 1 && pg.nb > 0) {      // the first pg.nb workgroups group the (query, probe) pairs by list (rsx_internal.h: group_pairs_block)
@@ -716,29 +714,64 @@ __global__ __launch_bounds__(256) void k_pq_lut_mfma(const float* Q32, int ldq, 
         if (hh == 0 && qok && mpad) *reinterpret_cast<float2*>(mnmx + (q * Mpad + m) * 2) = make_float2(mn, mx);
         return;
     }
-    // the queries' scales: 8 threads per query over m (max is order-free)
+    // the queries' scales: 8 threads per query over m (max is order-free).  The tile's first workgroup also derives the queries' PQQParam
+    // records here: everything they need is pass 0's (min, max) pairs and the coarse scores — the quantisation error is BOUNDED, not
+    // measured: u = rint((v - mn) / scale) leaves |v - (mn + scale u)| <= scale (1/2 + 255 x 3 x 2^-24) for every entry, and the measured
+    // maximum over a sub-quantiser's 256 entries is within a percent of that anyway.  (Summing measured errors needs every workgroup of the
+    // tile: a counter, an agent-scope round trip and a tail of ~8 us in this launch.)
     {
         const int qi = tid >> 3, part = tid & 7;
-        float r = 0.0f;
+        const int64_t qq = q0 + qi;
+        const bool params = qp != nullptr && m0 == 0;
+        float r = 0.0f, absmax_sum = 0.0f, bias = 0.0f, d0 = 0.0f;
         if (qi < nqc) {
-            const float2* mm = reinterpret_cast<const float2*>(mnmx + (q0 + qi) * Mpad * 2);
+            const float2* mm = reinterpret_cast<const float2*>(mnmx + qq * Mpad * 2);
 #pragma unroll 4
-            for (int mm_ = part; mm_ < Mpad; mm_ += 8) { const float2 p = mm[mm_]; r = fmaxf(r, p.y - p.x); }
+            for (int mm_ = part; mm_ < Mpad; mm_ += 8) { const float2 p = mm[mm_]; r = fmaxf(r, p.y - p.x); absmax_sum += fmaxf(fabsf(p.x), fabsf(p.y)); bias += p.x; }
+            if (params)
+                for (int jj = part; jj < nprobe; jj += 8) { const float dv = probe_dis0[qq * nprobe + jj]; if (dv > -__builtin_inff()) d0 = fmaxf(d0, fabsf(dv)); }
         }
         r = fmaxf(r, __shfl_xor(r, 1)); r = fmaxf(r, __shfl_xor(r, 2)); r = fmaxf(r, __shfl_xor(r, 4));
-        if (part == 0 && qi < nqc) {
-            const float scale = r > 0.0f ? r / 255.0f : 1.0f;
-            s_scale[qi] = scale; s_scale[LM_Q + qi] = 1.0f / scale;
+        const float scale = r > 0.0f ? r / 255.0f : 1.0f, inv_s = 1.0f / scale;
+        if (part == 0 && qi < nqc) { s_scale[qi] = scale; s_scale[LM_Q + qi] = inv_s; }
+        if (params) {          // sums in a fixed order (m strided by 8 per thread, then a three-step tree): any fixed order is fine, see k_pq_qparam
+            float smax = 0.0f;
+            if (qi < nqc) {
+                const float2* mm = reinterpret_cast<const float2*>(mnmx + qq * Mpad * 2);
+#pragma unroll 4
+                for (int mm_ = part; mm_ < Mpad; mm_ += 8) {
+                    const float2 p = mm[mm_];
+#ifdef RSX_MEASURE
+                    smax += lut_coarsen(fminf(fmaxf(rintf((p.y - p.x) * inv_s), 0.0f), 255.0f)) + (g_lut_step > 1 ? (float)g_lut_step : 0.0f);
+#else
+                    smax += fminf(fmaxf(rintf((p.y - p.x) * inv_s), 0.0f), 255.0f);
+#endif
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                absmax_sum += __shfl_xor(absmax_sum, off); bias += __shfl_xor(bias, off); smax += __shfl_xor(smax, off); d0 = fmaxf(d0, __shfl_xor(d0, off));
+            }
+            if (part == 0 && qi < nqc) {
+                float e_quant = (float)M * scale * 0.50005f;
+#ifdef RSX_MEASURE
+                if (g_lut_step > 1) e_quant *= (float)g_lut_step;
+#endif
+                const float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;       // the fp32 slack: see pq_qparam_wave
+                PQQParam pr; pr.scale = scale; pr.bias = bias; pr.eps = e_quant * 1.0001f + pq_round_slack(M) * B; pr.pad = smax;
+                qp[qq] = pr;
+            }
         }
     }
     const float mn = (qok && mpad) ? mnmx[(q * Mpad + m) * 2] : 0.0f;
     __syncthreads();
-    const float scale = qok ? s_scale[j] : 1.0f, inv = qok ? s_scale[LM_Q + j] : 1.0f;
-    float err = 0.0f;
+    const float inv = qok ? s_scale[LM_Q + j] : 1.0f;
+    float dep = 0.0f;
     uint8_t* ob = lt_obuf + ((size_t)j * 257) * 4 + w;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        const lm_f16 v = tile(t, err);
+        const lm_f16 v = tile(t, dep);
+        dep = v[15];
         if (lut32_out && mreal && qok) {
 #pragma unroll
             for (int g = 0; g < 4; g++)
@@ -753,11 +786,8 @@ __global__ __launch_bounds__(256) void k_pq_lut_mfma(const float* Q32, int ldq, 
             u = lut_coarsen(u);
 #endif
             ob[(size_t)c * 4] = (uint8_t)u;
-            err = fmaxf(err, fabsf(v[r] - (mn + scale * u)));
         }
     }
-    err = fmaxf(err, __shfl_xor(err, 32));
-    if (hh == 0 && qok && mpad) st_agent(errb + q * Mpad + m, err);
     __syncthreads();
     if (mode == 0) {        // [q][m][code]: 4 consecutive codes of one sub-quantiser per store
         for (int e = tid; e < nqc * LM_MB * 64; e += 256) {
@@ -776,61 +806,15 @@ __global__ __launch_bounds__(256) void k_pq_lut_mfma(const float* Q32, int ldq, 
             else for (int t = 0; m0 + t < Mpad; t++) dst[t] = (uint8_t)(v4 >> (8 * t));
         }
     }
-    if (!qp) return;
-    // the tile's last workgroup: per-query parameters, counter back to zero.  Eight threads per query, every load independent of every
-    // other (one wave per query as in k_pq_qparam would be 8 queries in turn per wave, 2-3 us of agent-scope round trips each); the
-    // sums in a fixed order (m strided by 8 per thread, then a three-step tree): any fixed order is fine, see k_pq_qparam
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(&sync[qt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(nmb - 1);
-    __syncthreads();
-    if (!s_last) return;
-    {
-        const int qi = tid >> 3, part = tid & 7;
-        const int64_t qq = q0 + qi;
-        float absmax_sum = 0.0f, maxrange = 0.0f, e_quant = 0.0f, bias = 0.0f, smax = 0.0f, d0 = 0.0f;
-        if (qi < nqc) {
-            const float2* mm = reinterpret_cast<const float2*>(mnmx + qq * Mpad * 2);
-            const float inv_s = s_scale[LM_Q + qi];
-#pragma unroll 4
-            for (int mm_ = part; mm_ < Mpad; mm_ += 8) {
-                const float2 p = mm[mm_];
-                absmax_sum += fmaxf(fabsf(p.x), fabsf(p.y));
-                maxrange = fmaxf(maxrange, p.y - p.x);
-                e_quant += ld_agent(errb + qq * Mpad + mm_);
-                bias += p.x;
-#ifdef RSX_MEASURE
-                smax += lut_coarsen(fminf(fmaxf(rintf((p.y - p.x) * inv_s), 0.0f), 255.0f)) + (g_lut_step > 1 ? (float)g_lut_step : 0.0f);
-#else
-                smax += fminf(fmaxf(rintf((p.y - p.x) * inv_s), 0.0f), 255.0f);
-#endif
-            }
-            for (int jj = part; jj < nprobe; jj += 8) { const float d = probe_dis0[qq * nprobe + jj]; if (d > -__builtin_inff()) d0 = fmaxf(d0, fabsf(d)); }
-        }
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            absmax_sum += __shfl_xor(absmax_sum, off); e_quant += __shfl_xor(e_quant, off); bias += __shfl_xor(bias, off);
-            smax += __shfl_xor(smax, off);
-            maxrange = fmaxf(maxrange, __shfl_xor(maxrange, off)); d0 = fmaxf(d0, __shfl_xor(d0, off));
-        }
-        if (part == 0 && qi < nqc) {
-            const float scale = maxrange > 0.0f ? maxrange / 255.0f : 1.0f;
-            const float B = absmax_sum + d0 + fabsf(bias) + scale * 255.0f * (float)M + 1.0f;       // the fp32 slack: see pq_qparam_wave
-            PQQParam r; r.scale = scale; r.bias = bias; r.eps = e_quant * 1.0001f + pq_round_slack(M) * B; r.pad = smax;
-            qp[qq] = r;
-        }
-    }
-    if (tid == 0) __hip_atomic_store(&sync[qt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad) { return (size_t)nq * Mpad * 3 * 4; }   // mnmx + err
-size_t pq_lut8_sync_bytes(int64_t nq) { return (size_t)((nq + LM_Q - 1) / LM_Q + 8) * 2 * 4; }   // k_pq_lut_mfma<1>: a counter per query tile (zero between launches)
 
 size_t pq_lut8_fused_lds(int M, int Mpad, int dsub) { return ((size_t)Mpad * 256 + (size_t)M * dsub + 3 * (size_t)Mpad) * 4; }
 
 void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* codebooks, int dsub, int64_t nq, int M,
                     int Mpad, const float* probe_dis0, int nprobe, uint8_t* lut8, void* qparam, void* ws, int transposed,
-                    hipStream_t st, int phase, float* lut32_out, uint32_t* sync, const PairGroupArgs* pg) {
+                    hipStream_t st, int phase, float* lut32_out, int mfma, const PairGroupArgs* pg) {
     if (nq <= 0) return;
     if (phase != 0 && !(ws && dsub == 8 && !lut32)) return;     // only the tiled build splits into tables (1) + per-query parameters (2)
     if (lut32) {
@@ -855,17 +839,17 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
         const size_t osm = transposed ? (size_t)LT_QC * 256 * LT_MB : 0;
         static DevOnce once;
         if (osm) once.once([&] { hipFuncSetAttribute((const void*)k_pq_lut_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)osm); });
-        if (sync && phase != 2) {      // matrix-core form; with phase 0 (the coarse scores exist) the per-query parameters come from its second launch
+        if (mfma && phase == 0) {      // matrix-core form: tables + per-query parameters in two launches (needs the coarse scores: phase 0 only)
             const int64_t nmb4 = (Mpad + LM_MB - 1) / LM_MB, nqt4 = (((nq + LM_Q - 1) / LM_Q) + 7) / 8;
             const size_t osm4 = (size_t)LM_Q * 257 * 4;
             const dim3 grid4((unsigned)(nmb4 * nqt4 * 8));
             PairGroupArgs pg0{};
             if (pg) pg0 = *pg;
             PairGroupArgs pgn{};
-            hipLaunchKernelGGL(k_pq_lut_mfma<0>, grid4, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed,
-                               lut32_out, sync, probe_dis0, nprobe, (PQQParam*)nullptr, pgn);
-            hipLaunchKernelGGL(k_pq_lut_mfma<1>, dim3(grid4.x + (unsigned)pg0.nb), dim3(256), osm4, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, errb, lut8, transposed,
-                               lut32_out, sync, probe_dis0, nprobe, phase == 0 ? (PQQParam*)qparam : (PQQParam*)nullptr, pg0);
+            hipLaunchKernelGGL(k_pq_lut_mfma<0>, grid4, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, lut8, transposed,
+                               lut32_out, probe_dis0, nprobe, (PQQParam*)nullptr, pgn);
+            hipLaunchKernelGGL(k_pq_lut_mfma<1>, dim3(grid4.x + (unsigned)pg0.nb), dim3(256), osm4, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, lut8, transposed,
+                               lut32_out, probe_dis0, nprobe, (PQQParam*)qparam, pg0);
             return;
         }
         if (phase != 2) {

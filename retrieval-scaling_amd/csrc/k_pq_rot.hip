@@ -117,17 +117,26 @@ static_assert(sizeof(PQRotItem) == 176, "PQRotItem is copied as 11 x 16 bytes");
 // ngq = records per work item: 1, or — M = 16, filtered scan (k_pq_scan_rot16) — 4: a work item is then a group of up to 16 probing
 // queries of a list tile, described by four consecutive 4-query records (a record without queries has np = 0).
 template <int M, bool FILTER>
-__global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* items, uint32_t* xcd_ctr, uint32_t* prog, int ngq) {
+__global__ __launch_bounds__(256) void k_pq_rot_items(PQScan8Args A, PQRotItem* items, uint32_t* xcd_ctr, uint32_t* prog, int ngq, int lds_lists) {
     const PQScanArgs& a = A.b;
     const int rec = blockIdx.x * 256 + threadIdx.x;
     if (rec < 8) xcd_ctr[rec * 32] = 0u;     // the scan's per-XCD work counters (one per 128-byte line)
     const int ti = *A.total_items;
     const int item = rec / ngq, h = rec - item * ngq;
+    // the item -> list bisection walks item_off: 12 dependent L2 round trips per thread on global memory (6 of the kernel's 17 us) — on a copy
+    // in LDS when the launcher granted one (lds_lists = nlist + 1 words)
+    extern __shared__ int32_t ri_off[];
+    const int32_t* ioff = A.item_off;
+    if (lds_lists > 0) {
+        for (int i = threadIdx.x; i < lds_lists; i += 256) ri_off[i] = A.item_off[i];
+        __syncthreads();
+        ioff = ri_off;
+    }
     if (item >= ti) return;
     int lo = 0, hi = A.nlist;   // largest l with item_off[l] <= item
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.item_off[mid] <= item) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ioff[mid] <= item) lo = mid; else hi = mid; }
     const int ng = A.group_off[lo + 1] - A.group_off[lo];
-    const int r = item - A.item_off[lo];
+    const int r = item - ioff[lo];
     const int tile = r / ng, gi = r - tile * ng;
     const int cnt = A.pair_off[lo + 1] - A.pair_off[lo];
     const int first = 4 * (gi * ngq + h);                 // this record's first pair within the list's sorted pairs
@@ -1681,7 +1690,7 @@ static int launch_pq_scan_rot_t(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, recs);
     uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
     uint32_t* prog = xcd_ctr + 256;
-    hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
+    { const int ll_ = A.nlist + 1 <= 12288 ? A.nlist + 1 : 0; hipLaunchKernelGGL((k_pq_rot_items<M, FILTER>), dim3((unsigned)((recs + 255) / 256)), dim3(256), (size_t)ll_ * 4, st, A, items, xcd_ctr, prog, G, ll_); }
     static const int var = measure_env("RSX_ROT_VARIANT", 0);
     // one persistent workgroup per CU; never more than the work items
     int64_t grid = nwg;
@@ -1713,7 +1722,7 @@ static int launch_pq_scan_rot16(const PQScan8Args& A, int bpw, void* desc_ws, in
     uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, recs);
     uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
     uint32_t* prog = xcd_ctr + 256;
-    hipLaunchKernelGGL((k_pq_rot_items<16, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
+    { const int ll_ = A.nlist + 1 <= 12288 ? A.nlist + 1 : 0; hipLaunchKernelGGL((k_pq_rot_items<16, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), (size_t)ll_ * 4, st, A, items, xcd_ctr, prog, G, ll_); }
     int64_t grid = nwg;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
     hipLaunchKernelGGL(k_pq_scan_rot16, dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, bpw);
@@ -1740,7 +1749,7 @@ static int launch_pq_scan_sl8_t(const PQScan8Args& A, int vpl, void* desc_ws, in
     uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, recs);
     uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, recs, log_cap, nwg * G);
     uint32_t* prog = xcd_ctr + 256;
-    hipLaunchKernelGGL((k_pq_rot_items<M, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, G);
+    { const int ll_ = A.nlist + 1 <= 12288 ? A.nlist + 1 : 0; hipLaunchKernelGGL((k_pq_rot_items<M, true>), dim3((unsigned)((recs + 255) / 256)), dim3(256), (size_t)ll_ * 4, st, A, items, xcd_ctr, prog, G, ll_); }
     int64_t grid = nwg;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
     hipLaunchKernelGGL((k_pq_scan_sl8<NS, NB, RD>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, 32 * vpl);
@@ -1766,7 +1775,7 @@ static int launch_pq_scan_sl4_t(const PQScan8Args& A, int vpl, void* desc_ws, in
     uint64_t* log_keys = pq_scan_rot_ws_keys(desc_ws, A.max_items);
     uint32_t* xcd_ctr = pq_scan_rot_ws_ctr(desc_ws, A.max_items, log_cap, nwg);
     uint32_t* prog = xcd_ctr + 256;
-    hipLaunchKernelGGL((k_pq_rot_items<M, true>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), 0, st, A, items, xcd_ctr, prog, 1);
+    { const int ll_ = A.nlist + 1 <= 12288 ? A.nlist + 1 : 0; hipLaunchKernelGGL((k_pq_rot_items<M, true>), dim3((unsigned)((A.max_items + 255) / 256)), dim3(256), (size_t)ll_ * 4, st, A, items, xcd_ctr, prog, 1, ll_); }
     int64_t grid = nwg;
     if (grid > ((A.max_items + 7) & ~7)) grid = (A.max_items + 7) & ~7;
     hipLaunchKernelGGL((k_pq_scan_sl4<NS>), dim3((unsigned)grid), dim3(1024), shm, st, A, items, log_keys, seg_desc, xcd_ctr, log_cap, 32 * vpl);

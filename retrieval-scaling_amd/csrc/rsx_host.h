@@ -72,10 +72,13 @@ static inline int guarded(F&& f) {
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool host_mapped = false;     // page-locked HOST memory mapped into the device (the per-query flag words: kernels write them across the
+                                  // bus, the host reads them after the stream's synchronisation — no copy command at the end of a batch)
     void ensure(size_t n) {
         if (n <= bytes) return;
         release();
         size_t want = n + n / 8;
+        if (host_mapped) { HIPCHECK(hipHostMalloc(&p, want, hipHostMallocMapped)); bytes = want; return; }
         if (hipMalloc(&p, want) != hipSuccess) {
             (void)hipGetLastError();
             p = nullptr;
@@ -85,7 +88,7 @@ struct DevBuf {
         bytes = want;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) (void)(host_mapped ? hipHostFree(p) : hipFree(p));
         p = nullptr; bytes = 0;
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -233,7 +236,7 @@ struct rsx_index {
     int64_t temp_budget = (int64_t)16 << 30;
 
     // workspace
-    DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_lutsync, w_pgflags, w_state,
+    DevBuf w_q32, w_q16, w_coarse, w_keys1, w_probekeys, w_probelist, w_dis0, w_segstart, w_temp, w_lut, w_lutws, w_pgflags, w_state,
         w_D, w_I, w_qin, w_pairs, w_flag, w_x, w_partial, w_assign, w_dest, w_idsin, w_misc, w_lut8, w_qparam, w_uncertain, w_fbq, w_fbD, w_fbI, w_cand, w_candcnt, w_itemdesc, w_tau, w_excl, w_state2, w_addcnt, w_addstart, w_qitems, w_tiews;
     std::map<std::string, double> timing;
 

@@ -291,11 +291,9 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
                     int transposed /* pq_lut8_index: 0: lut8 [nq][Mpad][256]; 1: [nq][256][Mpad] (rotated-layout scans); 2: [nq][Mpad/32][256][32] (sliced) */, hipStream_t st,
                     int phase = 0 /* tiled build only: 1 = the tables (independent of the probe selection), 2 = the per-query parameters */,
                     float* lut32_out = nullptr /* fused forms only: also store the fp32 tables [nq][Mpad][256] (k_pq_final_tab reads them) */,
-                    uint32_t* sync = nullptr /* tiled build: pq_lut8_sync_bytes(nq) of ZEROED counters -> the matrix-core form (k_pq_lut_mfma; with
-                                                phase 0 the per-query parameters too); the kernel leaves them zeroed */,
+                    int mfma = 0 /* tiled build, phase 0: the matrix-core form (k_pq_lut_mfma: tables and per-query parameters in two launches) */,
                     const struct PairGroupArgs* pg = nullptr /* matrix-core form: also group the (query, probe) pairs by list (extra workgroups) */);
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad);
-size_t pq_lut8_sync_bytes(int64_t nq);
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
                     const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                     const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
@@ -477,16 +475,16 @@ __device__ inline void group_pairs_block(const PairGroupArgs& g, int b, int32_t*
     const int nl = hi > lo ? hi - lo : 0;
     for (int i = t; i < nl; i += nt) hist[i] = 0;
     __syncthreads();
-    // every block reads ALL pairs, twice: 16-byte loads, eight in flight per thread (one load per loop turn was 128 exposed L2 round trips)
+    // every block reads ALL pairs, twice: 16-byte loads, sixteen in flight per thread (one load per loop turn was 128 exposed L2 round trips)
     const int np4 = ((reinterpret_cast<uintptr_t>(g.probe_list) & 15) == 0) ? g.npairs >> 2 : 0;
     const int4* pl4 = reinterpret_cast<const int4*>(g.probe_list);
     auto for_pairs = [&](auto&& f) {
-        for (int i0 = t; i0 < np4; i0 += 8 * nt) {
-            int4 v[8];
+        for (int i0 = t; i0 < np4; i0 += 16 * nt) {
+            int4 v[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = i0 + u * nt; v[u] = i < np4 ? pl4[i] : make_int4(-1, -1, -1, -1); }
+            for (int u = 0; u < 16; u++) { const int i = i0 + u * nt; v[u] = i < np4 ? pl4[i] : make_int4(-1, -1, -1, -1); }
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = 4 * (i0 + u * nt); f(v[u].x, i); f(v[u].y, i + 1); f(v[u].z, i + 2); f(v[u].w, i + 3); }
+            for (int u = 0; u < 16; u++) { const int i = 4 * (i0 + u * nt); f(v[u].x, i); f(v[u].y, i + 1); f(v[u].z, i + 2); f(v[u].w, i + 3); }
         }
         for (int i = 4 * np4 + t; i < g.npairs; i += nt) f(g.probe_list[i], i);
     };

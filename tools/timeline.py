@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 kernel trace (rocpd sqlite) -> timeline of the LAST search batch: every kernel from the last k_gemm_exact<false, false>
-(the coarse GEMM opens a batch) on, with start / end relative to it, duration, queue.  usage: timeline.py results.db out.md [batches_back]"""
+"""rocprofv3 kernel trace (rocpd sqlite) -> timeline of the LAST search batch: every kernel from the last query conversion (k_to_f32*) on, with start / end relative to it, duration, queue.  usage: timeline.py results.db out.md [batches_back]"""
 import sqlite3, sys
 db, out = sys.argv[1], sys.argv[2]
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -12,10 +11,10 @@ short = lambda n: n.split('(')[0].replace('void ', '').replace('rsx::', '')
 opens = [i for i, r in enumerate(rows) if "k_to_f32" in r[0] or "k_convert" in r[0]]
 scans = [i for i, r in enumerate(rows) if "k_pq_scan" in r[0]]
 last_scan = scans[-back]
-i0 = max(i for i in range(last_scan) if "k_gemm_exact" in rows[i][0])
-while i0 > 0 and rows[i0][1] - rows[i0 - 1][2] < 30000 and "k_pq_scan" not in rows[i0 - 1][0] and "k_finalize" not in rows[i0 - 1][0]: i0 -= 1
+opener = lambda n: "k_to_f32" in n          # the query conversion opens a batch (k_to_f32 / k_to_f32_f16)
+i0 = max(i for i in range(last_scan) if opener(rows[i][0]))
 i1 = last_scan
-while i1 + 1 < len(rows) and rows[i1 + 1][1] - rows[i1][2] < 30000 and "k_gemm_exact" not in rows[i1 + 1][0]: i1 += 1
+while i1 + 1 < len(rows) and rows[i1 + 1][1] - rows[i1][2] < 30000 and not opener(rows[i1 + 1][0]): i1 += 1
 t0 = rows[i0][1]
 with open(out, "w") as f:
     f.write("| kernel | queue | start us | end us | us |\n|---|---:|---:|---:|---:|\n")
