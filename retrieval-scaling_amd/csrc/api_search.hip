@@ -239,7 +239,12 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     const bool coarse_fast = h->kind != KIND_FLAT && allow_fast && h->coarse_fast != 0 && (h->kind == KIND_IVFPQ ? fast : certify) && nq >= 32 &&
                              np0 <= CP_MAXPROBE && h->nlist <= CP_MAXLIST && h->nlist > np0 && !h->h_centroids.empty() &&
                              coarse_pick_lds(h->nlist, d, np0) <= 150 * 1024;
-    if (h->kind == KIND_IVFPQ && coarse_fast) {
+    // ... whose fp16 operand is the caller's own batch when that is fp16, unpadded (d = ld) and whole tiles: the fp32 copy then rides in the
+    // GEMM's launch (extra grid rows) instead of a conversion launch of its own
+    // (not with the side-stream table build: it reads the fp32 copy before the GEMM has run)
+    const bool q16_direct = h->kind == KIND_IVFPQ && coarse_fast && h->overlap == 0 && dtype == RSX_F16 && d == ld && nq % 128 == 0 && ((uintptr_t)dq & 15) == 0;
+    if (q16_direct) {
+    } else if (h->kind == KIND_IVFPQ && coarse_fast) {
         h->w_q16.ensure((size_t)round_up(nq, 128) * ld * 2);
         launch_convert_to_f32_f16(dq, dtype == RSX_F16, d, nq, d, h->w_q32.as<float>(), h->w_q16.as<__half>(), ld, round_up(nq, 128), h->st);
     } else
@@ -464,7 +469,8 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             h->cent16_gen = h->cent_gen;
         }
         h->w_coarse.ensure((size_t)nqp * nlp * 4);
-        launch_coarse_approx(h->w_q16.as<__half>(), nqp, h->cent16.as<__half>(), nlist, ld, h->w_coarse.as<float>(), nlp, h->st);
+        if (q16_direct) launch_coarse_approx((const __half*)dq, nqp, h->cent16.as<__half>(), nlist, ld, h->w_coarse.as<float>(), nlp, h->st, h->w_q32.as<float>(), nq * (int64_t)ld);
+        else launch_coarse_approx(h->w_q16.as<__half>(), nqp, h->cent16.as<__half>(), nlist, ld, h->w_coarse.as<float>(), nlp, h->st);
         tm.mark("coarse");
         h->w_uncertain.ensure((size_t)nq * 8);
         CoarsePickArgs cp{};

@@ -290,6 +290,9 @@ struct FlatFilterArgs {
     uint64_t* cand; unsigned long long* cand_cnt; int cand_cap;
     int nq; int qt; int64_t ntiles;              // real queries, query tiles, db tiles in [v0, v0 + nv)
     int walk;                                    // k_flat_gemm2: persistent workgroups, fixed query tile, walking db tiles
+    // k_flat_gemm, unfiltered form only (launch_coarse_approx): grid rows >= cv_y0 do not multiply — they widen cv_n fp16 values at cv_src to
+    // fp32 at cv_dst (the query batch's fp32 copy the later kernels read, riding in this launch instead of one of its own)
+    const __half* cv_src; float* cv_dst; int64_t cv_n; int cv_y0;
 };
 
 template <bool XF16, bool FILTER>
@@ -311,6 +314,16 @@ __global__ __launch_bounds__(256) void k_flat_gemm(const __half* Q16, const void
         vt0 = vt * 128;
         if (tid < 128) s_tau[tid] = (q0 + tid < F.nq) ? F.tau[(q0 + tid) * F.tau_stride] : ~0ull;
     } else {
+        if (F.cv_n > 0 && (int)blockIdx.y >= F.cv_y0) {
+            const int64_t nb = (int64_t)gridDim.x * (gridDim.y - F.cv_y0), b = (int64_t)(blockIdx.y - F.cv_y0) * gridDim.x + blockIdx.x;
+            for (int64_t i8 = b * 256 + tid; i8 < F.cv_n / 8; i8 += nb * 256) {
+                const uint4 u = *reinterpret_cast<const uint4*>(F.cv_src + 8 * i8);
+                const __half* hv = reinterpret_cast<const __half*>(&u);
+                *reinterpret_cast<float4*>(F.cv_dst + 8 * i8) = make_float4(__half2float(hv[0]), __half2float(hv[1]), __half2float(hv[2]), __half2float(hv[3]));
+                *reinterpret_cast<float4*>(F.cv_dst + 8 * i8 + 4) = make_float4(__half2float(hv[4]), __half2float(hv[5]), __half2float(hv[6]), __half2float(hv[7]));
+            }
+            return;
+        }
         q0 = (int64_t)blockIdx.x * 128;
         vt0 = (int64_t)blockIdx.y * 128;  // column offset inside this chunk
     }
@@ -700,10 +713,15 @@ static bool fg2_applies(int nq_pad, int x_f16, int ld) {
 // where the bit-exact f32-input chain (k_gemm_exact) needs 65; k_coarse_pick (k_select.hip) re-scores the few centroids that can be
 // among a query's nprobe best with the exact chain.  Q16: [nq_pad][ld] (nq_pad % 128 == 0), C16: [round_up(nlist, 128)][ld] fp16
 // copies, zero padded; S: [nq_pad][lds_] fp32.
-void launch_coarse_approx(const __half* Q16, int64_t nq_pad, const __half* C16, int nlist, int ld, float* S, int64_t lds_, hipStream_t st) {
+// widen_n > 0: Q16 is the caller's own fp16 batch (contiguous rows of ld values, widen_n = rows x ld, a multiple of 8): eight extra grid rows
+// write its fp32 copy to Q32 in the same launch.
+void launch_coarse_approx(const __half* Q16, int64_t nq_pad, const __half* C16, int nlist, int ld, float* S, int64_t lds_, hipStream_t st,
+                          float* Q32, int64_t widen_n) {
     if (nq_pad <= 0 || nlist <= 0) return;
     FlatFilterArgs F{};
-    hipLaunchKernelGGL((k_flat_gemm<true, false>), dim3((unsigned)(nq_pad / 128), (unsigned)((nlist + 127) / 128)), dim3(256), 0, st, Q16, (const void*)C16,
+    const unsigned gy = (unsigned)((nlist + 127) / 128);
+    if (widen_n > 0 && Q32) { F.cv_src = Q16; F.cv_dst = Q32; F.cv_n = widen_n; F.cv_y0 = (int)gy; }
+    hipLaunchKernelGGL((k_flat_gemm<true, false>), dim3((unsigned)(nq_pad / 128), gy + (F.cv_n > 0 ? 8u : 0u)), dim3(256), 0, st, Q16, (const void*)C16,
                        (int64_t)0, (int64_t)nlist, ld, (const float*)nullptr, S, lds_, F);
 }
 

@@ -440,7 +440,8 @@ struct CoarsePickArgs {
     int cmax_rt;                                      // set by the launcher: candidate rows of this launch (coarse_pick_cmax)
 };
 size_t coarse_pick_lds(int nlist, int d, int nprobe);
-void launch_coarse_approx(const __half* Q16, int64_t nq_pad, const __half* C16, int nlist, int ld, float* S, int64_t lds_, hipStream_t st);
+void launch_coarse_approx(const __half* Q16, int64_t nq_pad, const __half* C16, int nlist, int ld, float* S, int64_t lds_, hipStream_t st,
+                          float* Q32 = nullptr, int64_t widen_n = 0);
 void launch_coarse_pick(const CoarsePickArgs& a, int64_t nq, hipStream_t st);
 void launch_probe_setup(const uint64_t* probe_keys, int KPp, int64_t nq, int nprobe, const int64_t* list_len,
                         int pad_to, int32_t* probe_list, float* probe_dis0, int64_t* seg_start, hipStream_t st);
