@@ -739,12 +739,13 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 // prefix included), so the scan kernel carries no per-slab "already scored" test and no key can
                 // arrive twice (the prefix keys above the threshold come back through the candidate buffer).
                 // (the selection wrote only the K'-th key of each query and reset the query's candidate counter)
-                tm.mark("select0");
+                // (a stage mark is an event record: ~5 us of stream time in profile mode — none for a stage that launched nothing)
+                if (!fused_pre) tm.mark("select0");
                 if (grouped_early) { if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_group, 0)); }
                 else launch_group_pairs(h->w_probelist.as<int32_t>(), pairs, nlist, 4 * ngq, cnt, cursor, pair_off, group_off, total_groups,
                                         pairs_sorted, h->d_len.as<int64_t>(), tile_rows, item_off, total_items, nprobe, 0, nprobe, 0,
                                         h->st);
-                tm.mark("group");
+                if (!(grouped_early && !side_lut)) tm.mark("group");
                 const int64_t mi_main = max_scan_items(h, nq, nprobe, 4 * ngq, tile_rows);
                 void* rws1 = rot ? rot_desc(mi_main, ngq) : nullptr;
                 // threshold keys: one per query from the one-launch pre-pass, else the K'-th key the selection left in the state rows
