@@ -92,3 +92,49 @@ def test_random_flat(gpu, orc, seed):
         D, I = ix.search(q, k)
         Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), k, metric)
         assert_same_results(D, I, Dr, Ir, f"flat seed={seed} d={d} n={n} nq={nq} metric={metric} k={k}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_coarse_quantiser(gpu, orc, seed):
+    """Round 6: the fast coarse quantiser (fp16 MFMA scores + exact chains of the candidates) and the matrix-core table build over random
+    shapes: list counts on both sides of the register-resident key row sizes (1024 / 4096), dimensions that are not multiples of 4 / 64 / 128,
+    nprobe from 1 to the 48 the fast form serves, fp16 and fp32 queries, batch sizes around the 32-query tiles, IVF-Flat and IVF-PQ.  The
+    centroids are data points (a query near one of them ties nothing) and partly scaled copies of each other (near-ties in the approximate
+    scores); every result must be the oracle's, with at most a few queries taking the exact re-run."""
+    rng = np.random.RandomState(300 + seed)
+    d = int([64, 100, 768, 96, 256, 130, 32, 512][seed])
+    nlist = int([300, 1025, 4096, 50, 2000, 1024, 4500, 97][seed])
+    nprobe = int(min(nlist - 1, [32, 48, 32, 7, 1, 20, 40, 48][seed]))
+    n = int(max(4 * nlist, 20000))
+    nq = int([33, 128, 200, 64, 97, 32, 130, 70][seed])
+    x, q = _data(orc, rng, d, n, nq, 64)
+    x32 = x.astype(np.float32)
+    cen = x32[rng.choice(n, nlist, replace=False)].copy()
+    dup = rng.choice(nlist, nlist // 10, replace=False)
+    cen[dup] = cen[(dup + 1) % nlist] * (1.0 + 1e-4 * rng.randn(len(dup), 1).astype(np.float32))
+    a, _ = orc.assign_ip(cen, x32)
+    pq = seed % 2 == 0 and d % 8 == 0
+    if pq:
+        M = d // 8
+        if M not in (4, 8, 12, 32, 64, 96): M = 8 if d % 8 == 0 else 4
+        res = orc.residuals(cen, x32, a)
+        cb = orc.pq_train(res[:3000], M, 1, 7)
+        lm = orc.ListMajor(a, np.arange(n), orc.pq_encode(cb, res), nlist)
+        ix = gpu.IndexIVFPQ(None, d, nlist, M, 8, gpu.METRIC_INNER_PRODUCT)
+        ix.set_centroids(cen); ix.set_codebooks(cb)
+    else:
+        lm = orc.ListMajor(a, np.arange(n), x32, nlist)
+        ix = gpu.IndexIVFFlat(None, d, nlist, gpu.METRIC_INNER_PRODUCT)
+        ix.set_centroids(cen)
+    ix.add(x); ix.nprobe = nprobe
+    ix.set_param("profile", 1)
+    for qq, what in ((q, "fp16"), (q.astype(np.float32) * (1.0 + 1e-3 * rng.randn(nq, 1).astype(np.float32)), "fp32")):
+        qf = qq.astype(np.float32)
+        for k in (1, 10):
+            D, I = ix.search(qq, k)
+            if pq:
+                Dr, Ir = orc.ivfpq_search(cen, cb, lm, qf, nprobe, k)
+            else:
+                Dr, Ir = orc.ivfflat_search(0, cen, lm, qf, nprobe, k)
+            assert_same_results(D, I, Dr, Ir, f"seed={seed} {'ivfpq' if pq else 'ivfflat'} d={d} nlist={nlist} nprobe={nprobe} nq={nq} k={k} {what} queries")
+    assert ix.get_timing("coarse_redo_queries") <= 0.2 * 4 * nq, "the fast coarse quantiser must settle nearly every query by itself"
