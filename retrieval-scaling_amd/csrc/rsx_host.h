@@ -222,7 +222,7 @@ struct rsx_index {
     int pq_gather = 1;       // rotated fast scan: candidate gather + selection in one launch (k_pq_gather_select) instead of compaction + merge
     int pq_final_tab = 1;    // rotated fast scan: finalize from the complete candidate row with the fp32 table in LDS (1 = when K' >= 512 or dsub > 8 and as the second chance, 2 = always, 0 = never)
     int pq_log_cap = 0;      // rotated fast scan: keys per survivor log (0 = from the pool budget); tests shrink it to force the overflow path
-    int pq_pre_mult = 160, pq_pre_max = 16384;   // ... and for larger k: pq_pre_mult x k rows, at most pq_pre_max (<= 32768: 64 KiB of 16-bit sums in LDS; 16384 measured best overall on the headline index at k = 100 / 1000 / 2000, profiles/r04u_pre_sweep.jsonl)
+    int pq_pre_mult = 80, pq_pre_max = 16384;    // ... and for larger k: pq_pre_mult x k rows, at most pq_pre_max (<= 32768: 64 KiB of 16-bit sums in LDS; 16384 measured best overall on the headline index at k = 100 / 1000 / 2000, profiles/r04u_pre_sweep.jsonl; round 6, after the four-query histogram pre-pass: 80 x k — k = 100 2.95 -> 2.88 ms per batch, k = 50 / 200 / 1000 unchanged, profiles/r06_fixed_cost.md 5)
     int pq_pre_rows = 4096;  // filtered fast scan: vectors of each query's closest list the threshold pre-pass scores (0 = one scan tile)
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
     int64_t ndropped = 0;                     // vectors seen by add but owned by other shards

@@ -98,7 +98,7 @@ def main():
             else:
                 ref[key] = (Dn, In)
             for name in kv:      # back to defaults for the next setting
-                ix.set_param(name, {"pq_pace": float(128 | (4 << 12)), "pq_pre_rows": 4096.0, "scan_chunk": 0.0, "pq_prune": 0.0, "pq_fast_kp": 0.0, "overlap": 0.0, "lut_tiled": 2.0}.get(name, 1.0))
+                ix.set_param(name, {"pq_pace": float(128 | (4 << 12)), "pq_pre_rows": 4096.0, "scan_chunk": 0.0, "pq_prune": 0.0, "pq_fast_kp": 0.0, "overlap": 0.0, "lut_tiled": 2.0, "pq_pre_mult": 80.0, "pq_pre_max": 16384.0}.get(name, 1.0))
             r = {"set": s, "layout": lay, "round": rnd, "qps": round(args.steps * nq / el, 1), "ms_per_step": round(el / args.steps * 1e3, 4), "ms_per_step_unprofiled": round(el0 / args.steps * 1e3, 4), "stages": st,
                  "fallback_queries": fb, "fb_stage_ms_total": fbst, "fb_launches": fbl, "fallback_overflow": fbo, "second_chance_queries": sec, "cand_mean": round(ck, 1), "cand_max": ckm, "same_as_first": same}
             print(json.dumps(r), flush=True); out.append(r)
