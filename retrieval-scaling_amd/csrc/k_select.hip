@@ -885,7 +885,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     // 2. candidates
     CP_MARK(2);
     const float an = ord2f(prefix);
-    const float e = xn * (a.cmax * (a.ef * 1.002f + (float)d * 2.4e-7f) + sqrtf((float)d) * 1.2e-7f);
+    // |approximate - exact chain| for ANY centroid: fp16 rounding of the operands (relative a.ef, Cauchy-Schwarz), the fp32 accumulation of both
+    // sums in any order (2 d 2^-24, doubled), and the ABSOLUTE rounding of operand values below fp16's normal range (2^-25 each: centroid
+    // components against |x|, fp32 query components against the largest centroid norm)
+    const float e = xn * (a.cmax * (a.ef * 1.002f + (float)d * 2.4e-7f) + sqrtf((float)d) * 1.2e-7f) + sqrtf((float)d) * a.cmax * 6.0e-8f;
     float T = an - 2.0f * e;
     T -= fabsf(T) * 1e-6f + 1e-30f;
     if (!(fabsf(T) < __builtin_inff())) badl = true;

@@ -778,6 +778,15 @@ def test_round6_fast_coarse_quantiser_is_exact(gpu, orc, kind, d, nlist, nprobe)
     ix.set_param("coarse_fast", 0); D0, I0 = ix.search(qn, k)
     ix.set_param("coarse_fast", 1)
     assert np.array_equal(I1, I0) and np.array_equal(D1, D0, equal_nan=True), f"{kind}: a query with a NaN"
+    # fp32 queries whose components sit below fp16's normal range (2^-14): their fp16 copies carry absolute, not relative, rounding errors —
+    # the bound has a term for that (such queries mostly leave through the exact re-run; the result must be the oracle's either way)
+    qt = (q32 * np.float32(2e-5)).astype(np.float32)
+    if kind == "ivfpq":
+        Dr, Ir = orc.ivfpq_search(cen, cb, lm, qt, nprobe, k)
+    else:
+        Dr, Ir = orc.ivfflat_search(0, cen, lm, qt, nprobe, k)
+    D1, I1 = ix.search(qt, k)
+    assert_same_results(D1, I1, Dr, Ir, f"{kind}: tiny fp32 queries, fast coarse quantiser vs oracle")
 
 
 @pytest.mark.parametrize("M", [96, 16])
