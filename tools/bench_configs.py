@@ -172,7 +172,7 @@ def measure_ivfpq(n=100_000_000, M=16, nlist=8192, nprobe=512, ks=(10, 1000), st
     Q = torch.empty((nq * (steps + 1), D), dtype=torch.float16, device=dev)
     rsx.synth_queries(D, NC, SC, SX, 0.5, n, SQ, 0.1, 0, Q.shape[0], out=Q)
     res = {"config": f"ivfpq {n}x{D} M={M} nlist={nlist} nprobe={nprobe} batch={nq}", "build_s": round(build_s, 1),
-           "code_layout": "rotated" if ix._get("pq_layout") == 1 else "granule", "by_k": {}}
+           "code_layout": {2: "sliced", 1: "rotated"}.get(int(ix._get("pq_layout")), "granule"), "by_k": {}}
     lm = None
     for k in ks:
         ix.search(Q[:nq], k)
