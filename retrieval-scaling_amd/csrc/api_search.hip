@@ -257,7 +257,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     }
     h->w_state.ensure((size_t)nq * KP * 8);
     uint64_t* state = h->w_state.as<uint64_t>();
-    tm.mark("convert");
+    if (!q16_direct) tm.mark("convert");       // (nothing was launched for it otherwise: the widening rides in the coarse GEMM)
     // Round 4 (overlap = 1, no longer the default): the 8-bit tables depend on the queries only — their build starts here on the side
     // stream and runs beside the coarse quantiser and the probe selection; the per-query parameters (k_pq_qparam: they need the coarse
     // scores) follow on the main stream once both have finished.  Round 6 measured the three cross-stream joins of a batch at ~12 us

@@ -697,7 +697,7 @@ def test_round4_engine_knobs_never_change_a_result(gpu, orc, M, d):
                     assert_same_results(D, I, De, Ie, f"M={M} k={k} overlap={overlap} pq_final_tab={tab} sample={mult}x/{mx}")
 
 
-@pytest.mark.parametrize("M,d,nlist", [(96, 768, 16), (16, 768, 40), (64, 256, 7), (20, 160, 16)])
+@pytest.mark.parametrize("M,d,nlist", [(96, 768, 16), (16, 768, 40), (64, 256, 7), (20, 160, 16), (6, 48, 9), (128, 1024, 12)])
 def test_round6_table_build_and_grouping_forms_never_change_a_result(gpu, orc, M, d, nlist):
     """Round 6: the 8-bit tables from the matrix cores (lut_tiled 2: k_pq_lut_mfma, per-query parameters in its tail) against the VALU
     forms (1: two passes + k_pq_qparam, 0: one workgroup per query), the pair grouping as extra workgroups of the table launch
