@@ -269,6 +269,9 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
     const bool tab_expected = pq_fused_lut && rot && h->pq_final_tab != 0 && (h->pq_final_tab == 2 || KP >= 512 || h->dsub > 8) &&
                               std::min(h->nprobe, h->nlist) > 1 && h->pq_filter != 0 && h->pq_prepass_fused != 0 &&
                               pq_final_tab_capacity(h->M, h->CB, k) > 0;
+    // the matrix-core table build will serve this batch and the fast coarse quantiser runs: its first pass rides in the probe-pick launch
+    const bool lut_pass0_early = coarse_fast && pq_fused_lut && !side_lut && h->dsub == 8 && h->lut_tiled >= 2 && h->metric == RSX_METRIC_INNER_PRODUCT &&
+                                 h->pq_lut_early != 0;
     float* lut32_out = nullptr;
     if (tab_expected) { h->w_lut.ensure((size_t)nq * h->Mpad * 256 * 4); lut32_out = h->w_lut.as<float>(); }
     // everything that can refuse this search is checked BEFORE work is forked onto the side stream ...
@@ -480,6 +483,11 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         cp.nprobe = nprobe; cp.list_len = h->d_len.as<int64_t>(); cp.pad_to = pad_to;
         cp.probe_list = h->w_probelist.as<int32_t>(); cp.dis0 = h->w_dis0.as<float>(); cp.seg_start = h->w_segstart.as<int64_t>();
         cp.bad = h->w_uncertain.as<int32_t>() + nq;
+        if (lut_pass0_early) {      // pass 0 of the table build needs the queries only: extra workgroups of this launch
+            h->w_lutws.ensure(pq_lut8_tiled_ws(nq, h->Mpad));
+            cp.lp0 = LutPass0Args{h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->M, h->Mpad, nq, reinterpret_cast<float*>(h->w_lutws.p),
+                                  pq_lut_pass0_blocks(nq, h->Mpad)};
+        }
         launch_coarse_pick(cp, nq, h->st);
         h->coarse_flags_live = true;
     } else {
@@ -562,7 +570,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 if (side_lut) HIPCHECK(hipStreamWaitEvent(h->st, h->ev_lut, 0));     // the tables were built beside the probe selection
                 launch_pq_lut8(fused_lut ? nullptr : h->w_lut.as<float>(), h->w_q32.as<float>(), ld, h->d_codebooks.as<float>(), h->dsub, nq, h->M, h->Mpad,
                                h->w_dis0.as<float>(), nprobe, h->w_lut8.as<uint8_t>(), h->w_qparam.p, lut_ws, sliced ? 2 : rot ? 1 : 0, h->st, side_lut ? 2 : 0,
-                               fused_lut ? lut32_out : nullptr, (lut_ws && !side_lut && h->lut_tiled >= 2) ? 1 : 0, pg);
+                               fused_lut ? lut32_out : nullptr, (lut_ws && !side_lut && h->lut_tiled >= 2) ? (lut_pass0_early ? 2 : 1) : 0, pg);
                 tm.mark("lut8");
             };
             const bool group_in_tables = lut_ws && !side_lut && h->lut_tiled >= 2 && h->pq_group_fused != 0 && pairs <= PG_MAX_PAIRS &&

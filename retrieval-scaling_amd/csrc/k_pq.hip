@@ -650,9 +650,6 @@ __global__ __launch_bounds__(64) void k_pq_qparam(int64_t nq, int M, int Mpad, c
 // (One launch with the tile's workgroups meeting at a counter between the passes was built and measured first: 77 us — every hand-over
 //  is a memory round trip of 2-3 us and the waiters hold their CU slots; profiles/r06_fixed_cost.md.)
 // ---------------------------------------------------------------------------------------
-#define LM_Q 32
-#define LM_MB 4
-typedef float lm_f16 __attribute__((ext_vector_type(16)));
 template <int PASS>
 __global__ __launch_bounds__(256) void k_pq_lut_mfma(const float* Q32, int ldq, const float* codebooks, int M, int Mpad, int64_t nq,
                                                      float* mnmx, uint8_t* lut8, int mode, float* lut32_out,
@@ -674,46 +671,14 @@ __global__ __launch_bounds__(256) void k_pq_lut_mfma(const float* Q32, int ldq, 
     const int64_t q0 = (int64_t)qt * LM_Q, q = q0 + j;
     const int nqc = (int)((nq - q0) < LM_Q ? (nq - q0) : LM_Q);
     const bool mreal = m < M, mpad = m < Mpad, qok = j < nqc;
-    // operands: dims 2 kk + h of the lane's query / codeword (K step kk: lanes 0-31 feed dim 2 kk, lanes 32-63 dim 2 kk + 1 — chain order)
-    float bq[4] = {0.f, 0.f, 0.f, 0.f}, ac[8][4];
-    if (mreal && qok) {
-        const float4* p = reinterpret_cast<const float4*>(Q32 + q * ldq + m * 8);
-        const float4 x = p[0], y = p[1];
-        bq[0] = hh ? x.y : x.x; bq[1] = hh ? x.w : x.z; bq[2] = hh ? y.y : y.x; bq[3] = hh ? y.w : y.z;
-    }
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        ac[t][0] = ac[t][1] = ac[t][2] = ac[t][3] = 0.f;
-        if (mreal) {
-            const float4* p = reinterpret_cast<const float4*>(codebooks + ((int64_t)m * 256 + 32 * t + j) * 8);
-            const float4 x = p[0], y = p[1];
-            ac[t][0] = hh ? x.y : x.x; ac[t][1] = hh ? x.w : x.z; ac[t][2] = hh ? y.y : y.x; ac[t][3] = hh ? y.w : y.z;
-        }
-    }
-    // (dep: a value of the previous tile's reductions — through an opaque asm it becomes this tile's accumulator zero, so the tiles are
-    //  computed one after the other: left alone the compiler computes all 8 first and spills 128 accumulators)
-    auto tile = [&](int t, float dep) {
-        lm_f16 acc;
-        float z = 0.0f;
-        asm volatile("" : "+v"(z) : "v"(dep));
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = z;
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][kk], bq[kk], acc, 0, 0, 0);
-        return acc;
-    };
-    if (PASS == 0) {        // (min, max) per (query, m)
-        float mn = __builtin_inff(), mx = -__builtin_inff();
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const lm_f16 v = tile(t, mn);
-#pragma unroll
-            for (int r = 0; r < 16; r++) { mn = fminf(mn, v[r]); mx = fmaxf(mx, v[r]); }
-        }
-        mn = fminf(mn, __shfl_xor(mn, 32)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (hh == 0 && qok && mpad) *reinterpret_cast<float2*>(mnmx + (q * Mpad + m) * 2) = make_float2(mn, mx);
+    if (PASS == 0) {        // (min, max) per (query, m): rsx_internal.h (the same block can ride in the probe-pick launch)
+        LutPass0Args p0{Q32, ldq, codebooks, M, Mpad, nq, mnmx, 0};
+        pq_lut_pass0_block(p0, bid);
         return;
     }
+    float bq[4], ac[8][4];
+    lut_mfma_operands(Q32, ldq, codebooks, q, m, mreal, qok, j, hh, bq, ac);
+    auto tile = [&](int t, float dep) { return lut_mfma_tile(ac, bq, t, dep); };
     // the queries' scales: 8 threads per query over m (max is order-free).  The tile's first workgroup also derives the queries' PQQParam
     // records here: everything they need is pass 0's (min, max) pairs and the coarse scores — the quantisation error is BOUNDED, not
     // measured: u = rint((v - mn) / scale) leaves |v - (mn + scale u)| <= scale (1/2 + 255 x 3 x 2^-24) for every entry, and the measured
@@ -809,6 +774,7 @@ __global__ __launch_bounds__(256) void k_pq_lut_mfma(const float* Q32, int ldq, 
 }
 
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad) { return (size_t)nq * Mpad * 3 * 4; }   // mnmx + err
+int pq_lut_pass0_blocks(int64_t nq, int Mpad) { return (int)(((Mpad + LM_MB - 1) / LM_MB) * ((((nq + LM_Q - 1) / LM_Q) + 7) / 8) * 8); }
 
 size_t pq_lut8_fused_lds(int M, int Mpad, int dsub) { return ((size_t)Mpad * 256 + (size_t)M * dsub + 3 * (size_t)Mpad) * 4; }
 
@@ -846,8 +812,9 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
             PairGroupArgs pg0{};
             if (pg) pg0 = *pg;
             PairGroupArgs pgn{};
-            hipLaunchKernelGGL(k_pq_lut_mfma<0>, grid4, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, lut8, transposed,
-                               lut32_out, probe_dis0, nprobe, (PQQParam*)nullptr, pgn);
+            if (mfma != 2)      // 2: pass 0 already ran as extra workgroups of the probe-pick launch (pq_lut_pass0_blocks)
+                hipLaunchKernelGGL(k_pq_lut_mfma<0>, grid4, dim3(256), 0, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, lut8, transposed,
+                                   lut32_out, probe_dis0, nprobe, (PQQParam*)nullptr, pgn);
             hipLaunchKernelGGL(k_pq_lut_mfma<1>, dim3(grid4.x + (unsigned)pg0.nb), dim3(256), osm4, st, Q32, ldq, codebooks, M, Mpad, nq, mnmx, lut8, transposed,
                                lut32_out, probe_dis0, nprobe, (PQQParam*)qparam, pg0);
             return;

@@ -828,6 +828,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ uint32_t wcnt[2][4][4];
     __shared__ float red[4];
     __shared__ int s_cnt, s_bad;
+    // workgroups behind the queries': pass 0 of the IVF-PQ table build (it needs the queries only; this kernel is a latency chain that leaves
+    // the CUs' issue slots to them)
+    if (blockIdx.x >= (unsigned)a.nq) { pq_lut_pass0_block(a.lp0, blockIdx.x - (unsigned)a.nq); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t q = blockIdx.x;
     const int nlist = a.nlist, d = a.d, dp = (d + CP_CH - 1) / CP_CH * CP_CH;
@@ -1002,7 +1005,8 @@ void launch_coarse_pick(const CoarsePickArgs& a0, int64_t nq, hipStream_t st) {
     auto kern = kerns[ki][li];
     static DevSize attr[6];
     attr[2 * ki + li].grow(shm, [&] { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); });
-    hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), shm, st, a);
+    a.nq = nq;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nq + a.lp0.nblocks)), dim3(256), shm, st, a);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -211,6 +211,7 @@ struct rsx_index {
                           // sliced layout (M = 96): 1 = k_pq_scan_sl8 for batches with >= 3 probing queries per list on lists of >= 4096 vectors on average,
                           // else the four-query single-pass k_pq_scan_sl4; 2 = always eight, 0 = always four
     int pq_prune = 0;     // rotated fast scan: skip (list, query group) items that cannot hold a survivor (exact bound; opt-in)
+    int pq_lut_early = 1;     // pass 0 of the matrix-core table build as extra workgroups of the probe-pick launch (0 = its own launch)
     int pq_group_fused = 1;   // the (query, probe) pairs grouped by list by extra workgroups of the table launch (0 = its own four launches)
     uint32_t pg_epoch = 0;    // ... whose hand-over words carry this launch counter
     int lut_tiled = 2;    // fast scan tables (dsub 8): tiled build sharing codebook slices across queries: 2 = one launch (k_pq_lut_once), 1 = two passes

@@ -291,9 +291,11 @@ void launch_pq_lut8(const float* lut32, const float* Q32, int ldq, const float* 
                     int transposed /* pq_lut8_index: 0: lut8 [nq][Mpad][256]; 1: [nq][256][Mpad] (rotated-layout scans); 2: [nq][Mpad/32][256][32] (sliced) */, hipStream_t st,
                     int phase = 0 /* tiled build only: 1 = the tables (independent of the probe selection), 2 = the per-query parameters */,
                     float* lut32_out = nullptr /* fused forms only: also store the fp32 tables [nq][Mpad][256] (k_pq_final_tab reads them) */,
-                    int mfma = 0 /* tiled build, phase 0: the matrix-core form (k_pq_lut_mfma: tables and per-query parameters in two launches) */,
+                    int mfma = 0 /* tiled build, phase 0: the matrix-core form (k_pq_lut_mfma: tables and per-query parameters in two launches; 2: its
+                                    first pass already ran in the probe-pick launch) */,
                     const struct PairGroupArgs* pg = nullptr /* matrix-core form: also group the (query, probe) pairs by list (extra workgroups) */);
 size_t pq_lut8_tiled_ws(int64_t nq, int Mpad);
+int pq_lut_pass0_blocks(int64_t nq, int Mpad);      // workgroups of pass 0 of the matrix-core form (mfma = 2: they already ran elsewhere)
 int launch_pq_scan8(const PQScanArgs& a, const uint8_t* lut8, const void* qparam, const int32_t* pairs_sorted,
                     const int32_t* pair_off, const int32_t* group_off, const int32_t* total_groups,
                     const int32_t* item_off, const int32_t* total_items, int nlist, int64_t max_items, int vpl,
@@ -424,6 +426,70 @@ void launch_pq_prepass(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
 int pq_prepass4_max_rows(int M);
 int launch_pq_prepass4(const PQPrepassArgs& a, int64_t nq, hipStream_t st);
 int launch_pq_prepass4_big(const PQPrepassArgs& a, int64_t nq, hipStream_t st);   // large samples (<= 32768 rows, several lists): histogram form
+// Pass 0 of the matrix-core table build (k_pq.hip: k_pq_lut_mfma) as a device function: the (min, max) pairs of the table entries of one
+// (32-query tile, 4 sub-quantisers) block — it needs the queries only, so it rides as extra workgroups of the probe-pick launch
+// (k_coarse_pick: a latency chain that leaves the CUs' issue slots idle) instead of a launch of its own.  256 threads; bid = linear
+// block number in the table build's XCD-aware order.
+struct LutPass0Args { const float* Q32; int ldq; const float* codebooks; int M, Mpad; int64_t nq; float* mnmx; int nblocks; };
+#define LM_Q 32
+#define LM_MB 4
+#ifdef __HIPCC__
+typedef float lm_f16 __attribute__((ext_vector_type(16)));
+// operands of the wave's sub-quantiser m for the tile's 32 queries: dims 2 kk + h of the lane's query / codeword (K step kk: lanes 0-31 feed
+// dim 2 kk, lanes 32-63 dim 2 kk + 1 — chain order)
+__device__ inline void lut_mfma_operands(const float* Q32, int ldq, const float* codebooks, int64_t q, int m, bool mreal, bool qok, int j, int hh,
+                                         float (&bq)[4], float (&ac)[8][4]) {
+    bq[0] = bq[1] = bq[2] = bq[3] = 0.f;
+    if (mreal && qok) {
+        const float4* p = reinterpret_cast<const float4*>(Q32 + q * ldq + m * 8);
+        const float4 x = p[0], y = p[1];
+        bq[0] = hh ? x.y : x.x; bq[1] = hh ? x.w : x.z; bq[2] = hh ? y.y : y.x; bq[3] = hh ? y.w : y.z;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        ac[t][0] = ac[t][1] = ac[t][2] = ac[t][3] = 0.f;
+        if (mreal) {
+            const float4* p = reinterpret_cast<const float4*>(codebooks + ((int64_t)m * 256 + 32 * t + j) * 8);
+            const float4 x = p[0], y = p[1];
+            ac[t][0] = hh ? x.y : x.x; ac[t][1] = hh ? x.w : x.z; ac[t][2] = hh ? y.y : y.x; ac[t][3] = hh ? y.w : y.z;
+        }
+    }
+}
+// (dep: a value of the previous tile's reductions — through an opaque asm it becomes this tile's accumulator zero, so the tiles are computed
+//  one after the other: left alone the compiler computes all 8 first and spills 128 accumulators)
+__device__ __forceinline__ lm_f16 lut_mfma_tile(const float (&ac)[8][4], const float (&bq)[4], int t, float dep) {
+    lm_f16 acc;
+    float z = 0.0f;
+    asm volatile("" : "+v"(z) : "v"(dep));
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = z;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][kk], bq[kk], acc, 0, 0, 0);
+    return acc;
+}
+__device__ inline void pq_lut_pass0_block(const LutPass0Args& a, unsigned bid) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, hh = lane >> 5;
+    const int nmb = (a.Mpad + LM_MB - 1) / LM_MB, nqt = (int)((a.nq + LM_Q - 1) / LM_Q);
+    const int rest = (int)(bid >> 3);
+    const int qt = (rest / nmb) * 8 + (int)(bid & 7);
+    if (qt >= nqt) return;
+    const int m = (rest % nmb) * LM_MB + w;
+    const int64_t q0 = (int64_t)qt * LM_Q, q = q0 + j;
+    const int nqc = (int)((a.nq - q0) < LM_Q ? (a.nq - q0) : LM_Q);
+    const bool mreal = m < a.M, mpad = m < a.Mpad, qok = j < nqc;
+    float bq[4], ac[8][4];
+    lut_mfma_operands(a.Q32, a.ldq, a.codebooks, q, m, mreal, qok, j, hh, bq, ac);
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const lm_f16 v = lut_mfma_tile(ac, bq, t, mn);
+#pragma unroll
+        for (int r = 0; r < 16; r++) { mn = fminf(mn, v[r]); mx = fmaxf(mx, v[r]); }
+    }
+    mn = fminf(mn, __shfl_xor(mn, 32)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (hh == 0 && qok && mpad) *reinterpret_cast<float2*>(a.mnmx + (q * a.Mpad + m) * 2) = make_float2(mn, mx);
+}
+#endif
 // fast coarse quantiser (k_gemm.hip: launch_coarse_approx; k_select.hip: k_coarse_pick)
 #define CP_CMAX 64             // most candidates a query may have (its nprobe best by approximate score + everything within 2 e of the last)
 #define CP_CH 128              // dimensions per staged chunk of the candidates' centroid rows
@@ -438,6 +504,8 @@ struct CoarsePickArgs {
     int nprobe; const int64_t* list_len; int pad_to;
     int32_t* probe_list; float* dis0; int64_t* seg_start; int32_t* bad;
     int cmax_rt;                                      // set by the launcher: candidate rows of this launch (coarse_pick_cmax)
+    int64_t nq;                                       // set by the launcher
+    LutPass0Args lp0;                                 // nblocks > 0: that many extra workgroups run pass 0 of the IVF-PQ table build (grid = nq + nblocks)
 };
 size_t coarse_pick_lds(int nlist, int d, int nprobe);
 void launch_coarse_approx(const __half* Q16, int64_t nq_pad, const __half* C16, int nlist, int ld, float* S, int64_t lds_, hipStream_t st,

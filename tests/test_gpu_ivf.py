@@ -714,9 +714,10 @@ def test_round6_table_build_and_grouping_forms_never_change_a_result(gpu, orc, M
         ix.set_param("scan_kernel", 0)
         for overlap, tiled, fused in ((0, 2, 1), (0, 2, 0), (1, 2, 1), (0, 1, 1), (1, 1, 0), (0, 0, 1), (0, 2, 1)):
             ix.set_param("overlap", overlap); ix.set_param("lut_tiled", tiled); ix.set_param("pq_group_fused", fused)
+            ix.set_param("pq_lut_early", (overlap + tiled + fused) & 1)        # the table build's first pass in the probe-pick launch or on its own
             D, I = ix.search(q[:nq], k)
             assert_same_results(D, I, De, Ie, f"M={M} nq={nq} k={k} overlap={overlap} lut_tiled={tiled} pq_group_fused={fused}")
-    ix.set_param("overlap", 0); ix.set_param("lut_tiled", 2); ix.set_param("pq_group_fused", 1)
+    ix.set_param("overlap", 0); ix.set_param("lut_tiled", 2); ix.set_param("pq_group_fused", 1); ix.set_param("pq_lut_early", 1)
 
 
 @pytest.mark.parametrize("kind", ["ivfpq", "ivfflat"])
