@@ -1,20 +1,28 @@
 // api_search.hip — the search drivers: search_batch (one internal batch: coarse quantiser, probe selection, table build, threshold
 // pre-pass, scan, selection, exact re-rank, certificate fallbacks) and search_impl (one rsx_search call).  Shared declarations: rsx_host.h.
+#include <cstring>
 #include "rsx_host.h"
 
 // ---------------------------------------------------------------------------------------
 // search
 // ---------------------------------------------------------------------------------------
+// profile = -1: events around the dominant scan launch ONLY (an event record is ~5 us of stream time: eight marks per batch are 1.5 % of the
+// headline batch — bench.py times its `value` in this mode and takes the stage breakdown from a separate pass in mode 1)
 struct StageTimer {
-    rsx_index* h; bool on; std::string prefix;
+    rsx_index* h; bool on; bool scan_only; std::string prefix;
     hipEvent_t ev[64]; const char* name[64]; int n = 0;
-    StageTimer(rsx_index* hh, const char* pre = "") : h(hh), on(hh->profile != 0), prefix(pre) {}
-    void mark(const char* nm) {
-        if (!on || n >= 64) return;
+    StageTimer(rsx_index* hh, const char* pre = "") : h(hh), on(hh->profile != 0), scan_only(hh->profile == -1), prefix(pre) {}
+    void record(const char* nm) {
         (void)hipEventCreate(&ev[n]);
         (void)hipEventRecord(ev[n], h->st);
         name[n] = nm; n++;
     }
+    void mark(const char* nm) {
+        if (!on || n >= 64) return;
+        if (scan_only && !(n == 1 && std::strcmp(nm, "scan") == 0)) return;
+        record(nm);
+    }
+    void pre_scan() { if (on && scan_only && n == 0) record("prescan"); }      // right before the dominant scan's launch
     void finish() {
         if (!on || n == 0) return;
         (void)hipEventSynchronize(ev[n - 1]);
@@ -771,6 +779,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     gs.cand = h->w_cand.as<uint64_t>(); gs.cand_cnt = h->w_candcnt.as<unsigned long long>(); gs.cand_cap = cand_cap;
                     gs.state = state; gs.KP = KP;
                 }
+                tm.pre_scan();
                 done = (rot ? launch_pq_scan_rot(a, h->w_lut8.as<uint8_t>(), h->w_qparam.p, pairs_sorted, pair_off, group_off,
                                                  total_groups, item_off, total_items, nlist,
                                                  mi_main, vpl, tau_ptr, tau_stride,
