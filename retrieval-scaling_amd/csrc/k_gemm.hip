@@ -438,6 +438,7 @@ __global__ __launch_bounds__(256) void k_flat_gemm(const __half* Q16, const void
 // different 16-byte slots of the 256-byte bank window: conflict-free without padding.
 // ---------------------------------------------------------------------------------------
 #define FG2_STAGE 65536
+#define FG2_QCAP 192        // entries of a wave's queue of passing keys (filtered epilogue); flushed beyond QCAP - 128
 
 // Cache policy of the LDS-DMA row streams (aux bits of the load; 2 = nt, "streamed once"), measured per kernel on one box
 // (profiles/r04_nt_loads.md): the IVF-Flat / small-batch row stream is read by ONE workgroup once per launch — nt: +5 % at
@@ -485,6 +486,8 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
         if (nitems == 0) return;
     }
     float* s_tf = reinterpret_cast<float*>(s_tau + 512);                        // tf[2][256]: the thresholds as floats
+    uint64_t* s_wq_key = reinterpret_cast<uint64_t*>(s_tf + 512);               // (FILTER) per-wave queue of passing keys [8][FG2_QCAP] ...
+    uint16_t* s_wq_q = reinterpret_cast<uint16_t*>(s_wq_key + 8 * FG2_QCAP);    // ... and their queries inside the tile
     if (FILTER && tid < 256) {
         const int64_t qn = (int64_t)qi0 * 256 + tid;
         const uint64_t t = (qn < F.nq) ? F.tau[qn * F.tau_stride] : ~0ull;
@@ -642,6 +645,24 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
                 bv[tj] = (bias && colv[tj] < nv) ? bias[v0 + colv[tj]] : 0.0f;
             }
             const bool in0 = colv[0] < nv, in1 = colv[1] < nv;
+            // Round 6: the keys that pass go to a queue of this wave in LDS (ballot + prefix: no atomics) and leave it 64 at a time —
+            // ONE atomic round trip per flush for all of them.  Before, every row pair with a hit paid its own atomicAdd-with-return
+            // in the middle of the epilogue (~13 serial L2 round trips per tile at the reference's n_docs = 1000: 3.4 ms of a 20 ms batch).
+            // Slots inside a candidate row come out in a different order; the selection behind does not depend on it (keys are unique).
+            uint64_t* wq_key = s_wq_key + w * FG2_QCAP;
+            uint16_t* wq_q = s_wq_q + w * FG2_QCAP;
+            int qn = 0;                                   // wave-uniform
+            auto flush = [&]() {
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < qn; i += 64) {
+                    const uint64_t key = wq_key[i];
+                    const int64_t qg = q0 + wq_q[i];
+                    const unsigned long long slot = atomicAdd(&F.cand_cnt[qg * CCS], 1ull);
+                    if (slot < (unsigned long long)F.cand_cap) F.cand[qg * F.cand_cap + slot] = key;
+                }
+                __builtin_amdgcn_wave_barrier();
+                qn = 0;
+            };
 #pragma unroll
             for (int ti = 0; ti < 4; ti++)
 #pragma unroll
@@ -659,17 +680,15 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
                         const uint64_t key = (colv[tj] < nv) ? make_key(sc, (uint32_t)(v0 + colv[tj])) : 0ull;
                         const bool pass = key > tau;
                         const uint64_t mask = __ballot(pass);
-                        const uint64_t mine = lh ? (mask >> 32) : (mask & 0xffffffffull);   // my half-wave = my query
-                        if (mine) {
-                            unsigned long long base = 0;
-                            const int leader = (__ffsll((unsigned long long)mine) - 1) + 32 * lh;
-                            if (lane == leader) base = atomicAdd(&F.cand_cnt[(int64_t)(q0 + ql) * CCS], (unsigned long long)__popcll(mine));
-                            base = __shfl(base, leader);
-                            const unsigned long long slot = base + __popcll(mine & ((1ull << lj) - 1ull));
-                            if (pass && slot < (unsigned long long)F.cand_cap) F.cand[(q0 + ql) * F.cand_cap + slot] = key;
+                        if (mask) {
+                            const int pos = qn + (int)__popcll(mask & ((1ull << lane) - 1ull));
+                            if (pass) { wq_key[pos] = key; wq_q[pos] = (uint16_t)ql; }
+                            qn += (int)__popcll(mask);
                         }
                     }
+                    if (qn > FG2_QCAP - 128) flush();
                 }
+            if (qn) flush();
             // thresholds of the next pass (read after at least one more barrier)
             if (!walk && qi + 1 < nitems && tid < 256) {
                 const int64_t qn = (int64_t)(qi + 1) * 256 + tid;
@@ -694,12 +713,13 @@ __global__ __launch_bounds__(512) void k_flat_gemm2(const __half* Q16, int nq_pa
 }
 
 static const size_t FG2_SHM = 2 * FG2_STAGE + 2 * 256 * 8 + 2 * 256 * 4;
+static const size_t FG2_SHM_FILTER = FG2_SHM + 8 * FG2_QCAP * (8 + 2);
 template <bool FILTER>
 static bool fg2_ready() {
     static DevOnce once;
     static std::atomic<int> failed{0};
     once.once([&] {
-        if (hipFuncSetAttribute((const void*)k_flat_gemm2<FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FG2_SHM) != hipSuccess) failed = 1;
+        if (hipFuncSetAttribute((const void*)k_flat_gemm2<FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FILTER ? FG2_SHM_FILTER : FG2_SHM)) != hipSuccess) failed = 1;
     });
     return !failed;
 }
@@ -765,7 +785,7 @@ void launch_flat_gemm_filter(const __half* Q16, int nq_pad, int nq, const void* 
         if (walk_on && slots > 0 && nv < ((int64_t)1 << 31) && F.ntiles >= (int64_t)4 * 8 * (slots / F.qt)) {
             F.walk = 1; grid = 8u * (unsigned)slots;
         }
-        hipLaunchKernelGGL((k_flat_gemm2<true>), dim3(grid), dim3(512), FG2_SHM, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias,
+        hipLaunchKernelGGL((k_flat_gemm2<true>), dim3(grid), dim3(512), FG2_SHM_FILTER, st, Q16, nq_pad, (const __half*)X, v0, nv, ld, bias,
                            (float*)nullptr, (int64_t)0, F);
         return;
     }

@@ -66,6 +66,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
                "scan_ms": round(scan_ms, 3), "select_ms": round(ix.get_timing("select") / steps, 3),
                "finalize_ms": round(ix.get_timing("finalize") / steps, 3), "build_s": round(build_s, 1),
                "storage_dtype": ix.storage_dtype,
+               "stage_ms": {x: round(ix.get_timing(x) / steps, 4) for x in ("convert", "coarse", "select_probe", "group", "scan0", "select0", "scan", "select", "finalize", "total")},
                "certificate_fallback_queries_per_step": round(ix.get_timing("fallback_queries") / steps, 3)}
         if which == "flat":
             fl = 2.0 * nq * n * D
@@ -136,7 +137,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
     # the reference's own n_docs (ric/conf/default.yaml:84: 1000) on the same index
     for kk in extra_ks:
         r2 = run_k(kk)
-        res[f"k{kk}"] = {key: r2[key] for key in ("queries_per_s", "ms_per_step", "scan_ms", "select_ms", "finalize_ms", "certificate_fallback_queries_per_step",
+        res[f"k{kk}"] = {key: r2[key] for key in ("queries_per_s", "ms_per_step", "scan_ms", "select_ms", "finalize_ms", "stage_ms", "certificate_fallback_queries_per_step",
                                                  "roofline", "oracle_parity_ids_and_scores", "oracle_checked_queries") if key in r2}
     del ix, buf, Q
     torch.cuda.synchronize()
