@@ -403,10 +403,14 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // the next: S stages of ratio r = (N / first)^(1/S) emit ~S K' (r - 1) keys.  Measured at 10M x 768, batch 1024
             // (profiles/r04_flat_staged_filter.md): k = 1000 36.5 -> 23.3 ms (S = 5), k = 10 18.9 -> 17.2 ms (S = 2: even 5 k keys
             // per query cost the single filtered launch 1.6 ms), k = 100 17.8 ms.
-            const int64_t nchunks = (N + CH - 1) / CH;
-            const int64_t n0 = std::min<int64_t>(nchunks, std::max<int64_t>(1, ((int64_t)KP * std::max(1, h->flat_pre_mult) + CH - 1) / CH));
-            for (int64_t c = 0; c < n0; c++) chunk_pass(c * CH, N);
-            done_rows = std::min<int64_t>(n0 * CH, N);
+            // (round 6: for small K' the threshold phase and the stage boundaries count in UNITS of a quarter chunk — at K' = 32 the selection
+            //  over a full 65536-column chunk cost 0.43 ms of a 16.9 ms batch, four times what a 16384-row threshold phase needs; the
+            //  stages pass ~1.5 k keys per query instead of ~700, which the queued epilogue does not notice.  flat_pre_unit: rows, 0 = default)
+            const int64_t U = h->flat_pre_unit > 0 ? std::min<int64_t>(CH, round_up(h->flat_pre_unit, 256)) : (KP <= 64 ? CH / 4 : CH);
+            const int64_t nchunks = (N + U - 1) / U;          // ... in units
+            const int64_t n0 = std::min<int64_t>(nchunks, std::max<int64_t>(1, ((int64_t)KP * std::max(1, h->flat_pre_mult) + U - 1) / U));
+            for (int64_t c = 0; c < n0; c++) chunk_pass(c * U, std::min<int64_t>(N, (c + 1) * U));
+            done_rows = std::min<int64_t>(n0 * U, N);
             tm.mark("scan0");
             if (done_rows < N && h->flat_filter != 0) {
                 int S = h->flat_stages;
@@ -414,26 +418,37 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                 const double r = pow((double)nchunks / (double)n0, 1.0 / S);
                 const int cap = KP <= 64 ? 32768 : 131072;
                 h->w_cand.ensure((size_t)nq * cap * 8);
-                h->w_candcnt.ensure((size_t)nq * 8 * CCS);
-                std::vector<unsigned long long> cnts((size_t)nq * CCS);
+                // With the certificate behind it (the default) a stage does not wait for its counts: every stage owns a set of per-query
+                // counters, the selection clamps an overflowed row to the buffer, and k_finalize flags a query any of whose stage rows
+                // overflowed — it joins the exact re-run like a query the certificate could not clear.  Round 6: the count read-back +
+                // host synchronisation per stage (five at the reference's n_docs = 1000) left the GPU idle between the stages.
+                // flat_cert = 0 has no re-run behind it and keeps the per-stage check (an overflowed stage is redone chunk by chunk).
+                const bool deferred = certify;
+                const size_t cc_stride = (size_t)nq * CCS;
+                h->w_candcnt.ensure(cc_stride * 8 * (deferred ? (size_t)S : 1));
+                if (deferred) HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, cc_stride * 8 * (size_t)S, h->st));
+                std::vector<unsigned long long> cnts(deferred ? 0 : cc_stride);
+                int stages_run = 0;
                 for (int st_ = 0; st_ < S && done_rows < N; st_++) {
                     // stage boundaries on chunk multiples (the database tiles of the GEMM stay aligned)
-                    int64_t endc = st_ == S - 1 ? nchunks : std::min<int64_t>(nchunks, std::max<int64_t>(done_rows / CH + 1, (int64_t)llround((double)n0 * pow(r, st_ + 1))));
-                    const int64_t end = std::min<int64_t>(N, endc * CH);
+                    int64_t endc = st_ == S - 1 ? nchunks : std::min<int64_t>(nchunks, std::max<int64_t>(done_rows / U + 1, (int64_t)llround((double)n0 * pow(r, st_ + 1))));
+                    const int64_t end = std::min<int64_t>(N, endc * U);
+                    unsigned long long* cc = h->w_candcnt.as<unsigned long long>() + (deferred ? cc_stride * (size_t)st_ : 0);
                     // ONE GEMM launch over the stage's rows whose epilogue keeps only keys beating the running K'-th key
-                    HIPCHECK(hipMemsetAsync(h->w_candcnt.p, 0, (size_t)nq * 8 * CCS, h->st));
+                    if (!deferred) HIPCHECK(hipMemsetAsync(cc, 0, cc_stride * 8, h->st));
                     launch_flat_gemm_filter(h->w_q16.as<__half>(), (int)nq_pad, (int)nq, h->data.p, h->storage_f16, done_rows,
-                                            end - done_rows, ld, bias, state + (KP - 1), KP, h->w_cand.as<uint64_t>(),
-                                            h->w_candcnt.as<unsigned long long>(), cap, h->st);
+                                            end - done_rows, ld, bias, state + (KP - 1), KP, h->w_cand.as<uint64_t>(), cc, cap, h->st);
                     tm.mark("scan");
-                    HIPCHECK(hipMemcpyAsync(cnts.data(), h->w_candcnt.p, (size_t)nq * 8 * CCS, hipMemcpyDeviceToHost, h->st));
-                    HIPCHECK(hipStreamSynchronize(h->st));
                     bool filtered_ok = true;
-                    for (int64_t qi = 0; qi < nq; qi++) if (cnts[(size_t)qi * CCS] > (unsigned long long)cap) { filtered_ok = false; break; }
+                    if (!deferred) {
+                        HIPCHECK(hipMemcpyAsync(cnts.data(), cc, cc_stride * 8, hipMemcpyDeviceToHost, h->st));
+                        HIPCHECK(hipStreamSynchronize(h->st));
+                        for (int64_t qi = 0; qi < nq; qi++) if (cnts[(size_t)qi * CCS] > (unsigned long long)cap) { filtered_ok = false; break; }
+                    }
                     if (filtered_ok) {
                         SelectArgs b{};
                         b.in = h->w_cand.p; b.in_is_keys = 1; b.row_stride = cap;
-                        b.row_n = reinterpret_cast<const int64_t*>(h->w_candcnt.p); b.row_n_stride = CCS; b.n_uniform = cap;
+                        b.row_n = reinterpret_cast<const int64_t*>(cc); b.row_n_stride = CCS; b.n_uniform = cap;
                         b.seg_len = cap; b.nseg = 1; b.idx_base = 0;
                         b.init = state; b.out = state; b.out_row_stride = KP;
                         b.nrows = nq; b.KP = KP; b.BUF = BUF; b.k = KP;
@@ -445,7 +460,9 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                         tm.mark("scan");
                     }
                     done_rows = end;
+                    stages_run = st_ + 1;
                 }
+                if (deferred) { fa.cand_cnt = h->w_candcnt.as<unsigned long long>(); fa.cand_cap = cap; fa.cand_cnt_n = stages_run; fa.cand_cnt_stride = (int64_t)cc_stride; }
             }
             if (done_rows < N) {       // flat_filter = 0
                 for (int64_t v0 = done_rows; v0 < N; v0 += CH) chunk_pass(v0, N);

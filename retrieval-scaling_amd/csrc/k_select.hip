@@ -1625,7 +1625,9 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
                         if (!(a_conv + e_conv < (double)s_k)) bad = 1;
                     }
                 }
-                if (a.cand_cnt && a.cand_cnt[q * CCS] > (unsigned long long)a.cand_cap) bad = 1;
+                if (a.cand_cnt)
+                    for (int sn = 0; sn < (a.cand_cnt_n > 0 ? a.cand_cnt_n : 1); sn++)
+                        if (a.cand_cnt[(int64_t)sn * a.cand_cnt_stride + q * CCS] > (unsigned long long)a.cand_cap) bad = 1;
             }
         }
         return __shfl(bad, 0);

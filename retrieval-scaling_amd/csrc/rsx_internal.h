@@ -638,6 +638,8 @@ struct FinalizeArgs {
     const float* codebooks; int dsub;
     const float* probe_dis0; const void* qparam; int32_t* uncertain;
     const unsigned long long* cand_cnt; int cand_cap;   // filtered scan: per-query candidate counts / capacity
+    int cand_cnt_n; int64_t cand_cnt_stride;            // Flat, staged filter: counter sets (one per stage; 0 = 1) and the words between them — k_finalize flags a
+                                                        // query any of whose stage rows overflowed
     // Flat / IVF-Flat certificate (uncertain != null): the scan ordered candidates by an APPROXIMATE score (fp16 MFMA, fp32
     // accumulation; queries or fp32 rows possibly rounded to fp16).  |approx - exact| <= cert_rel * |q| * cert_xmax + cert_abs
     // for every stored vector; a query whose K'-th approximate candidate could still beat its exact k-th is flagged.

@@ -227,3 +227,27 @@ def test_large_k_second_certificate_pass_settles_near_ties(gpu, orc, kind):
     # the near cluster really is inside the first cut's error bound: the k-th and the 1062nd exact scores are closer than one part in 10^4
     Dn, _ = orc.flat_search(q.astype(np.float32), x.astype(np.float32), 1100, 0)
     assert np.all((Dn[:, k - 1] - Dn[:, 1061]) < 1e-4 * np.abs(Dn[:, k - 1]))
+
+
+@pytest.mark.parametrize("cert", [1, 0])
+def test_staged_filter_overflow_is_settled_exactly(gpu, orc, cert):
+    """Flat, batch > 32: behind the threshold phase the rows are scanned by filtered GEMM launches whose epilogue appends the keys that
+    beat the running K'-th key to a per-query candidate row (api_search.hip: search_batch, k_gemm.hip: k_flat_gemm2<true>).  Rows stored
+    in ASCENDING score order defeat the threshold: every later row beats it and the candidate rows overflow.  With the certificate
+    behind the search (default) the stages do not wait for their counts — k_finalize flags the queries and they join the exact re-run;
+    with flat_cert = 0 the overflowed stage is redone chunk by chunk.  Either way: the oracle's ids and scores."""
+    rng = np.random.RandomState(11)
+    d, n, nq, k = 64, 400_000, 40, 10
+    u = rng.randn(d).astype(np.float32); u /= np.linalg.norm(u)
+    x = ((np.arange(n, dtype=np.float32)[:, None] / n) * u[None, :] + 0.001 * rng.randn(n, d).astype(np.float32)).astype(np.float16)
+    q = (u[None, :] + 0.01 * rng.randn(nq, d).astype(np.float32)).astype(np.float16)
+    ix = gpu.IndexFlatIP(d); ix.add(x)
+    ix.set_param("flat_cert", cert); ix.set_param("profile", 1)
+    D, I = ix.search(q, k)
+    sample = [0, 7, 39]
+    Dr, Ir = orc.flat_search(q[sample].astype(np.float32), x.astype(np.float32), k, 0)
+    assert_same_results(D[sample], I[sample], Dr, Ir, f"flat_cert={cert}: overflowing candidate rows")
+    if cert:
+        assert ix.get_timing("fallback_queries") > 0, "the overflow must have been seen (k_finalize flags the query)"
+    else:
+        assert ix.get_timing("flat_filter_overflows") > 0, "the overflow must have been seen (per-stage count check)"
