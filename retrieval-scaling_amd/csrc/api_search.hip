@@ -398,15 +398,16 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // 10M rows).  For the reference's n_docs = 1000 (K' = 2048) one chunk let 310 k keys through, overflowed every candidate row
             // and fell back to 153 chunk passes (550 ms per batch, round 4); 160 K' rows and ONE filtered launch over the rest still
             // emitted 62 k keys per query — 64 M atomically placed keys, the filtered GEMM 27.8 instead of 17.4 ms — behind five
-            // chunk selections of 0.93 ms.  Now: flat_pre_mult x K' rows through the score buffer (default 32: one chunk), then the rest
+            // chunk selections of 0.93 ms.  Now: flat_pre_mult x K' rows through the score buffer (default 16, in units: below), then the rest
             // in STAGES of geometrically growing row ranges, each one filtered launch + one selection that tightens the threshold for
             // the next: S stages of ratio r = (N / first)^(1/S) emit ~S K' (r - 1) keys.  Measured at 10M x 768, batch 1024
             // (profiles/r04_flat_staged_filter.md): k = 1000 36.5 -> 23.3 ms (S = 5), k = 10 18.9 -> 17.2 ms (S = 2: even 5 k keys
             // per query cost the single filtered launch 1.6 ms), k = 100 17.8 ms.
             // (round 6: for small K' the threshold phase and the stage boundaries count in UNITS of a quarter chunk — at K' = 32 the selection
             //  over a full 65536-column chunk cost 0.43 ms of a 16.9 ms batch, four times what a 16384-row threshold phase needs; the
-            //  stages pass ~1.5 k keys per query instead of ~700, which the queued epilogue does not notice.  flat_pre_unit: rows, 0 = default)
-            const int64_t U = h->flat_pre_unit > 0 ? std::min<int64_t>(CH, round_up(h->flat_pre_unit, 256)) : (KP <= 64 ? CH / 4 : CH);
+            //  stages pass ~1.5 k keys per query instead of ~700, which the queued epilogue does not notice.  Larger K': half a chunk and 16 K' rows —
+            //  k = 1000: scan0 1.32 -> 0.62 ms, one stage more, 20.07 -> 19.68 ms per batch (profiles/r06_large_k_flat.md).  flat_pre_unit: rows, 0 = default)
+            const int64_t U = h->flat_pre_unit > 0 ? std::min<int64_t>(CH, round_up(h->flat_pre_unit, 256)) : (KP <= 64 ? CH / 4 : CH / 2);
             const int64_t nchunks = (N + U - 1) / U;          // ... in units
             const int64_t n0 = std::min<int64_t>(nchunks, std::max<int64_t>(1, ((int64_t)KP * std::max(1, h->flat_pre_mult) + U - 1) / U));
             for (int64_t c = 0; c < n0; c++) chunk_pass(c * U, std::min<int64_t>(N, (c + 1) * U));

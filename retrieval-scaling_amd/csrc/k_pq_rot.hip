@@ -1440,6 +1440,11 @@ __global__ __launch_bounds__(1024) void k_pq_scan_sl8(PQScan8Args A, const PQRot
 #pragma unroll
             for (int j = 0; j < NB; j++) {
                 const int b = tb0 + 16 * (st * NB + j) + w;
+#if SL8_VAR & 32        // (32 / 64 = the sixteen waves meet before every block / every fourth block: do they fetch better in lock-step?  timing experiment)
+                __builtin_amdgcn_s_barrier();
+#elif SL8_VAR & 64
+                if (j % 4 == 0) __builtin_amdgcn_s_barrier();
+#endif
                 if (P == 2 && w == 0 && st == nsub - 1) {
                     if (j == 0 && dstate == 0) { if (lane == 0) drawn = atomicAdd(ctr, 1u); dstate = 1; }
                     if (j == NB / 2 && dstate == 1) { i1 = resolve_draw(); pre = load_records(i1); dstate = 2; }

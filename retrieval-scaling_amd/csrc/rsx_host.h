@@ -228,8 +228,8 @@ struct rsx_index {
     int add_list_mod = 1, add_list_rem = 0;   // IVF add keeps only lists l with l % mod == rem (list-sharded multi-GPU index)
     int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
     int flat_filter = 1;  // Flat: filtered GEMM launches after the threshold phase (0 = score buffer per chunk)
-    int flat_pre_mult = 32;  // Flat: rows of the threshold phase per K' (through the score buffer), rounded up to units of flat_pre_unit rows
-    int flat_pre_unit = 0;   // Flat: rows per unit of the threshold phase and the stage boundaries (0 = 16384 for K' <= 64, else one 65536-row chunk)
+    int flat_pre_mult = 16;  // Flat: rows of the threshold phase per K' (through the score buffer), rounded up to units of flat_pre_unit rows
+    int flat_pre_unit = 0;   // Flat: rows per unit of the threshold phase and the stage boundaries (0 = 16384 for K' <= 64, else 32768)
     int flat_stages = 0;     // Flat: filtered stages behind the threshold phase (0 = from K' and the row count; see search_batch)
     int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
     int ivf_pre_lists = 0;   // IVF-Flat threshold sample at large K': closest lists sampled (0 = 2)

@@ -273,7 +273,7 @@ def test_flat_staged_filter_at_the_reference_n_docs(gpu, orc, metric):
     for k in (1000, 100):
         Dr, Ir = orc.flat_search(q[sample].cpu().numpy().astype(np.float32), xs, k, metric)
         ref = None
-        for mult, stages, unit in ((32, 0, 0), (64, 1, 4096), (1, 4, 0), (16, 2, 65536), (160, 3, 1000), (4, 0, 16384)):
+        for mult, stages, unit in ((16, 0, 0), (32, 0, 65536), (64, 1, 4096), (1, 4, 0), (16, 2, 65536), (160, 3, 1000), (4, 0, 16384)):
             ix.set_param("flat_pre_mult", mult); ix.set_param("flat_stages", stages); ix.set_param("flat_pre_unit", unit); ix.set_param("profile", 1)
             D, I = ix.search(q, k)
             assert ix.get_timing("fallback_queries") == 0 and ix.get_timing("flat_filter_overflows") == 0
@@ -282,7 +282,7 @@ def test_flat_staged_filter_at_the_reference_n_docs(gpu, orc, metric):
             if ref is None:
                 ref = (Dn, In)
             assert np.array_equal(ref[1], In) and np.array_equal(ref[0], Dn), f"k={k} pre_mult={mult} stages={stages} unit={unit}: staging must be invisible"
-        ix.set_param("flat_pre_mult", 32); ix.set_param("flat_stages", 0); ix.set_param("flat_pre_unit", 0); ix.set_param("profile", 0)
+        ix.set_param("flat_pre_mult", 16); ix.set_param("flat_stages", 0); ix.set_param("flat_pre_unit", 0); ix.set_param("profile", 0)
 
 
 @pytest.mark.parametrize("metric", [0, 1])
