@@ -101,7 +101,10 @@ constexpr int CCS = 16;   // counter stride in 8-byte words: cand_cnt[q * CCS]
 // Lists start on 64-vector boundaries in the other layouts and a 64-vector slab is 64*Mpad bytes in them.
 // ---------------------------------------------------------------------------------------
 constexpr int PQ_SLICED = -1;
-constexpr int PQ_SLICED_GB = 16;          // blocks per slice-major group
+#ifndef PQ_SLICED_GB_V
+#define PQ_SLICED_GB_V 16
+#endif
+constexpr int PQ_SLICED_GB = PQ_SLICED_GB_V;          // blocks per slice-major group (A/B builds override it: the layout of every kernel follows)
 // byte offset of slice `sl` of the 32-vector block `blk` (absolute, or relative to a group-aligned list start) in the sliced layout
 __host__ __device__ inline int64_t pq_sliced_off(int64_t blk, int sl, int Mpad) {
     return (blk / PQ_SLICED_GB) * (int64_t)(PQ_SLICED_GB * 32 * Mpad) + (int64_t)sl * (PQ_SLICED_GB * 1024) + (blk % PQ_SLICED_GB) * 1024;
