@@ -7,6 +7,8 @@
 #   bench      the default bench line (all configs)                               bench_fast: headline only
 #   prof       rocprofv3 --kernel-trace --stats of the headline bench  -> ${TAG}_rocprof_stats_ivfpq100M.md + ${TAG}_timeline.md (last batch)
 #   pmc_fetch  FETCH_SIZE pass -> ${TAG}_pmc_fetch_size.md + stamped pmc_traffic.json
+#   stamp      copy the pmc_fetch stage's pmc_traffic.json over profiles/pmc_traffic.json ON THE BOX, so that a later bench stage of the same call reads it
+#              (final evidence session: env pmc_fetch stamp tests smoke bench prof per_rank latency flat; then copy gpurun_out/pmc_traffic.json to profiles/ here)
 #   pmc_sq     two SQ counter passes of the scan kernel -> ${TAG}_pmc_sq_counters.md
 #   per_rank   one rank of an N = 2 / 4 / 8 run and of config 5 on this one GPU -> ${TAG}_per_rank_workloads.txt
 #   m16        the reference's shipped IVF-PQ point (M 16, nlist 8192, nprobe 512; k 10 and 1000)
@@ -52,6 +54,8 @@ for s in "$@"; do
       python tools/pmc_summary.py /tmp/pmc_mfma/${TAG}_results.db $O/${TAG}_pmc_fetch_size.md '%k_pq_scan%'
       python tools/update_pmc_traffic.py /tmp/pmc_fetch/${TAG}_results.db $O/pmc_traffic.json 100000000 1 /tmp/pmc_mfma/${TAG}_results.db
       rm -rf /tmp/pmc_fetch /tmp/pmc_mfma ;;
+    stamp)
+      cp $O/pmc_traffic.json profiles/pmc_traffic.json ;;
     pmc_sq)
       ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $O/pmc_sq -o $TAG -- python $OLDPWD/bench.py --steps 2 --warmup 1 $FAST ${BENCH_ARGS:-} > /dev/null 2> $O/${TAG}_pmc_sq.log ); echo "exit $?" >> $O/${TAG}_pmc_sq.log
       rm -f $O/${TAG}_pmc_sq_counters.md
