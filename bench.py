@@ -582,7 +582,8 @@ def main():
         # sibling re-reads) runs at 5.5-5.8 TB/s, nine tenths of what this chip delivers into LDS (6.2 TB/s measured): memory bound.
         # k_pq_scan_rot (rounds 2-5): CU bound — one instruction per issue turn on every SIMD (profiles/r05_scan_plateau.md section 5).
         bound_note = ("memory: L2-miss traffic (roofline.traffic) at ~0.9 of the measured 6.2 TB/s fill rate; SQ issue 0.6-0.8 per turn, LDS ~0.35, "
-                      "MFMA ~0.36 busy (profiles/r06_sliced_scan.md)" if kernel == "k_pq_scan_sl8" else
+                      "MFMA ~0.36 busy (profiles/r06_sliced_scan.md); a build without the look-ups moves its requests at the same ~5.5 TB/s, "
+                      "more loads in flight only queue (profiles/r06_large_k_flat.md 2)" if kernel == "k_pq_scan_sl8" else
                       "cu (lds gather issue): one instruction per 4-clock issue turn on every SIMD, LDS 0.61, MFMA 0.30 busy "
                       "(profiles/r05_scan_plateau.md)" if kernel == "k_pq_scan_rot" else "lds bank conflicts (granule layout)")
         res = {
