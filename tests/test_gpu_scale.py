@@ -315,6 +315,46 @@ def test_ivfflat_filter_at_the_reference_n_docs(gpu, orc, metric):
         for pre_lists in (0, 1, 2, 4):
             ix.set_param("ivf_pre_lists", pre_lists); ix.set_param("profile", 1)
             D, I = ix.search(qf, k)
-            assert ix.get_timing("fallback_queries") == 0
+            # (round 6: one or two overflowed candidate rows no longer send the batch through the unfiltered scan — those queries join the
+            #  exact re-run; every fallback here must be such an overflow, never a failed certificate)
+            assert ix.get_timing("fallback_queries") == ix.get_timing("ivf_filter_overflow_queries") <= 2
             assert np.array_equal(Iu, I) and np.array_equal(Du, D), f"metric={metric} k={k} ivf_pre_lists={pre_lists}: the filter must be invisible"
         ix.set_param("profile", 0); ix.set_param("ivf_pre_lists", 0)
+
+
+def test_ivfflat_filter_overflow_of_a_few_queries_is_settled_per_query(gpu, orc):
+    """IVF-Flat behind the in-kernel filter: the threshold of a query is the K'-th key of a sample of the FIRST rows of its closest
+    list.  Two adversarial queries whose closest list starts with 8192 rows that score badly for them (and goes on with 22 000 that score
+    well) get a useless threshold and overflow their candidate rows.  Round 5 sent the whole batch through the unfiltered scan for
+    that; now k_finalize flags the overflowed rows' queries and they alone join the exact re-run (api_search.hip, k_select.hip:
+    certify_rows).  All 130 queries: the oracle's ids and scores."""
+    rng = np.random.RandomState(17)
+    d, nlist, per, nq, k = 128, 4, 30_000, 130, 10
+    cen = (3.0 * rng.randn(nlist, d)).astype(np.float32)
+    u = rng.randn(d).astype(np.float32)
+    for c in cen:                                   # u orthogonal to every centroid: +-u does not move a row to another list
+        u -= (u @ c) / (c @ c) * c
+    for _ in range(3):
+        for c in cen:
+            u -= (u @ c) / (c @ c) * c
+    u /= np.linalg.norm(u)
+    lab = np.repeat(np.arange(nlist), per)
+    x = cen[lab] + 0.3 * rng.randn(nlist * per, d).astype(np.float32)
+    bad = 8192
+    x[:bad] -= 8.0 * u[None, :]                                                           # list 0, first rows: far below for a query along +u
+    x[bad:per] += (4.0 + 4.0 * rng.rand(per - bad, 1).astype(np.float32)) * u[None, :]    # list 0, the rest: far above
+    x = x.astype(np.float16)
+    src = per + rng.randint(0, (nlist - 1) * per, nq)                              # ordinary queries: near rows of lists 1 .. 3
+    q = (x[src].astype(np.float32) + 0.05 * rng.randn(nq, d)).astype(np.float32)
+    q[5] = cen[0] + 6.0 * u; q[77] = cen[0] + 5.0 * u                               # the two adversarial ones
+    q = q.astype(np.float16)
+    a, _ = orc.assign_ip(cen, x.astype(np.float32))
+    assert np.array_equal(a, lab), "the construction keeps every row in its list"
+    ix = gpu.IndexIVFFlat(None, d, nlist, 0)
+    ix.set_centroids(cen); ix.add(x); ix.nprobe = nlist
+    ix.set_param("ivf_filter", 2); ix.set_param("profile", 1)
+    D, I = ix.search(q, k)
+    Dr, Ir = orc.flat_search(q.astype(np.float32), x.astype(np.float32), k, 0)       # nprobe = nlist: exhaustive
+    assert_same_results(D, I, Dr, Ir, "IVF-Flat, two queries with overflowing candidate rows")
+    assert ix.get_timing("ivf_filter_overflow_queries") == 2, "exactly the two adversarial queries overflow"
+    assert ix.get_timing("fallback_queries") >= 2

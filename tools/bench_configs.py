@@ -68,6 +68,8 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
                "storage_dtype": ix.storage_dtype,
                "stage_ms": {x: round(ix.get_timing(x) / steps, 4) for x in ("convert", "coarse", "select_probe", "group", "scan0", "select0", "scan", "select", "finalize", "total")},
                "certificate_fallback_queries_per_step": round(ix.get_timing("fallback_queries") / steps, 3)}
+        if which == "ivfflat":
+            res["filter_overflow_queries_per_step"] = round(ix.get_timing("ivf_filter_overflow_queries") / steps, 3)
         if which == "ivfflat" and ix.get_timing("cand_keys") > 0:      # filtered scan (profile 2): keys that passed the in-kernel filter
             res["filter_keys_per_query"] = {"mean": round(ix.get_timing("cand_keys") / steps / nq, 1), "max": ix.get_timing("cand_keys_max")}
         if which == "flat":
@@ -139,7 +141,7 @@ def measure(which, n=0, steps=5, batch=1024, nlist=4096, nprobe=32, check=4, sma
     # the reference's own n_docs (ric/conf/default.yaml:84: 1000) on the same index
     for kk in extra_ks:
         r2 = run_k(kk)
-        res[f"k{kk}"] = {key: r2[key] for key in ("queries_per_s", "ms_per_step", "scan_ms", "select_ms", "finalize_ms", "stage_ms", "filter_keys_per_query", "certificate_fallback_queries_per_step",
+        res[f"k{kk}"] = {key: r2[key] for key in ("queries_per_s", "ms_per_step", "scan_ms", "select_ms", "finalize_ms", "stage_ms", "filter_keys_per_query", "filter_overflow_queries_per_step", "certificate_fallback_queries_per_step",
                                                  "roofline", "oracle_parity_ids_and_scores", "oracle_checked_queries") if key in r2}
     del ix, buf, Q
     torch.cuda.synchronize()
