@@ -1763,6 +1763,19 @@ extern "C" int rsx_debug_ft_trace2(uint64_t* out) { return hipMemcpyFromSymbol(o
 #define FT_MARK(i)
 #define FT_MARK2(i)
 #endif
+// f(c, row[c]) for every c < n, a 1024-thread workgroup: EIGHT keys per thread are requested before the first is looked at.  (Round 6: the selection
+// passes of k_pq_final_tab walked the row one key per thread and step — at n = 6400 seven dependent L2 round trips per pass, four passes per
+// radix walk, three walks per query.)
+template <class F>
+__device__ __forceinline__ void ft_for_keys(const uint64_t* row, int n, int tid, F&& f) {
+    for (int c0 = tid; c0 < n; c0 += 8 * 1024) {
+        uint64_t kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int c = c0 + u * 1024; kk[u] = c < n ? row[c] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int c = c0 + u * 1024; if (c < n) f(c, kk[u]); }
+    }
+}
 template <int NRUN>      // M / 16: the 16-sub-quantiser runs of a code vector (1, 2, 4, 6, 8)
 __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t* cand, int cand_cap, int P, uint64_t* tie_ws, int stage_probes, int bm_off, int wq_off, int wq_cap) {
     extern __shared__ __attribute__((aligned(16))) float ft_T[];
@@ -1841,10 +1854,9 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         __syncthreads();
         {
             uint32_t lmin = 0xffffffffu, lmax = 0u;
-            for (int c = tid; c < n; c += 1024) {
-                const uint64_t key = row[c];
+            ft_for_keys(row, n, tid, [&](int c, uint64_t key) {
                 if (key != 0ull && (!only || ((only[c >> 5] >> (c & 31)) & 1u))) { const uint32_t o = (uint32_t)(key >> 32); lmin = o < lmin ? o : lmin; lmax = o > lmax ? o : lmax; }
-            }
+            });
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const uint32_t a0 = __shfl_xor(lmin, off), a1 = __shfl_xor(lmax, off);
@@ -1861,12 +1873,11 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
         for (int shift = shift0; shift >= 0; shift -= 8) {
             for (int i2 = tid; i2 < 256; i2 += 1024) hist[i2] = 0;
             __syncthreads();
-            for (int c = tid; c < n; c += 1024) {
-                const uint64_t key = row[c];
+            ft_for_keys(row, n, tid, [&](int c, uint64_t key) {
                 const uint32_t o = (uint32_t)(key >> 32);
                 if (key != 0ull && (!only || ((only[c >> 5] >> (c & 31)) & 1u)) && (shift == 24 || (o >> (shift + 8)) == (prefix >> (shift + 8))))
                     atomicAdd(&hist[(o >> shift) & 255u], 1);      // (at shift0 < 24 every key matches the common prefix)
-            }
+            });
             __syncthreads();
             if (tid < 64) {
                 const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
@@ -1908,7 +1919,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     uint32_t* bm = bm_off ? reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(ft_T) + bm_off) : nullptr;      // [ceil(cand_cap / 32)]
     {
         int cntv = 0;
-        for (int c = tid; c < n; c += 1024) cntv += row[c] != 0ull;
+        ft_for_keys(row, n, tid, [&](int, uint64_t key) { cntv += key != 0ull; });
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cntv += __shfl_xor(cntv, off);
         if (lane == 0 && cntv) atomicAdd(&ctl[7], cntv);
@@ -2080,10 +2091,9 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
     for (int i2 = tid; i2 < P; i2 += 1024) { sord[i2] = 0u; sid[i2] = INT64_MAX; }
     __syncthreads();
     uint64_t* tws = tie_ws + q * (int64_t)cand_cap;
-    for (int c = tid; c < n; c += 1024) {
-        const uint64_t key = row[c];
+    ft_for_keys(row, n, tid, [&](int, uint64_t key) {
         const uint32_t o = (uint32_t)(key >> 32);
-        if (key == 0ull || o < thr) continue;
+        if (key == 0ull || o < thr) return;
         int lo;
         const int64_t r = locate(key_idx(key), lo);
         const int64_t id = a.ids ? a.ids[r] : r;
@@ -2093,7 +2103,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
             const int pos = atomicAdd(&ctl[3], 1);
             if (pos < P) { sord[pos] = o; sid[pos] = id; }
         }
-    }
+    });
     __syncthreads();
     if (tie_select) {
         auto key_at = [&](int i2) -> uint64_t { return tws[i2]; };
