@@ -1045,11 +1045,11 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
         fa.pq_rescore = 1; fa.codes = h->data.as<uint8_t>(); fa.M = h->M; fa.Mpad = h->Mpad; fa.CB = h->CB;
         // large K' (the reference's n_docs = 100 ... 2000): thousands of candidates per query are re-scored, and in the scan layouts a candidate's
         // M code bytes are M / 16 pieces in as many 64-byte sectors — the finalize then runs at the HBM's random-sector rate.  A row-major copy
-        // of the codes (M bytes per vector more: 288 GB of HBM hold it) makes that two or three sectors; built on the first such search of an
+        // of the codes (pq_plain_stride(M) bytes per vector more — 128 at M = 96, so that a row is ONE 128-byte line: 288 GB of HBM hold it); built on the first such search of an
         // index state, dropped by the next add.  rsx_set_param "pq_plain_codes" = 0 turns it off.
         if (rot && KP >= 256 && h->pq_plain_codes != 0 && h->M >= 32 && h->M % 16 == 0 && h->M == h->Mpad) {
             if (h->plain_gen != h->dir_gen || h->plain_of != h->data.p) {
-                const size_t need = (size_t)std::max<int64_t>(h->total_cap, 1) * h->M;
+                const size_t need = (size_t)std::max<int64_t>(h->total_cap, 1) * (size_t)pq_plain_stride(h->M);
                 size_t fr = 0, tot = 0;
                 h->plain_of = nullptr;
                 if (hipMemGetInfo(&fr, &tot) == hipSuccess && (h->codes_plain.bytes >= need || fr > need + need / 8 + ((size_t)8 << 30))) {
@@ -1059,7 +1059,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
                     h->timing["plain_codes_builds"] += 1;
                 }
             }
-            if (h->plain_of == h->data.p && h->plain_gen == h->dir_gen) fa.codes_plain = h->codes_plain.as<uint8_t>();
+            if (h->plain_of == h->data.p && h->plain_gen == h->dir_gen) { fa.codes_plain = h->codes_plain.as<uint8_t>(); fa.plain_stride = pq_plain_stride(h->M); }
         }
         fa.lut32 = fused_lut ? nullptr : h->w_lut.as<float>(); fa.codebooks = h->d_codebooks.as<float>(); fa.dsub = h->dsub;
         fa.probe_dis0 = h->w_dis0.as<float>(); fa.qparam = h->w_qparam.p;

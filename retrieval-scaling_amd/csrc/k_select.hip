@@ -1311,13 +1311,13 @@ __device__ inline void rot16_bytes(uint32_t (&w)[4], int i) {     // byte t of t
     }
 }
 __device__ inline float pq_exact_sum_rot_wide(const uint8_t* codes, int64_t row, int M, const float* qv, const float* codebooks, int CB = 0,
-                                              const uint8_t* plain = nullptr) {
+                                              const uint8_t* plain = nullptr, int plain_stride = 0) {
     const int i = plain ? 0 : (int)(row & 15);       // the row-major copy holds the bytes in m order already: nothing to rotate back
     const int nrun = M >> 4;
     // the piece of a run as two 8-byte halves (pq_piece_ptrs: rotated or sliced layout; or straight from the row-major copy)
     auto piece = [&](int r, uint2& lo, uint2& hi) {
         const uint8_t* p0; const uint8_t* p1;
-        if (plain) { p0 = plain + row * M + r * 16; p1 = p0 + 8; }
+        if (plain) { p0 = plain + row * (plain_stride ? plain_stride : M) + r * 16; p1 = p0 + 8; }
         else pq_piece_ptrs(codes, row, M, CB, r, p0, p1);
         lo = *reinterpret_cast<const uint2*>(p0); hi = *reinterpret_cast<const uint2*>(p1);
     };
@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             const float dis0 = plds ? s_d0[lo] : a.probe_dis0[q * a.nprobe + lo];
             const int64_t slab = row >> 6; const int v = (int)(row & 63);
             const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-            const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB, a.codes_plain)
+            const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB, a.codes_plain, a.plain_stride)
                                                                   : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub, a.CB))
                             : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                          : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(256) void k_pq_rescore_all(FinalizeArgs a, uint64_t
         const float dis0 = a.probe_dis0[q * a.nprobe + lo];
         const int64_t slab = row >> 6; const int v = (int)(row & 63);
         const uint8_t* sp = a.codes + slab * (int64_t)(64 * a.Mpad);
-        const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB, a.codes_plain)
+        const float sum = pq_rot_family(a.CB) ? ((!T && a.dsub == 8 && a.M >= 32) ? pq_exact_sum_rot_wide(a.codes, row, a.M, qv, a.codebooks, a.CB, a.codes_plain, a.plain_stride)
                                                               : pq_exact_sum_rot(a.codes, row, a.M, T, qv, a.codebooks, a.dsub, a.CB))
                         : a.CB == 16 ? pq_exact_sum<16>(sp, v, a.M, T, qv, a.codebooks, a.dsub)
                                      : pq_exact_sum<4>(sp, v, a.M, T, qv, a.codebooks, a.dsub);
@@ -1972,7 +1972,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
             for (int run = 0; run < FT_RUNS; run++) {
                 if (run >= nrun) break;
                 const uint8_t* p0; const uint8_t* p1;
-                if (a.codes_plain) { p0 = a.codes_plain + x.r * M + run * 16; p1 = p0 + 8; }
+                if (a.codes_plain) { p0 = a.codes_plain + x.r * (a.plain_stride ? a.plain_stride : M) + run * 16; p1 = p0 + 8; }
                 else pq_piece_ptrs(a.codes, x.r, M, a.CB, run, p0, p1);
                 x.lo2[run] = *reinterpret_cast<const uint2*>(p0); x.hi2[run] = *reinterpret_cast<const uint2*>(p1);
             }
@@ -2149,7 +2149,7 @@ __global__ __launch_bounds__(1024) void k_pq_final_tab(FinalizeArgs a, uint64_t*
 }
 // Row-major copy of the codes for the finalize kernels (large K'): one thread per (storage row, 16-sub-quantiser run) reads the run's piece
 // of the scan layout, rotates it back into m order and writes 16 contiguous bytes.
-__global__ __launch_bounds__(256) void k_pq_plain_rows(const uint8_t* __restrict__ codes, int64_t nrows, int M, int CB, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_pq_plain_rows(const uint8_t* __restrict__ codes, int64_t nrows, int M, int CB, uint8_t* __restrict__ out, int stride) {
     const int nrun = M >> 4;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= nrows * nrun) return;
@@ -2160,12 +2160,19 @@ __global__ __launch_bounds__(256) void k_pq_plain_rows(const uint8_t* __restrict
     const uint2 lo = *reinterpret_cast<const uint2*>(p0), hi = *reinterpret_cast<const uint2*>(p1);
     uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
     rot16_bytes(w, (int)(row & 15));
-    *reinterpret_cast<uint4*>(out + row * M + run * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(out + row * stride + run * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+// row stride of the row-major code copy: a row never straddles a 128-byte line (M = 96 -> 128: a candidate is ONE line from HBM instead of 1.75 on
+// average — the large-k finalize kernels run at the HBM's random-line rate)
+int pq_plain_stride(int M) {
+    if (M >= 128) return (M + 127) / 128 * 128;
+    int s2 = 16; while (s2 < M) s2 <<= 1;
+    return s2;
 }
 void launch_pq_plain_rows(const uint8_t* codes, int64_t nrows, int M, int CB, uint8_t* out, hipStream_t st) {
     if (nrows <= 0) return;
     const int64_t units = nrows * (M >> 4);
-    hipLaunchKernelGGL(k_pq_plain_rows, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, codes, nrows, M, CB, out);
+    hipLaunchKernelGGL(k_pq_plain_rows, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, codes, nrows, M, CB, out, pq_plain_stride(M));
 }
 
 // sort capacity of k_pq_final_tab for this (M, k), 0 when the kernel does not apply (layout, or the table + sort do not fit the LDS)

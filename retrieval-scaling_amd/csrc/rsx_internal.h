@@ -635,6 +635,7 @@ struct FinalizeArgs {
     const void* X; int x_f16; int ld;
     // exact re-score + certificate (IVF-PQ fast scan): candidates carry APPROXIMATE scores
     int pq_rescore; const uint8_t* codes; int M; int Mpad; int CB;
+    int plain_stride;              // row stride of codes_plain in bytes (pq_plain_stride(M); 0 = M)
     const uint8_t* codes_plain;    // optional (large K'): a row-major copy of the codes, [storage row][M] — a candidate's M bytes are then two or
                                    // three 64-byte sectors instead of one per 16-byte piece of the scan layouts (launch_pq_plain_rows)
     const float* lut32;            // fp32 tables, or null: entries recomputed from Q32 and `codebooks`
@@ -658,6 +659,7 @@ struct FinalizeArgs {
 };
 void launch_finalize(const FinalizeArgs& a, hipStream_t st);
 // out[row * M + m] = the code of (storage row, sub-quantiser m) for every row < nrows of a rotated / sliced layout (M % 16 == 0, M >= 32)
+int pq_plain_stride(int M);        // bytes between the rows of that copy (a power of two / a multiple of 128: no row straddles a 128-byte line)
 void launch_pq_plain_rows(const uint8_t* codes, int64_t nrows, int M, int CB, uint8_t* out, hipStream_t st);
 // exact scores for every candidate key of the queries with a.row_filter[q] == 1, in place (a.cand_cnt gives the row lengths)
 void launch_pq_rescore_all(const FinalizeArgs& a, uint64_t* cand, int cand_cap, hipStream_t st);
