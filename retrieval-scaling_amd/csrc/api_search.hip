@@ -989,7 +989,7 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             // of them are cheaper than the rescan); more overflows mean the threshold failed for this data, and the batch is rescanned
             int64_t n_over = 0;
             for (int64_t qi = 0; qi < nq; qi++) n_over += cnts[(size_t)qi * CCS] > (unsigned long long)cand_cap;
-            if (n_over > 0 && !(certify && n_over <= std::max<int64_t>(2, nq / 256))) filtered = false;
+            if (n_over > 0 && !(certify && n_over <= (h->ivf_overflow_max > 0 ? (int64_t)h->ivf_overflow_max : std::max<int64_t>(2, nq / 256)))) filtered = false;
             if (filtered && n_over > 0) { flag_overflows = true; h->timing["ivf_filter_overflow_queries"] += (double)n_over; }
             a.tau_key = nullptr; a.cand = nullptr; a.cand_cnt = nullptr; a.cand_cap = 0;
         }

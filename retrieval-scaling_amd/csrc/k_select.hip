@@ -1695,8 +1695,80 @@ __global__ __launch_bounds__(256) void k_exact_scores(ExactScoreArgs a) {
     }
     if (lane == 0) a.temp[q * a.tstride + c] = out;
 }
+// The same scores for fp16 rows, SIXTEEN consecutive columns per wave, four rows in flight at a time with 16-byte loads (k_finalize's
+// rescore_rows), the probed list found by ONE bisection per wave and a walk from there.  Round 6: with k_exact_scores a query of the exact
+// re-run cost ~2 ms at 1.2 M probed rows (seven dependent loads of the bisection and twelve 2-byte loads per row and wave) — the price of every
+// certificate failure and, since this round, of every overflowed candidate row of the Flat / IVF-Flat filters.  fp64 sums of exact products: the
+// order of the terms differs from k_exact_scores' as rescore_rows' does (oracle: "fp64 accumulation of exact products, rounded once").
+#define XS_COLS 16
+__global__ __launch_bounds__(256) void k_exact_scores_f16(ExactScoreArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.y;
+    const int64_t c0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * XS_COLS;
+    if (c0 >= a.tstride) return;
+    const int64_t* ss = a.kind == KIND_FLAT ? nullptr : a.seg_start + q * (a.nprobe + 1);
+    const int64_t total = a.kind == KIND_FLAT ? a.flat_n : ss[a.nprobe];
+    int lo = 0;
+    int64_t seg_lo = 0, seg_hi = 0, seg_base = 0, seg_len = 0;      // the probed list under the cursor: columns [seg_lo, seg_hi), rows seg_base + [0, seg_len)
+    auto load_seg = [&]() {
+        seg_lo = ss[lo]; seg_hi = ss[lo + 1];
+        const int32_t l = a.probe_list[q * a.nprobe + lo];
+        seg_base = l >= 0 ? a.list_base[l] : 0; seg_len = l >= 0 ? a.list_len[l] : 0;
+    };
+    if (ss && c0 < total) {
+        int hi = a.nprobe;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ss[mid] <= c0) lo = mid; else hi = mid; }
+        load_seg();
+    }
+    const float* qv = a.Q32 + q * a.ldq;
+    for (int u4 = 0; u4 < XS_COLS; u4 += 4) {
+        int64_t rows[4]; double acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t c = c0 + u4 + u;
+            rows[u] = -1; acc[u] = 0.0;
+            if (c >= a.tstride || c >= total) continue;
+            if (!ss) { rows[u] = c; continue; }
+            while (c >= seg_hi && lo + 1 < a.nprobe) { lo++; load_seg(); }      // (padded segments: columns past the list's rows stay -inf)
+            if (c >= seg_lo && c - seg_lo < seg_len) rows[u] = seg_base + (c - seg_lo);
+        }
+        for (int c8 = lane; c8 < (a.ld >> 3); c8 += 64) {
+            const float4 qa = *reinterpret_cast<const float4*>(qv + 8 * c8), qb = *reinterpret_cast<const float4*>(qv + 8 * c8 + 4);
+            const float qf[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            uint4 xr[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) xr[u] = rows[u] >= 0 ? *reinterpret_cast<const uint4*>((const __half*)a.X + rows[u] * a.ld + 8 * c8) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t wds[4] = {xr[u].x, xr[u].y, xr[u].z, xr[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const __half hx = __ushort_as_half((unsigned short)((wds[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+                    const double qd = (double)qf[e], xd = (double)__half2float(hx);
+                    if (a.metric == 0) acc[u] += qd * xd; else { const double df = qd - xd; acc[u] += df * df; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t c = c0 + u4 + u;
+            if (c >= a.tstride) continue;
+            float out = -__builtin_inff();
+            if (rows[u] >= 0) {
+                const float sc = (float)wave_sum_f64(acc[u]);
+                out = (a.metric == 0 ? sc : 0.0f - sc) + 0.0f;
+            }
+            if (lane == 0) a.temp[q * a.tstride + c] = out;
+        }
+    }
+}
 void launch_exact_scores(const ExactScoreArgs& a, hipStream_t st) {
     if (a.nq <= 0 || a.tstride <= 0) return;
+    // fp16 rows whose zero padding up to ld the query rows cover as well (ldq >= ld: the padding contributes exact zeros)
+    if (a.x_f16 && (a.ldq & 7) == 0 && a.ldq >= a.ld && (a.ld & 7) == 0) {
+        hipLaunchKernelGGL(k_exact_scores_f16, dim3((unsigned)((a.tstride + 4 * XS_COLS - 1) / (4 * XS_COLS)), (unsigned)a.nq), dim3(256), 0, st, a);
+        return;
+    }
     hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((a.tstride + 3) / 4), (unsigned)a.nq), dim3(256), 0, st, a);
 }
 

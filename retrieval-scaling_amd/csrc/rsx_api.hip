@@ -443,6 +443,7 @@ int rsx_set_param(rsx_index_t* h, const char* key, double value) {
         else if (s == "flat_filter") h->flat_filter = (int)value;
         else if (s == "flat_pre_mult") h->flat_pre_mult = std::max(1, (int)value);
         else if (s == "flat_pre_unit") h->flat_pre_unit = std::max(0, (int)value);
+        else if (s == "ivf_overflow_max") h->ivf_overflow_max = std::max(0, (int)value);
         else if (s == "flat_stages") h->flat_stages = std::max(0, (int)value);
         else if (s == "flat_cert") h->flat_cert = (int)value;
         else if (s == "profile") { h->profile = (int)value; h->timing.clear(); }
