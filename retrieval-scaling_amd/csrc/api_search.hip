@@ -985,11 +985,11 @@ static void search_batch(rsx_index* h, int64_t nq, const void* dq, int dtype, in
             filtered = true;
             // A few overflowed rows (a query between clusters whose sample gave a weak threshold) no longer send the whole batch through the
             // unfiltered scan (10 -> 25 ms at nlist 2048 / nprobe 128 / k 1000 for ONE such query): with the certificate behind the search
-            // k_finalize flags them (cand_cnt > cand_cap) and they alone join the exact re-run (~2 ms per query at that size: up to nq / 256
+            // k_finalize flags them (cand_cnt > cand_cap) and they alone join the exact re-run (~1.1 ms per query at that size with k_exact_scores_f16: up to nq / 128
             // of them are cheaper than the rescan); more overflows mean the threshold failed for this data, and the batch is rescanned
             int64_t n_over = 0;
             for (int64_t qi = 0; qi < nq; qi++) n_over += cnts[(size_t)qi * CCS] > (unsigned long long)cand_cap;
-            if (n_over > 0 && !(certify && n_over <= (h->ivf_overflow_max > 0 ? (int64_t)h->ivf_overflow_max : std::max<int64_t>(2, nq / 256)))) filtered = false;
+            if (n_over > 0 && !(certify && n_over <= (h->ivf_overflow_max > 0 ? (int64_t)h->ivf_overflow_max : std::max<int64_t>(2, nq / 128)))) filtered = false;
             if (filtered && n_over > 0) { flag_overflows = true; h->timing["ivf_filter_overflow_queries"] += (double)n_over; }
             a.tau_key = nullptr; a.cand = nullptr; a.cand_cnt = nullptr; a.cand_cap = 0;
         }

@@ -229,7 +229,7 @@ struct rsx_index {
     int64_t ndropped = 0;                     // vectors seen by add but owned by other shards
     int flat_filter = 1;  // Flat: filtered GEMM launches after the threshold phase (0 = score buffer per chunk)
     int flat_pre_mult = 16;  // Flat: rows of the threshold phase per K' (through the score buffer), rounded up to units of flat_pre_unit rows
-    int ivf_overflow_max = 0; // IVF-Flat filtered scan: overflowed candidate rows whose queries are re-run exactly on their own before the batch is rescanned (0 = max(2, nq / 256))
+    int ivf_overflow_max = 0; // IVF-Flat filtered scan: overflowed candidate rows whose queries are re-run exactly on their own before the batch is rescanned (0 = max(2, nq / 128))
     int flat_pre_unit = 0;   // Flat: rows per unit of the threshold phase and the stage boundaries (0 = 16384 for K' <= 64, else 32768)
     int flat_stages = 0;     // Flat: filtered stages behind the threshold phase (0 = from K' and the row count; see search_batch)
     int ivf_filter = 1;   // IVF-Flat: candidates filtered inside the list scan (0 = full score rows + select)
