@@ -61,15 +61,20 @@ def test_config2_flat_10M_batch_1024(gpu, orc, metric):
         Ic = Ic + c0
         best = (Dc, Ic) if best is None else orc.merge_topk(np.stack([best[0], Dc]), np.stack([best[1], Ic]), mcode)
     assert_same_results(Dg.cpu().numpy()[SAMPLE], Ig.cpu().numpy()[SAMPLE], best[0], best[1], f"10M Flat {metric} vs CPU oracle (8 queries)")
-    # the reference's n_docs on the same index (ric/conf/default.yaml): k = 100, oracle on the same eight queries
+    # the reference's n_docs on the same index (ric/conf/default.yaml: 100 ... 1000), oracle on the same eight queries: k = 100 as a batch of
+    # eight (the list-scan form), k = 1000 as the WHOLE batch (round 6: the staged filtered GEMM launches with their queued epilogue, six stages
+    # that do not wait for their counts, the two-pass certificate of k_finalize) — the oracle's top 100 are the first 100 of its top 1000
     D1, I1 = ix.search(q[SAMPLE], 100)
+    Dk, Ik = ix.search(q, 1000)
+    assert ix.get_timing("fallback_queries") == 0 and ix.get_timing("flat_filter_overflows") == 0, "k = 1000: no re-run, no overflowed stage"
     best = None
     for c0 in range(0, n, buf.shape[0]):
         gpu.synth_vectors(D, NC, SC, SX, 0.5, c0, buf.shape[0], out=buf)
-        Dc, Ic = orc.flat_search(qs, buf.cpu().numpy().astype(np.float32), 100, mcode)
+        Dc, Ic = orc.flat_search(qs, buf.cpu().numpy().astype(np.float32), 1000, mcode)
         Ic = Ic + c0
         best = (Dc, Ic) if best is None else orc.merge_topk(np.stack([best[0], Dc]), np.stack([best[1], Ic]), mcode)
-    assert_same_results(D1.cpu().numpy(), I1.cpu().numpy(), best[0], best[1], f"10M Flat {metric} k = 100 vs CPU oracle")
+    assert_same_results(D1.cpu().numpy(), I1.cpu().numpy(), best[0][:, :100], best[1][:, :100], f"10M Flat {metric} k = 100 vs CPU oracle")
+    assert_same_results(Dk.cpu().numpy()[SAMPLE], Ik.cpu().numpy()[SAMPLE], best[0], best[1], f"10M Flat {metric} k = 1000 (whole batch) vs CPU oracle")
 
 
 def test_config3_ivfflat_100M_nlist4096_nprobe32(gpu, orc):
@@ -123,3 +128,9 @@ def test_config3_ivfflat_100M_nlist4096_nprobe32(gpu, orc):
     D1, I1 = ix.search(q[SAMPLE], 100)
     Do1, Io1 = orc.ivfflat_search(0, cen, lm, qs, nprobe, 100)
     assert_same_results(D1.cpu().numpy(), I1.cpu().numpy(), Do1, Io1, "100M IVF-Flat k = 100 vs CPU oracle")
+    # ... and the reference's n_docs = 1000 as the WHOLE batch: threshold sample of each query's two closest lists, the filtered list scan,
+    # the two-pass certificate — no candidate row may overflow and no query may need the exact re-run on this data
+    Dk, Ik = ix.search(q, 1000)
+    assert ix.get_timing("fallback_queries") == 0 and ix.get_timing("ivf_filter_overflow_queries") == 0
+    Dok, Iok = orc.ivfflat_search(0, cen, lm, qs, nprobe, 1000)
+    assert_same_results(Dk.cpu().numpy()[SAMPLE], Ik.cpu().numpy()[SAMPLE], Dok, Iok, "100M IVF-Flat k = 1000 (whole batch) vs CPU oracle")
