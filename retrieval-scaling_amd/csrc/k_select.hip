@@ -209,10 +209,20 @@ __device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf
     __syncthreads();
     int myvalid = 0;
     uint32_t lmin = 0xffffffffu, lmax = 0u;
-    for (int i = tid; i < N; i += NT) {
-        const uint64_t key = key_at(i);
+    // every pass over the keys requests EIGHT per thread before it looks at the first (round 6: a 32 768-column row was 136 dependent steps per
+    // thread and pass — the K' = 2048 selection of Flat's threshold phase took 0.5 ms per 1024 rows)
+    auto for_keys = [&](auto&& f) {
+        for (int i0 = tid; i0 < N; i0 += 8 * NT) {
+            uint64_t kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * NT; kk[u] = i < N ? key_at(i) : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) f(kk[u]);
+        }
+    };
+    for_keys([&](uint64_t key) {
         if (key != 0ull) { myvalid++; const uint32_t o = (uint32_t)(key >> 32); lmin = o < lmin ? o : lmin; lmax = o > lmax ? o : lmax; }
-    }
+    });
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         myvalid += __shfl_xor(myvalid, off);
@@ -234,11 +244,10 @@ __device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf
         for (int shift = 56 - 8 * nb; shift >= 0; shift -= 8) {
             for (int i = tid; i < 256; i += NT) hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < N; i += NT) {
-                const uint64_t key = key_at(i);
+            for_keys([&](uint64_t key) {
                 if (key != 0ull && (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8))))
                     atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
-            }
+            });
             __syncthreads();
             if (tid < 64) {             // wave 0: 4 bins per lane, suffix sums from the top
                 const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
@@ -274,10 +283,9 @@ __device__ inline void radix_topk_wg(KeyAt key_at, int N, int KP, uint64_t* obuf
         __syncthreads();
         return;
     }
-    for (int i = tid; i < N; i += NT) {
-        const uint64_t key = key_at(i);
+    for_keys([&](uint64_t key) {
         if (key != 0ull && key >= kth) { const int pos = atomicAdd(&ctl[3], 1); if (pos < KP) obuf[pos] = key; }
-    }
+    });
     __syncthreads();
     bitonic_sort_desc_wg(obuf, KP, tid, NT);
 }
